@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the BVH trace hot path on MI355X (driver contract in the task brief).
+
+A step = one pass of the hot path over one frame's ray batches on the 'atrium-262k'
+stand-in for Crytek Sponza (the OBJ is not in the reference checkout): the 1920x1080
+primary batch (closest hit) followed by the 8 x AO batches (any hit, <= 2^20 rays per
+batch as Renderer.cpp:45 / RayGen.cpp:582-602), all resident in HBM before the timed
+region.  Ray generation is excluded from the metric exactly as in the reference's
+runBenchmark (App.cpp:955-969).  One process per GPU; ranks trace their own screen
+tile set against a replicated BVH (weak scaling), and the final framebuffer gather over
+RCCL is timed separately.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--ao-samples", type=int, default=8)
+    ap.add_argument("--kernel", default=os.environ.get("NTR_BENCH_KERNEL", "kepler_dynamic_fetch"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import ntrace_amd as nt
+    from ntrace_amd import scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the tracer has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    nt.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+
+    # ---- scene + prebuilt BVH (host SAH build, Renderer.builder = SAHBVH, leaf prefs (1,1)) ----
+    tri, pos, cam = scenes.atrium()
+    t0 = time.time()
+    bvh = nt.sah_build(tri, pos, 1, 1)
+    sah_seconds = time.time() - t0
+    d_nodes, d_woop, d_idx = up(bvh.nodes), up(bvh.woop), up(bvh.tri_index)
+    flags = nt.bvh_validate(d_nodes.data_ptr(), bvh.nodes.nbytes, stream)
+
+    # ---- ray batches: rank r renders its own tile set = the frame seen from camera r ------------
+    cam = dict(cam)
+    eye = np.array(cam["eye"], dtype=np.float64)
+    eye[2] += 35.0 * rank  # weak scaling: every rank traces a full-resolution tile set
+    cam["eye"] = tuple(eye)
+    w, h = args.width, args.height
+    rays, slot_to_pixel = scenes.primary_rays(cam, w, h)
+    n_primary = rays.shape[0]
+    d_rays = up(rays)
+    d_res = torch.zeros(n_primary * 16, dtype=torch.uint8, device=dev)
+
+    batches = [dict(name="primary", n=n_primary, any_hit=False, rays=d_rays, res=d_res)]
+
+    def run_batch(b, timed=False):
+        return nt.trace_bvh(args.kernel, b["n"], b["any_hit"], b["rays"].data_ptr(), b["res"].data_ptr(),
+                            d_nodes.data_ptr(), d_woop.data_ptr(), d_idx.data_ptr(), bvh_flags=flags,
+                            stream=stream, timed=timed)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        for b in batches:
+            run_batch(b)
+    barrier()
+
+    # ---- timed region: exactly K steps -------------------------------------------------------------
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in batches]
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        for bi, b in enumerate(batches):
+            ev[s][bi][0].record()
+            run_batch(b)
+            ev[s][bi][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    kern_ms = np.array([[e0.elapsed_time(e1) for (e0, e1) in step] for step in ev])  # [steps, batches]
+    rays_per_step = sum(b["n"] for b in batches)
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(rays_per_step)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed_max = float(tmax.item())
+    total_rays_per_step = float(tot.item())
+
+    # ---- final framebuffer gather (hit records -> rank 0) over RCCL, timed separately ----------------
+    gather_ms = None
+    if world > 1:
+        outs = [torch.empty_like(d_res) for _ in range(world)] if rank == 0 else None
+        barrier()
+        g0 = time.perf_counter()
+        dist.gather(d_res, outs, dst=0)
+        barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    # ---- algorithmic bytes of the dominant kernel (instrumented trace, untimed) ----------------------
+    st = nt.trace_bvh_stats(args.kernel, n_primary, False, d_rays.data_ptr(), d_res.data_ptr(), d_nodes.data_ptr(),
+                            d_woop.data_ptr(), d_idx.data_ptr(), bvh_flags=flags, stream=stream)
+    alg_bytes = st.algorithmic_bytes()
+    prim_ms = float(kern_ms[:, 0].mean())
+    achieved = alg_bytes / (prim_ms * 1e-3) / 1e9
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = total_rays_per_step * args.steps / elapsed_max / 1e6
+    out = {
+        "metric": "Mrays/sec (primary + 8xAO) on Crytek Sponza",
+        "value": value,
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed_max / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (atrium-262k stand-in for Crytek Sponza, seed 262267; sponza.obj is absent from the reference checkout)",
+        "config": {"workload": "Sponza-262k prebuilt SAH BVH, %dx%d primary rays per GPU" % (w, h),
+                   "kernel": args.kernel, "triangles": int(tri.shape[0]), "rays_per_step_per_gpu": rays_per_step,
+                   "parallelism": "screen-tile sharded rays, BVH replicated, RCCL gather of hit records"},
+        "primary_mrays": n_primary / (prim_ms * 1e-3) / 1e6,
+        "kernel_ms": {"primary": prim_ms},
+        "gather_ms": gather_ms,
+        "host_sah_build_s": sah_seconds,
+        "trace_stats": st.as_dict(),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "trace_bvh (%s), primary batch" % args.kernel,
+                     "algorithmic_bytes_per_launch": alg_bytes},
+    }
+
+    # ---- CPU baseline: the oracle (restated reference CPU tracer) on a bounded sample ---------------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        cores = os.cpu_count() or 1
+        n_sample = args.cpu_sample_rays or min(n_primary, 1_000_000)
+        sel = np.arange(n_sample)  # leading rays of the PixelTable order = compact screen region
+        sample = rays[sel]
+        oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, sample[:20000], threads=cores)  # warm-up
+        c0 = time.perf_counter()
+        ref, _ = oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, sample[: n_sample // 8], threads=1)
+        c1 = time.perf_counter()
+        ref_mt, _ = oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, sample, threads=cores)
+        c2 = time.perf_counter()
+        got = d_res.cpu().numpy().view(nt.RESULT_DTYPE)[sel]
+        mism = int((got["id"] != ref_mt["id"]).sum() + (got["t"].view(np.uint32) != ref_mt["t"].view(np.uint32)).sum())
+        out["cpu_baseline"] = {"value": n_sample / (c2 - c1) / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                               "sample": "first %d primary rays (PixelTable order) of the same batch, all host cores; "
+                                         "1 thread on the first %d: %.3f Mrays/s" % (n_sample, n_sample // 8,
+                                                                                       (n_sample // 8) / (c1 - c0) / 1e6),
+                               "single_thread_mrays": (n_sample // 8) / (c1 - c0) / 1e6,
+                               "parity_mismatches_on_sample": mism}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

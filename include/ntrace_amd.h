@@ -1,0 +1,175 @@
+/*
+ * ntrace_amd.h -- C-ABI of the MI355X-native NTrace tracer backend (libntrace_amd.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * the NTrace checkout).  The reference-side binding is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns NTR_OK (0) or a negative NtrStatus; the message of
+ *     the last failure on the calling thread is ntr_last_error().  The C++ host
+ *     mirror (ntrace_amd/host) maps non-zero to FW::fail(), as the reference's
+ *     CudaModule::checkError does (src/framework/gpu/CudaModule.cpp).
+ *   - "d_" pointers are device (HIP) pointers owned by the caller (Buffer in the
+ *     reference, src/framework/gpu/Buffer.hpp:107-113); the library never frees
+ *     or retains them past the call (or past stream completion for async calls).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - calls are thread-compatible: one caller per device at a time.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry
+ *     point fails with NTR_ERR_NO_DEVICE.
+ */
+#ifndef NTRACE_AMD_H
+#define NTRACE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTR_API __attribute__((visibility("default")))
+
+typedef enum NtrStatus {
+    NTR_OK = 0,
+    NTR_ERR_INVALID = -1,     /* bad argument                                  */
+    NTR_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init   */
+    NTR_ERR_HIP = -3,         /* a HIP call failed (message has the HIP error) */
+    NTR_ERR_LAYOUT = -4,      /* "CudaBVHTracer: Incorrect BVH layout!"        */
+    NTR_ERR_UNKNOWN_KERNEL = -5,
+    NTR_ERR_OVERFLOW = -6,    /* traversal stack / workspace overflow          */
+    NTR_ERR_NOMEM = -7
+} NtrStatus;
+
+/* src/rt/kernels/CudaTracerKernels.hpp:52-63 */
+typedef enum NtrBVHLayout {
+    NTR_BVHLayout_AOS_AOS = 0,
+    NTR_BVHLayout_AOS_SOA,
+    NTR_BVHLayout_SOA_AOS,
+    NTR_BVHLayout_SOA_SOA,
+    NTR_BVHLayout_Compact,
+    NTR_BVHLayout_Compact2,
+    NTR_BVHLayout_CPU,
+    NTR_BVHLayout_Max
+} NtrBVHLayout;
+
+/* src/rt/kernels/CudaTracerKernels.hpp:69-75 (KernelConfig) */
+typedef struct NtrKernelConfig {
+    int32_t bvhLayout;
+    int32_t blockWidth;            /* wave64: 64                           */
+    int32_t blockHeight;           /* waves per workgroup                  */
+    int32_t usePersistentThreads;
+} NtrKernelConfig;
+
+/* src/rt/Util.hpp:62-71 */
+typedef struct NtrRay {
+    float ox, oy, oz, tmin;
+    float dx, dy, dz, tmax;
+} NtrRay;
+
+/* src/rt/Util.hpp:77-87.  The tracer writes id and t; padA/padB receive the
+ * barycentrics (u,v) bit patterns on a hit like STORE_RESULT
+ * (CudaTracerKernels.hpp:222) and are 0 on a miss.  Parity is on (id,t). */
+typedef struct NtrRayResult {
+    int32_t id;
+    float   t;
+    int32_t padA;
+    int32_t padB;
+} NtrRayResult;
+
+/* ---- library / device ------------------------------------------------------ */
+
+NTR_API const char* ntr_last_error(void);
+NTR_API int         ntr_version(void);
+
+/* Thin device-memory plumbing for the C++ Buffer mirror
+ * (src/framework/gpu/Buffer.cpp:238- cuMemAlloc/cuMemcpy* call sites). */
+NTR_API int ntr_device_count(int* count);
+NTR_API int ntr_set_device(int device);
+NTR_API int ntr_malloc(void** d_ptr, size_t bytes);
+NTR_API int ntr_free(void* d_ptr);
+NTR_API int ntr_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
+NTR_API int ntr_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
+NTR_API int ntr_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);
+NTR_API int ntr_memset(void* d_dst, int value, size_t bytes, void* stream);
+NTR_API int ntr_stream_synchronize(void* stream);
+
+/* ---- tracer ---------------------------------------------------------------- */
+
+/* Replaces the per-kernel-file `queryConfig` launch + g_config read-back
+ * (src/rt/cuda/CudaBVHTracer.cpp:52-84).  `kernelName` keeps the reference's
+ * file-name selectors: "fermi_speculative_while_while",
+ * "tesla_persistent_while_while", "tesla_persistent_speculative_while_while",
+ * "kepler_dynamic_fetch" (all mapped to precompiled CDNA4 variants). */
+NTR_API int ntr_query_config(const char* kernelName, NtrKernelConfig* config);
+
+/* Replaces the `trace_bvh` launch of CudaBVHTracer::traceBatch
+ * (src/rt/cuda/CudaBVHTracer.cpp:88-168; signature TRACE_FUNC_BVH,
+ * src/rt/kernels/CudaTracerKernels.hpp:99-112; nodesB-D / trisB-C exist only for
+ * the SOA layouts and are dropped).
+ *
+ *   numRays == 0          -> NTR_OK, *seconds = 0 (CudaBVHTracer.cpp:92-94)
+ *   layout != the kernel's desired layout -> NTR_ERR_LAYOUT (:99-100)
+ *   seconds != NULL       -> launch is bracketed by HIP events on `stream`, the
+ *                            call blocks and returns the kernel's GPU time in
+ *                            seconds (CudaKernel::launchTimed, CudaKernel.cpp:188-221)
+ *   seconds == NULL       -> asynchronous launch on `stream`.
+ *
+ * Results follow the reference CPU tracer bit for bit in (id, t): miss =
+ * (-1, ray.tmax) (CudaBVH.cpp:273-274).  `bvhFlags`: 0, or hints from
+ * ntr_bvh_validate(). */
+NTR_API int ntr_trace_bvh(const char* kernelName, int32_t numRays, int32_t anyHit,
+                          const NtrRay* d_rays, NtrRayResult* d_results,
+                          const void* d_nodes, const void* d_triWoop, const int32_t* d_triIndex,
+                          int32_t layout, uint32_t bvhFlags, void* stream, float* seconds);
+
+/* Traversal counters: the reference's RayStats (src/rt/bvh/BVH.hpp:44-60), filled by its
+ * CPU tracer at src/rt/cuda/CudaBVH.cpp:746-757 and 1107-1111.  numInnerVisits =
+ * numNodeTests / 2.  These define the algorithmic bytes of a batch:
+ *   48*numRays + 64*numInnerVisits + 48*numTriTests + 16*numLeafVisits + 4*numHits. */
+typedef struct NtrTraceStats {
+    int64_t numRays;
+    int64_t numInnerVisits;
+    int64_t numTriTests;
+    int64_t numLeafVisits;   /* leaf terminators read */
+    int64_t numHits;
+} NtrTraceStats;
+
+/* ntr_trace_bvh through an instrumented kernel: same results, plus the counters.
+ * Blocking; not a timed path. */
+NTR_API int ntr_trace_bvh_stats(const char* kernelName, int32_t numRays, int32_t anyHit,
+                                const NtrRay* d_rays, NtrRayResult* d_results,
+                                const void* d_nodes, const void* d_triWoop, const int32_t* d_triIndex,
+                                int32_t layout, uint32_t bvhFlags, void* stream, NtrTraceStats* stats);
+
+/* One pass over a Compact node buffer computing hint flags for ntr_trace_bvh:
+ *   NTR_BVH_FINITE  every box coordinate is finite and |x| < 2^100. */
+#define NTR_BVH_FINITE 1u
+NTR_API int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_t* flags, void* stream);
+
+/* ---- host-side BVH production (no device work) ---------------------------- */
+
+/* Host SAH build + Compact flatten: `BVH bvh(scene, platform, params);
+ * CudaBVH(bvh, BVHLayout_Compact)` of Renderer::getCudaBVH
+ * (src/rt/cuda/Renderer.cpp:282-285; SAHBVHBuilder.cpp:51-254; CudaBVH.cpp:579-687)
+ * with Platform("GPU") and setLeafPreferences(minLeaf,maxLeaf) (Renderer.cpp:88-89
+ * uses 1,1).  Returns an opaque handle holding host copies of the three buffers. */
+typedef struct NtrHostBvh NtrHostBvh;
+typedef struct NtrHostBvhInfo {
+    const void*    nodes;     int64_t nodesBytes;
+    const void*    triWoop;   int64_t triWoopBytes;
+    const int32_t* triIndex;  int64_t triIndexBytes;
+    int32_t layout;
+    int32_t numInnerNodes, numLeafNodes, maxDepth;
+    float   buildSeconds;
+} NtrHostBvhInfo;
+NTR_API int  ntr_sah_build(int32_t numTris, const int32_t* triVtxIndex /* 3 per tri */,
+                           int32_t numVerts, const float* vtxPos /* 3 per vertex */,
+                           int32_t minLeafSize, int32_t maxLeafSize, NtrHostBvh** out);
+NTR_API int  ntr_host_bvh_info(const NtrHostBvh* bvh, NtrHostBvhInfo* info);
+NTR_API void ntr_host_bvh_free(NtrHostBvh* bvh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,18 @@
+"""ntrace_amd -- MI355X-native tracer backend for NTrace (BVH trace + LBVH build).
+
+The product is libntrace_amd.so (hand-written HIP kernels for gfx950 behind the C-ABI
+of include/ntrace_amd.h) plus the C++ host mirror of the reference's Renderer / CudaBVH /
+RayBuffer classes in ntrace_amd/host.  This Python module is plumbing for tests and
+bench.py: it loads the library with ctypes and passes raw device pointers (e.g. torch
+tensors' data_ptr()).  There is no CPU or PyTorch fallback: if the library is missing the
+import of `ntrace_amd.lib()` fails loudly.
+"""
+from ._capi import (RAY_DTYPE, RESULT_DTYPE, HostBvh, KernelConfig, NtrError, TraceStats, bvh_validate, lib,
+                    lib_path, query_config, sah_build, trace_bvh, trace_bvh_stats)
+
+BVHLayout_Compact = 4
+KERNELS = ("fermi_speculative_while_while", "tesla_persistent_while_while",
+           "tesla_persistent_speculative_while_while", "kepler_dynamic_fetch")
+
+__all__ = ["RAY_DTYPE", "RESULT_DTYPE", "HostBvh", "KernelConfig", "NtrError", "bvh_validate", "lib",
+           "lib_path", "query_config", "sah_build", "trace_bvh", "trace_bvh_stats", "TraceStats", "BVHLayout_Compact", "KERNELS"]

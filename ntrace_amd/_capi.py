@@ -1,0 +1,158 @@
+"""ctypes binding of include/ntrace_amd.h (libntrace_amd.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+RAY_DTYPE = np.dtype([("ox", "<f4"), ("oy", "<f4"), ("oz", "<f4"), ("tmin", "<f4"),
+                      ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"), ("tmax", "<f4")])
+RESULT_DTYPE = np.dtype([("id", "<i4"), ("t", "<f4"), ("padA", "<i4"), ("padB", "<i4")])
+
+
+class NtrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ntrace_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class KernelConfig(C.Structure):
+    _fields_ = [("bvhLayout", C.c_int32), ("blockWidth", C.c_int32), ("blockHeight", C.c_int32),
+                ("usePersistentThreads", C.c_int32)]
+
+
+class TraceStats(C.Structure):
+    _fields_ = [("numRays", C.c_int64), ("numInnerVisits", C.c_int64), ("numTriTests", C.c_int64),
+                ("numLeafVisits", C.c_int64), ("numHits", C.c_int64)]
+
+    def algorithmic_bytes(self):
+        """DESIGN.md / SURVEY.md section 8(d): 32 B ray + 16 B result + 64 B per inner node visited +
+        48 B per triangle tested + 16 B per leaf terminator + 4 B index remap per hit."""
+        return (48 * self.numRays + 64 * self.numInnerVisits + 48 * self.numTriTests
+                + 16 * self.numLeafVisits + 4 * self.numHits)
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class _HostBvhInfo(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("nodesBytes", C.c_int64), ("triWoop", C.c_void_p),
+                ("triWoopBytes", C.c_int64), ("triIndex", C.c_void_p), ("triIndexBytes", C.c_int64),
+                ("layout", C.c_int32), ("numInnerNodes", C.c_int32), ("numLeafNodes", C.c_int32),
+                ("maxDepth", C.c_int32), ("buildSeconds", C.c_float)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libntrace_amd.so")
+
+
+_lib = None
+
+# every symbol include/ntrace_amd.h declares: (name, restype, argtypes)
+_vp, _i32, _i64, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+SYMBOLS = [
+    ("ntr_last_error", C.c_char_p, []),
+    ("ntr_version", C.c_int, []),
+    ("ntr_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("ntr_set_device", C.c_int, [C.c_int]),
+    ("ntr_malloc", C.c_int, [C.POINTER(_vp), C.c_size_t]),
+    ("ntr_free", C.c_int, [_vp]),
+    ("ntr_memcpy_h2d", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    ("ntr_memcpy_d2h", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    ("ntr_memcpy_d2d", C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    ("ntr_memset", C.c_int, [_vp, C.c_int, C.c_size_t, _vp]),
+    ("ntr_stream_synchronize", C.c_int, [_vp]),
+    ("ntr_query_config", C.c_int, [C.c_char_p, C.POINTER(KernelConfig)]),
+    ("ntr_trace_bvh", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _u32, _vp,
+                                C.POINTER(C.c_float)]),
+    ("ntr_trace_bvh_stats", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _u32, _vp,
+                                      C.POINTER(TraceStats)]),
+    ("ntr_bvh_validate", C.c_int, [_vp, _i64, C.POINTER(_u32), _vp]),
+    ("ntr_sah_build", C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
+    ("ntr_host_bvh_info", C.c_int, [_vp, C.POINTER(_HostBvhInfo)]),
+    ("ntr_host_bvh_free", None, [_vp]),
+]
+
+
+def lib():
+    """Load libntrace_amd.so; raises if it was not built (no fallback)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError("ntrace_amd: %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the HIP extension is mandatory; there is no CPU fallback)" % path)
+        L = C.CDLL(path)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise NtrError(rc, (lib().ntr_last_error() or b"").decode("utf-8", "replace"))
+
+
+def query_config(kernel):
+    cfg = KernelConfig()
+    _check(lib().ntr_query_config(kernel.encode(), C.byref(cfg)))
+    return cfg
+
+
+def trace_bvh(kernel, num_rays, any_hit, d_rays, d_results, d_nodes, d_woop, d_tri_index,
+              layout=4, bvh_flags=0, stream=0, timed=True):
+    """ntr_trace_bvh on raw device pointers (ints).  Returns GPU seconds if timed else None."""
+    sec = C.c_float(0.0)
+    _check(lib().ntr_trace_bvh(kernel.encode(), int(num_rays), int(bool(any_hit)), _vp(d_rays), _vp(d_results),
+                               _vp(d_nodes), _vp(d_woop), _vp(d_tri_index), int(layout), int(bvh_flags),
+                               _vp(stream), C.byref(sec) if timed else None))
+    return float(sec.value) if timed else None
+
+
+def trace_bvh_stats(kernel, num_rays, any_hit, d_rays, d_results, d_nodes, d_woop, d_tri_index,
+                    layout=4, bvh_flags=0, stream=0):
+    st = TraceStats()
+    _check(lib().ntr_trace_bvh_stats(kernel.encode(), int(num_rays), int(bool(any_hit)), _vp(d_rays), _vp(d_results),
+                                     _vp(d_nodes), _vp(d_woop), _vp(d_tri_index), int(layout), int(bvh_flags),
+                                     _vp(stream), C.byref(st)))
+    return st
+
+
+def bvh_validate(d_nodes, nodes_bytes, stream=0):
+    flags = _u32(0)
+    _check(lib().ntr_bvh_validate(_vp(d_nodes), int(nodes_bytes), C.byref(flags), _vp(stream)))
+    return int(flags.value)
+
+
+class HostBvh:
+    """Host Compact BVH (numpy copies of nodes / triWoop / triIndex) from ntr_sah_build."""
+
+    def __init__(self, nodes, woop, tri_index, info=None):
+        self.nodes = nodes          # uint8[nodesBytes]
+        self.woop = woop            # uint8[woopBytes]
+        self.tri_index = tri_index  # int32[]
+        self.info = info or {}
+        self.layout = 4
+
+
+def sah_build(tri_vtx_index, vtx_pos, min_leaf=1, max_leaf=1):
+    tri = np.ascontiguousarray(tri_vtx_index, dtype=np.int32).reshape(-1, 3)
+    pos = np.ascontiguousarray(vtx_pos, dtype=np.float32).reshape(-1, 3)
+    h = _vp()
+    _check(lib().ntr_sah_build(tri.shape[0], tri.ctypes.data_as(_vp), pos.shape[0], pos.ctypes.data_as(_vp),
+                               int(min_leaf), int(max_leaf), C.byref(h)))
+    try:
+        info = _HostBvhInfo()
+        _check(lib().ntr_host_bvh_info(h, C.byref(info)))
+        nodes = np.ctypeslib.as_array(C.cast(info.nodes, C.POINTER(C.c_uint8)), (info.nodesBytes,)).copy()
+        woop = np.ctypeslib.as_array(C.cast(info.triWoop, C.POINTER(C.c_uint8)), (info.triWoopBytes,)).copy()
+        tidx = np.ctypeslib.as_array(C.cast(info.triIndex, C.POINTER(C.c_int32)), (info.triIndexBytes // 4,)).copy()
+        meta = dict(numInnerNodes=info.numInnerNodes, numLeafNodes=info.numLeafNodes, maxDepth=info.maxDepth,
+                    buildSeconds=float(info.buildSeconds))
+    finally:
+        lib().ntr_host_bvh_free(h)
+    return HostBvh(nodes, woop, tidx, meta)

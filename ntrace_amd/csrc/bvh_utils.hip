@@ -1,0 +1,51 @@
+// bvh_utils.hip -- small whole-buffer passes over a Compact BVH.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ntr_internal.h"
+
+namespace ntr {
+
+// Flags a Compact node buffer whose 12 box floats per node (bytes 0..47 of each
+// 64-B node, src/rt/cuda/CudaBVH.hpp:42-46) are all finite with |x| < 2^100.
+__global__ __launch_bounds__(256) void bvh_validate_kernel(const float4* __restrict__ nodes, int64_t numFloat4,
+                                                           unsigned int* __restrict__ bad)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool isBad = false;
+    for (; i < numFloat4; i += stride) {
+        if ((i & 3) == 3) continue;  // child / split words
+        const float4 v = nodes[i];
+        const float lim = 0x1p100f;
+        // !(|x| < lim) is also true for NaN
+        isBad = isBad || !(fabsf(v.x) < lim) || !(fabsf(v.y) < lim) || !(fabsf(v.z) < lim) || !(fabsf(v.w) < lim);
+    }
+    if (__ballot(isBad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+}
+
+}  // namespace ntr
+
+extern "C" int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_t* flags, void* stream)
+{
+    using namespace ntr;
+    if (!flags) return set_error(NTR_ERR_INVALID, "ntr_bvh_validate: null flags");
+    *flags = 0;
+    if (!d_nodes || nodesBytes < 64 || (nodesBytes % 64) != 0)
+        return set_error(NTR_ERR_INVALID, "ntr_bvh_validate: node buffer must be a positive multiple of 64 bytes");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int* d_bad = nullptr;
+    NTR_HIP(hipMalloc((void**)&d_bad, sizeof(unsigned int)));
+    NTR_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), s));
+    const int64_t n4 = nodesBytes / 16;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(bvh_validate_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)d_nodes, n4, d_bad);
+    NTR_HIP(hipGetLastError());
+    unsigned int bad = 0;
+    NTR_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s));
+    NTR_HIP(hipStreamSynchronize(s));
+    NTR_HIP(hipFree(d_bad));
+    if (!bad) *flags |= NTR_BVH_FINITE;
+    return NTR_OK;
+}

@@ -1,0 +1,319 @@
+// ntr_api.cpp -- C-ABI of libntrace_amd.so (declared in include/ntrace_amd.h).
+//
+// Thin layer: argument checks mirroring the reference's host-side checks, HIP
+// event timing mirroring CudaKernel::launchTimed (src/framework/gpu/CudaKernel.cpp:188-221),
+// and kernel launches.  There is deliberately no CPU path here: with no HIP device
+// every compute entry point fails (NTR_ERR_NO_DEVICE / NTR_ERR_HIP).
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "ntrace_amd.h"
+#include "ntr_internal.h"
+#include "trace_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+}  // namespace
+
+namespace ntr {
+
+int set_error(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    int code = (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+                   ? NTR_ERR_NO_DEVICE : NTR_ERR_HIP;
+    return set_error(code, "%s: %s", what, hipGetErrorString(e));
+}
+
+// Per-device workspace: ring of pool counters + sticky status word.
+struct DeviceState {
+    bool init = false;
+    int32_t* counters = nullptr;  // kNumCounters ints
+    unsigned int* status = nullptr;
+    unsigned long long* stats = nullptr;  // 4 counters of the stats variant
+    int next = 0;
+    int numCUs = 0;
+};
+static constexpr int kNumCounters = 256;
+static constexpr int kMaxDevices = 64;
+static DeviceState g_dev[kMaxDevices];
+static std::mutex g_mu;
+
+int get_device_state(DeviceState** out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    if (dev < 0 || dev >= kMaxDevices) return set_error(NTR_ERR_INVALID, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceState& s = g_dev[dev];
+    if (!s.init) {
+        hipDeviceProp_t prop;
+        NTR_HIP(hipGetDeviceProperties(&prop, dev));
+        s.numCUs = prop.multiProcessorCount;
+        // Counters sit 64 B apart so concurrent launches never share a line.
+        NTR_HIP(hipMalloc((void**)&s.counters, kNumCounters * 64));
+        NTR_HIP(hipMalloc((void**)&s.status, 64));
+        NTR_HIP(hipMalloc((void**)&s.stats, 64));
+        NTR_HIP(hipMemset(s.status, 0, 64));
+        s.init = true;
+    }
+    *out = &s;
+    return NTR_OK;
+}
+
+struct KernelInfo {
+    const char* name;
+    int variant;
+    NtrKernelConfig cfg;
+};
+
+// Reference kernel selectors (file names under src/rt/kernels/) -> CDNA4 variants.
+// All CDNA4 variants consume BVHLayout_Compact (the reference fork asserts Compact
+// for every BVH it builds, src/rt/cuda/CudaBVH.cpp:65-82).
+static const KernelInfo kKernels[] = {
+    {"fermi_speculative_while_while", NTR_VARIANT_PERRAY,
+     {NTR_BVHLayout_Compact, 64, NTR_TRACE_WAVES_PER_BLOCK, 0}},
+    {"tesla_persistent_while_while", NTR_VARIANT_PERSISTENT,
+     {NTR_BVHLayout_Compact, 64, NTR_TRACE_WAVES_PER_BLOCK, 1}},
+    {"tesla_persistent_speculative_while_while", NTR_VARIANT_PERSISTENT,
+     {NTR_BVHLayout_Compact, 64, NTR_TRACE_WAVES_PER_BLOCK, 1}},
+    {"kepler_dynamic_fetch", NTR_VARIANT_PERSISTENT,
+     {NTR_BVHLayout_Compact, 64, NTR_TRACE_WAVES_PER_BLOCK, 1}},
+};
+
+static const KernelInfo* find_kernel(const char* name)
+{
+    if (!name) return nullptr;
+    for (const KernelInfo& k : kKernels)
+        if (strcmp(k.name, name) == 0) return &k;
+    return nullptr;
+}
+
+}  // namespace ntr
+
+using namespace ntr;
+
+extern "C" {
+
+const char* ntr_last_error(void) { return g_err; }
+int ntr_version(void) { return 100; }
+
+int ntr_device_count(int* count)
+{
+    if (!count) return set_error(NTR_ERR_INVALID, "ntr_device_count: null argument");
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { *count = 0; return hip_fail(e, "hipGetDeviceCount"); }
+    return NTR_OK;
+}
+
+int ntr_set_device(int device) { NTR_HIP(hipSetDevice(device)); return NTR_OK; }
+
+int ntr_malloc(void** d_ptr, size_t bytes)
+{
+    if (!d_ptr) return set_error(NTR_ERR_INVALID, "ntr_malloc: null argument");
+    *d_ptr = nullptr;
+    if (bytes == 0) return NTR_OK;
+    NTR_HIP(hipMalloc(d_ptr, bytes));
+    return NTR_OK;
+}
+
+int ntr_free(void* d_ptr)
+{
+    if (d_ptr) NTR_HIP(hipFree(d_ptr));
+    return NTR_OK;
+}
+
+int ntr_memcpy_h2d(void* d, const void* h, size_t n, void* stream)
+{
+    if (n == 0) return NTR_OK;
+    NTR_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)stream));
+    NTR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return NTR_OK;
+}
+
+int ntr_memcpy_d2h(void* h, const void* d, size_t n, void* stream)
+{
+    if (n == 0) return NTR_OK;
+    NTR_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    NTR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return NTR_OK;
+}
+
+int ntr_memcpy_d2d(void* dst, const void* src, size_t n, void* stream)
+{
+    if (n == 0) return NTR_OK;
+    NTR_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return NTR_OK;
+}
+
+int ntr_memset(void* d, int value, size_t n, void* stream)
+{
+    if (n == 0) return NTR_OK;
+    NTR_HIP(hipMemsetAsync(d, value, n, (hipStream_t)stream));
+    return NTR_OK;
+}
+
+int ntr_stream_synchronize(void* stream)
+{
+    NTR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return NTR_OK;
+}
+
+int ntr_query_config(const char* kernelName, NtrKernelConfig* config)
+{
+    if (!config) return set_error(NTR_ERR_INVALID, "ntr_query_config: null config");
+    const KernelInfo* k = find_kernel(kernelName);
+    if (!k) {
+        // CudaBVHTracer::setKernel leaves bvhLayout = BVHLayout_Max when queryConfig
+        // does not run (CudaBVHTracer.cpp:66-71).
+        config->bvhLayout = NTR_BVHLayout_Max;
+        config->blockWidth = config->blockHeight = config->usePersistentThreads = 0;
+        return set_error(NTR_ERR_UNKNOWN_KERNEL, "unknown kernel '%s'", kernelName ? kernelName : "(null)");
+    }
+    *config = k->cfg;
+    return NTR_OK;
+}
+
+// Tunables (environment overrides are for benchmarking sweeps only).
+static int env_int(const char* name, int def)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : def;
+}
+
+static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
+                      NtrRayResult* d_results, const void* d_nodes, const void* d_triWoop,
+                      const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags, void* stream, float* seconds,
+                      NtrTraceStats* stats)
+{
+    if (seconds) *seconds = 0.0f;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    const KernelInfo* k = find_kernel(kernelName);
+    if (!k) return set_error(NTR_ERR_UNKNOWN_KERNEL, "unknown kernel '%s'", kernelName ? kernelName : "(null)");
+    if (numRays < 0) return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: numRays < 0");
+    if (numRays == 0) return NTR_OK;  // CudaBVHTracer.cpp:92-94
+    if (!d_nodes || !d_triWoop || !d_triIndex)
+        return set_error(NTR_ERR_INVALID, "CudaBVHTracer: No BVH!");  // :97-98
+    if (layout != k->cfg.bvhLayout)
+        return set_error(NTR_ERR_LAYOUT, "CudaBVHTracer: Incorrect BVH layout!");  // :99-100
+    if (!d_rays || !d_results) return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: null ray/result buffer");
+
+    DeviceState* ds = nullptr;
+    int rc = get_device_state(&ds);
+    if (rc != NTR_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+
+    TraceParams p;
+    p.numRays = numRays;
+    p.anyHit = anyHit ? 1 : 0;
+    p.rays = d_rays;
+    p.results = d_results;
+    p.nodes = d_nodes;
+    p.woop = d_triWoop;
+    p.triIndex = d_triIndex;
+    p.status = ds->status;
+    p.counter = nullptr;
+    p.chunk = env_int("NTR_TRACE_CHUNK", 128);
+    p.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", 40);
+    p.bvhFlags = bvhFlags;
+    p.stats = ds->stats;
+    int variant = k->variant;
+    if (stats) {
+        // RayStats counters (src/rt/bvh/BVH.hpp:44-, filled at CudaBVH.cpp:746-757,1107-1111) are
+        // produced by the instrumented per-ray kernel; every variant visits nodes in the same
+        // per-ray order, so the counts do not depend on the variant.
+        variant = NTR_VARIANT_PERRAY_STATS;
+        NTR_HIP(hipMemsetAsync(ds->stats, 0, 4 * sizeof(unsigned long long), s));
+    }
+
+    constexpr int blockThreads = NTR_TRACE_WAVES_PER_BLOCK * 64;
+    int numBlocks;
+    if (variant == NTR_VARIANT_PERSISTENT) {
+        // Persistent grid: CUs x resident blocks per CU (the reference hard-codes
+        // 720 warps for GT200/Fermi, CudaBVHTracer.cpp:155-159).
+        const int blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 4);
+        numBlocks = ds->numCUs * blocksPerCU;
+        const int needed = (numRays + blockThreads - 1) / blockThreads;
+        if (numBlocks > needed) numBlocks = needed;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            p.counter = ds->counters + 16 * ds->next;
+            ds->next = (ds->next + 1) % kNumCounters;
+        }
+        NTR_HIP(hipMemsetAsync(p.counter, 0, sizeof(int32_t), s));
+    } else {
+        numBlocks = (numRays + blockThreads - 1) / blockThreads;
+    }
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (seconds) {
+        NTR_HIP(hipEventCreate(&ev0));
+        NTR_HIP(hipEventCreate(&ev1));
+        NTR_HIP(hipStreamSynchronize(s));  // launchTimed syncs first (CudaKernel.cpp:193)
+        NTR_HIP(hipEventRecord(ev0, s));
+    }
+    hipError_t le = ntr_launch_trace(variant, &p, numBlocks, s);
+    if (le != hipSuccess) return hip_fail(le, "trace_bvh launch");
+    if (seconds) {
+        NTR_HIP(hipEventRecord(ev1, s));
+        NTR_HIP(hipEventSynchronize(ev1));
+        float ms = 0.0f;
+        NTR_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        *seconds = ms * 1e-3f;
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+        unsigned int st = 0;
+        NTR_HIP(hipMemcpy(&st, ds->status, sizeof(st), hipMemcpyDeviceToHost));
+        if (st & NTR_STATUS_STACK_OVERFLOW) {
+            (void)hipMemset(ds->status, 0, sizeof(st));
+            return set_error(NTR_ERR_OVERFLOW, "trace_bvh: traversal stack overflow");
+        }
+    }
+    if (stats) {
+        unsigned long long h[4];
+        NTR_HIP(hipMemcpyAsync(h, ds->stats, sizeof(h), hipMemcpyDeviceToHost, s));
+        NTR_HIP(hipStreamSynchronize(s));
+        stats->numRays = numRays;
+        stats->numInnerVisits = (int64_t)h[0];
+        stats->numTriTests = (int64_t)h[1];
+        stats->numLeafVisits = (int64_t)h[2];
+        stats->numHits = (int64_t)h[3];
+    }
+    return NTR_OK;
+}
+
+int ntr_trace_bvh(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
+                  NtrRayResult* d_results, const void* d_nodes, const void* d_triWoop,
+                  const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags, void* stream, float* seconds)
+{
+    return trace_impl(kernelName, numRays, anyHit, d_rays, d_results, d_nodes, d_triWoop, d_triIndex, layout,
+                      bvhFlags, stream, seconds, nullptr);
+}
+
+int ntr_trace_bvh_stats(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
+                        NtrRayResult* d_results, const void* d_nodes, const void* d_triWoop,
+                        const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags, void* stream,
+                        NtrTraceStats* stats)
+{
+    if (!stats) return set_error(NTR_ERR_INVALID, "ntr_trace_bvh_stats: null stats");
+    return trace_impl(kernelName, numRays, anyHit, d_rays, d_results, d_nodes, d_triWoop, d_triIndex, layout,
+                      bvhFlags, stream, nullptr, stats);
+}
+
+}  // extern "C"

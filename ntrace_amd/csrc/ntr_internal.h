@@ -1,0 +1,16 @@
+// ntr_internal.h -- helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ntrace_amd.h"
+
+namespace ntr {
+int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int hip_fail(hipError_t e, const char* what);
+}  // namespace ntr
+
+#define NTR_HIP(call)                                            \
+    do {                                                         \
+        hipError_t _e = (call);                                  \
+        if (_e != hipSuccess) return ::ntr::hip_fail(_e, #call); \
+    } while (0)

@@ -1,0 +1,38 @@
+// trace_kernels.h -- launch contract between ntr_api.cpp and trace_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ntrace_amd.h"
+
+#define NTR_TRACE_WAVES_PER_BLOCK 4  // 256-thread workgroups
+
+// kernel variants (selected by the reference's kernel file names, see ntr_query_config)
+#define NTR_VARIANT_PERRAY 0      // one ray per lane, while-while
+#define NTR_VARIANT_PERSISTENT 1  // persistent waves, ballot/mbcnt dynamic fetch
+#define NTR_VARIANT_PERRAY_STATS 2 // per-ray kernel + traversal counters
+
+// bits of the device status word
+#define NTR_STATUS_STACK_OVERFLOW 1u
+
+namespace ntr {
+
+struct TraceParams {
+    int32_t numRays;
+    int32_t anyHit;
+    const NtrRay* rays;
+    NtrRayResult* results;
+    const void* nodes;
+    const void* woop;
+    const int32_t* triIndex;
+    int32_t* counter;        // persistent: global ray-pool head (zeroed on the stream before launch)
+    unsigned int* status;    // sticky error bits
+    int32_t chunk;           // persistent: rays per pool grab
+    int32_t fetchThreshold;  // persistent: refill when fewer lanes are live
+    uint32_t bvhFlags;
+    unsigned long long* stats;  // STATS variant: {innerVisits, triTests, leafVisits, hits}
+};
+
+}  // namespace ntr
+
+extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, int numBlocks, hipStream_t stream);

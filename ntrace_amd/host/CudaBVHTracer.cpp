@@ -1,0 +1,44 @@
+#include "CudaBVHTracer.hpp"
+
+namespace FW {
+
+CudaBVHTracer::CudaBVHTracer(void) : m_bvh(NULL)
+{
+    m_scene = NULL;
+    m_kernelConfig.bvhLayout = BVHLayout_Max;
+    m_kernelConfig.blockWidth = m_kernelConfig.blockHeight = m_kernelConfig.usePersistentThreads = 0;
+}
+
+// CudaBVHTracer::setKernel (CudaBVHTracer.cpp:52-84).
+void CudaBVHTracer::setKernel(const String& kernelName)
+{
+    if (m_kernelName == kernelName) return;
+    m_kernelName = kernelName;
+    if (ntr_query_config(kernelName.c_str(), &m_kernelConfig) != NTR_OK)
+        fail("CudaBVHTracer: %s", ntr_last_error());
+}
+
+// CudaBVHTracer::traceBatch (CudaBVHTracer.cpp:88-168).
+F32 CudaBVHTracer::traceBatch(RayBuffer& rays)
+{
+    int numRays = rays.getSize();
+    if (!numRays) return 0.0f;
+
+    if (!m_bvh) fail("CudaBVHTracer: No BVH!");
+    if (m_bvh->getLayout() != getDesiredBVHLayout()) fail("CudaBVHTracer: Incorrect BVH layout!");
+
+    U32 flags = 0;
+    if (CudaBVH* cb = dynamic_cast<CudaBVH*>(m_bvh)) flags = cb->getTraceFlags();
+
+    float seconds = 0.0f;
+    int rc = ntr_trace_bvh(m_kernelName.c_str(), numRays, rays.getNeedClosestHit() ? 0 : 1,
+                           (const NtrRay*)rays.getRayBuffer().getCudaPtr(),
+                           (NtrRayResult*)rays.getResultBuffer().getMutableCudaPtr(),
+                           m_bvh->getNodeBuffer().getCudaPtr(), m_bvh->getTriWoopBuffer().getCudaPtr(),
+                           (const int32_t*)m_bvh->getTriIndexBuffer().getCudaPtr(), (int32_t)m_bvh->getLayout(),
+                           flags, NULL, &seconds);
+    if (rc != NTR_OK) fail("CudaBVHTracer: %s", ntr_last_error());
+    return seconds;
+}
+
+}  // namespace FW

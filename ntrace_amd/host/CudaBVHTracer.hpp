@@ -1,0 +1,29 @@
+// CudaBVHTracer.hpp -- BVH tracer launcher (src/rt/cuda/CudaBVHTracer.hpp:46-107).
+// Same methods; runtime nvcc compilation, texrefs and g_config read-back are
+// replaced by the C-ABI (ntr_query_config / ntr_trace_bvh).
+#pragma once
+#include "CudaBVH.hpp"
+#include "CudaVirtualTracer.hpp"
+
+namespace FW {
+
+class CudaBVHTracer : public CudaVirtualTracer {
+public:
+    CudaBVHTracer(void);
+    virtual ~CudaBVHTracer(void) {}
+
+    virtual void      setMessageWindow(Window*) {}
+    virtual void      setKernel(const String& kernelName);
+    virtual BVHLayout getDesiredBVHLayout(void) const { return (BVHLayout)m_kernelConfig.bvhLayout; }
+    virtual void      setBVH(CudaAS* bvh) { m_bvh = bvh; }
+    virtual F32       traceBatch(RayBuffer& rays);
+
+    const KernelConfig& getKernelConfig(void) const { return m_kernelConfig; }
+
+private:
+    String       m_kernelName;
+    KernelConfig m_kernelConfig;
+    CudaAS*      m_bvh;
+};
+
+}  // namespace FW

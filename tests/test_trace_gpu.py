@@ -1,0 +1,147 @@
+"""GPU parity: HIP tracer (through the C-ABI) vs the CPU oracle, bit-exact on (id, t)."""
+import numpy as np
+import pytest
+
+import ntrace_amd as nt
+from ntrace_amd import scenes
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = ["fermi_speculative_while_while", "kepler_dynamic_fetch"]
+
+
+@pytest.fixture(scope="module")
+def soup():
+    from gpu_util import DeviceBvh
+    tri, pos, cam = scenes.random_soup(20000, seed=11)
+    bvh = nt.sah_build(tri, pos)
+    return DeviceBvh(bvh), cam
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_soup_primary_and_random(soup, kernel, any_hit):
+    from gpu_util import assert_parity, gpu_trace
+    dbvh, cam = soup
+    rays = np.concatenate([scenes.primary_rays(cam, 256, 256)[0], scenes.random_rays(50000, seed=3)])
+    got, _ = gpu_trace(kernel, dbvh, rays, any_hit)
+    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit, threads=8)
+    assert_parity(got, ref, "%s anyHit=%d" % (kernel, any_hit))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_cornell(kernel):
+    from gpu_util import DeviceBvh, assert_parity, gpu_trace
+    tri, pos, cam = scenes.cornell_box()
+    dbvh = DeviceBvh(nt.sah_build(tri, pos))
+    rays, _ = scenes.primary_rays(cam, 200, 120)
+    for any_hit in (False, True):
+        got, _ = gpu_trace(kernel, dbvh, rays, any_hit)
+        ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit)
+        assert_parity(got, ref, "cornell %s anyHit=%d" % (kernel, any_hit))
+
+
+def edge_rays(cam_extent=10.0):
+    """Axis-parallel rays (zero direction components, +0 and -0), rays starting on geometry
+    planes, degenerate rays (tmax < tmin), infinite / NaN tmax, tiny directions."""
+    r = []
+
+    def ray(o, d, tmin=0.0, tmax=1e30):
+        r.append((o[0], o[1], o[2], tmin, d[0], d[1], d[2], tmax))
+    g = np.linspace(-9.0, 9.0, 13)
+    for x in g:
+        for y in g:
+            ray((x, y, -14.0), (0.0, 0.0, 1.0))
+            ray((x, y, -14.0), (-0.0, 0.0, 1.0))
+            ray((x, -14.0, y), (0.0, 1.0, -0.0))
+            ray((-14.0, x, y), (1.0, 0.0, 0.0))
+            ray((x, y, -15.0), (0.0, 0.0, 1.0))          # origin on the wall plane (e = 15)
+            ray((x, y, 0.0), (0.0, 0.0, 1.0), 0.0, float("inf"))
+            ray((x, y, 0.0), (1e-30, 1.0, 1e-38), 0.0, float("inf"))
+            ray((x, y, 0.0), (0.3, 0.4, 0.5), 5.0, 4.0)  # degenerate
+            ray((x, y, 0.0), (0.3, 0.4, 0.5), 0.0, float("nan"))
+            ray((x, y, 0.0), (0.0, 0.0, 0.0))
+            ray((x, y, 0.0), (0.6, 0.0, 0.8), 0.0, 3.0)  # short rays (AO-like)
+    a = np.array(r, dtype=np.float32)
+    return a.view(nt.RAY_DTYPE).reshape(-1)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_edge_rays(soup, kernel, any_hit):
+    from gpu_util import assert_parity, gpu_trace
+    dbvh, _ = soup
+    rays = edge_rays()
+    got, _ = gpu_trace(kernel, dbvh, rays, any_hit)
+    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit)
+    assert_parity(got, ref, "edge %s anyHit=%d" % (kernel, any_hit))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 257, 1000])
+def test_ragged_sizes(soup, kernel, n):
+    from gpu_util import assert_parity, gpu_trace
+    dbvh, cam = soup
+    rays = scenes.random_rays(max(n, 1), seed=n)[:n]
+    got, sec = gpu_trace(kernel, dbvh, rays, False)
+    if n == 0:
+        assert sec == 0.0  # CudaBVHTracer.cpp:92-94
+        return
+    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays)
+    assert_parity(got, ref, "ragged %s n=%d" % (kernel, n))
+
+
+def test_full_size_properties():
+    """BASELINE size (1920x1080 primary on atrium-262k): size-independent properties --
+    persistent == per-ray kernel bit for bit, any-hit hits iff closest-hit hits, t within
+    [tmin, tmax], and a bounded sample checked against the oracle."""
+    from gpu_util import DeviceBvh, assert_parity, gpu_trace
+    tri, pos, cam = scenes.atrium()
+    dbvh = DeviceBvh(nt.sah_build(tri, pos))
+    rays, _ = scenes.primary_rays(cam, 1920, 1080)
+    a, _ = gpu_trace("fermi_speculative_while_while", dbvh, rays, False)
+    b, _ = gpu_trace("kepler_dynamic_fetch", dbvh, rays, False)
+    assert_parity(a, b, "perray vs persistent")
+    ah, _ = gpu_trace("kepler_dynamic_fetch", dbvh, rays, True)
+    assert np.array_equal(ah["id"] >= 0, a["id"] >= 0)
+    hit = a["id"] >= 0
+    assert (a["t"][hit] > rays["tmin"][hit]).all() and (a["t"][hit] < rays["tmax"][hit]).all()
+    assert np.array_equal(a["t"][~hit].view(np.uint32), rays["tmax"][~hit].view(np.uint32))
+    sel = np.arange(0, rays.shape[0], 17)
+    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays[sel], threads=8)
+    assert_parity(a[sel], ref, "atrium sample")
+
+
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_gpu_traversal_counters_equal_oracle(soup, any_hit):
+    """The instrumented kernel visits exactly the nodes / triangles the CPU tracer visits
+    (same per-ray order), so the RayStats counters -- and hence the algorithmic bytes used
+    for the roofline -- are identical."""
+    import torch
+    from gpu_util import up
+    dbvh, cam = soup
+    rays = np.concatenate([scenes.primary_rays(cam, 128, 128)[0], scenes.random_rays(20000, seed=8)])
+    d_rays = up(rays)
+    d_res = torch.zeros(rays.shape[0] * 16, dtype=torch.uint8, device="cuda:0")
+    st = nt.trace_bvh_stats("kepler_dynamic_fetch", rays.shape[0], any_hit, d_rays.data_ptr(), d_res.data_ptr(),
+                            dbvh.nodes.data_ptr(), dbvh.woop.data_ptr(), dbvh.idx.data_ptr(), bvh_flags=dbvh.flags)
+    ref, rst = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit, threads=8)
+    assert st.as_dict() == {k: v for k, v in rst.as_dict().items() if k != "maxStackDepth"}
+    assert st.algorithmic_bytes() == rst.algorithmic_bytes()
+    got = d_res.cpu().numpy().view(nt.RESULT_DTYPE)
+    assert np.array_equal(got["id"], ref["id"])
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_golden_fixtures_on_gpu(kernel):
+    import os
+    from gpu_util import DeviceBvh, assert_parity, gpu_trace
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for f in sorted(x for x in os.listdir(gold) if x.endswith(".npz")):
+        g = np.load(os.path.join(gold, f))
+        dbvh = DeviceBvh(nt.HostBvh(g["nodes"], g["woop"], g["tri_index"]))
+        rays = g["rays"].view(nt.RAY_DTYPE).reshape(-1)
+        for any_hit, key in ((False, "closest"), (True, "any")):
+            got, _ = gpu_trace(kernel, dbvh, rays, any_hit)
+            assert_parity(got, g["res_" + key].view(nt.RESULT_DTYPE).reshape(-1), "%s %s %s" % (f, kernel, key))
