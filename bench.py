@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--ao-samples", type=int, default=8)
+    ap.add_argument("--ao-radius", type=float, default=5.0, help="Raygen.aoRadius of the reference's config.conf")
     ap.add_argument("--kernel", default=os.environ.get("NTR_BENCH_KERNEL", "kepler_dynamic_fetch"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
@@ -75,17 +76,42 @@ def main():
     eye[2] += 35.0 * rank  # weak scaling: every rank traces a full-resolution tile set
     cam["eye"] = tuple(eye)
     w, h = args.width, args.height
-    rays, slot_to_pixel = scenes.primary_rays(cam, w, h)
-    n_primary = rays.shape[0]
-    d_rays = up(rays)
+    n_primary = w * h
+    i32 = torch.int32
+    d_tab = torch.zeros(n_primary, dtype=i32, device=dev)
+    nt.pixel_table(w, h, d_tab.data_ptr(), 0, stream)
+    d_rays = torch.zeros(n_primary * 32, dtype=torch.uint8, device=dev)
     d_res = torch.zeros(n_primary * 16, dtype=torch.uint8, device=dev)
-
-    batches = [dict(name="primary", n=n_primary, any_hit=False, rays=d_rays, res=d_res)]
+    d_i2s = torch.zeros(n_primary, dtype=i32, device=dev)
+    d_s2i = torch.zeros(n_primary, dtype=i32, device=dev)
+    nt.raygen_primary(d_rays.data_ptr(), d_i2s.data_ptr(), d_s2i.data_ptr(), d_tab.data_ptr(), cam["eye"],
+                      scenes.nscreen_to_world(cam, w, h), w, h, cam["far"], 0, stream)
+    batches = [dict(name="primary", n=n_primary, any_hit=False, rays=d_rays, res=d_res, live=n_primary)]
 
     def run_batch(b, timed=False):
         return nt.trace_bvh(args.kernel, b["n"], b["any_hit"], b["rays"].data_ptr(), b["res"].data_ptr(),
                             d_nodes.data_ptr(), d_woop.data_ptr(), d_idx.data_ptr(), bvh_flags=flags,
                             stream=stream, timed=timed)
+
+    # AO batches (Renderer::nextBatch -> RayGen::ao, batching of RayGen.cpp:582-602: <= 2^20 output
+    # rays per batch), generated on the device from the primary hits and kept resident in HBM.
+    run_batch(batches[0])
+    n_hits = nt.count_hits(d_res.data_ptr(), n_primary, stream)
+    ns = args.ao_samples
+    if ns > 0:
+        d_nrm = up(scenes.tri_normals(tri, pos))
+        per = (1 << 20) // ns
+        ao_seed = 0xFFF2D5E4  # any fixed kernel seed; Raygen.random = false in config.conf
+        for lo in range(0, n_primary, per):
+            cnt = min(per, n_primary - lo)
+            b_rays = torch.zeros(cnt * ns * 32, dtype=torch.uint8, device=dev)
+            b_res = torch.zeros(cnt * ns * 16, dtype=torch.uint8, device=dev)
+            b_a = torch.zeros(cnt * ns, dtype=i32, device=dev)
+            nt.raygen_ao(b_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(), d_res.data_ptr(),
+                         d_nrm.data_ptr(), lo, cnt, ns, args.ao_radius, ao_seed, stream)
+            live = nt.count_hits(d_res.data_ptr() + lo * 16, cnt, stream) * ns
+            batches.append(dict(name="ao", n=cnt * ns, any_hit=True, rays=b_rays, res=b_res, live=live))
+    torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
@@ -110,7 +136,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kern_ms = np.array([[e0.elapsed_time(e1) for (e0, e1) in step] for step in ev])  # [steps, batches]
-    rays_per_step = sum(b["n"] for b in batches)
+    # the metric counts non-degenerate rays only (Renderer::getTotalNumRays, Renderer.cpp:676-709)
+    rays_per_step = sum(b["live"] for b in batches)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(rays_per_step)], dtype=torch.float64, device=dev)
@@ -136,6 +163,13 @@ def main():
     alg_bytes = st.algorithmic_bytes()
     prim_ms = float(kern_ms[:, 0].mean())
     achieved = alg_bytes / (prim_ms * 1e-3) / 1e9
+    ao_ms = float(kern_ms[:, 1:].sum(axis=1).mean()) if len(batches) > 1 else 0.0
+    ao_live = sum(b["live"] for b in batches[1:])
+    ao_alg = 0
+    for b in batches[1:]:
+        sb = nt.trace_bvh_stats(args.kernel, b["n"], True, b["rays"].data_ptr(), b["res"].data_ptr(), d_nodes.data_ptr(),
+                                d_woop.data_ptr(), d_idx.data_ptr(), bvh_flags=flags, stream=stream)
+        ao_alg += sb.algorithmic_bytes()
 
     if rank != 0:
         if world > 1:
@@ -156,18 +190,23 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (atrium-262k stand-in for Crytek Sponza, seed 262267; sponza.obj is absent from the reference checkout)",
-        "config": {"workload": "Sponza-262k prebuilt SAH BVH, %dx%d primary rays per GPU" % (w, h),
+        "config": {"workload": "Sponza-262k prebuilt SAH BVH, %dx%d primary + %dxAO (radius %g) per GPU" % (w, h, ns, args.ao_radius),
                    "kernel": args.kernel, "triangles": int(tri.shape[0]), "rays_per_step_per_gpu": rays_per_step,
+                   "primary_rays": n_primary, "primary_hits": n_hits, "ao_rays_nondegenerate": ao_live,
+                   "ao_batches": len(batches) - 1,
                    "parallelism": "screen-tile sharded rays, BVH replicated, RCCL gather of hit records"},
         "primary_mrays": n_primary / (prim_ms * 1e-3) / 1e6,
-        "kernel_ms": {"primary": prim_ms},
+        "ao_mrays": (ao_live / (ao_ms * 1e-3) / 1e6) if ao_ms > 0 else None,
+        "kernel_ms": {"primary": prim_ms, "ao_total": ao_ms},
         "gather_ms": gather_ms,
         "host_sah_build_s": sah_seconds,
         "trace_stats": st.as_dict(),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "trace_bvh (%s), primary batch" % args.kernel,
-                     "algorithmic_bytes_per_launch": alg_bytes},
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "ao": {"achieved": (ao_alg / (ao_ms * 1e-3) / 1e9) if ao_ms > 0 else None,
+                            "algorithmic_bytes_all_batches": ao_alg}},
     }
 
     # ---- CPU baseline: the oracle (restated reference CPU tracer) on a bounded sample ---------------
@@ -176,6 +215,7 @@ def main():
         cores = os.cpu_count() or 1
         n_sample = args.cpu_sample_rays or min(n_primary, 1_000_000)
         sel = np.arange(n_sample)  # leading rays of the PixelTable order = compact screen region
+        rays = d_rays.cpu().numpy().view(nt.RAY_DTYPE)
         sample = rays[sel]
         oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, sample[:20000], threads=cores)  # warm-up
         c0 = time.perf_counter()
@@ -183,6 +223,8 @@ def main():
         c1 = time.perf_counter()
         ref_mt, _ = oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, sample, threads=cores)
         c2 = time.perf_counter()
+        run_batch(batches[0])
+        torch.cuda.synchronize()
         got = d_res.cpu().numpy().view(nt.RESULT_DTYPE)[sel]
         mism = int((got["id"] != ref_mt["id"]).sum() + (got["t"].view(np.uint32) != ref_mt["t"].view(np.uint32)).sum())
         out["cpu_baseline"] = {"value": n_sample / (c2 - c1) / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",

@@ -147,6 +147,32 @@ NTR_API int ntr_trace_bvh_stats(const char* kernelName, int32_t numRays, int32_t
 #define NTR_BVH_FINITE 1u
 NTR_API int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_t* flags, void* stream);
 
+/* ---- ray production (callers of the hot path) -------- */
+
+/* PixelTable::recalculate (src/rt/ray/PixelTable.cpp:57-143): 8x8 pixel blocks in Morton
+ * order then edge stripes.  Either output may be NULL. */
+NTR_API int ntr_pixel_table(int32_t w, int32_t h, int32_t* d_indexToPixel, int32_t* d_pixelToIndex, void* stream);
+
+/* rayGenPrimaryKernel (src/rt/ray/RayGenKernels.cu:77-125; RayGenPrimaryInput,
+ * RayGenKernels.hpp:37-49).  nscreenToWorld is row-major 4x4.  kernelSeed is the value the
+ * reference kernel receives: 0, or Random(seed).getU32() (RayGen.cpp:66). */
+NTR_API int ntr_raygen_primary(NtrRay* d_rays, int32_t* d_idToSlot, int32_t* d_slotToID,
+                               const int32_t* d_indexToPixel, const float origin[3],
+                               const float nscreenToWorld[16], int32_t w, int32_t h, float maxDist,
+                               uint32_t kernelSeed, void* stream);
+
+/* rayGenAOKernel (src/rt/ray/RayGenKernels.cu:129-236; RayGenAOInput, RayGenKernels.hpp:53-66):
+ * numSamples cosine-hemisphere rays per input ray [firstInputSlot, +numInputRays); rays of
+ * missed inputs are degenerate (tmax = -1).  d_triNormals: 3 floats per scene triangle. */
+NTR_API int ntr_raygen_ao(NtrRay* d_outRays, int32_t* d_outIDToSlot, int32_t* d_outSlotToID,
+                          const NtrRay* d_inRays, const NtrRayResult* d_inResults,
+                          const float* d_triNormals, int32_t firstInputSlot, int32_t numInputRays,
+                          int32_t numSamples, float maxDist, uint32_t kernelSeed, void* stream);
+
+/* countHitsKernel (src/rt/cuda/RendererKernels.cu:174-226; Renderer::getTotalNumRays,
+ * Renderer.cpp:676-709): number of results with id != -1.  Blocking. */
+NTR_API int ntr_count_hits(const NtrRayResult* d_results, int32_t numRays, int32_t* count, void* stream);
+
 /* ---- host-side BVH production (no device work) ---------------------------- */
 
 /* Host SAH build + Compact flatten: `BVH bvh(scene, platform, params);

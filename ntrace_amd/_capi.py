@@ -69,6 +69,11 @@ SYMBOLS = [
     ("ntr_trace_bvh_stats", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _u32, _vp,
                                       C.POINTER(TraceStats)]),
     ("ntr_bvh_validate", C.c_int, [_vp, _i64, C.POINTER(_u32), _vp]),
+    ("ntr_pixel_table", C.c_int, [_i32, _i32, _vp, _vp, _vp]),
+    ("ntr_raygen_primary", C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i32, _i32,
+                                     C.c_float, _u32, _vp]),
+    ("ntr_raygen_ao", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _u32, _vp]),
+    ("ntr_count_hits", C.c_int, [_vp, _i32, C.POINTER(_i32), _vp]),
     ("ntr_sah_build", C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
     ("ntr_host_bvh_info", C.c_int, [_vp, C.POINTER(_HostBvhInfo)]),
     ("ntr_host_bvh_free", None, [_vp]),
@@ -83,6 +88,13 @@ def lib():
         if not os.path.exists(path):
             raise ImportError("ntrace_amd: %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(the HIP extension is mandatory; there is no CPU fallback)" % path)
+        # When torch is in the process it must load its bundled libamdhip64 first: our library
+        # then binds to that same HIP runtime (two HIP runtimes in one process do not share the
+        # device).  Without torch (C++ hosts) the system /opt/rocm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)
@@ -126,6 +138,31 @@ def bvh_validate(d_nodes, nodes_bytes, stream=0):
     flags = _u32(0)
     _check(lib().ntr_bvh_validate(_vp(d_nodes), int(nodes_bytes), C.byref(flags), _vp(stream)))
     return int(flags.value)
+
+
+def pixel_table(w, h, d_index_to_pixel, d_pixel_to_index=0, stream=0):
+    _check(lib().ntr_pixel_table(int(w), int(h), _vp(d_index_to_pixel), _vp(d_pixel_to_index), _vp(stream)))
+
+
+def raygen_primary(d_rays, d_id_to_slot, d_slot_to_id, d_index_to_pixel, origin, nscreen_to_world, w, h, max_dist,
+                   kernel_seed=0, stream=0):
+    o = (C.c_float * 3)(*[float(x) for x in origin])
+    m = (C.c_float * 16)(*[float(x) for x in np.asarray(nscreen_to_world, dtype=np.float32).reshape(-1)])
+    _check(lib().ntr_raygen_primary(_vp(d_rays), _vp(d_id_to_slot), _vp(d_slot_to_id), _vp(d_index_to_pixel), o, m,
+                                    int(w), int(h), float(max_dist), int(kernel_seed), _vp(stream)))
+
+
+def raygen_ao(d_out_rays, d_out_id_to_slot, d_out_slot_to_id, d_in_rays, d_in_results, d_tri_normals, first_input_slot,
+              num_input_rays, num_samples, max_dist, kernel_seed=0, stream=0):
+    _check(lib().ntr_raygen_ao(_vp(d_out_rays), _vp(d_out_id_to_slot), _vp(d_out_slot_to_id), _vp(d_in_rays),
+                               _vp(d_in_results), _vp(d_tri_normals), int(first_input_slot), int(num_input_rays),
+                               int(num_samples), float(max_dist), int(kernel_seed), _vp(stream)))
+
+
+def count_hits(d_results, num_rays, stream=0):
+    cnt = _i32(0)
+    _check(lib().ntr_count_hits(_vp(d_results), int(num_rays), C.byref(cnt), _vp(stream)))
+    return int(cnt.value)
 
 
 class HostBvh:

@@ -320,3 +320,27 @@ def random_rays(n, seed, extent=10.0, tmax=1e30):
     rays["tmin"] = 0.0
     rays["tmax"] = np.float32(tmax)
     return rays
+
+
+def nscreen_to_world(cam, w, h):
+    """Row-major 4x4 mapping normalised screen (nx, ny, 0, 1) to a world point on the image plane
+    at unit distance: the `nscreenToWorld` input of rayGenPrimaryKernel for this pinhole camera
+    (the reference builds it as invert(fitToView * perspective * worldToCamera), Renderer.cpp:473-477)."""
+    eye, fwd, right, up = camera_basis(cam)
+    th = math.tan(math.radians(cam["fov_deg"]) * 0.5)
+    aspect = w / float(h)
+    m = np.zeros((4, 4), dtype=np.float64)
+    m[:3, 0] = th * aspect * right
+    m[:3, 1] = -th * up
+    m[:3, 3] = eye + fwd
+    m[3, 3] = 1.0
+    return m.astype(np.float32)
+
+
+def tri_normals(tri, pos):
+    """Scene::getTriNormalBuffer contents (src/rt/Scene.cpp:127-134): normalised geometric normals."""
+    a, b, c = pos[tri[:, 0]].astype(np.float64), pos[tri[:, 1]].astype(np.float64), pos[tri[:, 2]].astype(np.float64)
+    n = np.cross(b - a, c - a)
+    ln = np.linalg.norm(n, axis=1, keepdims=True)
+    n = np.where(ln > 0, n / np.maximum(ln, 1e-300), n)
+    return n.astype(np.float32)
