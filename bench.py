@@ -68,7 +68,8 @@ def main():
     bvh = nt.sah_build(tri, pos, 1, 1)
     sah_seconds = time.time() - t0
     d_nodes, d_woop, d_idx = up(bvh.nodes), up(bvh.woop), up(bvh.tri_index)
-    flags = nt.bvh_validate(d_nodes.data_ptr(), bvh.nodes.nbytes, stream)
+    view = nt.BvhView(d_nodes.data_ptr(), bvh.nodes.nbytes, d_woop.data_ptr(), bvh.woop.nbytes, d_idx.data_ptr())
+    view.validate(stream)
 
     # ---- ray batches: rank r renders its own tile set = the frame seen from camera r ------------
     cam = dict(cam)
@@ -89,9 +90,7 @@ def main():
     batches = [dict(name="primary", n=n_primary, any_hit=False, rays=d_rays, res=d_res, live=n_primary)]
 
     def run_batch(b, timed=False):
-        return nt.trace_bvh(args.kernel, b["n"], b["any_hit"], b["rays"].data_ptr(), b["res"].data_ptr(),
-                            d_nodes.data_ptr(), d_woop.data_ptr(), d_idx.data_ptr(), bvh_flags=flags,
-                            stream=stream, timed=timed)
+        return view.trace(args.kernel, b["n"], b["any_hit"], b["rays"].data_ptr(), b["res"].data_ptr(), stream, timed)
 
     # AO batches (Renderer::nextBatch -> RayGen::ao, batching of RayGen.cpp:582-602: <= 2^20 output
     # rays per batch), generated on the device from the primary hits and kept resident in HBM.
@@ -158,8 +157,7 @@ def main():
         gather_ms = (time.perf_counter() - g0) * 1e3
 
     # ---- algorithmic bytes of the dominant kernel (instrumented trace, untimed) ----------------------
-    st = nt.trace_bvh_stats(args.kernel, n_primary, False, d_rays.data_ptr(), d_res.data_ptr(), d_nodes.data_ptr(),
-                            d_woop.data_ptr(), d_idx.data_ptr(), bvh_flags=flags, stream=stream)
+    st = view.trace_stats(args.kernel, n_primary, False, d_rays.data_ptr(), d_res.data_ptr(), stream)
     alg_bytes = st.algorithmic_bytes()
     prim_ms = float(kern_ms[:, 0].mean())
     achieved = alg_bytes / (prim_ms * 1e-3) / 1e9
@@ -167,8 +165,7 @@ def main():
     ao_live = sum(b["live"] for b in batches[1:])
     ao_alg = 0
     for b in batches[1:]:
-        sb = nt.trace_bvh_stats(args.kernel, b["n"], True, b["rays"].data_ptr(), b["res"].data_ptr(), d_nodes.data_ptr(),
-                                d_woop.data_ptr(), d_idx.data_ptr(), bvh_flags=flags, stream=stream)
+        sb = view.trace_stats(args.kernel, b["n"], True, b["rays"].data_ptr(), b["res"].data_ptr(), stream)
         ao_alg += sb.algorithmic_bytes()
 
     if rank != 0:
@@ -191,7 +188,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic (atrium-262k stand-in for Crytek Sponza, seed 262267; sponza.obj is absent from the reference checkout)",
         "config": {"workload": "Sponza-262k prebuilt SAH BVH, %dx%d primary + %dxAO (radius %g) per GPU" % (w, h, ns, args.ao_radius),
-                   "kernel": args.kernel, "triangles": int(tri.shape[0]), "rays_per_step_per_gpu": rays_per_step,
+                   "kernel": args.kernel, "bvh_flags": view.flags, "triangles": int(tri.shape[0]), "rays_per_step_per_gpu": rays_per_step,
                    "primary_rays": n_primary, "primary_hits": n_hits, "ao_rays_nondegenerate": ao_live,
                    "ao_batches": len(batches) - 1,
                    "parallelism": "screen-tile sharded rays, BVH replicated, RCCL gather of hit records"},

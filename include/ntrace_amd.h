@@ -115,12 +115,17 @@ NTR_API int ntr_query_config(const char* kernelName, NtrKernelConfig* config);
  *                            seconds (CudaKernel::launchTimed, CudaKernel.cpp:188-221)
  *   seconds == NULL       -> asynchronous launch on `stream`.
  *
+ * nodesBytes / triWoopBytes are the buffer extents the reference binds as texture sizes
+ * (setTexRef(..., size), CudaBVHTracer.cpp:142-150); here they bound the kernels' buffer
+ * descriptors (< 4 GiB each).
+ *
  * Results follow the reference CPU tracer bit for bit in (id, t): miss =
  * (-1, ray.tmax) (CudaBVH.cpp:273-274).  `bvhFlags`: 0, or hints from
- * ntr_bvh_validate(). */
+ * ntr_bvh_validate() (hints only select between two exact code paths). */
 NTR_API int ntr_trace_bvh(const char* kernelName, int32_t numRays, int32_t anyHit,
                           const NtrRay* d_rays, NtrRayResult* d_results,
-                          const void* d_nodes, const void* d_triWoop, const int32_t* d_triIndex,
+                          const void* d_nodes, int64_t nodesBytes,
+                          const void* d_triWoop, int64_t triWoopBytes, const int32_t* d_triIndex,
                           int32_t layout, uint32_t bvhFlags, void* stream, float* seconds);
 
 /* Traversal counters: the reference's RayStats (src/rt/bvh/BVH.hpp:44-60), filled by its
@@ -139,13 +144,26 @@ typedef struct NtrTraceStats {
  * Blocking; not a timed path. */
 NTR_API int ntr_trace_bvh_stats(const char* kernelName, int32_t numRays, int32_t anyHit,
                                 const NtrRay* d_rays, NtrRayResult* d_results,
-                                const void* d_nodes, const void* d_triWoop, const int32_t* d_triIndex,
+                                const void* d_nodes, int64_t nodesBytes,
+                                const void* d_triWoop, int64_t triWoopBytes, const int32_t* d_triIndex,
                                 int32_t layout, uint32_t bvhFlags, void* stream, NtrTraceStats* stats);
 
 /* One pass over a Compact node buffer computing hint flags for ntr_trace_bvh:
- *   NTR_BVH_FINITE  every box coordinate is finite and |x| < 2^100. */
+ *   NTR_BVH_FINITE   every box coordinate is finite and |x| < 2^100.
+ *   NTR_BVH_FASTDIV  every box coordinate has |x| < 2^55: together with a per-ray check this
+ *                    is the range in which the kernels' refactored divide is the hardware
+ *                    divide (see trace_kernels.hip).
+ *   NTR_BVH_NOTINY   every box coordinate is 0 or |x| >= 2^-93 (lets rays with an exactly-zero
+ *                    origin component use the same path). */
 #define NTR_BVH_FINITE 1u
+#define NTR_BVH_FASTDIV 2u
+#define NTR_BVH_NOTINY 4u
 NTR_API int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_t* flags, void* stream);
+
+/* Device self test: counts quotients x[i]/d[j] for which the FAST divide differs from the
+ * hardware `/` (must be 0 inside the FASTDIV range).  Diagnostic, blocking. */
+NTR_API int ntr_selftest_division(const float* d_x, int32_t nx, const float* d_d, int32_t nd,
+                                  uint32_t* mismatches, void* stream);
 
 /* ---- ray production (callers of the hot path) -------- */
 

@@ -7,13 +7,14 @@ bench.py: it loads the library with ctypes and passes raw device pointers (e.g. 
 tensors' data_ptr()).  There is no CPU or PyTorch fallback: if the library is missing the
 import of `ntrace_amd.lib()` fails loudly.
 """
-from ._capi import (RAY_DTYPE, RESULT_DTYPE, HostBvh, KernelConfig, NtrError, TraceStats, bvh_validate, lib,
+from ._capi import (BvhView, RAY_DTYPE, RESULT_DTYPE, HostBvh, KernelConfig, NtrError, TraceStats, bvh_validate, lib,
                     lib_path, query_config, sah_build, trace_bvh, trace_bvh_stats, pixel_table,
-                    raygen_primary, raygen_ao, count_hits)
+                    raygen_primary, raygen_ao, count_hits, selftest_division)
 
 BVHLayout_Compact = 4
+BVH_FINITE, BVH_FASTDIV, BVH_NOTINY = 1, 2, 4
 KERNELS = ("fermi_speculative_while_while", "tesla_persistent_while_while",
            "tesla_persistent_speculative_while_while", "kepler_dynamic_fetch")
 
-__all__ = ["RAY_DTYPE", "RESULT_DTYPE", "HostBvh", "KernelConfig", "NtrError", "bvh_validate", "lib",
-           "lib_path", "query_config", "sah_build", "trace_bvh", "trace_bvh_stats", "TraceStats", "pixel_table", "raygen_primary", "raygen_ao", "count_hits", "BVHLayout_Compact", "KERNELS"]
+__all__ = ["BvhView", "RAY_DTYPE", "RESULT_DTYPE", "HostBvh", "KernelConfig", "NtrError", "bvh_validate", "lib",
+           "lib_path", "query_config", "sah_build", "trace_bvh", "trace_bvh_stats", "TraceStats", "pixel_table", "raygen_primary", "raygen_ao", "count_hits", "selftest_division", "BVHLayout_Compact", "KERNELS"]

@@ -44,7 +44,8 @@ class _HostBvhInfo(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libntrace_amd.so")
+    # NTR_LIB_OVERRIDE: A/B experiments with alternative builds (scripts/ only)
+    return os.environ.get("NTR_LIB_OVERRIDE") or os.path.join(_HERE, "libntrace_amd.so")
 
 
 _lib = None
@@ -64,9 +65,10 @@ SYMBOLS = [
     ("ntr_memset", C.c_int, [_vp, C.c_int, C.c_size_t, _vp]),
     ("ntr_stream_synchronize", C.c_int, [_vp]),
     ("ntr_query_config", C.c_int, [C.c_char_p, C.POINTER(KernelConfig)]),
-    ("ntr_trace_bvh", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _u32, _vp,
+    ("ntr_trace_bvh", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _u32, _vp,
                                 C.POINTER(C.c_float)]),
-    ("ntr_trace_bvh_stats", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _u32, _vp,
+    ("ntr_selftest_division", C.c_int, [_vp, _i32, _vp, _i32, C.POINTER(_u32), _vp]),
+    ("ntr_trace_bvh_stats", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _u32, _vp,
                                       C.POINTER(TraceStats)]),
     ("ntr_bvh_validate", C.c_int, [_vp, _i64, C.POINTER(_u32), _vp]),
     ("ntr_pixel_table", C.c_int, [_i32, _i32, _vp, _vp, _vp]),
@@ -115,22 +117,28 @@ def query_config(kernel):
     return cfg
 
 
-def trace_bvh(kernel, num_rays, any_hit, d_rays, d_results, d_nodes, d_woop, d_tri_index,
+def trace_bvh(kernel, num_rays, any_hit, d_rays, d_results, d_nodes, nodes_bytes, d_woop, woop_bytes, d_tri_index,
               layout=4, bvh_flags=0, stream=0, timed=True):
     """ntr_trace_bvh on raw device pointers (ints).  Returns GPU seconds if timed else None."""
     sec = C.c_float(0.0)
     _check(lib().ntr_trace_bvh(kernel.encode(), int(num_rays), int(bool(any_hit)), _vp(d_rays), _vp(d_results),
-                               _vp(d_nodes), _vp(d_woop), _vp(d_tri_index), int(layout), int(bvh_flags),
-                               _vp(stream), C.byref(sec) if timed else None))
+                               _vp(d_nodes), int(nodes_bytes), _vp(d_woop), int(woop_bytes), _vp(d_tri_index),
+                               int(layout), int(bvh_flags), _vp(stream), C.byref(sec) if timed else None))
     return float(sec.value) if timed else None
 
 
-def trace_bvh_stats(kernel, num_rays, any_hit, d_rays, d_results, d_nodes, d_woop, d_tri_index,
-                    layout=4, bvh_flags=0, stream=0):
+def selftest_division(d_x, nx, d_d, nd, stream=0):
+    m = _u32(0)
+    _check(lib().ntr_selftest_division(_vp(d_x), int(nx), _vp(d_d), int(nd), C.byref(m), _vp(stream)))
+    return int(m.value)
+
+
+def trace_bvh_stats(kernel, num_rays, any_hit, d_rays, d_results, d_nodes, nodes_bytes, d_woop, woop_bytes,
+                    d_tri_index, layout=4, bvh_flags=0, stream=0):
     st = TraceStats()
     _check(lib().ntr_trace_bvh_stats(kernel.encode(), int(num_rays), int(bool(any_hit)), _vp(d_rays), _vp(d_results),
-                                     _vp(d_nodes), _vp(d_woop), _vp(d_tri_index), int(layout), int(bvh_flags),
-                                     _vp(stream), C.byref(st)))
+                                     _vp(d_nodes), int(nodes_bytes), _vp(d_woop), int(woop_bytes), _vp(d_tri_index),
+                                     int(layout), int(bvh_flags), _vp(stream), C.byref(st)))
     return st
 
 
@@ -163,6 +171,28 @@ def count_hits(d_results, num_rays, stream=0):
     cnt = _i32(0)
     _check(lib().ntr_count_hits(_vp(d_results), int(num_rays), C.byref(cnt), _vp(stream)))
     return int(cnt.value)
+
+
+class BvhView:
+    """Device-side Compact BVH as raw pointers + extents (what CudaBVHTracer::traceBatch passes)."""
+
+    def __init__(self, d_nodes, nodes_bytes, d_woop, woop_bytes, d_tri_index, flags=0, layout=4):
+        self.d_nodes, self.nodes_bytes = int(d_nodes), int(nodes_bytes)
+        self.d_woop, self.woop_bytes = int(d_woop), int(woop_bytes)
+        self.d_tri_index, self.flags, self.layout = int(d_tri_index), int(flags), int(layout)
+
+    def validate(self, stream=0):
+        self.flags = bvh_validate(self.d_nodes, self.nodes_bytes, stream)
+        return self.flags
+
+    def trace(self, kernel, num_rays, any_hit, d_rays, d_results, stream=0, timed=True, flags=None):
+        return trace_bvh(kernel, num_rays, any_hit, d_rays, d_results, self.d_nodes, self.nodes_bytes, self.d_woop,
+                         self.woop_bytes, self.d_tri_index, self.layout, self.flags if flags is None else flags,
+                         stream, timed)
+
+    def trace_stats(self, kernel, num_rays, any_hit, d_rays, d_results, stream=0):
+        return trace_bvh_stats(kernel, num_rays, any_hit, d_rays, d_results, self.d_nodes, self.nodes_bytes,
+                               self.d_woop, self.woop_bytes, self.d_tri_index, self.layout, self.flags, stream)
 
 
 class HostBvh:

@@ -7,21 +7,28 @@
 namespace ntr {
 
 // Flags a Compact node buffer whose 12 box floats per node (bytes 0..47 of each
-// 64-B node, src/rt/cuda/CudaBVH.hpp:42-46) are all finite with |x| < 2^100.
+// 64-B node, src/rt/cuda/CudaBVH.hpp:42-46) are all finite with |x| < 2^100
+// (plus the FASTDIV / NOTINY ranges documented in include/ntrace_amd.h).
 __global__ __launch_bounds__(256) void bvh_validate_kernel(const float4* __restrict__ nodes, int64_t numFloat4,
                                                            unsigned int* __restrict__ bad)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    bool isBad = false;
+    bool notFinite = false, notFast = false, tiny = false;
     for (; i < numFloat4; i += stride) {
         if ((i & 3) == 3) continue;  // child / split words
         const float4 v = nodes[i];
-        const float lim = 0x1p100f;
-        // !(|x| < lim) is also true for NaN
-        isBad = isBad || !(fabsf(v.x) < lim) || !(fabsf(v.y) < lim) || !(fabsf(v.z) < lim) || !(fabsf(v.w) < lim);
+        const float c[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 0; k < 4; k++) {
+            const float a = fabsf(c[k]);
+            notFinite = notFinite || !(a < 0x1p100f);  // also true for NaN
+            notFast = notFast || !(a < 0x1p55f);
+            tiny = tiny || (c[k] != 0.0f && a < 0x1p-93f);
+        }
     }
-    if (__ballot(isBad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+    const unsigned int bits = (__ballot(notFinite) != 0ull ? 1u : 0u) | (__ballot(notFast) != 0ull ? 2u : 0u) |
+                              (__ballot(tiny) != 0ull ? 4u : 0u);
+    if (bits && (threadIdx.x & 63) == 0) atomicOr(bad, bits);
 }
 
 }  // namespace ntr
@@ -46,6 +53,8 @@ extern "C" int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_
     NTR_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s));
     NTR_HIP(hipStreamSynchronize(s));
     NTR_HIP(hipFree(d_bad));
-    if (!bad) *flags |= NTR_BVH_FINITE;
+    if (!(bad & 1u)) *flags |= NTR_BVH_FINITE;
+    if (!(bad & 2u)) *flags |= NTR_BVH_FASTDIV;
+    if (!(bad & 4u)) *flags |= NTR_BVH_NOTINY;
     return NTR_OK;
 }

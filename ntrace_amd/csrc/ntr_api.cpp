@@ -69,7 +69,7 @@ int get_device_state(DeviceState** out)
         // Counters sit 64 B apart so concurrent launches never share a line.
         NTR_HIP(hipMalloc((void**)&s.counters, kNumCounters * 64));
         NTR_HIP(hipMalloc((void**)&s.status, 64));
-        NTR_HIP(hipMalloc((void**)&s.stats, 64));
+        NTR_HIP(hipMalloc((void**)&s.stats, 256));
         NTR_HIP(hipMemset(s.status, 0, 64));
         s.init = true;
     }
@@ -198,9 +198,9 @@ static int env_int(const char* name, int def)
 }
 
 static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
-                      NtrRayResult* d_results, const void* d_nodes, const void* d_triWoop,
-                      const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags, void* stream, float* seconds,
-                      NtrTraceStats* stats)
+                      NtrRayResult* d_results, const void* d_nodes, int64_t nodesBytes, const void* d_triWoop,
+                      int64_t triWoopBytes, const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags,
+                      void* stream, float* seconds, NtrTraceStats* stats)
 {
     if (seconds) *seconds = 0.0f;
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -213,6 +213,12 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     if (layout != k->cfg.bvhLayout)
         return set_error(NTR_ERR_LAYOUT, "CudaBVHTracer: Incorrect BVH layout!");  // :99-100
     if (!d_rays || !d_results) return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: null ray/result buffer");
+    // The sizes play the role of the reference's texref extents (setTexRef(..., size),
+    // CudaBVHTracer.cpp:142-150); buffer descriptors address at most 4 GiB.
+    if (nodesBytes < 64 || (nodesBytes % 64) != 0 || nodesBytes > 0xFFFFFFFFll)
+        return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: node buffer size must be a multiple of 64 in [64, 4 GiB)");
+    if (triWoopBytes < 16 || (triWoopBytes % 16) != 0 || triWoopBytes > 0xFFFFFFFFll)
+        return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: triWoop buffer size must be a multiple of 16 in [16, 4 GiB)");
 
     DeviceState* ds = nullptr;
     int rc = get_device_state(&ds);
@@ -226,12 +232,15 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.results = d_results;
     p.nodes = d_nodes;
     p.woop = d_triWoop;
+    p.nodesBytes = (uint32_t)nodesBytes;
+    p.woopBytes = (uint32_t)triWoopBytes;
     p.triIndex = d_triIndex;
     p.status = ds->status;
     p.counter = nullptr;
     p.chunk = env_int("NTR_TRACE_CHUNK", 128);
     p.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", 40);
     p.bvhFlags = bvhFlags;
+    p.coop = env_int("NTR_TRACE_COOP", 0);
     p.stats = ds->stats;
     int variant = k->variant;
     if (stats) {
@@ -299,21 +308,39 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
 }
 
 int ntr_trace_bvh(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
-                  NtrRayResult* d_results, const void* d_nodes, const void* d_triWoop,
-                  const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags, void* stream, float* seconds)
+                  NtrRayResult* d_results, const void* d_nodes, int64_t nodesBytes, const void* d_triWoop,
+                  int64_t triWoopBytes, const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags, void* stream,
+                  float* seconds)
 {
-    return trace_impl(kernelName, numRays, anyHit, d_rays, d_results, d_nodes, d_triWoop, d_triIndex, layout,
-                      bvhFlags, stream, seconds, nullptr);
+    return trace_impl(kernelName, numRays, anyHit, d_rays, d_results, d_nodes, nodesBytes, d_triWoop, triWoopBytes,
+                      d_triIndex, layout, bvhFlags, stream, seconds, nullptr);
 }
 
 int ntr_trace_bvh_stats(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
-                        NtrRayResult* d_results, const void* d_nodes, const void* d_triWoop,
-                        const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags, void* stream,
-                        NtrTraceStats* stats)
+                        NtrRayResult* d_results, const void* d_nodes, int64_t nodesBytes, const void* d_triWoop,
+                        int64_t triWoopBytes, const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags,
+                        void* stream, NtrTraceStats* stats)
 {
     if (!stats) return set_error(NTR_ERR_INVALID, "ntr_trace_bvh_stats: null stats");
-    return trace_impl(kernelName, numRays, anyHit, d_rays, d_results, d_nodes, d_triWoop, d_triIndex, layout,
-                      bvhFlags, stream, nullptr, stats);
+    return trace_impl(kernelName, numRays, anyHit, d_rays, d_results, d_nodes, nodesBytes, d_triWoop, triWoopBytes,
+                      d_triIndex, layout, bvhFlags, stream, nullptr, stats);
+}
+
+int ntr_selftest_division(const float* d_x, int32_t nx, const float* d_d, int32_t nd, uint32_t* mismatches, void* stream)
+{
+    if (!mismatches || !d_x || !d_d || nx <= 0 || nd <= 0) return set_error(NTR_ERR_INVALID, "ntr_selftest_division: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int* d_m = nullptr;
+    NTR_HIP(hipMalloc((void**)&d_m, sizeof(unsigned int)));
+    NTR_HIP(hipMemsetAsync(d_m, 0, sizeof(unsigned int), s));
+    hipError_t le = ntr_launch_selftest_division(d_x, d_d, nx, nd, d_m, s);
+    if (le != hipSuccess) return hip_fail(le, "selftest launch");
+    unsigned int m = 0;
+    NTR_HIP(hipMemcpyAsync(&m, d_m, sizeof(m), hipMemcpyDeviceToHost, s));
+    NTR_HIP(hipStreamSynchronize(s));
+    NTR_HIP(hipFree(d_m));
+    *mismatches = m;
+    return NTR_OK;
 }
 
 }  // extern "C"

@@ -24,15 +24,20 @@ struct TraceParams {
     NtrRayResult* results;
     const void* nodes;
     const void* woop;
+    uint32_t nodesBytes;  // buffer-descriptor ranges (out-of-range loads return 0)
+    uint32_t woopBytes;
     const int32_t* triIndex;
     int32_t* counter;        // persistent: global ray-pool head (zeroed on the stream before launch)
     unsigned int* status;    // sticky error bits
     int32_t chunk;           // persistent: rays per pool grab
     int32_t fetchThreshold;  // persistent: refill when fewer lanes are live
     uint32_t bvhFlags;
+    int32_t coop;            // quad-cooperative LDS-DMA node fetch instead of per-lane loads
     unsigned long long* stats;  // STATS variant: {innerVisits, triTests, leafVisits, hits}
 };
 
 }  // namespace ntr
 
 extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, int numBlocks, hipStream_t stream);
+extern "C" hipError_t ntr_launch_selftest_division(const float* d_x, const float* d_d, int nx, int nd,
+                                                   unsigned int* d_mismatches, hipStream_t stream);

@@ -2,7 +2,7 @@
 //
 // Replaces the reference's `trace_bvh` kernels (contract TRACE_FUNC_BVH,
 // src/rt/kernels/CudaTracerKernels.hpp:99-112) for BVHLayout_Compact:
-//   fermi_speculative_while_while.cu:54-263   -> trace_bvh_perray   (one ray per lane)
+//   fermi_speculative_while_while.cu:54-263   -> trace_bvh_perray     (one ray per lane)
 //   tesla_persistent_while_while.cu:71-316,
 //   kepler_dynamic_fetch.cu:61-322            -> trace_bvh_persistent (persistent waves,
 //                                                 ballot/mbcnt refill, LDS stack)
@@ -16,10 +16,28 @@
 //   order      near child = smaller tmin, ties -> child 0         (CudaBVH.cpp:761)
 //   Woop       unfused left-to-right dots incl. the leading 0 and the w term
 //              (Util.cpp:106-121, Math.hpp:185), 1.f/x then multiply
-// This file is compiled with -ffp-contract=off and without fast-math; hipcc's
-// default correctly-rounded f32 divide is relied on (checked by the parity tests).
+// Compiled with -ffp-contract=off and without fast-math.
 //
-// No MFMA: there is no dense contraction on this path.
+// Two code paths compute the slab test, both exact:
+//   GENERIC  `/` (hipcc's correctly rounded f32 divide: v_div_scale / v_rcp / fma chain /
+//            v_div_fmas / v_div_fixup) and select-form min/max.  Valid for every input
+//            (zero direction components, NaN, infinities, denormals).
+//   FAST     for waves whose rays are all "nice" (see ray_is_nice) over a BVH flagged
+//            NTR_BVH_FASTDIV: in that range v_div_scale never rescales and v_div_fixup is the
+//            identity, so the hardware divide reduces to  rcp(d) refined once (per ray) and,
+//            per quotient,  q0=x*r; e1=fma(-d,q0,x); q1=fma(e1,r,q0); e2=fma(-d,q1,x);
+//            q=fma(e2,r,q1)  -- the same five operations the GENERIC path executes after
+//            its scaling steps, hence the same correctly rounded bits.  No NaN/inf can
+//            arise there either, so v_min3/v_max3 equal the select-form folds up to the
+//            sign of zero, which no later comparison can observe.
+//   ntr_selftest_division() checks FAST == GENERIC bit for bit on the device.
+//
+// DATA PATH.  Nodes and Woop triangles are fetched with buffer loads through
+// wave-uniform resource descriptors (voffset = the Compact layout's own byte offsets, so
+// no 64-bit address arithmetic; out-of-range reads return 0 instead of faulting, which
+// lets a leaf fetch its triangle and the following terminator word in one round trip).
+// The traversal stack lives in LDS ([entry][lane], conflict-free), spilling to scratch
+// beyond LDS_DEPTH.  No MFMA: there is no dense contraction on this path.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,6 +48,36 @@
 namespace ntr {
 
 static constexpr int kSentinel = 0x76543210;  // CudaTracerKernels.hpp:38 (EntrypointSentinel)
+static constexpr int LDS_DEPTH = 16;
+#ifdef NTR_EXPERIMENT_NO_SPILL
+static constexpr int SPILL_DEPTH = 1;
+#else
+static constexpr int SPILL_DEPTH = 88;        // 16 + 88 >= the reference CPU stack of 100 (CudaBVH.cpp:701)
+#endif
+
+// Node staging area of one wave in LDS for the quad-cooperative fetch: 4 pieces of
+// 64 lanes x 16 B, each piece skewed by 16 B so that the 4 lanes of a quad (which read
+// different pieces at the same in-piece offset) fall on different banks.
+static constexpr int STAGE_PIECE = 1024 + 16;
+static constexpr int STAGE_BYTES = 4 * STAGE_PIECE;
+
+typedef __amdgpu_buffer_rsrc_t Rsrc;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ Rsrc make_rsrc(const void* p, unsigned int bytes)
+{
+    // built from kernel arguments only -> provably wave-uniform (no waterfall loops)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 ld4(Rsrc r, int byteOfs)
+{
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byteOfs, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ unsigned int ld1(Rsrc r, int byteOfs)
+{
+    return __builtin_amdgcn_raw_buffer_load_b32(r, byteOfs, 0, 0);
+}
 
 __device__ __forceinline__ float sel_min(float a, float b) { return (a < b) ? a : b; }
 __device__ __forceinline__ float sel_max(float a, float b) { return (a > b) ? a : b; }
@@ -37,17 +85,88 @@ __device__ __forceinline__ float sel_max(float a, float b) { return (a > b) ? a 
 struct RayRegs {
     float ox, oy, oz, tmin;
     float dx, dy, dz, tmax;  // tmax shrinks to the closest accepted t (CudaBVH.cpp:1215)
+    float rx, ry, rz;        // FAST path: refined reciprocals of dx,dy,dz
 };
 
-// Intersect::RayBox for one child (Util.cpp:34-46), exact form.
-__device__ __forceinline__ void ray_box(const RayRegs& r, float lox, float hix, float loy, float hiy,
-                                        float loz, float hiz, float& tmn, float& tmx)
+// ---- FAST-path preconditions ---------------------------------------------------------
+// FAST-path ranges.  Directions: 2^-40 <= |d| <= 2^20.  Box coordinates: |c| < 2^55 (BVH flag
+// NTR_BVH_FASTDIV).  Ray origin components: 2^-36 <= |o| < 2^55 -- then x = c - o is 0 or
+// |x| >= 2^-84 for ANY such c (a c much smaller than o leaves x = -o; otherwise both operands
+// are >= 2^-61 and a non-zero difference is at least one ulp of that).  An origin component
+// that is exactly 0 makes x = c, which is only safe when the BVH has no tiny coordinates
+// (flag NTR_BVH_NOTINY: c == 0 or |c| >= 2^-93).  In these ranges |x| < 2^56,
+// exponent(x) - exponent(d) < 96, |x| >= 2^-103 and |x/d| >= 2^-113: none of v_div_scale's
+// rescaling cases, and every residual of the fma chain is exactly representable.
+__device__ __forceinline__ bool nice_dir(float v) { const float a = fabsf(v); return a >= 0x1p-40f && a <= 0x1p20f; }
+__device__ __forceinline__ bool nice_pos(float v, bool zeroOk)
 {
-    float t0x = (lox - r.ox) / r.dx, t1x = (hix - r.ox) / r.dx;
-    float t0y = (loy - r.oy) / r.dy, t1y = (hiy - r.oy) / r.dy;
-    float t0z = (loz - r.oz) / r.dz, t1z = (hiz - r.oz) / r.dz;
-    tmn = sel_max(sel_max(sel_min(t0x, t1x), sel_min(t0y, t1y)), sel_min(t0z, t1z));
-    tmx = sel_min(sel_min(sel_max(t0x, t1x), sel_max(t0y, t1y)), sel_max(t0z, t1z));
+    const float a = fabsf(v);
+    return (a >= 0x1p-36f && a < 0x1p55f) || (zeroOk && v == 0.0f);
+}
+__device__ __forceinline__ bool ray_is_nice(const RayRegs& r, uint32_t bvhFlags)
+{
+    const bool zeroOk = (bvhFlags & NTR_BVH_NOTINY) != 0;
+    return nice_dir(r.dx) && nice_dir(r.dy) && nice_dir(r.dz) && nice_pos(r.ox, zeroOk) && nice_pos(r.oy, zeroOk) &&
+           nice_pos(r.oz, zeroOk);
+}
+// rcp refined by one Newton step: the value hipcc's f32 divide expansion builds from the
+// denominator (v_rcp_f32, fma(-d,r0,1), fma(e0,r0,r0)) when v_div_scale does not rescale.
+__device__ __forceinline__ float refined_rcp(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    return __builtin_fmaf(e0, r0, r0);
+}
+__device__ __forceinline__ float fast_div(float x, float d, float r)
+{
+    const float q0 = x * r;
+    const float e1 = __builtin_fmaf(-d, q0, x);
+    const float q1 = __builtin_fmaf(e1, r, q0);
+    const float e2 = __builtin_fmaf(-d, q1, x);
+    return __builtin_fmaf(e2, r, q1);
+}
+
+// Intersect::RayBox for BOTH children of a node (Util.cpp:34-46).  The FAST form evaluates
+// the twelve quotients stage by stage (all q0, then all e1, ...) so that consecutive
+// instructions are independent: a lone wave cannot issue a VALU op that depends on the
+// previous one back to back.
+template <bool FAST>
+__device__ __forceinline__ void ray_box2(const RayRegs& r, const float4& n0, const float4& n1, const float4& nz,
+                                         float& mn0, float& mx0, float& mn1, float& mx1)
+{
+    if (FAST) {
+        // x[k] = plane - origin ; axis of slot k: x x y y z z (child 0), x x y y z z (child 1)
+        float x[12] = {n0.x - r.ox, n0.y - r.ox, n0.z - r.oy, n0.w - r.oy, nz.x - r.oz, nz.y - r.oz,
+                       n1.x - r.ox, n1.y - r.ox, n1.z - r.oy, n1.w - r.oy, nz.z - r.oz, nz.w - r.oz};
+        const float d[3] = {r.dx, r.dy, r.dz};
+        const float rc[3] = {r.rx, r.ry, r.rz};
+        float q[12], e[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) q[k] = x[k] * rc[(k % 6) >> 1];
+#pragma unroll
+        for (int k = 0; k < 12; k++) e[k] = __builtin_fmaf(-d[(k % 6) >> 1], q[k], x[k]);
+#pragma unroll
+        for (int k = 0; k < 12; k++) q[k] = __builtin_fmaf(e[k], rc[(k % 6) >> 1], q[k]);
+#pragma unroll
+        for (int k = 0; k < 12; k++) e[k] = __builtin_fmaf(-d[(k % 6) >> 1], q[k], x[k]);
+#pragma unroll
+        for (int k = 0; k < 12; k++) q[k] = __builtin_fmaf(e[k], rc[(k % 6) >> 1], q[k]);
+        mn0 = fmaxf(fmaxf(fminf(q[0], q[1]), fminf(q[2], q[3])), fminf(q[4], q[5]));
+        mx0 = fminf(fminf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])), fmaxf(q[4], q[5]));
+        mn1 = fmaxf(fmaxf(fminf(q[6], q[7]), fminf(q[8], q[9])), fminf(q[10], q[11]));
+        mx1 = fminf(fminf(fmaxf(q[6], q[7]), fmaxf(q[8], q[9])), fmaxf(q[10], q[11]));
+    } else {
+        float t0x = (n0.x - r.ox) / r.dx, t1x = (n0.y - r.ox) / r.dx;
+        float t0y = (n0.z - r.oy) / r.dy, t1y = (n0.w - r.oy) / r.dy;
+        float t0z = (nz.x - r.oz) / r.dz, t1z = (nz.y - r.oz) / r.dz;
+        mn0 = sel_max(sel_max(sel_min(t0x, t1x), sel_min(t0y, t1y)), sel_min(t0z, t1z));
+        mx0 = sel_min(sel_min(sel_max(t0x, t1x), sel_max(t0y, t1y)), sel_max(t0z, t1z));
+        t0x = (n1.x - r.ox) / r.dx; t1x = (n1.y - r.ox) / r.dx;
+        t0y = (n1.z - r.oy) / r.dy; t1y = (n1.w - r.oy) / r.dy;
+        t0z = (nz.z - r.oz) / r.dz; t1z = (nz.w - r.oz) / r.dz;
+        mn1 = sel_max(sel_max(sel_min(t0x, t1x), sel_min(t0y, t1y)), sel_min(t0z, t1z));
+        mx1 = sel_min(sel_min(sel_max(t0x, t1x), sel_max(t0y, t1y)), sel_max(t0z, t1z));
+    }
 }
 
 // dot(Vec4f a, Vec4f(b,bw)) as Math.hpp:185: r = 0; r += a[i]*b[i].
@@ -61,83 +180,129 @@ __device__ __forceinline__ float dot4(float4 a, float bx, float by, float bz, fl
     return r;
 }
 
-// Per-lane traversal stack: the first kLdsDepth entries live in LDS laid out
-// [entry][lane] (bank = lane % 32 whatever the per-lane depth -> conflict-free,
-// MI355X_MICROARCH LDS table), deeper entries spill to scratch.  The reference CPU
-// stack holds 100 entries (CudaBVH.cpp:701); SAH trees are at most 64 deep
-// (SAHBVHBuilder.hpp MaxDepth) and LBVH trees at most 30 inner levels.
-template <int LDS_DEPTH, int SPILL_DEPTH>
-struct LaneStack {
-    int* lds;               // &s_stack[wave][0][lane]
-    int  spill[SPILL_DEPTH];
-    int  sp;
+// Per-lane traversal stack: entries [0, LDS_DEPTH) in LDS laid out [entry][lane] (bank =
+// lane % 32 whatever the per-lane depth -> conflict-free), deeper entries in a scratch array
+// that only the (rare) overflow branches touch.  `sp` and the LDS base stay in registers.
+typedef __attribute__((address_space(3))) int lds_int;
 
-    __device__ __forceinline__ void push(int v, unsigned int* status)
-    {
-        if (sp < LDS_DEPTH) lds[sp * 64] = v;
-        else if (sp < LDS_DEPTH + SPILL_DEPTH) spill[sp - LDS_DEPTH] = v;
-        else { atomicOr(status, NTR_STATUS_STACK_OVERFLOW); return; }
-        sp++;
-    }
-    __device__ __forceinline__ int pop()
-    {
-        sp--;
-        return (sp < LDS_DEPTH) ? lds[sp * 64] : spill[sp - LDS_DEPTH];
-    }
+struct LaneStack {
+    lds_int* lds;  // &s_stack[wave][0][lane]
+    int sp;
 };
 
-// One inner-node step of trace<BVHLayout_Compact> (CudaBVH.cpp:721-775) for one lane.
+#define NTR_STACK_RESET(st) do { (st).sp = 1; (st).lds[0] = kSentinel; } while (0)
+
+__device__ __forceinline__ void stack_push(LaneStack& st, int (&spill)[SPILL_DEPTH], int v, unsigned int* status)
+{
+    if (__builtin_expect(st.sp < LDS_DEPTH, 1)) st.lds[st.sp * 64] = v;
+    else if (st.sp < LDS_DEPTH + SPILL_DEPTH) spill[st.sp - LDS_DEPTH] = v;
+    else { atomicOr(status, NTR_STATUS_STACK_OVERFLOW); return; }
+    st.sp++;
+}
+__device__ __forceinline__ int stack_pop(LaneStack& st, int (&spill)[SPILL_DEPTH])
+{
+    st.sp--;
+    if (__builtin_expect(st.sp < LDS_DEPTH, 1)) return st.lds[st.sp * 64];
+    return spill[st.sp - LDS_DEPTH];
+}
+
+// Keeps a loaded value live at this point so that hipcc cannot sink its load into a later
+// conditional block (which would turn one memory round trip per node into two).
+__device__ __forceinline__ void keep(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void keep(unsigned int& v) { asm volatile("" : "+v"(v)); }
+
 struct LaneStats {
     unsigned int inner, tris, leaves;
 };
 
-template <class Stack>
-__device__ __forceinline__ void inner_step(const char* __restrict__ nodes, const RayRegs& r,
-                                           int& node, Stack& st, unsigned int* status)
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+
+template <int K>
+__device__ __forceinline__ int quad_bcast(int v)  // value of lane (lane & ~3) + K
 {
-    const float4* n = reinterpret_cast<const float4*>(nodes + (size_t)(unsigned)node);
-    const float4 n0 = n[0];  // c0.lo.x c0.hi.x c0.lo.y c0.hi.y
-    const float4 n1 = n[1];  // c1.lo.x c1.hi.x c1.lo.y c1.hi.y
-    const float4 nz = n[2];  // c0.lo.z c0.hi.z c1.lo.z c1.hi.z
-    const int4   nc = reinterpret_cast<const int4*>(n)[3];
+    return __builtin_amdgcn_mov_dpp(v, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true);
+}
+
+// Quad-cooperative node fetch.  A lane reading its own 64-B node with four 16-B loads costs
+// the L1 four tag look-ups per lane (measured: ~44 clk per divergent dwordx4 wave-instruction,
+// scripts/microbench/gather64.hip).  Here the 4 lanes of a quad fetch the 4 nodes of the quad
+// together: in load j every lane reads the 16-B piece (lane & 3) of the node of quad-lane j, so
+// 4 adjacent lanes cover one contiguous 64-B node (one look-up, ~16 clk per wave-instruction).
+// The loads go straight to LDS (buffer_load ... lds); each lane then reads its node back as
+// 4 x ds_read_b128.  Must be executed with all 64 lanes enabled; lanes without an inner node
+// pass an out-of-range offset (the range-checked load fetches nothing).
+__device__ __forceinline__ void fetch_node_coop(Rsrc nodes, lds_char* stage, int lane, int ofs,
+                                                float4& n0, float4& n1, float4& nz, float4& nc)
+{
+    const int piece = (lane & 3) << 4;
+    const int o0 = quad_bcast<0>(ofs) + piece, o1 = quad_bcast<1>(ofs) + piece;
+    const int o2 = quad_bcast<2>(ofs) + piece, o3 = quad_bcast<3>(ofs) + piece;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(nodes, (lds_void*)(stage + 0 * STAGE_PIECE), 16, o0, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(nodes, (lds_void*)(stage + 1 * STAGE_PIECE), 16, o1, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(nodes, (lds_void*)(stage + 2 * STAGE_PIECE), 16, o2, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(nodes, (lds_void*)(stage + 3 * STAGE_PIECE), 16, o3, 0, 0, 0);
+    // LDS-DMA completion is ordered for this wave's ds_read only by its own vmcnt.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const lds_f32x4* mine = (const lds_f32x4*)(stage + (lane & 3) * STAGE_PIECE + ((lane & ~3) << 4));
+    const f32x4 a = mine[0], b = mine[1], c = mine[2], d = mine[3];
+    n0 = make_float4(a.x, a.y, a.z, a.w); n1 = make_float4(b.x, b.y, b.z, b.w);
+    nz = make_float4(c.x, c.y, c.z, c.w); nc = make_float4(d.x, d.y, d.z, d.w);
+}
+
+static constexpr int kNoNode = (int)0xFFFFFF00u;  // buffer offset beyond any extent (< 4 GiB)
+
+// One inner-node step of trace<BVHLayout_Compact> (CudaBVH.cpp:721-775).  Executed by the whole
+// wave (cooperative fetch); only lanes whose current node is an inner node (`inner`) update
+// their state.
+template <bool FAST, bool COOP>
+__device__ __forceinline__ void inner_step(Rsrc nodes, lds_char* stage, int lane, bool inner, const RayRegs& r,
+                                           int& node, LaneStack& st, int (&spill)[SPILL_DEPTH], unsigned int* status)
+{
+    float4 n0, n1, nz, nc;
+    if (COOP) {
+        fetch_node_coop(nodes, stage, lane, inner ? node : kNoNode, n0, n1, nz, nc);
+    } else {  // every lane fetches its own node (4 x 16 B)
+        const int ofs = inner ? node : kNoNode;
+        n0 = ld4(nodes, ofs); n1 = ld4(nodes, ofs + 16); nz = ld4(nodes, ofs + 32); nc = ld4(nodes, ofs + 48);
+        keep(nc);
+    }
 
     float mn0, mx0, mn1, mx1;
-    ray_box(r, n0.x, n0.y, n0.z, n0.w, nz.x, nz.y, mn0, mx0);
-    ray_box(r, n1.x, n1.y, n1.z, n1.w, nz.z, nz.w, mn1, mx1);
+    ray_box2<FAST>(r, n0, n1, nz, mn0, mx0, mn1, mx1);
 
     const bool i0 = (mn0 <= mx0) && (mx0 >= r.tmin) && (mn0 <= r.tmax);
     const bool i1 = (mn1 <= mx1) && (mx1 >= r.tmin) && (mn1 <= r.tmax);
 
-    int c0 = nc.x, c1 = nc.y;
-    if (i0 && i1) {
-        if (mn0 > mn1) { int t = c0; c0 = c1; c1 = t; }
-        node = c0;
-        st.push(c1, status);
-    } else if (i0) {
-        node = c0;
-    } else if (i1) {
-        node = c1;
-    } else {
-        node = st.pop();
+    const int c0 = __float_as_int(nc.x), c1 = __float_as_int(nc.y);
+    const bool swp = i1 && (!i0 || mn0 > mn1);  // visit c1 first (ties -> c0, CudaBVH.cpp:761)
+    const int nearC = swp ? c1 : c0;
+    const int farC = swp ? c0 : c1;
+    if (inner) {
+        if (i0 && i1) stack_push(st, spill, farC, status);
+        node = (i0 || i1) ? nearC : stack_pop(st, spill);
     }
 }
 
 // intersectTriangles<BVHLayout_Compact> + updateHit (CudaBVH.cpp:1084-1126, 1183-1225).
 // Returns true when an any-hit ray terminates.
-template <bool STATS = false>
-__device__ __forceinline__ bool leaf_step(const float4* __restrict__ woop, RayRegs& r, int leaf,
-                                          bool anyHit, int& hitAddr, float& hitU, float& hitV,
-                                          LaneStats* ls = nullptr)
+template <bool STATS>
+__device__ __forceinline__ bool leaf_step(Rsrc woop, RayRegs& r, int leaf, bool anyHit, int& hitAddr,
+                                          float& hitU, float& hitV, LaneStats& ls)
 {
-    for (int triAddr = ~leaf;; triAddr += 3) {
-        const float4 z = woop[triAddr];
+    for (int ofs = (~leaf) * 16;; ofs += 48) {
+        const float4 z = ld4(woop, ofs);
+        float4 u4 = ld4(woop, ofs + 16);         // past a terminator these may run off the
+        float4 v4 = ld4(woop, ofs + 32);         // buffer: range-checked loads return 0
+        unsigned int nextWord = ld1(woop, ofs + 48);
+        keep(u4); keep(v4); keep(nextWord);      // one round trip per triangle, not four
         if (__float_as_uint(z.x) == 0x80000000u) {  // terminator (CudaBVH.cpp:1091)
-            if (STATS) ls->leaves++;
+            if (STATS) ls.leaves++;
             break;
         }
-        if (STATS) ls->tris++;  // numTriangleTests (CudaBVH.cpp:1107-1111)
-        const float4 u4 = woop[triAddr + 1];
-        const float4 v4 = woop[triAddr + 2];
+        if (STATS) ls.tris++;  // numTriangleTests (CudaBVH.cpp:1107-1111)
 
         // Intersect::RayTriangleWoop (Util.cpp:99-127)
         const float Oz = z.w - r.ox * z.x - r.oy * z.y - r.oz * z.z;
@@ -155,10 +320,14 @@ __device__ __forceinline__ bool leaf_step(const float4* __restrict__ woop, RayRe
         // is recorded at t = FLT_MAX exactly like the reference (CudaBVH.cpp:1200).
         if (tt > r.tmin && tt < r.tmax) {
             r.tmax = tt;
-            hitAddr = triAddr;
+            hitAddr = ofs >> 4;
             hitU = uu;
             hitV = vv;
             if (anyHit) return true;
+        }
+        if (nextWord == 0x80000000u) {  // the terminator was fetched with this triangle
+            if (STATS) ls.leaves++;
+            break;
         }
     }
     return false;
@@ -175,50 +344,79 @@ __device__ __forceinline__ void store_result(NtrRayResult* __restrict__ results,
     reinterpret_cast<int4*>(results)[rayIdx] = out;
 }
 
+__device__ __forceinline__ void load_ray(const NtrRay* __restrict__ rays, int rayIdx, RayRegs& r)
+{
+    const float4 o = reinterpret_cast<const float4*>(rays)[rayIdx * 2 + 0];
+    const float4 d = reinterpret_cast<const float4*>(rays)[rayIdx * 2 + 1];
+    r.ox = o.x; r.oy = o.y; r.oz = o.z; r.tmin = o.w;
+    r.dx = d.x; r.dy = d.y; r.dz = d.z; r.tmax = d.w;
+    r.rx = refined_rcp(d.x); r.ry = refined_rcp(d.y); r.rz = refined_rcp(d.z);
+}
+
+// While-while traversal of the lanes' current rays until every lane is done (or, in the
+// persistent kernel, until too few lanes are live).  Both loops are wave-uniform (ballots), so
+// all 64 lanes stay enabled for the cooperative node fetch; per-ray visiting order is exactly
+// the CPU tracer's depth-first order, whatever the other lanes do.
+template <bool FAST, bool STATS, bool DYNAMIC_FETCH, bool COOP>
+__device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, lds_char* stage, int lane, RayRegs& r, int& node,
+                                         LaneStack& st, int (&spill)[SPILL_DEPTH], bool anyHit,
+                                         int& hitAddr, float& hitU, float& hitV, LaneStats& ls, unsigned int* status,
+                                         bool poolEmpty, int fetchThreshold)
+{
+    unsigned long long live = __ballot(node != kSentinel);
+    while (live != 0ull) {
+        for (;;) {
+            const bool inner = (unsigned)node < (unsigned)kSentinel;
+            if (__ballot(inner) == 0ull) break;
+            inner_step<FAST, COOP>(nodes, stage, lane, inner, r, node, st, spill, status);
+            if (STATS && inner) ls.inner++;
+        }
+        if (node < 0) {
+            if (leaf_step<STATS>(woop, r, node, anyHit, hitAddr, hitU, hitV, ls)) node = kSentinel;
+            else node = stack_pop(st, spill);
+        }
+        live = __ballot(node != kSentinel);
+        // dynamic fetch (kepler_dynamic_fetch.cu:310): too few live lanes while rays remain
+        // in the pool -> leave the loop so that the idle lanes are refilled.
+        if (DYNAMIC_FETCH && !poolEmpty && __popcll(live) < fetchThreshold) break;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Variant 1: one ray per lane, while-while ("fermi_speculative_while_while" slot).
 // ---------------------------------------------------------------------------------
-template <int WAVES, bool STATS>
+template <int WAVES, bool STATS, bool COOP>
 __global__ __launch_bounds__(WAVES * 64) void trace_bvh_perray(TraceParams p)
 {
-    constexpr int LDS_DEPTH = 16, SPILL_DEPTH = 88;
-    __shared__ int s_stack[WAVES][LDS_DEPTH][64];
-
+    __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
+    __shared__ __attribute__((aligned(16))) char s_stage[WAVES][COOP ? STAGE_BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rayIdx = blockIdx.x * (WAVES * 64) + threadIdx.x;
-    if (rayIdx >= p.numRays) return;
+    const bool valid = rayIdx < p.numRays;
+    const Rsrc nodes = make_rsrc(p.nodes, p.nodesBytes), woop = make_rsrc(p.woop, p.woopBytes);
+    lds_char* stage = (lds_char*)&s_stage[__builtin_amdgcn_readfirstlane(wave)][0];
 
-    const float4 o = reinterpret_cast<const float4*>(p.rays)[rayIdx * 2 + 0];
-    const float4 d = reinterpret_cast<const float4*>(p.rays)[rayIdx * 2 + 1];
-    RayRegs r = {o.x, o.y, o.z, o.w, d.x, d.y, d.z, d.w};
-
-    LaneStack<LDS_DEPTH, SPILL_DEPTH> st;
-    st.lds = &s_stack[wave][0][lane];
-    st.sp = 0;
-    st.push(kSentinel, p.status);
+    RayRegs r;
+    load_ray(p.rays, valid ? rayIdx : 0, r);
+    LaneStack st;
+    int spill[SPILL_DEPTH];
+    st.lds = (lds_int*)&s_stack[wave][0][lane];
+    NTR_STACK_RESET(st);
 
     int hitAddr = -1;
     float hitU = 0.0f, hitV = 0.0f;
     // No triangle can be accepted unless tmin < tmax (t>tmin && t<tmax), so a
     // degenerate ray (Ray::degenerate, Util.hpp:65) is a miss without traversal.
-    int node = (r.tmin < r.tmax) ? 0 : kSentinel;
-    const char* nodes = reinterpret_cast<const char*>(p.nodes);
-    const float4* woop = reinterpret_cast<const float4*>(p.woop);
-
+    int node = (valid && r.tmin < r.tmax) ? 0 : kSentinel;
     LaneStats ls = {0u, 0u, 0u};
-    while (node != kSentinel) {
-        while ((unsigned)node < (unsigned)kSentinel) {
-            inner_step(nodes, r, node, st, p.status);
-            if (STATS) ls.inner++;
-        }
-        if (node < 0) {
-            if (leaf_step<STATS>(woop, r, node, p.anyHit != 0, hitAddr, hitU, hitV, &ls)) break;
-            node = st.pop();
-        }
-    }
+
+    const bool fastWave = (p.bvhFlags & NTR_BVH_FASTDIV) && __ballot(node != kSentinel && !ray_is_nice(r, p.bvhFlags)) == 0ull;
+    if (fastWave) traverse<true, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0);
+    else traverse<false, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0);
+
+    if (!valid) return;
     store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
-    if (STATS) {
-        // diagnostics variant only: plain per-lane atomics
+    if (STATS) {  // diagnostics variant only: plain per-lane atomics
         atomicAdd(&p.stats[0], (unsigned long long)ls.inner);
         atomicAdd(&p.stats[1], (unsigned long long)ls.tris);
         atomicAdd(&p.stats[2], (unsigned long long)ls.leaves);
@@ -229,29 +427,32 @@ __global__ __launch_bounds__(WAVES * 64) void trace_bvh_perray(TraceParams p)
 // ---------------------------------------------------------------------------------
 // Variant 2: persistent waves.  Each wave owns a chunk [next,end) of the ray index
 // space taken from one global counter (one returning atomic per chunk, lane 0);
-// terminated lanes are refilled from the chunk by ballot + mbcnt prefix
+// empty lanes are refilled from the chunk by ballot + mbcnt prefix
 // (kepler_dynamic_fetch.cu:97-111 on wave64: 64-bit ballot, v_mbcnt_lo/hi).
 // ---------------------------------------------------------------------------------
-template <int WAVES>
+template <int WAVES, bool COOP>
 __global__ __launch_bounds__(WAVES * 64) void trace_bvh_persistent(TraceParams p)
 {
-    constexpr int LDS_DEPTH = 16, SPILL_DEPTH = 88;
-    __shared__ int s_stack[WAVES][LDS_DEPTH][64];
-
+    __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
+    __shared__ __attribute__((aligned(16))) char s_stage[WAVES][COOP ? STAGE_BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const char* nodes = reinterpret_cast<const char*>(p.nodes);
-    const float4* woop = reinterpret_cast<const float4*>(p.woop);
+    const Rsrc nodes = make_rsrc(p.nodes, p.nodesBytes), woop = make_rsrc(p.woop, p.woopBytes);
+    lds_char* stage = (lds_char*)&s_stage[__builtin_amdgcn_readfirstlane(wave)][0];
     const bool anyHit = p.anyHit != 0;
+    const bool bvhFast = (p.bvhFlags & NTR_BVH_FASTDIV) != 0;
 
-    LaneStack<LDS_DEPTH, SPILL_DEPTH> st;
-    st.lds = &s_stack[wave][0][lane];
+    LaneStack st;
+    int spill[SPILL_DEPTH];
+    st.lds = (lds_int*)&s_stack[wave][0][lane];
     st.sp = 0;
 
-    RayRegs r = {0, 0, 0, 0, 0, 0, 0, 0};
+    RayRegs r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int node = kSentinel, rayIdx = -1, hitAddr = -1;
     float hitU = 0.0f, hitV = 0.0f;
+    bool nice = true;                 // this lane's current ray qualifies for the FAST path
     int chunkNext = 0, chunkEnd = 0;  // wave-uniform
     bool poolEmpty = false;           // wave-uniform
+    LaneStats ls = {0u, 0u, 0u};
 
     // Invariant at the top of the loop: a lane either holds a live ray
     // (rayIdx >= 0, node != sentinel) or is empty (rayIdx < 0, node == sentinel).
@@ -273,33 +474,23 @@ __global__ __launch_bounds__(WAVES * 64) void trace_bvh_persistent(TraceParams p
             const int avail = chunkEnd - chunkNext;
             if (rayIdx < 0 && prefix < avail) {
                 rayIdx = chunkNext + prefix;
-                const float4 o = reinterpret_cast<const float4*>(p.rays)[rayIdx * 2 + 0];
-                const float4 d = reinterpret_cast<const float4*>(p.rays)[rayIdx * 2 + 1];
-                r = {o.x, o.y, o.z, o.w, d.x, d.y, d.z, d.w};
+                load_ray(p.rays, rayIdx, r);
                 hitAddr = -1;
                 hitU = hitV = 0.0f;
-                st.sp = 0;
-                st.push(kSentinel, p.status);
+                NTR_STACK_RESET(st);
                 // tmin < tmax is necessary for any accept (t>tmin && t<tmax):
                 // degenerate rays (Util.hpp:65) are misses without traversal.
                 node = (r.tmin < r.tmax) ? 0 : kSentinel;
+                nice = ray_is_nice(r, p.bvhFlags);
             }
             chunkNext += min(__popcll(empty), avail);
             empty = __ballot(rayIdx < 0);
         }
 
         // ---- while-while traversal ------------------------------------------------
-        while (node != kSentinel) {
-            while ((unsigned)node < (unsigned)kSentinel)
-                inner_step(nodes, r, node, st, p.status);
-            if (node < 0) {
-                if (leaf_step(woop, r, node, anyHit, hitAddr, hitU, hitV)) node = kSentinel;
-                else node = st.pop();
-            }
-            // dynamic fetch (kepler_dynamic_fetch.cu:310): too few live lanes while
-            // rays remain in the pool -> leave the loop and refill the idle lanes.
-            if (!poolEmpty && __popcll(__ballot(true)) < p.fetchThreshold) break;
-        }
+        const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
+        if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold);
+        else traverse<false, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold);
 
         // ---- retire finished rays ---------------------------------------------------
         if (rayIdx >= 0 && node == kSentinel) {
@@ -310,6 +501,27 @@ __global__ __launch_bounds__(WAVES * 64) void trace_bvh_persistent(TraceParams p
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Self test: FAST division == GENERIC division, bit for bit, on device.
+// mismatches += number of differing quotients among x[i] / d[j] for all i, j.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void selftest_division_kernel(const float* __restrict__ x, const float* __restrict__ d,
+                                                                int nx, int nd, unsigned int* __restrict__ mismatches)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nx) return;
+    const float xv = x[i];
+    unsigned int bad = 0;
+    for (int j = 0; j < nd; j++) {
+        const float dv = d[j];
+        const float q0 = xv / dv;
+        const float q1 = fast_div(xv, dv, refined_rcp(dv));
+        // the sign of a zero quotient is not observable by the tracer's comparisons
+        bad += (__float_as_uint(q0) != __float_as_uint(q1)) && !(q0 == 0.0f && q1 == 0.0f);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace ntr
 
 // ---- host-side launchers (called from ntr_api.cpp) -----------------------------------
@@ -318,16 +530,25 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
     constexpr int WAVES = NTR_TRACE_WAVES_PER_BLOCK;
     switch (variant) {
     case NTR_VARIANT_PERRAY:
-        hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        if (p->coop) hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, false, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        else hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, false, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_STATS:
-        hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERSISTENT:
-        hipLaunchKernelGGL(ntr::trace_bvh_persistent<WAVES>, dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        if (p->coop) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     default:
         return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ntr_launch_selftest_division(const float* d_x, const float* d_d, int nx, int nd,
+                                                   unsigned int* d_mismatches, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ntr::selftest_division_kernel, dim3((nx + 255) / 256), dim3(256), 0, stream, d_x, d_d, nx, nd, d_mismatches);
     return hipGetLastError();
 }

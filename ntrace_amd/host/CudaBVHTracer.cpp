@@ -34,7 +34,8 @@ F32 CudaBVHTracer::traceBatch(RayBuffer& rays)
     int rc = ntr_trace_bvh(m_kernelName.c_str(), numRays, rays.getNeedClosestHit() ? 0 : 1,
                            (const NtrRay*)rays.getRayBuffer().getCudaPtr(),
                            (NtrRayResult*)rays.getResultBuffer().getMutableCudaPtr(),
-                           m_bvh->getNodeBuffer().getCudaPtr(), m_bvh->getTriWoopBuffer().getCudaPtr(),
+                           m_bvh->getNodeBuffer().getCudaPtr(), m_bvh->getNodeBuffer().getSize(),
+                           m_bvh->getTriWoopBuffer().getCudaPtr(), m_bvh->getTriWoopBuffer().getSize(),
                            (const int32_t*)m_bvh->getTriIndexBuffer().getCudaPtr(), (int32_t)m_bvh->getLayout(),
                            flags, NULL, &seconds);
     if (rc != NTR_OK) fail("CudaBVHTracer: %s", ntr_last_error());

@@ -71,6 +71,11 @@ int orc_trace_compact_mt(const void* nodes, const void* woop, const int32_t* tri
                          const OrcRay* rays, OrcResult* results, int32_t numRays,
                          int32_t anyHit, int32_t nthreads, OrcTraceStats* stats);
 
+/* Single-threaded trace that also returns per-ray visit counts (workload analysis). */
+int orc_trace_compact_counts(const void* nodes, const void* woop, const int32_t* triIndex,
+                             const OrcRay* rays, OrcResult* results, int32_t numRays, int32_t anyHit,
+                             int32_t* perRayInner, int32_t* perRayTris);
+
 /* Intersect::RayBox (Util.cpp:34-46): out[0]=tmin, out[1]=tmax. */
 void orc_ray_box(const float lo[3], const float hi[3], const OrcRay* ray, float out[2]);
 

@@ -279,6 +279,27 @@ int orc_trace_compact_mt(const void* nodes, const void* woop, const int32_t* tri
     return overflow ? -1 : 0;
 }
 
+/* Per-ray visit counts (inner nodes, triangle tests) for workload analysis. */
+int orc_trace_compact_counts(const void* nodes, const void* woop, const int32_t* triIndex,
+                             const OrcRay* rays, OrcResult* results, int32_t numRays, int32_t anyHit,
+                             int32_t* perRayInner, int32_t* perRayTris)
+{
+    TraceCtx c;
+    memset(&c, 0, sizeof(c));
+    c.nodes = (const uint8_t*)nodes;
+    c.woop = (const uint8_t*)woop;
+    c.triIndex = triIndex;
+    c.anyHit = anyHit;
+    for (int32_t i = 0; i < numRays; i++) {
+        int64_t i0 = c.st.numInnerVisits, t0 = c.st.numTriTests;
+        trace_range(&c, rays, results, i, i + 1);
+        perRayInner[i] = (int32_t)(c.st.numInnerVisits - i0);
+        perRayTris[i] = (int32_t)(c.st.numTriTests - t0);
+        if (c.overflow) return -1;
+    }
+    return 0;
+}
+
 void orc_bruteforce_closest(const void* woop, const int32_t* triIndex, int32_t numFloat4,
                             const OrcRay* rays, OrcResult* results, int32_t numRays)
 {

@@ -7,9 +7,9 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 2 --no-cpu-baseline $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 bench.py $ARGS > $OUT/bench_pmc_$N.log 2>&1
+  timeout -k 5 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 bench.py $ARGS > $OUT/bench_pmc_$N.log 2>&1
 done
 find $OUT -name "*.csv" | head -50

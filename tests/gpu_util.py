@@ -13,16 +13,17 @@ class DeviceBvh:
     def __init__(self, bvh, dev="cuda:0"):
         self.host = bvh
         self.nodes, self.woop, self.idx = up(bvh.nodes, dev), up(bvh.woop, dev), up(bvh.tri_index, dev)
-        self.flags = nt.bvh_validate(self.nodes.data_ptr(), bvh.nodes.nbytes)
+        self.view = nt.BvhView(self.nodes.data_ptr(), bvh.nodes.nbytes, self.woop.data_ptr(), bvh.woop.nbytes,
+                               self.idx.data_ptr())
+        self.flags = self.view.validate()
 
 
 def gpu_trace(kernel, dbvh, rays, any_hit=False, flags=None, prefill=0xCD):
     n = rays.shape[0]
     d_rays = up(rays) if n else torch.zeros(32, dtype=torch.uint8, device="cuda:0")
     d_res = torch.full((max(n, 1) * 16,), prefill, dtype=torch.uint8, device="cuda:0")
-    sec = nt.trace_bvh(kernel, n, any_hit, d_rays.data_ptr(), d_res.data_ptr(), dbvh.nodes.data_ptr(),
-                       dbvh.woop.data_ptr(), dbvh.idx.data_ptr(), bvh_flags=dbvh.flags if flags is None else flags,
-                       stream=torch.cuda.current_stream().cuda_stream)
+    sec = dbvh.view.trace(kernel, n, any_hit, d_rays.data_ptr(), d_res.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream, True, flags)
     torch.cuda.synchronize()
     return d_res.cpu().numpy().view(nt.RESULT_DTYPE)[:n], sec
 

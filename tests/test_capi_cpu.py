@@ -43,17 +43,17 @@ def test_query_config_known_and_unknown_kernels():
 
 def test_trace_argument_checks_precede_device_work():
     # empty batch -> 0 seconds, no error (CudaBVHTracer.cpp:92-94)
-    assert nt.trace_bvh("kepler_dynamic_fetch", 0, False, 0, 0, 0, 0, 0) == 0.0
+    assert nt.trace_bvh("kepler_dynamic_fetch", 0, False, 0, 0, 0, 0, 0, 0, 0) == 0.0
     # missing BVH (CudaBVHTracer.cpp:97-98)
     with pytest.raises(nt.NtrError) as e:
-        nt.trace_bvh("kepler_dynamic_fetch", 10, False, 1, 1, 0, 0, 0)
+        nt.trace_bvh("kepler_dynamic_fetch", 10, False, 1, 1, 0, 0, 0, 0, 0)
     assert "No BVH" in str(e.value)
     # wrong layout (CudaBVHTracer.cpp:99-100)
     with pytest.raises(nt.NtrError) as e:
-        nt.trace_bvh("kepler_dynamic_fetch", 10, False, 1, 1, 1, 1, 1, layout=0)
+        nt.trace_bvh("kepler_dynamic_fetch", 10, False, 1, 1, 1, 64, 1, 16, 1, layout=0)
     assert e.value.code == -4 and "Incorrect BVH layout" in str(e.value)
     with pytest.raises(nt.NtrError):
-        nt.trace_bvh("bogus", 10, False, 1, 1, 1, 1, 1)
+        nt.trace_bvh("bogus", 10, False, 1, 1, 1, 64, 1, 16, 1)
 
 
 def test_no_cpu_fallback_without_device():
@@ -66,5 +66,10 @@ def test_no_cpu_fallback_without_device():
     buf = np.zeros(4096, dtype=np.uint8)
     with pytest.raises(nt.NtrError) as e:
         nt.trace_bvh("fermi_speculative_while_while", 64, False, rays.ctypes.data, buf.ctypes.data,
-                     buf.ctypes.data, buf.ctypes.data, buf.ctypes.data)
+                     buf.ctypes.data, 4096, buf.ctypes.data, 4096, buf.ctypes.data)
+    # bad extents are rejected before any device work
+    with pytest.raises(nt.NtrError) as e2:
+        nt.trace_bvh("fermi_speculative_while_while", 64, False, rays.ctypes.data, buf.ctypes.data,
+                     buf.ctypes.data, 100, buf.ctypes.data, 4096, buf.ctypes.data)
+    assert e2.value.code == -1
     assert e.value.code in (-2, -3)

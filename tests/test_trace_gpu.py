@@ -124,8 +124,7 @@ def test_gpu_traversal_counters_equal_oracle(soup, any_hit):
     rays = np.concatenate([scenes.primary_rays(cam, 128, 128)[0], scenes.random_rays(20000, seed=8)])
     d_rays = up(rays)
     d_res = torch.zeros(rays.shape[0] * 16, dtype=torch.uint8, device="cuda:0")
-    st = nt.trace_bvh_stats("kepler_dynamic_fetch", rays.shape[0], any_hit, d_rays.data_ptr(), d_res.data_ptr(),
-                            dbvh.nodes.data_ptr(), dbvh.woop.data_ptr(), dbvh.idx.data_ptr(), bvh_flags=dbvh.flags)
+    st = dbvh.view.trace_stats("kepler_dynamic_fetch", rays.shape[0], any_hit, d_rays.data_ptr(), d_res.data_ptr())
     ref, rst = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit, threads=8)
     assert st.as_dict() == {k: v for k, v in rst.as_dict().items() if k != "maxStackDepth"}
     assert st.algorithmic_bytes() == rst.algorithmic_bytes()
@@ -145,3 +144,41 @@ def test_golden_fixtures_on_gpu(kernel):
         for any_hit, key in ((False, "closest"), (True, "any")):
             got, _ = gpu_trace(kernel, dbvh, rays, any_hit)
             assert_parity(got, g["res_" + key].view(nt.RESULT_DTYPE).reshape(-1), "%s %s %s" % (f, kernel, key))
+
+
+def test_fast_division_equals_hardware_division():
+    """FAST path precondition: inside the FASTDIV range the refactored divide (per-ray refined
+    reciprocal + 5 ops per quotient) is bit-identical to the hardware `/`; and the hardware `/`
+    is IEEE correctly rounded (checked against numpy binary32 division on a subsample)."""
+    import torch
+    rng = np.random.default_rng(123)
+
+    def rnd(n, emin, emax):
+        m = rng.uniform(1.0, 2.0, n)
+        e = rng.integers(emin, emax + 1, n)
+        s = rng.choice([-1.0, 1.0], n)
+        return (s * m * np.exp2(e.astype(np.float64))).astype(np.float32)
+    x = np.concatenate([rnd(60000, -93, 55), rnd(20000, -10, 12), np.array([0.0, -0.0, 2.0 ** -93, 2.0 ** 55 * 1.999], np.float32),
+                        (rng.integers(1, 2 ** 24, 5000) * 2.0 ** -10).astype(np.float32)])
+    d = np.concatenate([rnd(1500, -40, 19), rnd(500, -3, 3), np.array([2.0 ** -40, 2.0 ** 20, -1.0, 1.0, 3.0, 1.0 / 3.0], np.float32),
+                        np.nextafter(np.float32(2.0), np.float32(0.0)).reshape(1)])
+    d_x, d_d = torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda()
+    assert nt.selftest_division(d_x.data_ptr(), x.shape[0], d_d.data_ptr(), d.shape[0]) == 0
+    # hardware `/` itself vs numpy binary32 division (torch's elementwise divide is the same instruction sequence)
+    q = (d_x[:20000, None] / d_d[None, :256]).cpu().numpy()
+    with np.errstate(all="ignore"):
+        ref = x[:20000, None] / d[None, :256]
+    assert np.array_equal(q.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_generic_and_fast_paths_agree(soup, kernel):
+    """bvh_flags = 0 forces the GENERIC path; both must give identical hit records."""
+    from gpu_util import assert_parity, gpu_trace
+    dbvh, cam = soup
+    assert dbvh.flags & nt.BVH_FASTDIV
+    rays = np.concatenate([scenes.primary_rays(cam, 200, 200)[0], scenes.random_rays(30000, seed=13)])
+    for any_hit in (False, True):
+        a, _ = gpu_trace(kernel, dbvh, rays, any_hit)
+        b, _ = gpu_trace(kernel, dbvh, rays, any_hit, flags=0)
+        assert_parity(a, b, "fast vs generic %s" % kernel)
