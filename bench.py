@@ -24,6 +24,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic_bytes(n_primary):
+    """HBM-side bytes per primary launch from the committed rocprofv3 PMC passes (scripts/profile.sh ->
+    profiles/*_pmc_summary.json; FETCH_SIZE and WRITE_SIZE collected in separate passes, in KiB).  gfx950
+    correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request, so the read side is
+    doubled; WRITE_SIZE is exact.  None when no profile of this launch shape is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        fs = [v for k, v in d.items() if k.endswith("|%d|FETCH_SIZE" % n_primary) and "false" in k]
+        ws = [v for k, v in d.items() if k.endswith("|%d|WRITE_SIZE" % n_primary) and "false" in k]
+        if fs and ws:
+            best = (2.0 * fs[0] + ws[0]) * 1024.0
+    return best
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -33,7 +52,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--ao-samples", type=int, default=8)
     ap.add_argument("--ao-radius", type=float, default=5.0, help="Raygen.aoRadius of the reference's config.conf")
-    ap.add_argument("--kernel", default=os.environ.get("NTR_BENCH_KERNEL", "kepler_dynamic_fetch"))
+    ap.add_argument("--kernel", default=os.environ.get("NTR_BENCH_KERNEL", "fermi_speculative_while_while"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     return ap.parse_args()
@@ -199,7 +218,7 @@ def main():
         "host_sah_build_s": sah_seconds,
         "trace_stats": st.as_dict(),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(n_primary),
                      "kernel": "trace_bvh (%s), primary batch" % args.kernel,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "ao": {"achieved": (ao_alg / (ao_ms * 1e-3) / 1e9) if ao_ms > 0 else None,

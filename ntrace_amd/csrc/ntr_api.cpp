@@ -49,7 +49,7 @@ struct DeviceState {
     int next = 0;
     int numCUs = 0;
 };
-static constexpr int kNumCounters = 256;
+static constexpr int kNumCounters = 64;  // ring of counter sets (8 heads x 64 B each)
 static constexpr int kMaxDevices = 64;
 static DeviceState g_dev[kMaxDevices];
 static std::mutex g_mu;
@@ -67,7 +67,7 @@ int get_device_state(DeviceState** out)
         NTR_HIP(hipGetDeviceProperties(&prop, dev));
         s.numCUs = prop.multiProcessorCount;
         // Counters sit 64 B apart so concurrent launches never share a line.
-        NTR_HIP(hipMalloc((void**)&s.counters, kNumCounters * 64));
+        NTR_HIP(hipMalloc((void**)&s.counters, kNumCounters * 8 * 64));
         NTR_HIP(hipMalloc((void**)&s.status, 64));
         NTR_HIP(hipMalloc((void**)&s.stats, 256));
         NTR_HIP(hipMemset(s.status, 0, 64));
@@ -237,6 +237,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.triIndex = d_triIndex;
     p.status = ds->status;
     p.counter = nullptr;
+    p.shardRays = 0;
     p.chunk = env_int("NTR_TRACE_CHUNK", 128);
     p.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", 40);
     p.bvhFlags = bvhFlags;
@@ -262,10 +263,12 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         if (numBlocks > needed) numBlocks = needed;
         {
             std::lock_guard<std::mutex> lk(g_mu);
-            p.counter = ds->counters + 16 * ds->next;
+            p.counter = ds->counters + 8 * 16 * ds->next;
             ds->next = (ds->next + 1) % kNumCounters;
         }
-        NTR_HIP(hipMemsetAsync(p.counter, 0, sizeof(int32_t), s));
+        NTR_HIP(hipMemsetAsync(p.counter, 0, 8 * 64, s));
+        const int chunksTotal = (numRays + p.chunk - 1) / p.chunk;
+        p.shardRays = ((chunksTotal + 7) / 8) * p.chunk;
     } else {
         numBlocks = (numRays + blockThreads - 1) / blockThreads;
     }

@@ -5,7 +5,12 @@
 
 #include "ntrace_amd.h"
 
+#ifndef NTR_TRACE_WAVES_PER_BLOCK
 #define NTR_TRACE_WAVES_PER_BLOCK 4  // 256-thread workgroups
+#endif
+#ifndef NTR_TRACE_MIN_WAVES_PER_SIMD
+#define NTR_TRACE_MIN_WAVES_PER_SIMD 1
+#endif
 
 // kernel variants (selected by the reference's kernel file names, see ntr_query_config)
 #define NTR_VARIANT_PERRAY 0      // one ray per lane, while-while
@@ -27,9 +32,10 @@ struct TraceParams {
     uint32_t nodesBytes;  // buffer-descriptor ranges (out-of-range loads return 0)
     uint32_t woopBytes;
     const int32_t* triIndex;
-    int32_t* counter;        // persistent: global ray-pool head (zeroed on the stream before launch)
+    int32_t* counter;        // persistent: 8 pool heads 64 B apart (zeroed on the stream before launch)
     unsigned int* status;    // sticky error bits
     int32_t chunk;           // persistent: rays per pool grab
+    int32_t shardRays;       // persistent: rays per pool shard (8 shards, a multiple of chunk)
     int32_t fetchThreshold;  // persistent: refill when fewer lanes are live
     uint32_t bvhFlags;
     int32_t coop;            // quad-cooperative LDS-DMA node fetch instead of per-lane loads

@@ -386,7 +386,7 @@ __device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, lds_char* stage,
 // Variant 1: one ray per lane, while-while ("fermi_speculative_while_while" slot).
 // ---------------------------------------------------------------------------------
 template <int WAVES, bool STATS, bool COOP>
-__global__ __launch_bounds__(WAVES * 64) void trace_bvh_perray(TraceParams p)
+__global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_perray(TraceParams p)
 {
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     __shared__ __attribute__((aligned(16))) char s_stage[WAVES][COOP ? STAGE_BYTES : 16];
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(WAVES * 64) void trace_bvh_perray(TraceParams p)
 // (kepler_dynamic_fetch.cu:97-111 on wave64: 64-bit ballot, v_mbcnt_lo/hi).
 // ---------------------------------------------------------------------------------
 template <int WAVES, bool COOP>
-__global__ __launch_bounds__(WAVES * 64) void trace_bvh_persistent(TraceParams p)
+__global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_persistent(TraceParams p)
 {
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     __shared__ __attribute__((aligned(16))) char s_stage[WAVES][COOP ? STAGE_BYTES : 16];
@@ -452,6 +452,9 @@ __global__ __launch_bounds__(WAVES * 64) void trace_bvh_persistent(TraceParams p
     bool nice = true;                 // this lane's current ray qualifies for the FAST path
     int chunkNext = 0, chunkEnd = 0;  // wave-uniform
     bool poolEmpty = false;           // wave-uniform
+    // HW_REG_XCC_ID (id 20), bits [3:0]: which of the 8 XCDs this wave runs on (speed only)
+    int shard = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7;
+    int shardTries = 0;
     LaneStats ls = {0u, 0u, 0u};
 
     // Invariant at the top of the loop: a lane either holds a live ray
@@ -461,12 +464,27 @@ __global__ __launch_bounds__(WAVES * 64) void trace_bvh_persistent(TraceParams p
         unsigned long long empty = __ballot(rayIdx < 0);
         while (empty != 0ull && !poolEmpty) {
             if (chunkNext >= chunkEnd) {  // wave-uniform: grab the next chunk
-                int base = 0;
-                if (lane == 0) base = atomicAdd(p.counter, p.chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= p.numRays) { poolEmpty = true; break; }
-                chunkNext = base;
-                chunkEnd = min(base + p.chunk, p.numRays);
+                // The ray index space is cut into 8 contiguous ranges with one pool head each
+                // (a single head saturates near 88 dequeues/us, MI355X_MICROARCH price list
+                // "dequeue").  A wave starts on the range of its own XCD -- so an XCD's L2 sees
+                // one screen region -- and moves on to the next range when that one runs dry.
+                bool got = false;
+                while (shardTries < 8) {
+                    const int rangeBeg = shard * p.shardRays;
+                    const int rangeEnd = min(rangeBeg + p.shardRays, p.numRays);
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(p.counter + shard * 16, p.chunk);
+                    base = __builtin_amdgcn_readfirstlane(base) + rangeBeg;
+                    if (base < rangeEnd) {
+                        chunkNext = base;
+                        chunkEnd = min(base + p.chunk, rangeEnd);
+                        got = true;
+                        break;
+                    }
+                    shard = (shard + 1) & 7;
+                    shardTries++;
+                }
+                if (!got) { poolEmpty = true; break; }
             }
             // rank of this lane among the empty lanes (wave64 prefix popcount)
             const int prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(empty >> 32),

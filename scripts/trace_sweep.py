@@ -56,20 +56,14 @@ def main():
     ao_live = sum(a[3] for a in ao)
 
     print("bvh flags", view.flags)
-    configs = [
-        ("perray", "fermi_speculative_while_while", {}),
-        ("perray coop", "fermi_speculative_while_while", {"NTR_TRACE_COOP": 1}),
-        ("perray coop generic", "fermi_speculative_while_while", {"NTR_TRACE_COOP": 1, "_flags": 0}),
-        ("persist coop c64 t0 b4", "kepler_dynamic_fetch", {"NTR_TRACE_COOP": 1, "NTR_TRACE_CHUNK": 64, "NTR_TRACE_FETCH_THRESHOLD": 0, "NTR_TRACE_BLOCKS_PER_CU": 4}),
-        ("persist coop c64 t32 b4", "kepler_dynamic_fetch", {"NTR_TRACE_COOP": 1, "NTR_TRACE_CHUNK": 64, "NTR_TRACE_FETCH_THRESHOLD": 32, "NTR_TRACE_BLOCKS_PER_CU": 4}),
-        ("perray generic", "fermi_speculative_while_while", {"_flags": 0}),
-        ("persist c128 t40 b4", "kepler_dynamic_fetch", {}),
-        ("persist c64 t32 b8", "kepler_dynamic_fetch", {"NTR_TRACE_CHUNK": 64, "NTR_TRACE_FETCH_THRESHOLD": 32, "NTR_TRACE_BLOCKS_PER_CU": 8}),
-        ("persist c64 t48 b8", "kepler_dynamic_fetch", {"NTR_TRACE_CHUNK": 64, "NTR_TRACE_FETCH_THRESHOLD": 48, "NTR_TRACE_BLOCKS_PER_CU": 8}),
-        ("persist c256 t20 b8", "kepler_dynamic_fetch", {"NTR_TRACE_CHUNK": 256, "NTR_TRACE_FETCH_THRESHOLD": 20, "NTR_TRACE_BLOCKS_PER_CU": 8}),
-        ("persist c64 t0 b8", "kepler_dynamic_fetch", {"NTR_TRACE_CHUNK": 64, "NTR_TRACE_FETCH_THRESHOLD": 0, "NTR_TRACE_BLOCKS_PER_CU": 8}),
-        ("persist c64 t56 b6", "kepler_dynamic_fetch", {"NTR_TRACE_CHUNK": 64, "NTR_TRACE_FETCH_THRESHOLD": 56, "NTR_TRACE_BLOCKS_PER_CU": 6}),
-    ]
+    configs = [("perray", "fermi_speculative_while_while", {})]
+    for c in (32, 64, 128):
+        for t in (0, 24, 40, 56):
+            for b in (7,):
+                configs.append(("persist c%d t%d b%d" % (c, t, b), "kepler_dynamic_fetch",
+                                {"NTR_TRACE_CHUNK": c, "NTR_TRACE_FETCH_THRESHOLD": t, "NTR_TRACE_BLOCKS_PER_CU": b}))
+    configs.append(("persist c64 t40 b4", "kepler_dynamic_fetch", {"NTR_TRACE_CHUNK": 64, "NTR_TRACE_FETCH_THRESHOLD": 40, "NTR_TRACE_BLOCKS_PER_CU": 4}))
+    configs.append(("persist c64 t40 b5", "kepler_dynamic_fetch", {"NTR_TRACE_CHUNK": 64, "NTR_TRACE_FETCH_THRESHOLD": 40, "NTR_TRACE_BLOCKS_PER_CU": 5}))
     if args.configs:
         keep = set(args.configs.split(","))
         configs = [c for c in configs if c[0] in keep]
