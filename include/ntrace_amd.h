@@ -191,6 +191,32 @@ NTR_API int ntr_raygen_ao(NtrRay* d_outRays, int32_t* d_outIDToSlot, int32_t* d_
  * Renderer.cpp:676-709): number of results with id != -1.  Blocking. */
 NTR_API int ntr_count_hits(const NtrRayResult* d_results, int32_t numRays, int32_t* count, void* stream);
 
+/* ---- on-device LBVH build ------------------------------------------------------------------ */
+
+/* Result of ntr_lbvh_build: exact buffer sizes (the reference resizes its buffers to these,
+ * HLBVHBuilder.cpp:382-386) and per-phase GPU times (HLBVHBuilder::getGPUTime, :571-573). */
+typedef struct NtrLbvhResult {
+    int32_t numNodes, numLeaves, numLevels, pad;
+    int64_t nodesBytes, triWoopBytes, triIndexBytes;
+    float   seconds;                                   /* whole build, GPU time          */
+    float   mortonMs, sortMs, woopMs, emitMs, refitMs; /* L1, L2, L4, L3, L5             */
+} NtrLbvhResult;
+
+/* Worst-case output sizes for numTris triangles (what HLBVHBuilder allocates before the build,
+ * HLBVHBuilder.cpp:532-538, 772-784). */
+NTR_API int ntr_lbvh_capacity(int32_t numTris, int64_t* nodesBytes, int64_t* triWoopBytes, int64_t* triIndexBytes);
+
+/* HLBVHBuilder::buildLBVH (src/rt/bvh/HLBVH/HLBVHBuilder.cpp:451-593; the path taken for
+ * !hlbvh || hlbvhBits == 10, :44-47): Morton codes -> stable radix sort -> Woop rows -> level-by-level
+ * emit -> bottom-up refit, all on the device, into caller-owned BVHLayout_Compact buffers of at least
+ * ntr_lbvh_capacity() bytes.  d_triVtxIndex: 3 ints per triangle, d_vtxPos: 3 floats per vertex
+ * (Scene::getTriVtxIndexBuffer / getVtxPosBuffer), sceneMin/Max = Scene::getBBox.  Renderer passes
+ * leafSize 8, epsilon 0.001 (Renderer.cpp:203-207).  Blocking. */
+NTR_API int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVerts, const float* d_vtxPos,
+                           const float sceneMin[3], const float sceneMax[3], int32_t leafSize, float epsilon,
+                           void* d_nodes, int64_t nodesCapacity, void* d_triWoop, int64_t triWoopCapacity,
+                           int32_t* d_triIndex, int64_t triIndexCapacity, NtrLbvhResult* result, void* stream);
+
 /* ---- host-side BVH production (no device work) ---------------------------- */
 
 /* Host SAH build + Compact flatten: `BVH bvh(scene, platform, params);

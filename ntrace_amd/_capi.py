@@ -36,6 +36,16 @@ class TraceStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class LbvhResult(C.Structure):
+    _fields_ = [("numNodes", C.c_int32), ("numLeaves", C.c_int32), ("numLevels", C.c_int32), ("pad", C.c_int32),
+                ("nodesBytes", C.c_int64), ("triWoopBytes", C.c_int64), ("triIndexBytes", C.c_int64),
+                ("seconds", C.c_float), ("mortonMs", C.c_float), ("sortMs", C.c_float), ("woopMs", C.c_float),
+                ("emitMs", C.c_float), ("refitMs", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
+
+
 class _HostBvhInfo(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("nodesBytes", C.c_int64), ("triWoop", C.c_void_p),
                 ("triWoopBytes", C.c_int64), ("triIndex", C.c_void_p), ("triIndexBytes", C.c_int64),
@@ -76,6 +86,9 @@ SYMBOLS = [
                                      C.c_float, _u32, _vp]),
     ("ntr_raygen_ao", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _u32, _vp]),
     ("ntr_count_hits", C.c_int, [_vp, _i32, C.POINTER(_i32), _vp]),
+    ("ntr_lbvh_capacity", C.c_int, [_i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    ("ntr_lbvh_build", C.c_int, [_i32, _vp, _i32, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i32, C.c_float,
+                                 _vp, _i64, _vp, _i64, _vp, _i64, C.POINTER(LbvhResult), _vp]),
     ("ntr_sah_build", C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
     ("ntr_host_bvh_info", C.c_int, [_vp, C.POINTER(_HostBvhInfo)]),
     ("ntr_host_bvh_free", None, [_vp]),
@@ -171,6 +184,23 @@ def count_hits(d_results, num_rays, stream=0):
     cnt = _i32(0)
     _check(lib().ntr_count_hits(_vp(d_results), int(num_rays), C.byref(cnt), _vp(stream)))
     return int(cnt.value)
+
+
+def lbvh_capacity(num_tris):
+    a, b, c = _i64(0), _i64(0), _i64(0)
+    _check(lib().ntr_lbvh_capacity(int(num_tris), C.byref(a), C.byref(b), C.byref(c)))
+    return int(a.value), int(b.value), int(c.value)
+
+
+def lbvh_build(num_tris, d_tri, num_verts, d_pos, scene_min, scene_max, leaf_size, epsilon, d_nodes, nodes_cap,
+               d_woop, woop_cap, d_idx, idx_cap, stream=0):
+    res = LbvhResult()
+    mn = (C.c_float * 3)(*[float(x) for x in scene_min])
+    mx = (C.c_float * 3)(*[float(x) for x in scene_max])
+    _check(lib().ntr_lbvh_build(int(num_tris), _vp(d_tri), int(num_verts), _vp(d_pos), mn, mx, int(leaf_size),
+                                float(epsilon), _vp(d_nodes), int(nodes_cap), _vp(d_woop), int(woop_cap), _vp(d_idx),
+                                int(idx_cap), C.byref(res), _vp(stream)))
+    return res
 
 
 class BvhView:

@@ -30,6 +30,12 @@ class TraceStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class Lbvh(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("nodesBytes", C.c_int64), ("woop", C.c_void_p), ("woopBytes", C.c_int64),
+                ("triIndex", C.c_void_p), ("triIndexBytes", C.c_int64), ("mortonSorted", C.c_void_p),
+                ("triSorted", C.c_void_p), ("numInner", C.c_int32), ("numLeaves", C.c_int32), ("numLevels", C.c_int32)]
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
@@ -50,6 +56,16 @@ def lib():
         L.orc_trace_compact_mt.restype = C.c_int
         L.orc_bruteforce_closest.argtypes = [vp, vp, i32, vp, vp, i32]
         L.orc_bruteforce_closest.restype = None
+        L.orc_lbvh_build.argtypes = [i32, vp, i32, vp, vp, vp, i32, C.c_float, C.POINTER(Lbvh)]
+        L.orc_lbvh_build.restype = C.c_int
+        L.orc_lbvh_free.argtypes = [C.POINTER(Lbvh)]
+        L.orc_lbvh_free.restype = None
+        L.orc_bvh_canonical_hash.argtypes = [vp, i64, vp, vp, i32]
+        L.orc_bvh_canonical_hash.restype = C.c_uint64
+        L.orc_lbvh_morton.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+        L.orc_lbvh_morton.restype = None
+        L.orc_lbvh_woop.argtypes = [i32, vp, vp, vp]
+        L.orc_lbvh_woop.restype = None
         _lib = L
     return _lib
 
@@ -93,3 +109,42 @@ def bruteforce_closest(woop, tri_index, rays):
     res = np.zeros(rays.shape[0], dtype=RESULT_DTYPE)
     lib().orc_bruteforce_closest(_ptr(woop), _ptr(tri_index), woop.nbytes // 16, _ptr(rays), _ptr(res), rays.shape[0])
     return res
+
+
+def scene_bbox(pos):
+    """Scene::getBBox (src/rt/Scene.cpp:112-126): min/max over the vertex positions."""
+    pos = np.asarray(pos, dtype=np.float32).reshape(-1, 3)
+    return pos.min(axis=0), pos.max(axis=0)
+
+
+def lbvh_build(tri, pos, leaf_size=8, epsilon=0.001, bbox=None):
+    """HLBVHBuilder::buildLBVH restated on the CPU.  Returns dict(nodes, woop, tri_index, morton_sorted,
+    tri_sorted, num_inner, num_leaves, num_levels) with numpy copies of the Compact buffers."""
+    tri = np.ascontiguousarray(tri, dtype=np.int32).reshape(-1, 3)
+    pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+    mn, mx = bbox if bbox is not None else scene_bbox(pos)
+    mn = np.ascontiguousarray(mn, dtype=np.float32)
+    mx = np.ascontiguousarray(mx, dtype=np.float32)
+    b = Lbvh()
+    rc = lib().orc_lbvh_build(tri.shape[0], _ptr(tri), pos.shape[0], _ptr(pos), _ptr(mn), _ptr(mx), int(leaf_size),
+                              float(epsilon), C.byref(b))
+    if rc != 0:
+        raise RuntimeError("oracle: orc_lbvh_build failed")
+    try:
+        def arr(p, nbytes, dt):
+            return np.frombuffer(C.string_at(p, nbytes), dtype=dt).copy()
+        out = dict(nodes=arr(b.nodes, b.nodesBytes, np.uint8), woop=arr(b.woop, b.woopBytes, np.uint8),
+                   tri_index=arr(b.triIndex, b.triIndexBytes, np.int32),
+                   morton_sorted=arr(b.mortonSorted, tri.shape[0] * 4, np.uint32),
+                   tri_sorted=arr(b.triSorted, tri.shape[0] * 4, np.int32),
+                   num_inner=int(b.numInner), num_leaves=int(b.numLeaves), num_levels=int(b.numLevels))
+    finally:
+        lib().orc_lbvh_free(C.byref(b))
+    return out
+
+
+def bvh_canonical_hash(nodes, woop, tri_index, hash_woop=True):
+    nodes = np.ascontiguousarray(nodes)
+    woop = np.ascontiguousarray(woop)
+    tri_index = np.ascontiguousarray(tri_index, dtype=np.int32)
+    return int(lib().orc_bvh_canonical_hash(_ptr(nodes), nodes.nbytes, _ptr(woop), _ptr(tri_index), int(bool(hash_woop))))

@@ -1,0 +1,132 @@
+"""On-device LBVH build vs the CPU restatement of HLBVHBuilder::buildLBVH.
+
+Node numbering / leaf placement depend on atomic order (in the reference too), so trees are
+compared in canonical form: same topology, same split-axis words, same child boxes bit for
+bit, same triangles per leaf in sorted order, same Woop rows bit for bit."""
+import numpy as np
+import pytest
+
+import ntrace_amd as nt
+from ntrace_amd import scenes
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_lbvh(tri, pos, leaf_size=8, epsilon=0.001):
+    import torch
+    from gpu_util import up
+    tri = np.ascontiguousarray(tri, dtype=np.int32)
+    pos = np.ascontiguousarray(pos, dtype=np.float32)
+    n = tri.shape[0]
+    capn, capw, capi = nt.lbvh_capacity(n)
+    d_tri, d_pos = up(tri), up(pos)
+    d_nodes = torch.zeros(capn, dtype=torch.uint8, device="cuda:0")
+    d_woop = torch.zeros(capw, dtype=torch.uint8, device="cuda:0")
+    d_idx = torch.zeros(capi, dtype=torch.uint8, device="cuda:0")
+    mn, mx = oracle.scene_bbox(pos)
+    res = nt.lbvh_build(n, d_tri.data_ptr(), pos.shape[0], d_pos.data_ptr(), mn, mx, leaf_size, epsilon,
+                        d_nodes.data_ptr(), capn, d_woop.data_ptr(), capw, d_idx.data_ptr(), capi)
+    torch.cuda.synchronize()
+    nodes = d_nodes.cpu().numpy()[:res.nodesBytes].copy()
+    woop = d_woop.cpu().numpy()[:res.triWoopBytes].copy()
+    idx = d_idx.cpu().numpy()[:res.triIndexBytes].view(np.int32).copy()
+    return nodes, woop, idx, res, (d_nodes, d_woop, d_idx)
+
+
+def check_against_oracle(tri, pos, leaf_size=8, epsilon=0.001):
+    nodes, woop, idx, res, keep = gpu_lbvh(tri, pos, leaf_size, epsilon)
+    ref = oracle.lbvh_build(tri, pos, leaf_size, epsilon)
+    assert res.numNodes == ref["num_inner"] and res.numLeaves == ref["num_leaves"] and res.numLevels == ref["num_levels"]
+    assert nodes.nbytes == ref["nodes"].nbytes and woop.nbytes == ref["woop"].nbytes and idx.nbytes == ref["tri_index"].nbytes
+    assert oracle.bvh_canonical_hash(nodes, woop, idx) == oracle.bvh_canonical_hash(ref["nodes"], ref["woop"], ref["tri_index"])
+    return nodes, woop, idx, res, ref, keep
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (7, 3), (9, 4), (64, 5), (1000, 6), (5000, 7), (70000, 8)])
+def test_lbvh_matches_oracle_random_soups(n, seed):
+    tri, pos, _ = scenes.random_soup(n, seed=seed, walls=(n > 100))
+    check_against_oracle(tri, pos)
+
+
+@pytest.mark.parametrize("leaf_size", [1, 2, 8, 16])
+def test_lbvh_leaf_sizes(leaf_size):
+    tri, pos, _ = scenes.random_soup(3000, seed=21)
+    check_against_oracle(tri, pos, leaf_size=leaf_size)
+
+
+def test_lbvh_duplicate_morton_codes_median_split_and_depth_limit():
+    """Many triangles in one Morton cell: median splits (emitTreeKernel.cu:282) and the forced
+    leaves of the last level (oldLevel == 0, :289-292) -> leaves larger than leafSize."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    c = np.array([0.3, 0.4, 0.5]) + rng.normal(0, 1e-6, size=(n, 1, 3))
+    p = (c + rng.normal(0, 1e-7, size=(n, 3, 3))).reshape(-1, 3)
+    far = np.array([[-10, -10, -10], [10, -10, -10], [-10, 10, 10], [10, 10, 10], [9, 10, 10], [10, 9, 10]], dtype=np.float64)
+    pos = np.concatenate([p, far]).astype(np.float32)
+    tri = np.concatenate([np.arange(n * 3).reshape(-1, 3), np.array([[n * 3, n * 3 + 1, n * 3 + 2], [n * 3 + 3, n * 3 + 4, n * 3 + 5]])]).astype(np.int32)
+    nodes, woop, idx, res, ref, _ = check_against_oracle(tri, pos, leaf_size=2)
+    assert res.numLevels >= 12  # ~log2(6000 / 2) median levels below the split that isolates the cluster
+
+
+def test_lbvh_depth_limit_forces_oversized_leaves():
+    """A chain of Morton codes 0 (x10), 2^0, 2^1, ..., 2^29: one level per bit, and at the last
+    level (kernel bit 0, `oldLevel == 0`, emitTreeKernel.cu:289-292) the 10 duplicates become one
+    leaf although leafSize is 2."""
+    cells = [(0, 0, 0)] * 10
+    for k in range(30):
+        c = [0, 0, 0]
+        c[k % 3] = 1 << (k // 3)
+        cells.append(tuple(c))
+    ctr = (np.array(cells, dtype=np.float64) + 0.5)
+    d = 0.05
+    p = np.stack([ctr + [-d, -d, 0], ctr + [d, -d, 0], ctr + [0, d, 0]], axis=1).reshape(-1, 3)
+    corner = np.array([[0, 0, 0], [0.01, 0, 0], [0, 0.01, 0], [1024, 1024, 1024], [1023.99, 1024, 1024], [1024, 1023.99, 1024]])
+    pos = np.concatenate([p, corner]).astype(np.float32)
+    nt_ = len(cells)
+    tri = np.concatenate([np.arange(nt_ * 3).reshape(-1, 3), [[nt_ * 3, nt_ * 3 + 1, nt_ * 3 + 2], [nt_ * 3 + 3, nt_ * 3 + 4, nt_ * 3 + 5]]]).astype(np.int32)
+    nodes, woop, idx, res, ref, _ = check_against_oracle(tri, pos, leaf_size=2)
+    assert res.numLevels == 30
+    w = woop.view(np.uint32).reshape(-1, 4)
+    sizes, a, cur = [], 0, 0
+    while a < w.shape[0]:
+        if w[a, 0] == 0x80000000:
+            sizes.append(cur); cur = 0; a += 1
+        else:
+            cur += 1; a += 3
+    assert max(sizes) >= 10
+
+
+def test_trace_on_gpu_built_lbvh_matches_oracle_trace():
+    """Parity hazard 8: Woop data from the GPU builder differs from the host
+    woopifyTri, so parity is defined on the downloaded GPU-built buffers fed to both tracers."""
+    import torch
+    from gpu_util import assert_parity, up
+    tri, pos, cam = scenes.random_soup(30000, seed=31)
+    nodes, woop, idx, res, ref, (d_nodes, d_woop, d_idx) = check_against_oracle(tri, pos)
+    view = nt.BvhView(d_nodes.data_ptr(), res.nodesBytes, d_woop.data_ptr(), res.triWoopBytes, d_idx.data_ptr())
+    view.validate()
+    rays = np.concatenate([scenes.primary_rays(cam, 256, 192)[0], scenes.random_rays(40000, seed=9)])
+    d_rays = up(rays)
+    for kernel in ("fermi_speculative_while_while", "kepler_dynamic_fetch"):
+        for any_hit in (False, True):
+            d_res = torch.zeros(rays.shape[0] * 16, dtype=torch.uint8, device="cuda:0")
+            view.trace(kernel, rays.shape[0], any_hit, d_rays.data_ptr(), d_res.data_ptr())
+            got = d_res.cpu().numpy().view(nt.RESULT_DTYPE)
+            exp, _ = oracle.trace(nodes, woop, idx, rays, any_hit=any_hit, threads=8)
+            assert_parity(got, exp, "lbvh %s anyHit=%d" % (kernel, any_hit))
+
+
+def test_lbvh_atrium_262k_every_triangle_once():
+    tri, pos, _ = scenes.atrium()
+    nodes, woop, idx, res, ref, _ = check_against_oracle(tri, pos)
+    assert res.seconds > 0
+    w = woop.view(np.uint32).reshape(-1, 4)
+    ids, a = [], 0
+    while a < w.shape[0]:
+        if w[a, 0] == 0x80000000:
+            a += 1
+        else:
+            ids.append(idx[a])
+            a += 3
+    assert np.array_equal(np.sort(np.array(ids)), np.arange(tri.shape[0]))
