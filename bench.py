@@ -157,13 +157,8 @@ def main():
     # the metric counts non-degenerate rays only (Renderer::getTotalNumRays, Renderer.cpp:676-709)
     rays_per_step = sum(b["live"] for b in batches)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(rays_per_step)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed_max = float(tmax.item())
-    total_rays_per_step = float(tot.item())
+    from ntrace_amd import dist as ntd
+    total_rays_per_step, elapsed_max = ntd.job_throughput(rays_per_step, elapsed, dev)  # SUM rays, MAX time
 
     # ---- final framebuffer gather (hit records -> rank 0) over RCCL, timed separately ----------------
     gather_ms = None

@@ -1,0 +1,112 @@
+#include "Renderer.hpp"
+
+namespace FW {
+
+// Renderer::Renderer (Renderer.cpp:44-94): m_raygen(1 << 20), Platform("GPU") with leaf preferences (1,1).
+Renderer::Renderer(const String& builder)
+    : m_builder(builder), m_raygen(1 << 20), m_enableRandom(false), m_scene(NULL), m_cameraFar(0.0f), m_newBatch(true),
+      m_batchRays(NULL), m_batchStart(0), m_accelStruct(NULL)
+{
+    m_cudaTracer = new CudaBVHTracer();
+    m_cudaTracer->setScene(NULL);
+    m_platform = Platform("GPU");
+    m_platform.setLeafPreferences(1, 1);
+    m_buildParams.builder = (builder == "HLBVH") ? "SAHBVH" : builder;
+}
+
+Renderer::~Renderer(void)
+{
+    delete m_accelStruct;
+    delete m_cudaTracer;
+}
+
+void Renderer::setScene(Scene* scene)
+{
+    if (scene == m_scene) return;
+    invalidateBVH();
+    m_scene = scene;
+    m_cudaTracer->setScene(scene);
+}
+
+void Renderer::setParams(const Params& params)  // Renderer.cpp:138-143
+{
+    m_params = params;
+    m_cudaTracer->setKernel(params.kernelName);
+}
+
+// Renderer::getCudaBVH (Renderer.cpp:147-305) without the cache-file and OcclusionBVH branches.
+CudaAS* Renderer::getCudaBVH(void)
+{
+    BVHLayout layout = m_cudaTracer->getDesiredBVHLayout();
+    if (!m_scene || (m_accelStruct && m_accelStruct->getLayout() == layout)) return m_accelStruct;
+    delete m_accelStruct;
+    m_accelStruct = NULL;
+    if (m_builder == "HLBVH") {
+        HLBVHParams params;  // Renderer.cpp:203-207 asks for hlbvh = true, hlbvhBits = 4; this backend
+        params.hlbvh = false;  // provides the plain LBVH pipeline of the same builder
+        params.leafSize = 8;
+        params.epsilon = 0.001f;
+        m_accelStruct = new HLBVHBuilder(m_scene, m_platform, params);
+    } else {
+        BVH bvh(m_scene, m_platform, m_buildParams);
+        m_accelStruct = new CudaBVH(bvh, layout);
+        failIfError();
+    }
+    return m_accelStruct;
+}
+
+// Renderer::beginFrame (Renderer.cpp:405-497)
+void Renderer::beginFrame(const CameraView& camera)
+{
+    if (!m_scene) fail("Renderer: no scene");
+    m_cudaTracer->setBVH(getCudaBVH());
+    m_raygen.primary(m_primaryRays, camera.position, camera.nscreenToWorld, camera.width, camera.height, camera.cameraFar, 0);
+    if (m_params.rayType != RayType_Primary) m_cudaTracer->traceBatch(m_primaryRays);  // :482-488
+    m_cameraFar = camera.cameraFar;
+    m_newBatch = true;
+    m_batchRays = NULL;
+    m_batchStart = 0;
+}
+
+// Renderer::nextBatch (Renderer.cpp:501-564)
+bool Renderer::nextBatch(void)
+{
+    if (m_batchRays) m_batchStart += m_batchRays->getSize();
+    m_batchRays = NULL;
+    switch (m_params.rayType) {
+    case RayType_Primary:
+        if (!m_newBatch) return false;
+        m_newBatch = false;
+        m_batchRays = &m_primaryRays;
+        break;
+    case RayType_AO:
+        if (!m_raygen.ao(m_secondaryRays, m_primaryRays, *m_scene, m_params.numSamples, m_params.aoRadius, m_newBatch, 0)) return false;
+        m_batchRays = &m_secondaryRays;
+        break;
+    case RayType_Diffuse:
+        if (!m_raygen.ao(m_secondaryRays, m_primaryRays, *m_scene, m_params.numSamples, m_cameraFar, m_newBatch, 0)) return false;
+        m_secondaryRays.setNeedClosestHit(true);
+        m_batchRays = &m_secondaryRays;
+        break;
+    default:
+        return false;
+    }
+    return true;
+}
+
+F32 Renderer::traceBatch(void)  // Renderer.cpp:568-579
+{
+    if (!m_batchRays) fail("Renderer::traceBatch: no batch");
+    return m_cudaTracer->traceBatch(*m_batchRays);
+}
+
+int Renderer::getTotalNumRays(void)  // Renderer.cpp:676-710
+{
+    if (m_params.rayType == RayType_Primary) return m_primaryRays.getSize();
+    int32_t hits = 0;
+    if (ntr_count_hits((const NtrRayResult*)m_primaryRays.getResultBuffer().getCudaPtr(), m_primaryRays.getSize(), &hits, NULL) != NTR_OK)
+        fail("Renderer: %s", ntr_last_error());
+    return hits * m_params.numSamples;
+}
+
+}  // namespace FW

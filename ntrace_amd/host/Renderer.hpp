@@ -1,0 +1,75 @@
+// Renderer.hpp -- frame driver with the reference's batching semantics
+// (src/rt/cuda/Renderer.hpp:78-115; Renderer.cpp:44-94, 147-305, 405-497, 501-579, 676-710).
+// Kept: setParams / getCudaBVH / beginFrame / nextBatch / traceBatch / getTotalNumRays for the
+// primary, AO and diffuse ray types.  Out of scope: mesh import, GL display, visualisation, VPL,
+// kd-tree, image reconstruction (updateResult).
+#pragma once
+#include "CudaBVHTracer.hpp"
+#include "HLBVHBuilder.hpp"
+#include "RayGen.hpp"
+
+namespace FW {
+
+// What beginFrame needs from CameraControls / GLContext in the reference (Renderer.cpp:473-477).
+struct CameraView {
+    Vec3f position;
+    Mat4f nscreenToWorld;  // invert(fitToView * worldToClip)
+    F32   cameraFar;
+    S32   width, height;
+};
+
+class Renderer {
+public:
+    enum RayType { RayType_Primary = 0, RayType_AO, RayType_Diffuse, RayType_Max };
+
+    struct Params {
+        String  kernelName;
+        RayType rayType;
+        F32     aoRadius;
+        S32     numSamples;
+        bool    sortSecondary;
+        Params(void) : kernelName(""), rayType(RayType_Primary), aoRadius(1.0f), numSamples(32), sortSecondary(false) {}
+    };
+
+    // builder: "SAHBVH" (host, leaf preferences (1,1)) or "HLBVH" (device LBVH) -- Renderer.builder in config.conf
+    explicit Renderer(const String& builder = "SAHBVH");
+    ~Renderer(void);
+
+    void   setScene(Scene* scene);  // replaces setMesh(): the Scene is built by the caller
+    Scene* getScene(void) const { return m_scene; }
+    void   setBuildParams(const BVH::BuildParams& params) { invalidateBVH(); m_buildParams = params; }
+    void   invalidateBVH(void) { delete m_accelStruct; m_accelStruct = NULL; }
+    void   setParams(const Params& params);
+    void   setEnableRandom(bool enable) { m_enableRandom = enable; }
+    CudaVirtualTracer& getCudaTracer(void) { return *m_cudaTracer; }
+    CudaAS* getCudaBVH(void);
+
+    void beginFrame(const CameraView& camera);
+    bool nextBatch(void);
+    F32  traceBatch(void);       // launch time in seconds
+    int  getTotalNumRays(void);  // for the selected ray type, excluding degenerates
+    RayBuffer& getPrimaryRays(void) { return m_primaryRays; }
+    RayBuffer* getBatchRays(void) { return m_batchRays; }
+
+private:
+    Renderer(const Renderer&);
+    Renderer& operator=(const Renderer&);
+
+    String             m_builder;
+    Platform           m_platform;
+    BVH::BuildParams   m_buildParams;
+    RayGen             m_raygen;
+    Params             m_params;
+    bool               m_enableRandom;
+    Scene*             m_scene;
+    F32                m_cameraFar;
+    RayBuffer          m_primaryRays;
+    RayBuffer          m_secondaryRays;
+    bool               m_newBatch;
+    RayBuffer*         m_batchRays;
+    S32                m_batchStart;
+    CudaAS*            m_accelStruct;
+    CudaVirtualTracer* m_cudaTracer;
+};
+
+}  // namespace FW

@@ -1,0 +1,248 @@
+// host_test.cpp -- exercises the C++ host mirror (ntrace_amd/host) the way NTrace's own code uses
+// the reference classes.  `host_test cpu` needs no GPU; `host_test gpu` runs the device paths.
+// Compiled with plain g++ against libntrace_amd.so: the mirror's headers contain no HIP types.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <vector>
+
+#include "HLBVHBuilder.hpp"
+#include "Random.hpp"
+#include "Renderer.hpp"
+
+using namespace FW;
+
+static int g_failed = 0;
+#define CHECK(X) do { if (!(X)) { std::printf("CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #X); g_failed++; } } while (0)
+
+// A room of 6 tessellated walls with a few boxes: nTess^2 * 2 triangles per face.
+static void makeScene(std::vector<Vec3i>& tris, std::vector<Vec3f>& verts, int nTess)
+{
+    auto quad = [&](Vec3f p0, Vec3f du, Vec3f dv) {
+        int base = (int)verts.size();
+        for (int i = 0; i <= nTess; i++)
+            for (int j = 0; j <= nTess; j++) verts.push_back(p0 + du * ((F32)i / nTess) + dv * ((F32)j / nTess));
+        for (int i = 0; i < nTess; i++)
+            for (int j = 0; j < nTess; j++) {
+                int a = base + i * (nTess + 1) + j, b = a + nTess + 1;
+                tris.push_back(Vec3i(a, b, b + 1));
+                tris.push_back(Vec3i(a, b + 1, a + 1));
+            }
+    };
+    auto box = [&](Vec3f lo, Vec3f hi) {
+        Vec3f d = hi - lo;
+        quad(lo, Vec3f(d.x, 0, 0), Vec3f(0, d.y, 0));
+        quad(Vec3f(lo.x, lo.y, hi.z), Vec3f(d.x, 0, 0), Vec3f(0, d.y, 0));
+        quad(lo, Vec3f(d.x, 0, 0), Vec3f(0, 0, d.z));
+        quad(Vec3f(lo.x, hi.y, lo.z), Vec3f(d.x, 0, 0), Vec3f(0, 0, d.z));
+        quad(lo, Vec3f(0, d.y, 0), Vec3f(0, 0, d.z));
+        quad(Vec3f(hi.x, lo.y, lo.z), Vec3f(0, d.y, 0), Vec3f(0, 0, d.z));
+    };
+    box(Vec3f(-10.5f, -10.25f, -10.75f), Vec3f(10.25f, 10.5f, 10.125f));
+    box(Vec3f(-3.5f, -10.25f, 1.5f), Vec3f(0.5f, -4.0f, 5.25f));
+    box(Vec3f(2.25f, -10.25f, -2.0f), Vec3f(5.0f, -1.5f, 1.75f));
+}
+
+static CameraView makeCamera(int w, int h)
+{
+    CameraView c;
+    c.position = Vec3f(0.3f, 0.7f, -9.0f);
+    const float th = std::tan(0.5f), aspect = (float)w / h;
+    // pinhole looking down +z: world = position + (0,0,1) + nx*th*aspect*(1,0,0) - ny*th*(0,1,0)
+    const float m[16] = {th * aspect, 0, 0, c.position.x, 0, -th, 0, c.position.y, 0, 0, 0, c.position.z + 1.0f, 0, 0, 0, 1};
+    std::memcpy(c.nscreenToWorld.m, m, sizeof(m));
+    c.cameraFar = 100.0f;
+    c.width = w;
+    c.height = h;
+    return c;
+}
+
+static void cpuTests()
+{
+    // Buffer: CPU-only use never touches the device
+    Buffer b;
+    b.resize(64);
+    std::memset(b.getMutablePtr(), 7, 64);
+    b.resize(128);  // keeps contents
+    CHECK(b.getSize() == 128 && b.getPtr()[63] == 7);
+    b.resizeDiscard(16);
+    CHECK(b.getSize() == 16 && b.getOwner() == Buffer::Module_None);
+    int ext[4] = {1, 2, 3, 4};
+    Buffer wrap;
+    wrap.wrapCPU(ext, sizeof(ext));
+    ((int*)wrap.getMutablePtr())[2] = 9;
+    CHECK(ext[2] == 9);
+
+    // RayBuffer: resize never shrinks allocations; id <-> slot maps (RayBuffer.cpp:38-65)
+    RayBuffer rb(8);
+    Ray r;
+    r.origin = Vec3f(1, 2, 3);
+    r.tmax = 5.0f;
+    rb.setRay(3, r, 5);
+    CHECK(rb.getSlotForID(5) == 3 && rb.getIDForSlot(3) == 5 && rb.getRayForID(5).tmax == 5.0f);
+    rb.resize(4);
+    CHECK(rb.getSize() == 4 && rb.getRayBuffer().getSize() == 8 * (S64)sizeof(Ray));
+    Ray d;
+    d.tmin = 2.0f;
+    d.degenerate();
+    CHECK(d.tmax == 1.0f);
+    RayResult rr;
+    CHECK(!rr.hit());
+
+    // RANROT-A: deterministic, seed 0 == seed 0xFFFFFFFF (Random.cpp:61-62)
+    CHECK(Random(0).getU32() == Random(0xFFFFFFFFu).getU32());
+    CHECK(Random(1).getU32() != Random(2).getU32());
+    Random a(42), a2(42);
+    bool same = true;
+    for (int i = 0; i < 100; i++) same = same && (a.getU32() == a2.getU32());
+    CHECK(same);
+
+    // host SAH build -> Compact, serialisation round trip in the bvhcache format
+    std::vector<Vec3i> tris;
+    std::vector<Vec3f> verts;
+    makeScene(tris, verts, 4);
+    Scene scene((S32)tris.size(), tris.data(), (S32)verts.size(), verts.data());
+    Platform platform("GPU");
+    platform.setLeafPreferences(1, 1);
+    BVH::Stats stats;
+    BVH::BuildParams params;
+    params.stats = &stats;
+    BVH bvh(&scene, platform, params);
+    CHECK(stats.numLeafNodes == (S32)tris.size() && stats.numInnerNodes == stats.numLeafNodes - 1 && stats.maxDepth <= 64);
+    CudaBVH cbvh(bvh, BVHLayout_Compact);
+    CHECK(cbvh.getNodeBuffer().getSize() == (S64)stats.numInnerNodes * 64);
+    CHECK(cbvh.getTriWoopBuffer().getSize() == (S64)(tris.size() * 3 + stats.numLeafNodes) * 16);
+    CHECK(cbvh.getTriIndexBuffer().getSize() * 4 == cbvh.getTriWoopBuffer().getSize());
+    std::stringstream ss;
+    cbvh.serialize(ss);
+    CudaBVH back(ss);
+    CHECK(!hasError() && back.getLayout() == BVHLayout_Compact);
+    CHECK(back.getNodeBuffer().getSize() == cbvh.getNodeBuffer().getSize() &&
+          std::memcmp(back.getNodeBuffer().getPtr(), cbvh.getNodeBuffer().getPtr(), (size_t)cbvh.getNodeBuffer().getSize()) == 0);
+    CHECK(std::memcmp(back.getTriWoopBuffer().getPtr(), cbvh.getTriWoopBuffer().getPtr(), (size_t)cbvh.getTriWoopBuffer().getSize()) == 0);
+    bool threw = false;
+    try { BVH::BuildParams p2; p2.builder = "Nope"; BVH bad(&scene, platform, p2); } catch (const FatalError&) { threw = true; }
+    CHECK(threw);
+
+    // tracer front end: argument checks that precede device work (CudaBVHTracer.cpp:92-100)
+    CudaBVHTracer tracer;
+    tracer.setKernel("kepler_dynamic_fetch");
+    CHECK(tracer.getDesiredBVHLayout() == BVHLayout_Compact && tracer.getKernelConfig().usePersistentThreads == 1);
+    RayBuffer empty(0);
+    CHECK(tracer.traceBatch(empty) == 0.0f);
+    threw = false;
+    try { RayBuffer one(1); tracer.traceBatch(one); } catch (const FatalError& e) { threw = e.message.find("No BVH") != std::string::npos; }
+    CHECK(threw);
+    threw = false;
+    try { tracer.setKernel("no_such_kernel"); } catch (const FatalError&) { threw = true; }
+    CHECK(threw);
+    // sticky error model (Defs.hpp:142-151)
+    clearError();
+    setError("first %d", 1);
+    setError("second");
+    CHECK(hasError() && getError() == "first 1");
+    clearError();
+    CHECK(!hasError());
+}
+
+static void gpuTests()
+{
+    std::vector<Vec3i> tris;
+    std::vector<Vec3f> verts;
+    makeScene(tris, verts, 24);
+    Scene scene((S32)tris.size(), tris.data(), (S32)verts.size(), verts.data());
+    const int W = 320, H = 200;
+    CameraView cam = makeCamera(W, H);
+
+    std::vector<RayResult> prim[2];
+    int b = 0;
+    for (const char* builder : {"SAHBVH", "HLBVH"}) {
+        Renderer renderer(builder);
+        renderer.setScene(&scene);
+        for (const char* kernel : {"fermi_speculative_while_while", "kepler_dynamic_fetch"}) {
+            Renderer::Params p;
+            p.kernelName = kernel;
+            p.rayType = Renderer::RayType_Primary;
+            renderer.setParams(p);
+            renderer.beginFrame(cam);
+            CHECK(renderer.getTotalNumRays() == W * H);
+            int batches = 0;
+            F32 sec = 0.0f;
+            while (renderer.nextBatch()) { sec += renderer.traceBatch(); batches++; }
+            CHECK(batches == 1 && sec > 0.0f);
+            RayBuffer& rays = renderer.getPrimaryRays();
+            int hits = 0;
+            prim[b].resize(W * H);
+            for (int i = 0; i < W * H; i++) {
+                prim[b][i] = rays.getResultForSlot(i);  // D->H migration through Buffer
+                hits += prim[b][i].hit();
+            }
+            CHECK(hits == W * H);  // closed room: every primary ray hits
+            CHECK(rays.getIDForSlot(rays.getSlotForID(1234)) == 1234);
+
+            // AO: 8 samples, <= 2^20 rays per batch (Renderer.cpp:45), any-hit
+            p.rayType = Renderer::RayType_AO;
+            p.numSamples = 8;
+            p.aoRadius = 2.0f;
+            renderer.setParams(p);
+            renderer.beginFrame(cam);
+            CHECK(renderer.getTotalNumRays() == W * H * 8);
+            S64 traced = 0;
+            batches = 0;
+            while (renderer.nextBatch()) {
+                CHECK(!renderer.getBatchRays()->getNeedClosestHit() && renderer.getBatchRays()->getSize() <= (1 << 20));
+                renderer.traceBatch();
+                traced += renderer.getBatchRays()->getSize();
+                batches++;
+            }
+            CHECK(traced == (S64)W * H * 8 && batches == 1);
+            // diffuse: same generator, closest hit, camera-far length (Renderer.cpp:533-537)
+            p.rayType = Renderer::RayType_Diffuse;
+            renderer.setParams(p);
+            renderer.beginFrame(cam);
+            while (renderer.nextBatch()) {
+                CHECK(renderer.getBatchRays()->getNeedClosestHit());
+                renderer.traceBatch();
+            }
+        }
+        b++;
+    }
+    // the two builders give the same visible triangle almost everywhere (Woop rows differ in the last bits)
+    int sameId = 0;
+    double maxRel = 0;
+    for (int i = 0; i < W * H; i++) {
+        sameId += prim[0][i].id == prim[1][i].id;
+        maxRel = std::fmax(maxRel, std::fabs(prim[0][i].t - prim[1][i].t) / prim[0][i].t);
+    }
+    CHECK(sameId > W * H * 0.995 && maxRel < 1e-4);
+
+    // layout mismatch is fatal (CudaBVHTracer.cpp:99-100)
+    {
+        HLBVHParams hp;
+        HLBVHBuilder lb(&scene, Platform("GPU"), hp);
+        CHECK(lb.getGPUTime() > 0.0f && lb.getNodeBuffer().getSize() == lb.getBuildResult().nodesBytes);
+        struct WrongLayout : CudaBVH { WrongLayout() : CudaBVH(BVHLayout_AOS_AOS) {} } wrong;
+        CudaBVHTracer t;
+        t.setKernel("fermi_speculative_while_while");
+        t.setBVH(&wrong);
+        RayBuffer one(1);
+        bool threw = false;
+        try { t.traceBatch(one); } catch (const FatalError& e) { threw = e.message.find("Incorrect BVH layout") != std::string::npos; }
+        CHECK(threw);
+    }
+}
+
+int main(int argc, char** argv)
+{
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    try {
+        if (gpu) gpuTests(); else cpuTests();
+    } catch (const FatalError& e) {
+        std::printf("unexpected FW::fail: %s\n", e.message.c_str());
+        return 2;
+    }
+    std::printf("host_test %s: %s\n", gpu ? "gpu" : "cpu", g_failed ? "FAILED" : "ok");
+    return g_failed ? 1 : 0;
+}
