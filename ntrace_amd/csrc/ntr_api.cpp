@@ -243,6 +243,11 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.bvhFlags = bvhFlags;
     p.coop = env_int("NTR_TRACE_COOP", 0);
     p.stats = ds->stats;
+    p.timeline = nullptr;
+    {   // diagnostic: NTR_TRACE_TIMELINE=<hex device pointer> (scripts/timeline*.py)
+        const char* tl = getenv("NTR_TRACE_TIMELINE");
+        if (tl && *tl) p.timeline = (unsigned long long*)strtoull(tl, nullptr, 16);
+    }
     int variant = k->variant;
     if (stats) {
         // RayStats counters (src/rt/bvh/BVH.hpp:44-, filled at CudaBVH.cpp:746-757,1107-1111) are

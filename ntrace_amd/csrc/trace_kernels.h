@@ -39,6 +39,7 @@ struct TraceParams {
     int32_t fetchThreshold;  // persistent: refill when fewer lanes are live
     uint32_t bvhFlags;
     int32_t coop;            // quad-cooperative LDS-DMA node fetch instead of per-lane loads
+    unsigned long long* timeline;  // diagnostic: per-wave realtime stamps (scripts/timeline*.py), or null
     unsigned long long* stats;  // STATS variant: {innerVisits, triTests, leafVisits, hits}
 };
 

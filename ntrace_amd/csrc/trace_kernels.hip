@@ -187,23 +187,31 @@ typedef __attribute__((address_space(3))) int lds_int;
 
 struct LaneStack {
     lds_int* lds;  // &s_stack[wave][0][lane]
-    int sp;
+    int sp;        // entries held in memory (LDS, then scratch)
+    int tos;       // top of the stack, kept in a register: a pop hands out the next node without
+                   // waiting for LDS; the entry below it is fetched off the critical path
 };
 
-#define NTR_STACK_RESET(st) do { (st).sp = 1; (st).lds[0] = kSentinel; } while (0)
+#define NTR_STACK_RESET(st) do { (st).sp = 0; (st).tos = kSentinel; } while (0)
 
 __device__ __forceinline__ void stack_push(LaneStack& st, int (&spill)[SPILL_DEPTH], int v, unsigned int* status)
 {
-    if (__builtin_expect(st.sp < LDS_DEPTH, 1)) st.lds[st.sp * 64] = v;
-    else if (st.sp < LDS_DEPTH + SPILL_DEPTH) spill[st.sp - LDS_DEPTH] = v;
+    if (__builtin_expect(st.sp < LDS_DEPTH, 1)) st.lds[st.sp * 64] = st.tos;
+    else if (st.sp < LDS_DEPTH + SPILL_DEPTH) spill[st.sp - LDS_DEPTH] = st.tos;
     else { atomicOr(status, NTR_STATUS_STACK_OVERFLOW); return; }
     st.sp++;
+    st.tos = v;
 }
 __device__ __forceinline__ int stack_pop(LaneStack& st, int (&spill)[SPILL_DEPTH])
 {
-    st.sp--;
-    if (__builtin_expect(st.sp < LDS_DEPTH, 1)) return st.lds[st.sp * 64];
-    return spill[st.sp - LDS_DEPTH];
+    const int r = st.tos;
+    if (st.sp > 0) {
+        st.sp--;
+        st.tos = __builtin_expect(st.sp < LDS_DEPTH, 1) ? st.lds[st.sp * 64] : spill[st.sp - LDS_DEPTH];
+    } else {
+        st.tos = kSentinel;
+    }
+    return r;
 }
 
 // Keeps a loaded value live at this point so that hipcc cannot sink its load into a later
@@ -396,6 +404,9 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     const Rsrc nodes = make_rsrc(p.nodes, p.nodesBytes), woop = make_rsrc(p.woop, p.woopBytes);
     lds_char* stage = (lds_char*)&s_stage[__builtin_amdgcn_readfirstlane(wave)][0];
 
+    unsigned long long tl0 = 0;
+    if (p.timeline) tl0 = __builtin_amdgcn_s_memrealtime();  // diagnostic only (NTR_TRACE_TIMELINE)
+
     RayRegs r;
     load_ray(p.rays, valid ? rayIdx : 0, r);
     LaneStack st;
@@ -414,6 +425,12 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     if (fastWave) traverse<true, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0);
     else traverse<false, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0);
 
+    if (p.timeline && lane == 0) {
+        const unsigned int w = blockIdx.x * WAVES + wave;
+        p.timeline[3 * w + 0] = tl0;
+        p.timeline[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
+        p.timeline[3 * w + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+    }
     if (!valid) return;
     store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
     if (STATS) {  // diagnostics variant only: plain per-lane atomics
@@ -445,6 +462,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     int spill[SPILL_DEPTH];
     st.lds = (lds_int*)&s_stack[wave][0][lane];
     st.sp = 0;
+    st.tos = kSentinel;
 
     RayRegs r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int node = kSentinel, rayIdx = -1, hitAddr = -1;
@@ -457,11 +475,17 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     int shardTries = 0;
     LaneStats ls = {0u, 0u, 0u};
 
+    // diagnostic stamps (NTR_TRACE_TIMELINE): wave start, end, cycles spent refilling, refill count
+    unsigned long long tlStart = 0, tlRefill = 0, tlCount = 0, tlRays = 0;
+    if (p.timeline) tlStart = __builtin_amdgcn_s_memrealtime();
+
     // Invariant at the top of the loop: a lane either holds a live ray
     // (rayIdx >= 0, node != sentinel) or is empty (rayIdx < 0, node == sentinel).
     for (;;) {
         // ---- refill empty lanes from the wave's chunk ----------------------------
         unsigned long long empty = __ballot(rayIdx < 0);
+        unsigned long long tlA = 0;
+        if (p.timeline) { tlA = __builtin_amdgcn_s_memtime(); tlCount++; tlRays += __popcll(empty); }
         while (empty != 0ull && !poolEmpty) {
             if (chunkNext >= chunkEnd) {  // wave-uniform: grab the next chunk
                 // The ray index space is cut into 8 contiguous ranges with one pool head each
@@ -505,6 +529,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
             empty = __ballot(rayIdx < 0);
         }
 
+        if (p.timeline) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tlRefill += __builtin_amdgcn_s_memtime() - tlA; }
         // ---- while-while traversal ------------------------------------------------
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
         if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold);
@@ -516,6 +541,15 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
             rayIdx = -1;
         }
         if (poolEmpty && __ballot(rayIdx >= 0) == 0ull) break;
+    }
+    if (p.timeline && lane == 0) {
+        const unsigned int w = blockIdx.x * WAVES + wave;
+        p.timeline[6 * w + 0] = tlStart;
+        p.timeline[6 * w + 1] = __builtin_amdgcn_s_memrealtime();
+        p.timeline[6 * w + 2] = tlRefill;
+        p.timeline[6 * w + 3] = tlCount;
+        p.timeline[6 * w + 4] = tlRays;
+        p.timeline[6 * w + 5] = __builtin_amdgcn_s_memtime();
     }
 }
 
