@@ -217,6 +217,22 @@ NTR_API int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_
                            void* d_nodes, int64_t nodesCapacity, void* d_triWoop, int64_t triWoopCapacity,
                            int32_t* d_triIndex, int64_t triIndexCapacity, NtrLbvhResult* result, void* stream);
 
+/* reconstructKernel (src/rt/cuda/RendererKernels.cu:59-172; ReconstructInput, RendererKernels.hpp:46-70;
+ * Renderer::updateResult, Renderer.cpp:583-659): hit records of one batch -> ABGR8 pixels.
+ * rayType 0 = primary, 1 = AO, 2 = diffuse (textured / path-traced / VPL shading: out of scope). */
+NTR_API int ntr_reconstruct(int32_t rayType, int32_t numRaysPerPrimary, int32_t firstPrimary, int32_t numPrimary,
+                            const int32_t* d_primarySlotToID, const NtrRayResult* d_primaryResults,
+                            const int32_t* d_batchIDToSlot, const NtrRayResult* d_batchResults,
+                            const uint32_t* d_triMaterialColor, const uint32_t* d_triShadedColor,
+                            uint32_t* d_pixels, void* stream);
+
+/* RayBuffer::mortonSort (src/rt/ray/RayBuffer.cpp:103-165; kernels RayBufferKernels.cu:70-197): reorder a
+ * batch by the 192-bit origin/direction Morton key.  The reference sorts the keys on the CPU; here the
+ * whole pipeline runs on the device.  Ties keep their original slot order.  Out-of-place. Blocking. */
+NTR_API int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* d_inSlotToID,
+                                NtrRay* d_outRays, int32_t* d_outIDToSlot, int32_t* d_outSlotToID,
+                                void* stream, float* seconds);
+
 /* ---- host-side BVH production (no device work) ---------------------------- */
 
 /* Host SAH build + Compact flatten: `BVH bvh(scene, platform, params);

@@ -89,6 +89,8 @@ SYMBOLS = [
     ("ntr_lbvh_capacity", C.c_int, [_i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     ("ntr_lbvh_build", C.c_int, [_i32, _vp, _i32, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i32, C.c_float,
                                  _vp, _i64, _vp, _i64, _vp, _i64, C.POINTER(LbvhResult), _vp]),
+    ("ntr_reconstruct", C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("ntr_ray_morton_sort", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float)]),
     ("ntr_sah_build", C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
     ("ntr_host_bvh_info", C.c_int, [_vp, C.POINTER(_HostBvhInfo)]),
     ("ntr_host_bvh_free", None, [_vp]),
@@ -184,6 +186,21 @@ def count_hits(d_results, num_rays, stream=0):
     cnt = _i32(0)
     _check(lib().ntr_count_hits(_vp(d_results), int(num_rays), C.byref(cnt), _vp(stream)))
     return int(cnt.value)
+
+
+def reconstruct(ray_type, rays_per_primary, first_primary, num_primary, d_primary_slot_to_id, d_primary_results,
+                d_batch_id_to_slot, d_batch_results, d_tri_material_color, d_tri_shaded_color, d_pixels, stream=0):
+    _check(lib().ntr_reconstruct(int(ray_type), int(rays_per_primary), int(first_primary), int(num_primary),
+                                 _vp(d_primary_slot_to_id), _vp(d_primary_results), _vp(d_batch_id_to_slot),
+                                 _vp(d_batch_results), _vp(d_tri_material_color), _vp(d_tri_shaded_color), _vp(d_pixels),
+                                 _vp(stream)))
+
+
+def ray_morton_sort(num_rays, d_in_rays, d_in_slot_to_id, d_out_rays, d_out_id_to_slot, d_out_slot_to_id, stream=0):
+    sec = C.c_float(0.0)
+    _check(lib().ntr_ray_morton_sort(int(num_rays), _vp(d_in_rays), _vp(d_in_slot_to_id), _vp(d_out_rays),
+                                     _vp(d_out_id_to_slot), _vp(d_out_slot_to_id), _vp(stream), C.byref(sec)))
+    return float(sec.value)
 
 
 def lbvh_capacity(num_tris):

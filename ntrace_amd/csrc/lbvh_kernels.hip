@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include "ntr_internal.h"
+#include "radix_sort.h"
 
 namespace ntr {
 
@@ -95,111 +96,6 @@ __global__ __launch_bounds__(256) void lbvh_woop_kernel(int n, const int* __rest
     out[3 * t + 0] = make_float4(o0x, i2y, i2z, o0w);
     out[3 * t + 1] = make_float4(i0x, i0y, i0z, o1w);
     out[3 * t + 2] = make_float4(i1x, i1y, i1z, o2w);
-}
-
-// ---- LSD radix sort, 8 bits per pass ------------------------------------------------------------
-static constexpr int SORT_THREADS = 256;
-static constexpr int SORT_ITEMS = 8;
-static constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // keys per workgroup
-
-__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(int n, const unsigned int* __restrict__ keys, int shift,
-                                                                 unsigned int* __restrict__ hist, int numBlocks)
-{
-    __shared__ unsigned int s_hist[256];
-    s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    const int base = blockIdx.x * SORT_TILE;
-#pragma unroll
-    for (int i = 0; i < SORT_ITEMS; i++) {
-        const int k = base + i * SORT_THREADS + threadIdx.x;
-        if (k < n) atomicAdd(&s_hist[(keys[k] >> shift) & 255], 1u);
-    }
-    __syncthreads();
-    hist[threadIdx.x * numBlocks + blockIdx.x] = s_hist[threadIdx.x];  // digit-major
-}
-
-// Exclusive scan of `count` unsigned ints by one workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void sort_scan_kernel(unsigned int* __restrict__ data, int count)
-{
-    __shared__ unsigned int s_part[1024];
-    const int per = (count + 1023) / 1024;
-    const int beg = min(threadIdx.x * per, count), end = min(beg + per, count);
-    unsigned int sum = 0;
-    for (int i = beg; i < end; i++) sum += data[i];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        const unsigned int v = (threadIdx.x >= off) ? s_part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned int run = s_part[threadIdx.x] - sum;  // exclusive prefix of this thread's chunk
-    for (int i = beg; i < end; i++) {
-        const unsigned int v = data[i];
-        data[i] = run;
-        run += v;
-    }
-}
-
-// Stable scatter.  Wave w of a workgroup owns SORT_ITEMS rounds of 64 consecutive keys; inside a
-// round the lanes holding the same digit are found with 8 ballots (match-any) and ranked with a
-// prefix popcount, rounds are chained through per-wave LDS counters, waves through a small scan.
-__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(int n, const unsigned int* __restrict__ keysIn,
-                                                                    const int* __restrict__ valsIn,
-                                                                    unsigned int* __restrict__ keysOut, int* __restrict__ valsOut,
-                                                                    int shift, const unsigned int* __restrict__ hist, int numBlocks)
-{
-    constexpr int WAVES = SORT_THREADS / 64;
-    __shared__ unsigned int s_cnt[WAVES][256];
-    __shared__ unsigned int s_base[WAVES][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < WAVES * 256; i += SORT_THREADS) (&s_cnt[0][0])[i] = 0;
-    __syncthreads();
-
-    const int chunk = blockIdx.x * SORT_TILE + wave * (64 * SORT_ITEMS);
-    unsigned int key[SORT_ITEMS], rank[SORT_ITEMS];
-    int val[SORT_ITEMS];
-    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; r++) {
-        const int k = chunk + r * 64 + lane;
-        const bool valid = k < n;
-        key[r] = valid ? keysIn[k] : 0xFFFFFFFFu;
-        val[r] = valid ? valsIn[k] : 0;
-        const unsigned int d = (key[r] >> shift) & 255;
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1;
-            const unsigned long long bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
-        const unsigned int before = s_cnt[wave][d];  // same address for all peers (broadcast)
-        rank[r] = before + __popcll(peers & ltMask);
-        if (valid && (peers & ltMask) == 0ull) s_cnt[wave][d] = before + __popcll(peers);  // lowest peer lane
-    }
-    __syncthreads();
-    {   // digit threadIdx.x: offsets of the waves and the global base of this tile
-        const unsigned int d = threadIdx.x;
-        unsigned int run = hist[d * numBlocks + blockIdx.x];
-#pragma unroll
-        for (int w = 0; w < WAVES; w++) {
-            s_base[w][d] = run;
-            run += s_cnt[w][d];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; r++) {
-        const int k = chunk + r * 64 + lane;
-        if (k < n) {
-            const unsigned int d = (key[r] >> shift) & 255;
-            const unsigned int dst = s_base[wave][d] + rank[r];
-            keysOut[dst] = key[r];
-            valsOut[dst] = val[r];
-        }
-    }
 }
 
 // ---- tree emission, one level per launch (emitTreeKernel.cu:233-381) ------------------------------
@@ -425,10 +321,11 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     int *vIn = (int*)idxA.p, *vOut = (int*)idxB.p;
     for (int pass = 0; pass < 4; pass++) {
         const int shift = pass * 8;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, shift, (unsigned int*)hist.p, nb);
+        hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, 1, shift,
+                           (unsigned int*)hist.p, nb);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, (unsigned int*)hist.p, nb * 256);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, vIn, kOut, vOut, shift,
-                           (const unsigned int*)hist.p, nb);
+        hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, kOut, vOut, 1,
+                           shift, (const unsigned int*)hist.p, nb);
         unsigned int* tk = kIn; kIn = kOut; kOut = tk;
         int* tv = vIn; vIn = vOut; vOut = tv;
     }

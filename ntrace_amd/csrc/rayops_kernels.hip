@@ -1,0 +1,233 @@
+// rayops_kernels.hip -- the callers on either side of the tracer:
+//   reconstructKernel    src/rt/cuda/RendererKernels.cu:59-172 (primary / AO / diffuse branches;
+//                        textured, path-traced and VPL shading are out of scope)
+//   secondary-ray sort   src/rt/ray/RayBuffer.cpp:103-165 + RayBufferKernels.cu:70-197:
+//                        findAABB -> 192-bit Morton keys -> sort -> reorder.  The reference sorts the
+//                        keys on the CPU (RayBuffer.cpp:149); here the sort is the LSD radix sort of
+//                        radix_sort.h over an index array (19 passes cover the 150 significant bits).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#include "ntr_internal.h"
+#include "radix_sort.h"
+
+namespace ntr {
+
+// ---- reconstructKernel ---------------------------------------------------------------------------
+struct Col { float x, y, z, w; };
+__device__ __forceinline__ Col from_abgr(uint32_t c)  // RendererKernels.cu:37-44
+{
+    return {(float)(c & 0xFF) * (1.0f / 255.0f), (float)((c >> 8) & 0xFF) * (1.0f / 255.0f),
+            (float)((c >> 16) & 0xFF) * (1.0f / 255.0f), (float)(c >> 24) * (1.0f / 255.0f)};
+}
+__device__ __forceinline__ uint32_t to_abgr(Col v)    // RendererKernels.cu:48-55
+{
+    return (uint32_t)(fminf(fmaxf(v.x, 0.0f), 1.0f) * 255.0f) | ((uint32_t)(fminf(fmaxf(v.y, 0.0f), 1.0f) * 255.0f) << 8) |
+           ((uint32_t)(fminf(fmaxf(v.z, 0.0f), 1.0f) * 255.0f) << 16) | ((uint32_t)(fminf(fmaxf(v.w, 0.0f), 1.0f) * 255.0f) << 24);
+}
+
+__global__ __launch_bounds__(256) void reconstruct_kernel(int rayType, int numRaysPerPrimary, int firstPrimary, int numPrimary,
+                                                          const int* __restrict__ primarySlotToID,
+                                                          const NtrRayResult* __restrict__ primaryResults,
+                                                          const int* __restrict__ batchIDToSlot,
+                                                          const NtrRayResult* __restrict__ batchResults,
+                                                          const uint32_t* __restrict__ triMaterialColor,
+                                                          const uint32_t* __restrict__ triShadedColor, uint32_t* __restrict__ pixels)
+{
+    const int taskIdx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (taskIdx >= numPrimary) return;
+    const bool isPrimary = rayType == 0, isAO = rayType == 1, isDiffuse = rayType == 2;
+    const int primarySlot = firstPrimary + taskIdx;
+    const int primaryID = primarySlotToID[primarySlot];
+    const int primaryTri = primaryResults[primarySlot].id;
+    const int* batchSlots = batchIDToSlot + (isPrimary ? primaryID : taskIdx * numRaysPerPrimary);
+    const Col bg = {0.2f, 0.4f, 0.8f, 1.0f};
+
+    Col color = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < numRaysPerPrimary; i++) {
+        const int tri = batchResults[batchSlots[i]].id;
+        Col add;
+        if (tri == -1) add = isPrimary ? bg : Col{1.0f, 1.0f, 1.0f, 1.0f};
+        else if (isAO) add = Col{0.0f, 0.0f, 0.0f, 1.0f};
+        else add = from_abgr(triShadedColor[tri]);
+        color.x += add.x; color.y += add.y; color.z += add.z; color.w += add.w;
+    }
+    const float s = 1.0f / (float)numRaysPerPrimary;
+    color.x *= s; color.y *= s; color.z *= s; color.w *= s;
+    if (isAO && primaryTri == -1) color = bg;
+    if (isDiffuse) {
+        const Col m = (primaryTri == -1) ? bg : from_abgr(triMaterialColor[primaryTri]);
+        color.x *= m.x; color.y *= m.y; color.z *= m.z; color.w *= m.w;
+    }
+    pixels[primaryID] = to_abgr(color);
+}
+
+// ---- ray sort --------------------------------------------------------------------------------------
+// order-preserving float <-> uint mapping for atomicMin/Max on floats
+__device__ __forceinline__ unsigned int f2ord(float f) { unsigned int u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned int u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+// findAABBKernel (RayBufferKernels.cu:70-136): box of ray origins and end points origin + direction * tmax.
+__global__ __launch_bounds__(256) void ray_aabb_kernel(int n, const NtrRay* __restrict__ rays, unsigned int* __restrict__ box /* lo xyz, hi xyz (ordered uints) */)
+{
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 o = reinterpret_cast<const float4*>(rays)[2 * i], d = reinterpret_cast<const float4*>(rays)[2 * i + 1];
+        const float p[3] = {o.x, o.y, o.z}, e[3] = {o.x + d.x * d.w, o.y + d.y * d.w, o.z + d.z * d.w};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            lo[k] = fminf(fminf(lo[k], p[k]), e[k]);
+            hi[k] = fmaxf(fmaxf(hi[k], p[k]), e[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&box[k], f2ord(lo[k]));
+            atomicMax(&box[3 + k], f2ord(hi[k]));
+        }
+    }
+}
+
+__global__ void ray_aabb_decode_kernel(const unsigned int* __restrict__ box, float* __restrict__ out)
+{
+    if (threadIdx.x < 6) out[threadIdx.x] = ord2f(box[threadIdx.x]);
+}
+
+// genMortonKeysKernel (RayBufferKernels.cu:140-175): 6 x 32 bits interleaved (component c, bit i -> bit c + 6 i).
+__global__ __launch_bounds__(256) void ray_keys_kernel(int n, const NtrRay* __restrict__ rays, const float* __restrict__ box,
+                                                       unsigned int* __restrict__ keys /* 6 words per ray */, int* __restrict__ idx)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float4 o = reinterpret_cast<const float4*>(rays)[2 * t], d = reinterpret_cast<const float4*>(rays)[2 * t + 1];
+    const float ax = (o.x - box[0]) / (box[3] - box[0]), ay = (o.y - box[1]) / (box[4] - box[1]), az = (o.z - box[2]) / (box[5] - box[2]);
+    // normalize(v) = v * (1 * rcp(length(v)))  (Math.hpp:141-142)
+    const float inv = 1.0f * (1.0f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z));
+    const float bx = (d.x * inv + 1.0f) * 0.5f, by = (d.y * inv + 1.0f) * 0.5f, bz = (d.z * inv + 1.0f) * 0.5f;
+    const unsigned int c[6] = {(unsigned int)(ax * 256.0f * 65536.0f), (unsigned int)(ay * 256.0f * 65536.0f),
+                               (unsigned int)(az * 256.0f * 65536.0f), (unsigned int)(bx * 32.0f * 65536.0f),
+                               (unsigned int)(by * 32.0f * 65536.0f), (unsigned int)(bz * 32.0f * 65536.0f)};
+    unsigned int h[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int pos = k + i * 6;
+            h[pos >> 5] |= ((c[k] >> i) & 1u) << (pos & 31);
+        }
+#pragma unroll
+    for (int k = 0; k < 6; k++) keys[6 * t + k] = h[k];
+    idx[t] = t;
+}
+
+// reorderRaysKernel (RayBufferKernels.cu:179-197)
+__global__ __launch_bounds__(256) void ray_reorder_kernel(int n, const int* __restrict__ order, const NtrRay* __restrict__ inRays,
+                                                          const int* __restrict__ inSlotToID, NtrRay* __restrict__ outRays,
+                                                          int* __restrict__ outIDToSlot, int* __restrict__ outSlotToID)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int oldSlot = order[t];
+    const int id = inSlotToID[oldSlot];
+    reinterpret_cast<float4*>(outRays)[2 * t] = reinterpret_cast<const float4*>(inRays)[2 * oldSlot];
+    reinterpret_cast<float4*>(outRays)[2 * t + 1] = reinterpret_cast<const float4*>(inRays)[2 * oldSlot + 1];
+    outIDToSlot[id] = t;
+    outSlotToID[t] = id;
+}
+
+}  // namespace ntr
+
+using namespace ntr;
+
+namespace {
+struct DevMem {
+    void* p = nullptr;
+    ~DevMem() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+extern "C" {
+
+int ntr_reconstruct(int32_t rayType, int32_t numRaysPerPrimary, int32_t firstPrimary, int32_t numPrimary,
+                    const int32_t* d_primarySlotToID, const NtrRayResult* d_primaryResults, const int32_t* d_batchIDToSlot,
+                    const NtrRayResult* d_batchResults, const uint32_t* d_triMaterialColor, const uint32_t* d_triShadedColor,
+                    uint32_t* d_pixels, void* stream)
+{
+    if (rayType < 0 || rayType > 2 || numRaysPerPrimary < 1 || firstPrimary < 0 || numPrimary < 0)
+        return set_error(NTR_ERR_INVALID, "ntr_reconstruct: bad argument");
+    if (numPrimary == 0) return NTR_OK;
+    if (!d_primarySlotToID || !d_primaryResults || !d_batchIDToSlot || !d_batchResults || !d_pixels ||
+        (rayType == 2 && (!d_triMaterialColor || !d_triShadedColor)) || (rayType == 0 && !d_triShadedColor))
+        return set_error(NTR_ERR_INVALID, "ntr_reconstruct: null buffer");
+    hipLaunchKernelGGL(reconstruct_kernel, dim3((numPrimary + 255) / 256), dim3(256), 0, (hipStream_t)stream, rayType,
+                       numRaysPerPrimary, firstPrimary, numPrimary, d_primarySlotToID, d_primaryResults, d_batchIDToSlot,
+                       d_batchResults, d_triMaterialColor, d_triShadedColor, d_pixels);
+    NTR_HIP(hipGetLastError());
+    return NTR_OK;
+}
+
+int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* d_inSlotToID, NtrRay* d_outRays,
+                        int32_t* d_outIDToSlot, int32_t* d_outSlotToID, void* stream, float* seconds)
+{
+    if (seconds) *seconds = 0.0f;
+    if (numRays < 0) return set_error(NTR_ERR_INVALID, "ntr_ray_morton_sort: numRays < 0");
+    if (numRays == 0) return NTR_OK;
+    if (!d_inRays || !d_inSlotToID || !d_outRays || !d_outIDToSlot || !d_outSlotToID || d_inRays == d_outRays)
+        return set_error(NTR_ERR_INVALID, "ntr_ray_morton_sort: null or aliased buffer");
+    hipStream_t s = (hipStream_t)stream;
+    const int n = numRays, nb = (n + SORT_TILE - 1) / SORT_TILE;
+    DevMem keys, idxA, idxB, hist, box;
+    NTR_HIP(hipMalloc(&keys.p, (size_t)n * 24));
+    NTR_HIP(hipMalloc(&idxA.p, (size_t)n * 4));
+    NTR_HIP(hipMalloc(&idxB.p, (size_t)n * 4));
+    NTR_HIP(hipMalloc(&hist.p, (size_t)nb * 256 * 4));
+    NTR_HIP(hipMalloc(&box.p, 64));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (seconds) { NTR_HIP(hipEventCreate(&e0)); NTR_HIP(hipEventCreate(&e1)); NTR_HIP(hipEventRecord(e0, s)); }
+
+    unsigned int* ubox = (unsigned int*)box.p;
+    float* fbox = (float*)box.p + 8;
+    const unsigned int init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    NTR_HIP(hipMemcpyAsync(ubox, init, sizeof(init), hipMemcpyHostToDevice, s));
+    int blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ray_aabb_kernel, dim3(blocks), dim3(256), 0, s, n, d_inRays, ubox);
+    hipLaunchKernelGGL(ray_aabb_decode_kernel, dim3(1), dim3(64), 0, s, (const unsigned int*)ubox, fbox);
+    hipLaunchKernelGGL(ray_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_inRays, (const float*)fbox,
+                       (unsigned int*)keys.p, (int*)idxA.p);
+    // stable LSD sort of the index array by the 192-bit key: words 0..3 fully, word 4 bits 0..23
+    // (the highest set bit is 5 + 6*24 = 149: a* < 2^25, b* < 2^22); word 5 is always zero.
+    int *vIn = (int*)idxA.p, *vOut = (int*)idxB.p;
+    for (int word = 0; word < 5; word++)
+        for (int shift = 0; shift < (word == 4 ? 24 : 32); shift += 8) {
+            const unsigned int* kw = (const unsigned int*)keys.p + word;
+            hipLaunchKernelGGL(sort_hist_kernel<true>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kw, (const int*)vIn, 6, shift,
+                               (unsigned int*)hist.p, nb);
+            hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, (unsigned int*)hist.p, nb * 256);
+            hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kw, (const int*)vIn,
+                               (unsigned int*)nullptr, vOut, 6, shift, (const unsigned int*)hist.p, nb);
+            int* t = vIn; vIn = vOut; vOut = t;
+        }
+    hipLaunchKernelGGL(ray_reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, (const int*)vIn, d_inRays, d_inSlotToID,
+                       d_outRays, d_outIDToSlot, d_outSlotToID);
+    NTR_HIP(hipGetLastError());
+    if (seconds) {
+        NTR_HIP(hipEventRecord(e1, s));
+        NTR_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        NTR_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *seconds = ms * 1e-3f;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    NTR_HIP(hipStreamSynchronize(s));  // temporaries are freed on return
+    return NTR_OK;
+}
+
+}  // extern "C"

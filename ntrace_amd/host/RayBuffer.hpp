@@ -25,6 +25,9 @@ public:
     S32              getSlotForID(S32 id) const { return ((const S32*)m_IDToSlot.getPtr())[id]; }
     S32              getIDForSlot(S32 slot) const { return ((const S32*)m_slotToID.getPtr())[slot]; }
 
+    // RayBuffer::mortonSort (RayBuffer.cpp:103-165): reorder by the 192-bit origin/direction key, on the device
+    void mortonSort();
+
     void setNeedClosestHit(bool c) { m_needClosestHit = c; }
     bool getNeedClosestHit() const { return m_needClosestHit; }
 

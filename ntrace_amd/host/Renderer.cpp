@@ -91,7 +91,24 @@ bool Renderer::nextBatch(void)
     default:
         return false;
     }
+    // Renderer.cpp:559-563
+    if (m_params.sortSecondary && m_params.rayType != RayType_Primary) m_batchRays->mortonSort();
     return true;
+}
+
+void Renderer::updateResult(Buffer& pixels, Buffer& triMaterialColor, Buffer& triShadedColor)
+{
+    if (!m_batchRays) fail("Renderer::updateResult: no batch");
+    const int perPrimary = (m_params.rayType == RayType_Primary) ? 1 : m_params.numSamples;
+    int rc = ntr_reconstruct((int)m_params.rayType, perPrimary, m_batchStart / perPrimary, m_batchRays->getSize() / perPrimary,
+                             (const int32_t*)m_primaryRays.getSlotToIDBuffer().getCudaPtr(),
+                             (const NtrRayResult*)m_primaryRays.getResultBuffer().getCudaPtr(),
+                             (const int32_t*)m_batchRays->getIDToSlotBuffer().getCudaPtr(),
+                             (const NtrRayResult*)m_batchRays->getResultBuffer().getCudaPtr(),
+                             (const uint32_t*)triMaterialColor.getCudaPtr(), (const uint32_t*)triShadedColor.getCudaPtr(),
+                             (uint32_t*)pixels.getMutableCudaPtr(), NULL);
+    if (rc != NTR_OK) fail("Renderer::updateResult: %s", ntr_last_error());
+    if (ntr_stream_synchronize(NULL) != NTR_OK) fail("Renderer::updateResult: %s", ntr_last_error());
 }
 
 F32 Renderer::traceBatch(void)  // Renderer.cpp:568-579

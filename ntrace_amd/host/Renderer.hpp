@@ -48,6 +48,9 @@ public:
     bool nextBatch(void);
     F32  traceBatch(void);       // launch time in seconds
     int  getTotalNumRays(void);  // for the selected ray type, excluding degenerates
+    // Renderer::updateResult (Renderer.cpp:583-659): current batch -> ABGR8 pixels (width*height, by pixel id).
+    // Per-triangle colours replace Scene::getTriMaterialColorBuffer / getTriShadedColorBuffer.
+    void updateResult(Buffer& pixels, Buffer& triMaterialColor, Buffer& triShadedColor);
     RayBuffer& getPrimaryRays(void) { return m_primaryRays; }
     RayBuffer* getBatchRays(void) { return m_batchRays; }
 

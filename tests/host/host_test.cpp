@@ -198,6 +198,27 @@ static void gpuTests()
                 batches++;
             }
             CHECK(traced == (S64)W * H * 8 && batches == 1);
+            // sorted AO batches + image reconstruction: AO image = fraction of unoccluded samples
+            {
+                p.sortSecondary = true;
+                renderer.setParams(p);
+                renderer.beginFrame(cam);
+                Buffer pixels, matCol, shCol;
+                pixels.resizeDiscard((S64)W * H * 4);
+                pixels.clear(0);
+                std::vector<U32> cols(tris.size(), 0xFF8090A0u);
+                matCol.set(cols.data(), (S64)cols.size() * 4);
+                shCol.set(cols.data(), (S64)cols.size() * 4);
+                while (renderer.nextBatch()) { renderer.traceBatch(); renderer.updateResult(pixels, matCol, shCol); }
+                const U32* px = (const U32*)pixels.getPtr();
+                int grey = 0;
+                for (int i = 0; i < W * H; i++) {
+                    const U32 r = px[i] & 0xFF, g = (px[i] >> 8) & 0xFF, b2 = (px[i] >> 16) & 0xFF;
+                    grey += (r == g && g == b2 && (px[i] >> 24) == 0xFF);  // closed room: every pixel is an AO grey
+                }
+                CHECK(grey == W * H);
+                p.sortSecondary = false;
+            }
             // diffuse: same generator, closest hit, camera-far length (Renderer.cpp:533-537)
             p.rayType = Renderer::RayType_Diffuse;
             renderer.setParams(p);
