@@ -255,6 +255,24 @@ NTR_API int  ntr_sah_build(int32_t numTris, const int32_t* triVtxIndex /* 3 per 
 NTR_API int  ntr_host_bvh_info(const NtrHostBvh* bvh, NtrHostBvhInfo* info);
 NTR_API void ntr_host_bvh_free(NtrHostBvh* bvh);
 
+/* ---- scene ingest (host only) ----------------------------------------------- */
+
+/* CameraControls::decodeSignature / encodeSignature (src/framework/3d/CameraControls.cpp:342-399, 471-545):
+ * out = position[3], forward[3], up[3], speed, fov, near, far, keepAligned. */
+NTR_API int ntr_camera_decode(const char* signature, float out[16]);
+NTR_API int ntr_camera_reencode(const char* signature, char* out, int32_t outSize);
+/* invert(fitToView(-1, 2) * perspective * worldToCamera) of Renderer::beginFrame (Renderer.cpp:473-477),
+ * row-major, ready for ntr_raygen_primary. */
+NTR_API int ntr_camera_nscreen_to_world(const char* signature, int32_t viewW, int32_t viewH, float matrix[16],
+                                        float position[3], float* cameraFar);
+
+/* Wavefront OBJ import with the reference's vertex / triangle numbering
+ * (src/framework/io/MeshWavefrontIO.cpp:412-485, src/rt/Scene.cpp:101-136). */
+typedef struct NtrObjMesh NtrObjMesh;
+NTR_API int  ntr_obj_load(const char* path, NtrObjMesh** out, int32_t* numTris, int32_t* numVerts, int32_t* numSubmeshes);
+NTR_API int  ntr_obj_get(const NtrObjMesh* mesh, int32_t* triVtxIndex /* 3/tri */, float* vtxPos /* 3/vertex */);
+NTR_API void ntr_obj_free(NtrObjMesh* mesh);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,13 @@ SYMBOLS = [
                                  _vp, _i64, _vp, _i64, _vp, _i64, C.POINTER(LbvhResult), _vp]),
     ("ntr_reconstruct", C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("ntr_ray_morton_sort", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float)]),
+    ("ntr_camera_decode", C.c_int, [C.c_char_p, C.POINTER(C.c_float)]),
+    ("ntr_camera_reencode", C.c_int, [C.c_char_p, C.c_char_p, _i32]),
+    ("ntr_camera_nscreen_to_world", C.c_int, [C.c_char_p, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                              C.POINTER(C.c_float)]),
+    ("ntr_obj_load", C.c_int, [C.c_char_p, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    ("ntr_obj_get", C.c_int, [_vp, _vp, _vp]),
+    ("ntr_obj_free", None, [_vp]),
     ("ntr_sah_build", C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
     ("ntr_host_bvh_info", C.c_int, [_vp, C.POINTER(_HostBvhInfo)]),
     ("ntr_host_bvh_free", None, [_vp]),
@@ -218,6 +225,38 @@ def lbvh_build(num_tris, d_tri, num_verts, d_pos, scene_min, scene_max, leaf_siz
                                 float(epsilon), _vp(d_nodes), int(nodes_cap), _vp(d_woop), int(woop_cap), _vp(d_idx),
                                 int(idx_cap), C.byref(res), _vp(stream)))
     return res
+
+
+def camera_decode(signature):
+    out = (C.c_float * 16)()
+    _check(lib().ntr_camera_decode(signature.encode(), out))
+    v = list(out)
+    return dict(position=v[0:3], forward=v[3:6], up=v[6:9], speed=v[9], fov=v[10], near=v[11], far=v[12], keep_aligned=bool(v[13]))
+
+
+def camera_reencode(signature):
+    buf = C.create_string_buffer(256)
+    _check(lib().ntr_camera_reencode(signature.encode(), buf, 256))
+    return buf.value.decode()
+
+
+def camera_nscreen_to_world(signature, w, h):
+    m, p, f = (C.c_float * 16)(), (C.c_float * 3)(), C.c_float(0)
+    _check(lib().ntr_camera_nscreen_to_world(signature.encode(), int(w), int(h), m, p, C.byref(f)))
+    return np.array(list(m), dtype=np.float32).reshape(4, 4), np.array(list(p), dtype=np.float32), float(f.value)
+
+
+def obj_load(path):
+    """Returns (tri[int32 n,3], pos[float32 m,3], numSubmeshes) with the reference's numbering."""
+    h, nt_, nv, ns = _vp(), _i32(0), _i32(0), _i32(0)
+    _check(lib().ntr_obj_load(path.encode(), C.byref(h), C.byref(nt_), C.byref(nv), C.byref(ns)))
+    try:
+        tri = np.zeros((nt_.value, 3), dtype=np.int32)
+        pos = np.zeros((nv.value, 3), dtype=np.float32)
+        _check(lib().ntr_obj_get(h, tri.ctypes.data_as(_vp), pos.ctypes.data_as(_vp)))
+    finally:
+        lib().ntr_obj_free(h)
+    return tri, pos, int(ns.value)
 
 
 class BvhView:

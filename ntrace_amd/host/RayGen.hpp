@@ -10,6 +10,14 @@ struct Mat4f {
     F32 m[16];  // row-major
 };
 
+// What beginFrame needs from CameraControls / GLContext in the reference (Renderer.cpp:473-477).
+struct CameraView {
+    Vec3f position;
+    Mat4f nscreenToWorld;  // invert(fitToView * worldToClip)
+    F32   cameraFar;
+    S32   width, height;
+};
+
 class PixelTable {
 public:
     PixelTable(void) : m_size(0, 0) {}

@@ -10,14 +10,6 @@
 
 namespace FW {
 
-// What beginFrame needs from CameraControls / GLContext in the reference (Renderer.cpp:473-477).
-struct CameraView {
-    Vec3f position;
-    Mat4f nscreenToWorld;  // invert(fitToView * worldToClip)
-    F32   cameraFar;
-    S32   width, height;
-};
-
 class Renderer {
 public:
     enum RayType { RayType_Primary = 0, RayType_AO, RayType_Diffuse, RayType_Max };

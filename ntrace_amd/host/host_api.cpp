@@ -1,7 +1,11 @@
 // host_api.cpp -- C-ABI entry points that are pure host work (no device).
+#include <cstring>
 #include <new>
+#include <vector>
 
+#include "CameraControls.hpp"
 #include "CudaBVH.hpp"
+#include "MeshWavefrontIO.hpp"
 #include "bvh/BVH.hpp"
 #include "ntr_internal.h"
 
@@ -60,6 +64,84 @@ int ntr_host_bvh_info(const NtrHostBvh* bvh, NtrHostBvhInfo* info)
     info->buildSeconds = bvh->stats.buildTime;
     return NTR_OK;
 }
+
+int ntr_camera_decode(const char* signature, float out[16])
+{
+    if (!signature || !out) return ntr::set_error(NTR_ERR_INVALID, "ntr_camera_decode: null argument");
+    clearError();
+    CameraControls c;
+    c.decodeSignature(signature);
+    if (hasError()) { int rc = ntr::set_error(NTR_ERR_INVALID, "%s", getError().c_str()); clearError(); return rc; }
+    const float v[13] = {c.getPosition().x, c.getPosition().y, c.getPosition().z, c.getForward().x, c.getForward().y, c.getForward().z,
+                         c.getUp().x, c.getUp().y, c.getUp().z, c.getSpeed(), c.getFOV(), c.getNear(), c.getFar()};
+    memcpy(out, v, sizeof(v));
+    out[13] = c.getKeepAligned() ? 1.0f : 0.0f;
+    out[14] = out[15] = 0.0f;
+    return NTR_OK;
+}
+
+int ntr_camera_reencode(const char* signature, char* out, int32_t outSize)
+{
+    if (!signature || !out || outSize < 2) return ntr::set_error(NTR_ERR_INVALID, "ntr_camera_reencode: bad argument");
+    clearError();
+    CameraControls c;
+    c.decodeSignature(signature);
+    if (hasError()) { int rc = ntr::set_error(NTR_ERR_INVALID, "%s", getError().c_str()); clearError(); return rc; }
+    String s = c.encodeSignature();
+    if ((int)s.size() + 1 > outSize) return ntr::set_error(NTR_ERR_INVALID, "ntr_camera_reencode: buffer too small");
+    memcpy(out, s.c_str(), s.size() + 1);
+    return NTR_OK;
+}
+
+int ntr_camera_nscreen_to_world(const char* signature, int32_t viewW, int32_t viewH, float matrix[16], float position[3], float* cameraFar)
+{
+    if (!signature || !matrix || !position || !cameraFar || viewW < 1 || viewH < 1)
+        return ntr::set_error(NTR_ERR_INVALID, "ntr_camera_nscreen_to_world: bad argument");
+    clearError();
+    CameraControls c;
+    c.decodeSignature(signature);
+    if (hasError()) { int rc = ntr::set_error(NTR_ERR_INVALID, "%s", getError().c_str()); clearError(); return rc; }
+    CameraView v = c.getView(viewW, viewH);
+    memcpy(matrix, v.nscreenToWorld.m, sizeof(float) * 16);
+    position[0] = v.position.x; position[1] = v.position.y; position[2] = v.position.z;
+    *cameraFar = v.cameraFar;
+    return NTR_OK;
+}
+
+struct NtrObjMesh {
+    std::vector<Vec3i> tris;
+    WavefrontMesh mesh;
+};
+
+int ntr_obj_load(const char* path, NtrObjMesh** out, int32_t* numTris, int32_t* numVerts, int32_t* numSubmeshes)
+{
+    if (!path || !out) return ntr::set_error(NTR_ERR_INVALID, "ntr_obj_load: null argument");
+    *out = nullptr;
+    clearError();
+    NtrObjMesh* m = new NtrObjMesh();
+    if (!importWavefrontMesh(m->mesh, path)) {
+        int rc = ntr::set_error(NTR_ERR_INVALID, "%s", getError().c_str());
+        clearError();
+        delete m;
+        return rc;
+    }
+    m->mesh.flatten(m->tris);
+    if (numTris) *numTris = (int32_t)m->tris.size();
+    if (numVerts) *numVerts = (int32_t)m->mesh.vertices.size();
+    if (numSubmeshes) *numSubmeshes = (int32_t)m->mesh.submeshes.size();
+    *out = m;
+    return NTR_OK;
+}
+
+int ntr_obj_get(const NtrObjMesh* mesh, int32_t* triVtxIndex, float* vtxPos)
+{
+    if (!mesh) return ntr::set_error(NTR_ERR_INVALID, "ntr_obj_get: null mesh");
+    if (triVtxIndex) memcpy(triVtxIndex, mesh->tris.data(), mesh->tris.size() * sizeof(Vec3i));
+    if (vtxPos) memcpy(vtxPos, mesh->mesh.vertices.data(), mesh->mesh.vertices.size() * sizeof(Vec3f));
+    return NTR_OK;
+}
+
+void ntr_obj_free(NtrObjMesh* mesh) { delete mesh; }
 
 void ntr_host_bvh_free(NtrHostBvh* bvh)
 {
