@@ -300,7 +300,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     NTR_HIP(hipMalloc(&inWoop.p, (size_t)n * 48));
     NTR_HIP(hipMalloc(&q0.p, ((size_t)n + 2) * 12));
     NTR_HIP(hipMalloc(&q1.p, ((size_t)n + 2) * 12));
-    NTR_HIP(hipMalloc(&hist.p, (size_t)nb * 256 * 4));
+    NTR_HIP(hipMalloc(&hist.p, ((size_t)nb * 256 + 256) * 4));
     NTR_HIP(hipMalloc(&state.p, sizeof(LbvhState)));
 
     Timer tAll(s), tPhase(s);
@@ -323,9 +323,10 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         const int shift = pass * 8;
         hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, 1, shift,
                            (unsigned int*)hist.p, nb);
-        hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, (unsigned int*)hist.p, nb * 256);
+        hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(256), dim3(256), 0, s, (unsigned int*)hist.p, nb, (unsigned int*)hist.p + (size_t)nb * 256);
+        hipLaunchKernelGGL(sort_scan_totals_kernel, dim3(1), dim3(256), 0, s, (unsigned int*)hist.p + (size_t)nb * 256);
         hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, kOut, vOut, 1,
-                           shift, (const unsigned int*)hist.p, nb);
+                           shift, (const unsigned int*)hist.p, (const unsigned int*)hist.p + (size_t)nb * 256, nb);
         unsigned int* tk = kIn; kIn = kOut; kOut = tk;
         int* tv = vIn; vIn = vOut; vOut = tv;
     }

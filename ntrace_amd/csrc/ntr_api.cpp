@@ -242,6 +242,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", 40);
     p.bvhFlags = bvhFlags;
     p.coop = env_int("NTR_TRACE_COOP", 0);
+    p.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", 24);  // sweep: flat optimum 16..64 (scripts/trace_sweep.py)
     p.stats = ds->stats;
     p.timeline = nullptr;
     {   // diagnostic: NTR_TRACE_TIMELINE=<hex device pointer> (scripts/timeline*.py)

@@ -2,7 +2,7 @@
 // the LBVH builder (sort_by_key of Morton codes, radixSort.cu:22-50) and the ray sort (192-bit keys,
 // RayBuffer::mortonSort, src/rt/ray/RayBuffer.cpp:103-165).
 //   sort_hist_kernel     per-tile digit histogram in LDS -> hist[digit][tile]
-//   sort_scan_kernel     exclusive scan of the histogram array (one workgroup)
+//   sort_scan_*_kernel   exclusive scan of the histogram array (one workgroup per digit + one for the totals)
 //   sort_scatter_kernel  stable scatter: each wave ranks 64 keys per round with 8 ballots
 //                        (match-any) + prefix popcount; rounds chain through per-wave LDS counters
 // INDEXED = false: keys[i] is the key of element i, keys and values both move.
@@ -41,28 +41,49 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(int n, const un
     hist[threadIdx.x * numBlocks + blockIdx.x] = s_hist[threadIdx.x];  // digit-major
 }
 
-// Exclusive scan of `count` unsigned ints by one workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) static void sort_scan_kernel(unsigned int* __restrict__ data, int count)
+// Scan of the digit-major histogram hist[256][numBlocks] in two small parallel steps:
+//   sort_scan_rows_kernel    one workgroup per digit: exclusive prefix over the tiles, row total out
+//   sort_scan_totals_kernel  exclusive scan of the 256 row totals -> global base of every digit
+// (the scatter adds base[digit] to its tile's row prefix).
+__global__ __launch_bounds__(256) static void sort_scan_rows_kernel(unsigned int* __restrict__ hist, int numBlocks,
+                                                                    unsigned int* __restrict__ rowTotal)
 {
-    __shared__ unsigned int s_part[1024];
-    const int per = (count + 1023) / 1024;
-    const int beg = min((int)threadIdx.x * per, count), end = min(beg + per, count);
+    __shared__ unsigned int s_part[256];
+    unsigned int* row = hist + (size_t)blockIdx.x * numBlocks;
+    const int per = (numBlocks + 255) / 256;
+    const int beg = min((int)threadIdx.x * per, numBlocks), end = min(beg + per, numBlocks);
     unsigned int sum = 0;
-    for (int i = beg; i < end; i++) sum += data[i];
+    for (int i = beg; i < end; i++) sum += row[i];
     s_part[threadIdx.x] = sum;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    for (int off = 1; off < 256; off <<= 1) {
         const unsigned int v = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0u;
         __syncthreads();
         s_part[threadIdx.x] += v;
         __syncthreads();
     }
-    unsigned int run = s_part[threadIdx.x] - sum;  // exclusive prefix of this thread's chunk
+    unsigned int run = s_part[threadIdx.x] - sum;
     for (int i = beg; i < end; i++) {
-        const unsigned int v = data[i];
-        data[i] = run;
+        const unsigned int v = row[i];
+        row[i] = run;
         run += v;
     }
+    if (threadIdx.x == 255) rowTotal[blockIdx.x] = s_part[255];
+}
+
+__global__ __launch_bounds__(256) static void sort_scan_totals_kernel(unsigned int* __restrict__ rowTotal)
+{
+    __shared__ unsigned int s_part[256];
+    const unsigned int mine = rowTotal[threadIdx.x];
+    s_part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned int v = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    rowTotal[threadIdx.x] = s_part[threadIdx.x] - mine;
 }
 
 template <bool INDEXED>
@@ -70,7 +91,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(int n, const
                                                                     const int* __restrict__ valsIn,
                                                                     unsigned int* __restrict__ keysOut, int* __restrict__ valsOut,
                                                                     int stride, int shift, const unsigned int* __restrict__ hist,
-                                                                    int numBlocks)
+                                                                    const unsigned int* __restrict__ digitBase, int numBlocks)
 {
     constexpr int WAVES = SORT_THREADS / 64;
     __shared__ unsigned int s_cnt[WAVES][256];
@@ -104,7 +125,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(int n, const
     __syncthreads();
     {   // digit threadIdx.x: offsets of the waves and the global base of this tile
         const unsigned int d = threadIdx.x;
-        unsigned int run = hist[d * numBlocks + blockIdx.x];
+        unsigned int run = hist[d * numBlocks + blockIdx.x] + digitBase[d];
 #pragma unroll
         for (int w = 0; w < WAVES; w++) {
             s_base[w][d] = run;

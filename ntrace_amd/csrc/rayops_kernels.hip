@@ -186,7 +186,7 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
     NTR_HIP(hipMalloc(&keys.p, (size_t)n * 24));
     NTR_HIP(hipMalloc(&idxA.p, (size_t)n * 4));
     NTR_HIP(hipMalloc(&idxB.p, (size_t)n * 4));
-    NTR_HIP(hipMalloc(&hist.p, (size_t)nb * 256 * 4));
+    NTR_HIP(hipMalloc(&hist.p, ((size_t)nb * 256 + 256) * 4));
     NTR_HIP(hipMalloc(&box.p, 64));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (seconds) { NTR_HIP(hipEventCreate(&e0)); NTR_HIP(hipEventCreate(&e1)); NTR_HIP(hipEventRecord(e0, s)); }
@@ -209,9 +209,10 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
             const unsigned int* kw = (const unsigned int*)keys.p + word;
             hipLaunchKernelGGL(sort_hist_kernel<true>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kw, (const int*)vIn, 6, shift,
                                (unsigned int*)hist.p, nb);
-            hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, (unsigned int*)hist.p, nb * 256);
+            hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(256), dim3(256), 0, s, (unsigned int*)hist.p, nb, (unsigned int*)hist.p + (size_t)nb * 256);
+        hipLaunchKernelGGL(sort_scan_totals_kernel, dim3(1), dim3(256), 0, s, (unsigned int*)hist.p + (size_t)nb * 256);
             hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kw, (const int*)vIn,
-                               (unsigned int*)nullptr, vOut, 6, shift, (const unsigned int*)hist.p, nb);
+                               (unsigned int*)nullptr, vOut, 6, shift, (const unsigned int*)hist.p, (const unsigned int*)hist.p + (size_t)nb * 256, nb);
             int* t = vIn; vIn = vOut; vOut = t;
         }
     hipLaunchKernelGGL(ray_reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, (const int*)vIn, d_inRays, d_inSlotToID,

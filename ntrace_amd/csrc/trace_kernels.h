@@ -38,6 +38,7 @@ struct TraceParams {
     int32_t shardRays;       // persistent: rays per pool shard (8 shards, a multiple of chunk)
     int32_t fetchThreshold;  // persistent: refill when fewer lanes are live
     uint32_t bvhFlags;
+    int32_t leafSwitchBelow; // serve waiting leaves when fewer lanes than this still hold an inner node
     int32_t coop;            // quad-cooperative LDS-DMA node fetch instead of per-lane loads
     unsigned long long* timeline;  // diagnostic: per-wave realtime stamps (scripts/timeline*.py), or null
     unsigned long long* stats;  // STATS variant: {innerVisits, triTests, leafVisits, hits}

@@ -369,13 +369,18 @@ template <bool FAST, bool STATS, bool DYNAMIC_FETCH, bool COOP>
 __device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, lds_char* stage, int lane, RayRegs& r, int& node,
                                          LaneStack& st, int (&spill)[SPILL_DEPTH], bool anyHit,
                                          int& hitAddr, float& hitU, float& hitV, LaneStats& ls, unsigned int* status,
-                                         bool poolEmpty, int fetchThreshold)
+                                         bool poolEmpty, int fetchThreshold, int leafSwitchBelow)
 {
     unsigned long long live = __ballot(node != kSentinel);
     while (live != 0ull) {
         for (;;) {
             const bool inner = (unsigned)node < (unsigned)kSentinel;
-            if (__ballot(inner) == 0ull) break;
+            const unsigned long long innerMask = __ballot(inner);
+            if (innerMask == 0ull) break;
+            // Phase switch policy (affects scheduling only, never a ray's own visiting order): when few
+            // lanes still hold an inner node while others already wait at a leaf, serve the leaves first
+            // instead of letting a handful of stragglers stall the wave.
+            if (__popcll(innerMask) < leafSwitchBelow && __ballot(node < 0) != 0ull) break;
             inner_step<FAST, COOP>(nodes, stage, lane, inner, r, node, st, spill, status);
             if (STATS && inner) ls.inner++;
         }
@@ -422,8 +427,8 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     LaneStats ls = {0u, 0u, 0u};
 
     const bool fastWave = (p.bvhFlags & NTR_BVH_FASTDIV) && __ballot(node != kSentinel && !ray_is_nice(r, p.bvhFlags)) == 0ull;
-    if (fastWave) traverse<true, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0);
-    else traverse<false, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0);
+    if (fastWave) traverse<true, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
+    else traverse<false, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
 
     if (p.timeline && lane == 0) {
         const unsigned int w = blockIdx.x * WAVES + wave;
@@ -532,8 +537,8 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
         if (p.timeline) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tlRefill += __builtin_amdgcn_s_memtime() - tlA; }
         // ---- while-while traversal ------------------------------------------------
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
-        if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold);
-        else traverse<false, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold);
+        if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
+        else traverse<false, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
 
         // ---- retire finished rays ---------------------------------------------------
         if (rayIdx >= 0 && node == kSentinel) {

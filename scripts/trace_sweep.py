@@ -57,17 +57,22 @@ def main():
 
     print("bvh flags", view.flags)
     configs = [("perray", "fermi_speculative_while_while", {})]
+    for ls in (4, 8, 16, 24, 32, 40, 48, 56, 65):
+        configs.append(("perray ls%d" % ls, "fermi_speculative_while_while", {"NTR_TRACE_LEAF_SWITCH": ls}))
     for c in (32, 64, 128):
         for t in (0, 24, 40, 56):
             for b in (7,):
                 configs.append(("persist c%d t%d b%d" % (c, t, b), "kepler_dynamic_fetch",
                                 {"NTR_TRACE_CHUNK": c, "NTR_TRACE_FETCH_THRESHOLD": t, "NTR_TRACE_BLOCKS_PER_CU": b}))
+    for (c, t, b, ls) in ((64, 0, 7, 32), (64, 32, 7, 32), (64, 48, 7, 32), (32, 40, 7, 32), (64, 40, 7, 16), (64, 56, 7, 48)):
+        configs.append(("persist c%d t%d b%d ls%d" % (c, t, b, ls), "kepler_dynamic_fetch",
+                        {"NTR_TRACE_CHUNK": c, "NTR_TRACE_FETCH_THRESHOLD": t, "NTR_TRACE_BLOCKS_PER_CU": b, "NTR_TRACE_LEAF_SWITCH": ls}))
     configs.append(("persist c64 t40 b4", "kepler_dynamic_fetch", {"NTR_TRACE_CHUNK": 64, "NTR_TRACE_FETCH_THRESHOLD": 40, "NTR_TRACE_BLOCKS_PER_CU": 4}))
     configs.append(("persist c64 t40 b5", "kepler_dynamic_fetch", {"NTR_TRACE_CHUNK": 64, "NTR_TRACE_FETCH_THRESHOLD": 40, "NTR_TRACE_BLOCKS_PER_CU": 5}))
     if args.configs:
         keep = set(args.configs.split(","))
         configs = [c for c in configs if c[0] in keep]
-    tunables = ("NTR_TRACE_CHUNK", "NTR_TRACE_FETCH_THRESHOLD", "NTR_TRACE_BLOCKS_PER_CU", "NTR_TRACE_COOP")
+    tunables = ("NTR_TRACE_LEAF_SWITCH", "NTR_TRACE_CHUNK", "NTR_TRACE_FETCH_THRESHOLD", "NTR_TRACE_BLOCKS_PER_CU", "NTR_TRACE_COOP")
     times = {c[0]: ([], []) for c in configs}
     for rnd in range(args.rounds + 1):
         for name, kernel, env in configs:
