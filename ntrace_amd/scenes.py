@@ -237,6 +237,34 @@ def atrium(num_tris=ATRIUM_TRIS, seed=262267):
     return tri, pos, cam
 
 
+def hairball(num_tris=2800000, seed=2800000):
+    """'hairball' stand-in (config 4): thin random triangles along seeded, wobbling strands in a ball."""
+    rng = np.random.default_rng(seed)
+    strands = max(num_tris // 200, 1)
+    per = (num_tris + strands - 1) // strands
+    d = rng.normal(size=(strands, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t = np.linspace(0.05, 1.0, per)[None, :, None]
+    wob = rng.normal(0, 0.04, size=(strands, per, 3)).cumsum(axis=1) * 0.2
+    c = (d[:, None, :] * t + wob).reshape(-1, 3)[:num_tris] * 100.0
+    a = rng.normal(0, 0.15, size=(num_tris, 3))
+    b = rng.normal(0, 0.6, size=(num_tris, 3))
+    pos = np.stack([c, c + a, c + b], axis=1).reshape(-1, 3).astype(np.float32)
+    tri = np.arange(num_tris * 3, dtype=np.int32).reshape(-1, 3)
+    cam = dict(eye=(0.0, 0.0, -260.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov_deg=50.0, far=1000.0)
+    return tri, pos, cam
+
+
+def conference_room(num_tris=331000, seed=331000):
+    """'room-331k' stand-in for Conference (config 3): the atrium generator at 331 k triangles."""
+    return atrium(num_tris=num_tris, seed=seed)
+
+
+def courtyard(num_tris=10000000, seed=10000000):
+    """'courtyard-10M' stand-in for San Miguel (config 5): atrium architecture + ~9.8 M foliage triangles."""
+    return atrium(num_tris=num_tris, seed=seed)
+
+
 # ------------------------------------------------------------------------------------
 # ray batches
 # ------------------------------------------------------------------------------------

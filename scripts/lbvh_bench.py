@@ -15,22 +15,6 @@ import ntrace_amd as nt  # noqa: E402
 from ntrace_amd import scenes  # noqa: E402
 
 
-def hairball(num_tris, seed=2800000):
-    """'hairball' stand-in: thin random triangles along seeded strands inside a ball (config 4)."""
-    rng = np.random.default_rng(seed)
-    strands = max(num_tris // 200, 1)
-    per = (num_tris + strands - 1) // strands
-    d = rng.normal(size=(strands, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
-    t = np.linspace(0.05, 1.0, per)[None, :, None]
-    wob = rng.normal(0, 0.04, size=(strands, per, 3)).cumsum(axis=1) * 0.2
-    c = (d[:, None, :] * t + wob).reshape(-1, 3)[:num_tris] * 100.0
-    a = rng.normal(0, 0.15, size=(num_tris, 3)); b = rng.normal(0, 0.6, size=(num_tris, 3))
-    pos = np.stack([c, c + a, c + b], axis=1).reshape(-1, 3).astype(np.float32)
-    tri = np.arange(num_tris * 3, dtype=np.int32).reshape(-1, 3)
-    cam = dict(eye=(0.0, 0.0, -260.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov_deg=50.0, far=1000.0)
-    return tri, pos, cam
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="atrium")
@@ -39,7 +23,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
-    tri, pos, cam = scenes.atrium() if args.scene == "atrium" else hairball(args.tris)
+    tri, pos, cam = scenes.atrium() if args.scene == "atrium" else scenes.hairball(args.tris)
     n = tri.shape[0]
 
     def up(a):
