@@ -182,6 +182,43 @@ def main():
         sb = view.trace_stats(args.kernel, b["n"], True, b["rays"].data_ptr(), b["res"].data_ptr(), stream)
         ao_alg += sb.algorithmic_bytes()
 
+    # ---- extras (outside the timed region): on-device LBVH build of the same scene, secondary-ray sort ----
+    extras = {}
+    if rank == 0:
+        try:
+            capn, capw, capi = nt.lbvh_capacity(tri.shape[0])
+            d_tri, d_pos = up(tri), up(pos)
+            ln = torch.zeros(capn, dtype=torch.uint8, device=dev)
+            lw = torch.zeros(capw, dtype=torch.uint8, device=dev)
+            li = torch.zeros(capi, dtype=torch.uint8, device=dev)
+            best = None
+            for _ in range(3):
+                r = nt.lbvh_build(tri.shape[0], d_tri.data_ptr(), pos.shape[0], d_pos.data_ptr(), pos.min(0), pos.max(0), 8, 0.001,
+                                  ln.data_ptr(), capn, lw.data_ptr(), capw, li.data_ptr(), capi, stream)
+                best = r if best is None or r.seconds < best.seconds else best
+            lview = nt.BvhView(ln.data_ptr(), best.nodesBytes, lw.data_ptr(), best.triWoopBytes, li.data_ptr())
+            lview.validate(stream)
+            lsec = min(lview.trace(args.kernel, n_primary, False, d_rays.data_ptr(), d_res.data_ptr(), stream) for _ in range(5))
+            extras["lbvh"] = {"build_ms": best.seconds * 1e3, "mtris_per_s": tri.shape[0] / best.seconds / 1e6,
+                              "phases_ms": {"morton": best.mortonMs, "sort": best.sortMs, "woop": best.woopMs, "emit": best.emitMs,
+                                            "refit": best.refitMs}, "nodes": best.numNodes, "leaves": best.numLeaves,
+                              "primary_mrays_on_lbvh": n_primary / lsec / 1e6}
+            run_batch(batches[0])  # restore the SAH-BVH primary results
+            if len(batches) > 1:
+                b1 = batches[1]
+                so = torch.zeros_like(b1["rays"])
+                sa = torch.zeros(b1["n"], dtype=i32, device=dev)
+                sb = torch.zeros(b1["n"], dtype=i32, device=dev)
+                ident = torch.arange(b1["n"], dtype=i32, device=dev)
+                ssec = min(nt.ray_morton_sort(b1["n"], b1["rays"].data_ptr(), ident.data_ptr(), so.data_ptr(), sa.data_ptr(),
+                                              sb.data_ptr(), stream) for _ in range(3))
+                sres = torch.zeros_like(b1["res"])
+                tsec = min(view.trace(args.kernel, b1["n"], True, so.data_ptr(), sres.data_ptr(), stream) for _ in range(5))
+                usec = min(view.trace(args.kernel, b1["n"], True, b1["rays"].data_ptr(), b1["res"].data_ptr(), stream) for _ in range(5))
+                extras["ray_sort"] = {"rays": b1["n"], "sort_ms": ssec * 1e3, "trace_sorted_ms": tsec * 1e3, "trace_unsorted_ms": usec * 1e3}
+        except Exception as e:  # extras never invalidate the headline
+            extras["error"] = repr(e)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -212,9 +249,12 @@ def main():
         "gather_ms": gather_ms,
         "host_sah_build_s": sah_seconds,
         "trace_stats": st.as_dict(),
+        "extras": extras,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(n_primary),
                      "kernel": "trace_bvh (%s), primary batch" % args.kernel,
+                     "note": "algorithmic bytes (SURVEY 8d accounting) / HIP-event time; > 1 means the bytes are served by L1/L2/"
+                             "Infinity Cache: measured HBM-side traffic is in `traffic` (bytes per launch)",
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "ao": {"achieved": (ao_alg / (ao_ms * 1e-3) / 1e9) if ao_ms > 0 else None,
                             "algorithmic_bytes_all_batches": ao_alg}},
