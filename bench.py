@@ -22,6 +22,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# MI355X_MICROARCH.md, 'Indexed rows: gather' table: chip-wide rate of row gathers served by the XCD L2s
+# (16.8-18.8 TB/s) and by the Infinity Cache (8.6 TB/s) -- the practical ceilings of a cache-resident BVH.
+L2_GATHER_PEAK_GBS = 18800.0
+MALL_GATHER_PEAK_GBS = 8600.0
 
 
 def pmc_traffic_bytes(n_primary):
@@ -53,6 +57,10 @@ def parse():
     ap.add_argument("--ao-samples", type=int, default=8)
     ap.add_argument("--ao-radius", type=float, default=5.0, help="Raygen.aoRadius of the reference's config.conf")
     ap.add_argument("--kernel", default=os.environ.get("NTR_BENCH_KERNEL", "fermi_speculative_while_while"))
+    ap.add_argument("--scene-obj", default=os.environ.get("NTR_SCENE_OBJ", ""),
+                    help="Wavefront OBJ to trace instead of the procedural stand-in (e.g. the real sponza.obj)")
+    ap.add_argument("--camera", default=os.environ.get("NTR_CAMERA", ""),
+                    help="NTrace camera signature (CameraControls::encodeSignature) for --scene-obj")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     return ap.parse_args()
@@ -73,7 +81,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (the tracer has no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # NTR_BENCH_FORCE_DIST=1 runs the RCCL code path (init, barrier, all-reduce, gather) at world size 1 too
+    use_dist = world > 1 or os.environ.get("NTR_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
     nt.lib()
     stream = torch.cuda.current_stream().cuda_stream
@@ -82,7 +92,26 @@ def main():
         return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
 
     # ---- scene + prebuilt BVH (host SAH build, Renderer.builder = SAHBVH, leaf prefs (1,1)) ----
+    scene_name = "atrium-262k stand-in for Crytek Sponza, seed 262267; sponza.obj is absent from the reference checkout"
     tri, pos, cam = scenes.atrium()
+    if args.scene_obj:
+        tri, pos, _ = nt.obj_load(args.scene_obj)
+        scene_name = "OBJ %s (%d triangles)" % (os.path.basename(args.scene_obj), tri.shape[0])
+        lo, hi = pos.min(0).astype(np.float64), pos.max(0).astype(np.float64)
+        diag = float(np.linalg.norm(hi - lo))
+        if args.camera:  # the reference's camera signature (CameraControls.cpp:342-399)
+            c = nt.camera_decode(args.camera)
+            eye = np.array(c["position"], dtype=np.float64)
+            cam = dict(eye=tuple(eye), target=tuple(eye + np.array(c["forward"], dtype=np.float64)), up=tuple(c["up"]),
+                       fov_deg=c["fov"], far=c["far"])
+        else:  # inside the bounding box, looking down its longest axis
+            ax = int(np.argmax(hi - lo))
+            eye = 0.5 * (lo + hi)
+            eye[ax] = lo[ax] + 0.15 * (hi[ax] - lo[ax])
+            tgt = eye.copy()
+            tgt[ax] = hi[ax]
+            cam = dict(eye=tuple(eye), target=tuple(tgt), up=(0.0, 1.0, 0.0) if ax != 1 else (0.0, 0.0, 1.0), fov_deg=60.0,
+                       far=3.0 * diag)
     t0 = time.time()
     bvh = nt.sah_build(tri, pos, 1, 1)
     sah_seconds = time.time() - t0
@@ -132,7 +161,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -162,7 +191,7 @@ def main():
 
     # ---- final framebuffer gather (hit records -> rank 0) over RCCL, timed separately ----------------
     gather_ms = None
-    if world > 1:
+    if use_dist:
         outs = [torch.empty_like(d_res) for _ in range(world)] if rank == 0 else None
         barrier()
         g0 = time.perf_counter()
@@ -186,6 +215,18 @@ def main():
     extras = {}
     if rank == 0:
         try:
+            # practical HBM ceiling: device-to-device copy of a buffer larger than the Infinity Cache
+            cp_src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            cp_dst = torch.empty_like(cp_src)
+            cp_dst.copy_(cp_src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                cp_dst.copy_(cp_src)
+            e1.record()
+            torch.cuda.synchronize()
+            extras["stream_copy_GBps"] = 2.0 * 4 * cp_src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del cp_src, cp_dst
             capn, capw, capi = nt.lbvh_capacity(tri.shape[0])
             d_tri, d_pos = up(tri), up(pos)
             ln = torch.zeros(capn, dtype=torch.uint8, device=dev)
@@ -203,6 +244,15 @@ def main():
                               "phases_ms": {"morton": best.mortonMs, "sort": best.sortMs, "woop": best.woopMs, "emit": best.emitMs,
                                             "refit": best.refitMs}, "nodes": best.numNodes, "leaves": best.numLeaves,
                               "primary_mrays_on_lbvh": n_primary / lsec / 1e6}
+            # algorithmic bytes of the build (SURVEY 8d accounting, exact from the counts): Morton 48 rd + 8 wr,
+            # 4 radix passes x (8 rd + 8 wr + 4 rd histogram), Woop 48 rd + 48 wr per triangle; emit 12 rd + 16 wr per
+            # inner node, (48+4) rd + (48+12) wr per triangle, 20 wr per leaf; refit (12+36) rd per triangle,
+            # 96 rd per inner child, 48 wr per node.
+            nt_, ni_, nl_ = int(tri.shape[0]), int(best.numNodes), int(best.numLeaves)
+            lb = nt_ * (56 + 4 * 20 + 96 + 112 + 48) + ni_ * (28 + 48) + nl_ * 20 + max(ni_ - 1, 0) * 96
+            extras["lbvh"]["algorithmic_bytes"] = lb
+            extras["lbvh"]["roofline"] = {"bound": "hbm", "achieved": lb / best.seconds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": lb / best.seconds / 1e9 / HBM_PEAK_GBS}
             run_batch(batches[0])  # restore the SAH-BVH primary results
             if len(batches) > 1:
                 b1 = batches[1]
@@ -220,7 +270,7 @@ def main():
             extras["error"] = repr(e)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -237,7 +287,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (atrium-262k stand-in for Crytek Sponza, seed 262267; sponza.obj is absent from the reference checkout)",
+        "data": ("synthetic (%s)" % scene_name) if not args.scene_obj else scene_name,
         "config": {"workload": "Sponza-262k prebuilt SAH BVH, %dx%d primary + %dxAO (radius %g) per GPU" % (w, h, ns, args.ao_radius),
                    "kernel": args.kernel, "bvh_flags": view.flags, "triangles": int(tri.shape[0]), "rays_per_step_per_gpu": rays_per_step,
                    "primary_rays": n_primary, "primary_hits": n_hits, "ao_rays_nondegenerate": ao_live,
@@ -256,6 +306,9 @@ def main():
                      "note": "algorithmic bytes (SURVEY 8d accounting) / HIP-event time; > 1 means the bytes are served by L1/L2/"
                              "Infinity Cache: measured HBM-side traffic is in `traffic` (bytes per launch)",
                      "algorithmic_bytes_per_launch": alg_bytes,
+                     "cache_ceilings": {"l2_gather_peak": L2_GATHER_PEAK_GBS, "frac_of_l2_gather": achieved / L2_GATHER_PEAK_GBS,
+                                        "infinity_cache_gather_peak": MALL_GATHER_PEAK_GBS,
+                                        "source": "MI355X_MICROARCH.md gather table; the 34 MB BVH is cache-resident"},
                      "ao": {"achieved": (ao_alg / (ao_ms * 1e-3) / 1e9) if ao_ms > 0 else None,
                             "algorithmic_bytes_all_batches": ao_alg}},
     }
@@ -264,28 +317,33 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         cores = os.cpu_count() or 1
-        n_sample = args.cpu_sample_rays or min(n_primary, 1_000_000)
-        sel = np.arange(n_sample)  # leading rays of the PixelTable order = compact screen region
         rays = d_rays.cpu().numpy().view(nt.RAY_DTYPE)
-        sample = rays[sel]
-        oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, sample[:20000], threads=cores)  # warm-up
+        oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, rays[:20000], threads=cores)  # warm-up
+        n1 = args.cpu_sample_rays or min(n_primary, 250_000)
         c0 = time.perf_counter()
-        ref, _ = oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, sample[: n_sample // 8], threads=1)
+        oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, rays[:n1], threads=1)
         c1 = time.perf_counter()
-        ref_mt, _ = oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, sample, threads=cores)
-        c2 = time.perf_counter()
         run_batch(batches[0])
         torch.cuda.synchronize()
-        got = d_res.cpu().numpy().view(nt.RESULT_DTYPE)[sel]
-        mism = int((got["id"] != ref_mt["id"]).sum() + (got["t"].view(np.uint32) != ref_mt["t"].view(np.uint32)).sum())
-        out["cpu_baseline"] = {"value": n_sample / (c2 - c1) / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-                               "sample": "first %d primary rays (PixelTable order) of the same batch, all host cores; "
-                                         "1 thread on the first %d: %.3f Mrays/s" % (n_sample, n_sample // 8,
-                                                                                       (n_sample // 8) / (c1 - c0) / 1e6),
-                               "single_thread_mrays": (n_sample // 8) / (c1 - c0) / 1e6,
-                               "parity_mismatches_on_sample": mism}
+        # the whole frame (every batch the GPU traced in one step), all host cores, compared record by record
+        cpu_s, mism, traced = 0.0, 0, 0
+        for b in batches:
+            hr = b["rays"].cpu().numpy().view(nt.RAY_DTYPE)
+            t0c = time.perf_counter()
+            ref, _ = oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, hr, any_hit=b["any_hit"], threads=cores)
+            cpu_s += time.perf_counter() - t0c
+            got = b["res"].cpu().numpy().view(nt.RESULT_DTYPE)
+            mism += int(((got["id"] != ref["id"]) | (got["t"].view(np.uint32) != ref["t"].view(np.uint32))).sum())
+            traced += b["n"]
+        out["cpu_baseline"] = {"value": rays_per_step / cpu_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                               "sample": "one whole step (primary + %d AO batches = %d rays, %d non-degenerate) on all %d host "
+                                         "cores, %.2f s wall = %.1f CPU-s; 1 thread on the first %d primary rays: %.3f Mrays/s"
+                                         % (len(batches) - 1, traced, rays_per_step, cores, cpu_s, cpu_s * cores, n1,
+                                            n1 / (c1 - c0) / 1e6),
+                               "single_thread_mrays": n1 / (c1 - c0) / 1e6,
+                               "parity_mismatches_whole_step": mism, "rays_compared": traced}
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -35,7 +35,7 @@ def job_throughput(units, seconds, device):
     """(sum of units over ranks, max of seconds over ranks): value = units / seconds."""
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     u = torch.tensor([float(units)], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(u.item()), float(t.item())

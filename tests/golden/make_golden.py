@@ -36,7 +36,44 @@ def make(name, tri, pos, rays):
     print(name, "tris", tri.shape[0], "rays", rays.shape[0], "hit", float((out["res_closest"][:, 0] >= 0).mean()))
 
 
+def bbox_camera(pos):
+    """Pinhole camera inside the bounding box looking down its longest axis (as bench.py --scene-obj)."""
+    lo, hi = pos.min(0).astype(np.float64), pos.max(0).astype(np.float64)
+    ax = int(np.argmax(hi - lo))
+    eye = 0.5 * (lo + hi)
+    eye[ax] = lo[ax] + 0.15 * (hi[ax] - lo[ax])
+    tgt = eye.copy()
+    tgt[ax] = hi[ax]
+    return dict(eye=tuple(eye), target=tuple(tgt), up=(0.0, 1.0, 0.0) if ax != 1 else (0.0, 0.0, 1.0), fov_deg=60.0,
+                far=3.0 * float(np.linalg.norm(hi - lo)))
+
+
+def bbox_rays(pos, n, seed):
+    """Random segments between points of the (slightly enlarged) bounding box."""
+    rng = np.random.default_rng(seed)
+    lo, hi = pos.min(0), pos.max(0)
+    c, e = 0.5 * (lo + hi), 0.6 * (hi - lo)
+    a = (c + rng.uniform(-1, 1, size=(n, 3)) * e).astype(np.float32)
+    b = (c + rng.uniform(-1, 1, size=(n, 3)) * e).astype(np.float32)
+    d = b - a
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20)
+    rays = np.zeros(n, dtype=nt.RAY_DTYPE)
+    d = d.astype(np.float32)
+    for k, col in (("ox", a[:, 0]), ("oy", a[:, 1]), ("oz", a[:, 2]), ("dx", d[:, 0]), ("dy", d[:, 1]), ("dz", d[:, 2])):
+        rays[k] = col
+    rays["tmin"], rays["tmax"] = 0.0, np.float32(2.0 * np.linalg.norm(hi - lo))
+    return rays
+
+
 if __name__ == "__main__":
+    # geometry of a reference asset (data/models/Map/Map.obj, 488 triangles) through this repo's OBJ importer;
+    # needs the reference checkout, so it is only regenerated in the build container
+    obj = "/root/reference/data/models/Map/Map.obj"
+    if os.path.exists(obj):
+        tri, pos, _ = nt.obj_load(obj)
+        cam = bbox_camera(pos)
+        rays = np.concatenate([scenes.primary_rays(cam, 48, 48)[0], bbox_rays(pos, 2048, seed=488)])
+        make("map_obj_mixed", tri, pos, rays)
     tri, pos, cam = scenes.cornell_box()
     make("cornell_primary", tri, pos, scenes.primary_rays(cam, 64, 36)[0])
     tri, pos, cam = scenes.random_soup(1500, seed=77)
