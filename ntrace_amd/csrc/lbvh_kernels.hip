@@ -6,11 +6,17 @@
 //                                                  per-tile LDS histograms, one scan, and a stable
 //                                                  scatter ranked with wave64 ballots (match-any)
 //   calcWoopKernel  emitTreeKernel.cu:574-645   -> lbvh_woop_kernel
-//   emitTreeKernel  emitTreeKernel.cu:233-381   -> lbvh_emit_kernel, one launch per level with the
-//   + createLeaf    :170-231                       queue counts kept on the device (the reference
-//                                                  reads g_outQueuePtr back to the host every level,
-//                                                  HLBVHBuilder.cpp:347)
-//   calcAABB        emitTreeKernel.cu:417-562   -> lbvh_refit_kernel, deepest level first
+//   emitTreeKernel  emitTreeKernel.cu:233-381   -> three launches instead of one per level (the
+//   + createLeaf    :170-231                       reference also reads g_outQueuePtr back to the host
+//   calcAABB        emitTreeKernel.cu:417-562      every level, HLBVHBuilder.cpp:347): lbvh_top_kernel
+//                                                  (one workgroup) splits ranges larger than S triangles
+//                                                  level by level; lbvh_subtree_kernel gives every range
+//                                                  of <= S triangles to one workgroup that emits the
+//                                                  whole subtree below it and refits it bottom-up, with
+//                                                  workgroup barriers only; lbvh_top_refit_kernel closes
+//                                                  the boxes of the top levels.  NTR_LBVH_LEVELSYNC=1
+//                                                  selects the older one-launch-per-level kernels
+//                                                  (lbvh_emit_kernel / lbvh_refit_kernel).
 //
 // The tree is the reference's tree: same split rule (highest differing Morton bit at or below the
 // level's bit, median when none), same leaf rule (count <= leafSize, or the level's bit is 0), same
@@ -22,6 +28,8 @@
 #include <stdint.h>
 #include <float.h>
 #include <string.h>
+#include <stdlib.h>
+#include <math.h>
 
 #include "ntr_internal.h"
 #include "radix_sort.h"
@@ -33,7 +41,12 @@ struct LbvhState {
     unsigned int lvlStart[34];   // first node index of each level
     unsigned long long leafPtr;  // (triCount << 32) | leafCount, like g_leafsPtr
     unsigned int overflow;
-    unsigned int pad;
+    unsigned int nodeCount;      // subtree path: next free node index (the root is node 0)
+    unsigned int numSub;         // subtree roots emitted by the top pass
+    unsigned int subNext;        // work counter of the subtree pass
+    unsigned int maxLevel;       // deepest level holding an inner node, plus one
+    unsigned int topLevels;      // levels the top pass processed
+    unsigned int topLvlOfs[34];  // per-level offsets into the top pass's node list
 };
 
 // ---- Morton codes ------------------------------------------------------------------------------
@@ -70,11 +83,9 @@ __global__ __launch_bounds__(256) void lbvh_morton_kernel(int n, const int* __re
 }
 
 // ---- Woop rows (emitTreeKernel.cu:574-635) ---------------------------------------------------------
-__global__ __launch_bounds__(256) void lbvh_woop_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
-                                                        float4* __restrict__ out)
+__device__ __forceinline__ void woop_rows(const int* __restrict__ tri, const float* __restrict__ pos, int t, float4& r0, float4& r1,
+                                          float4& r2)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
     const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
     const float v0x = pos[3 * i0], v0y = pos[3 * i0 + 1], v0z = pos[3 * i0 + 2];
     const float v1x = pos[3 * i1], v1y = pos[3 * i1 + 1], v1z = pos[3 * i1 + 2];
@@ -93,9 +104,57 @@ __global__ __launch_bounds__(256) void lbvh_woop_kernel(int n, const int* __rest
     const float o2w = (-i1x) * v2x + (-i1y) * v2y + (-i1z) * v2z;
     float o0x = i2x;
     if (o0x == 0.0f) o0x = 0.0f;  // -0 would alias the leaf terminator
-    out[3 * t + 0] = make_float4(o0x, i2y, i2z, o0w);
-    out[3 * t + 1] = make_float4(i0x, i0y, i0z, o1w);
-    out[3 * t + 2] = make_float4(i1x, i1y, i1z, o2w);
+    r0 = make_float4(o0x, i2y, i2z, o0w);
+    r1 = make_float4(i0x, i0y, i0z, o1w);
+    r2 = make_float4(i1x, i1y, i1z, o2w);
+}
+
+__global__ __launch_bounds__(256) void lbvh_woop_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
+                                                        float4* __restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float4 r0, r1, r2;
+    woop_rows(tri, pos, t, r0, r1, r2);
+    out[3 * t + 0] = r0;
+    out[3 * t + 1] = r1;
+    out[3 * t + 2] = r2;
+}
+
+// Subtree path, before the emit: the term every triangle contributes to its leaf's box
+// (calcLeaf, emitTreeKernel.cu:383-408: min/max over the three vertices, -/+ epsilon), in sorted order,
+// stored as (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z).
+__global__ __launch_bounds__(256) void lbvh_tribox_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
+                                                          const int* __restrict__ triSorted, float eps, float2* __restrict__ triBox)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int t = triSorted[j];
+    const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float a = pos[3 * i0 + k], b = pos[3 * i1 + k], c = pos[3 * i2 + k];
+        triBox[3 * j + k] = make_float2(fminf(a, fminf(b, c)) - eps, fmaxf(a, fmaxf(b, c)) + eps);
+    }
+}
+
+// Subtree path, after the emit: Woop rows and original index of every triangle, written straight to the
+// slot its leaf reserved (triOut[j] = float4 index of sorted triangle j).
+__global__ __launch_bounds__(256) void lbvh_place_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
+                                                         const int* __restrict__ triSorted, const int* __restrict__ triOut,
+                                                         float4* __restrict__ outWoop, int* __restrict__ outIdx)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int t = triSorted[j], o = triOut[j];
+    float4 r0, r1, r2;
+    woop_rows(tri, pos, t, r0, r1, r2);
+    outWoop[o + 0] = r0;
+    outWoop[o + 1] = r1;
+    outWoop[o + 2] = r2;
+    outIdx[o + 0] = t;
+    outIdx[o + 1] = 0;
+    outIdx[o + 2] = 0;
 }
 
 // ---- tree emission, one level per launch (emitTreeKernel.cu:233-381) ------------------------------
@@ -243,23 +302,321 @@ __global__ __launch_bounds__(256) void lbvh_refit_kernel(int lvl, float eps, con
     }
 }
 
+
+// ---- subtree path: emit + refit with workgroup barriers only ------------------------------------------
+// Position where bit `level` of the sorted keys flips inside [nStart, nEnd) (emitTreeKernel.cu:263-280).
+// keys[nStart] and keys[nEnd-1] differ in that bit and agree above it, so the flip is unique; K-1
+// independent probes per step shorten the dependent-load chain of the plain binary search.
+// `keys` is indexed relative to `base` (a subtree's keys live in LDS).
+template <int K>
+__device__ __forceinline__ int find_split(const unsigned int* keys, int base, int nStart, int nEnd, int level, unsigned int startBit)
+{
+    int a = nStart, b = nEnd - 1;
+    while (b - a > 1) {
+        const unsigned int len = (unsigned int)(b - a);
+        int na = a, nb = b;
+#pragma unroll
+        for (int j = 1; j < K; j++) {
+            const int p = a + (int)(((unsigned long long)len * j) / K);
+            const unsigned int bit = (keys[p - base] >> level) & 1;
+            if (bit == startBit) na = max(na, p); else nb = min(nb, p);
+        }
+        a = na; b = nb;
+    }
+    return b;
+}
+
+struct EmitCtx {
+    LbvhState* st;
+    const unsigned int* keys;
+    const float2* triBox;  // per sorted triangle: (lo, hi) per axis, epsilon applied (lbvh_tribox_kernel)
+    int* triOut;           // per sorted triangle: float4 index of its Woop rows (for lbvh_place_kernel)
+    int* nodes;
+    unsigned int nodeCap;
+    float4* outWoop;
+    int* outIdx;
+    int leafSize;
+    int4* subList;       // (node, start, end, level) of the ranges handed to lbvh_subtree_kernel
+    int spill;           // ranges of at most this many triangles are emitted by one workgroup each
+};
+
+struct EmitShared {      // LDS bookkeeping of one workgroup
+    unsigned long long leafCtr;   // (triangles << 32) | leaves reserved so far, like g_leafsPtr
+    unsigned long long leafBase;
+    unsigned int nodeCtr, nodeBase, numSub, item;
+    unsigned int cnt[3];          // queue lengths of three consecutive levels, rotating
+    unsigned int lvlOfs[34];
+};
+
+__device__ __forceinline__ void lds_barrier()
+{
+    // workgroup barrier that orders LDS traffic only: global stores of the emit stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// createLeaf (emitTreeKernel.cu:170-231) without the copy: the leaf's triangles learn their slot, the
+// terminator is stored, and the leaf's box (calcLeaf :383-408, folded in stored order from FLT_MAX) goes
+// straight into child slot k of its parent.  lbvh_place_kernel fills the Woop rows afterwards.
+__device__ __forceinline__ void emit_leaf(const EmitCtx& c, int out, int start, int end, int* nd, int k)
+{
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    const float2* __restrict__ tb = c.triBox;
+    // eight triangles per round trip; indices past the end repeat the last triangle, which min/max ignore
+    for (int j = start; j < end; j += 8) {
+        float2 b[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = min(j + u, end - 1);
+            b[u][0] = tb[3 * q]; b[u][1] = tb[3 * q + 1]; b[u][2] = tb[3 * q + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b[u][k].x); hi[k] = fmaxf(hi[k], b[u][k].y); }
+        }
+    }
+    for (int j = start; j < end; j++) c.triOut[j] = out + 3 * (j - start);
+    const int tpos = out + 3 * (end - start);
+    const float nz = __uint_as_float(0x80000000u);
+    c.outWoop[tpos] = make_float4(nz, nz, nz, nz);
+    c.outIdx[tpos] = 0;
+    float* nf = reinterpret_cast<float*>(nd);
+    reinterpret_cast<float4*>(nf)[k] = make_float4(lo[0], hi[0], lo[1], hi[1]);
+    reinterpret_cast<float2*>(nf)[4 + k] = make_float2(lo[2], hi[2]);
+}
+
+// Levels [root.w, 30) of the tree below `root`, by all threads of one workgroup.  Every queue entry is
+// split exactly as lbvh_emit_kernel splits it.  Node indices and leaf storage come from LDS counters
+// (sh.nodeCtr / sh.leafCtr, offset by sh.nodeBase / sh.leafBase), so a level costs one barrier and no
+// global atomic.  TOP: the single workgroup that owns the counters of the whole tree; ranges of at most
+// c.spill triangles are appended to c.subList instead of its own queue.  !WRITE: counting pass (only the
+// LDS counters advance).  Returns the number of levels that held inner nodes; with WRITE, lst receives
+// the node indices level by level (offsets in sh.lvlOfs) for the bottom-up refit.
+template <int THREADS, bool TOP, bool WRITE, int K>
+__device__ __forceinline__ int emit_subtree(const EmitCtx& c, EmitShared& sh, int4 root, const unsigned int* keys, int keyBase,
+                                            int* qA, int* qB, int* lst)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        qA[0] = root.x; qA[1] = root.y; qA[2] = root.z;
+        sh.cnt[0] = 1; sh.cnt[1] = 0; sh.cnt[2] = 0;
+    }
+    if (TOP) __syncthreads(); else lds_barrier();
+    unsigned int total = 0;
+    int lv = 0;
+    for (int lvl = root.w; lvl < 30; lvl++, lv++) {
+        const unsigned int inCount = sh.cnt[lv % 3];
+        if (inCount == 0) break;
+        unsigned int* outCount = &sh.cnt[(lv + 1) % 3];
+        if (tid == 0) {
+            sh.cnt[(lv + 2) % 3] = 0;  // read one level ago, added to one level ahead
+            if (WRITE) sh.lvlOfs[lv] = total;
+        }
+        const int levelBit = 29 - lvl;
+        for (unsigned int e = tid; e < inCount; e += THREADS) {
+            const int nIdx = qA[3 * e], nStart = qA[3 * e + 1], nEnd = qA[3 * e + 2];
+            const unsigned int kFirst = keys[nStart - keyBase], kLast = keys[nEnd - 1 - keyBase];
+            const unsigned int diff = (kFirst ^ kLast) & ((2u << levelBit) - 1u);
+            const int level = diff ? 31 - __clz((int)diff) : -1;  // highest differing bit at or below the level's bit
+            const int split = level >= 0 ? find_split<K>(keys, keyBase, nStart, nEnd, level, (kFirst >> level) & 1)
+                                         : (nStart + nEnd) >> 1;  // identical keys: median (:282)
+            const int cs[2] = {nStart, split}, ce[2] = {split, nEnd};
+            const bool isLeaf[2] = {(split - nStart) <= c.leafSize || levelBit == 0, (nEnd - split) <= c.leafSize || levelBit == 0};
+            const unsigned int inner = (isLeaf[0] ? 0u : 1u) + (isLeaf[1] ? 0u : 1u);
+            const unsigned long long lf = (isLeaf[0] ? (((unsigned long long)(split - nStart) << 32) + 1ull) : 0ull) +
+                                          (isLeaf[1] ? (((unsigned long long)(nEnd - split) << 32) + 1ull) : 0ull);
+            unsigned int childNode = sh.nodeBase + (inner ? atomicAdd(&sh.nodeCtr, inner) : 0u);
+            unsigned long long lp = sh.leafBase + (lf ? atomicAdd(&sh.leafCtr, lf) : 0ull);
+            if (WRITE) {
+                lst[total + e] = nIdx;
+                if (childNode + inner > c.nodeCap) {  // cannot happen with ntr_lbvh_capacity() buffers
+                    atomicOr(&c.st->overflow, 1u);
+                    continue;
+                }
+            }
+            int ch[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (isLeaf[k]) {
+                    const int out = (int)(lp >> 32) * 3 + (int)(lp & 0xFFFFFFFFull);  // createLeaf (:176-181)
+                    lp += ((unsigned long long)(ce[k] - cs[k]) << 32) + 1ull;
+                    ch[k] = ~out;
+                    if (WRITE) emit_leaf(c, out, cs[k], ce[k], c.nodes + (size_t)nIdx * 16, k);
+                } else {
+                    if (TOP && (ce[k] - cs[k]) <= c.spill) {
+                        const unsigned int si = atomicAdd(&sh.numSub, 1u);
+                        c.subList[si] = make_int4((int)childNode, cs[k], ce[k], lvl + 1);
+                    } else {
+                        const unsigned int slot = atomicAdd(outCount, 1u);
+                        qB[3 * slot] = (int)childNode; qB[3 * slot + 1] = cs[k]; qB[3 * slot + 2] = ce[k];
+                    }
+                    ch[k] = (int)childNode * 64;
+                    childNode++;
+                }
+            }
+            if (WRITE) {
+                int* nd = c.nodes + (size_t)nIdx * 16;
+                nd[12] = ch[0]; nd[13] = ch[1]; nd[14] = level % 3; nd[15] = 0;
+            }
+        }
+        total += inCount;
+        if (TOP) __syncthreads(); else lds_barrier();
+        int* t = qA; qA = qB; qB = t;
+    }
+    if (WRITE && tid == 0) sh.lvlOfs[lv] = total;
+    return lv;
+}
+
+// calcAABB (emitTreeKernel.cu:417-562) for the inner children of one node: the child's box is the union of
+// that child's two stored boxes.  Leaf children received their boxes when they were emitted.
+__device__ __forceinline__ void refit_node(int* ni, const int* nodes)
+{
+    float* nf = reinterpret_cast<float*>(ni);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int ch = ni[12 + k];
+        if (ch < 0) continue;
+        const float4* cn = reinterpret_cast<const float4*>(nodes + (size_t)(ch >> 6) * 16);
+        const float4 a = cn[0], b = cn[1], c = cn[2];
+        reinterpret_cast<float4*>(nf)[k] = make_float4(fminf(a.x, b.x), fmaxf(a.y, b.y), fminf(a.z, b.z), fmaxf(a.w, b.w));
+        reinterpret_cast<float2*>(nf)[4 + k] = make_float2(fminf(c.x, c.z), fmaxf(c.y, c.w));
+    }
+}
+
+template <int THREADS>
+__device__ __forceinline__ void refit_levels(const unsigned int* lvlOfs, int numLv, const int* lst, int* nodes)
+{
+    for (int lv = numLv - 1; lv >= 0; lv--) {
+        const unsigned int b = lvlOfs[lv], e = lvlOfs[lv + 1];
+        for (unsigned int q = b + threadIdx.x; q < e; q += THREADS)
+            refit_node(nodes + (size_t)lst[q] * 16, nodes);
+        __syncthreads();  // the level above reads these boxes (same workgroup, same CU)
+    }
+}
+
+constexpr int TOP_THREADS = 1024;
+
+__global__ __launch_bounds__(TOP_THREADS) void lbvh_top_kernel(EmitCtx c, int n, int* qA, int* qB, int* topLst)
+{
+    __shared__ EmitShared sh;
+    if (threadIdx.x == 0) {
+        sh.nodeCtr = 1; sh.nodeBase = 0;  // node 0 is the root
+        sh.leafCtr = 0ull; sh.leafBase = 0ull; sh.numSub = 0;
+    }
+    const int lv = emit_subtree<TOP_THREADS, true, true, 16>(c, sh, make_int4(0, 0, n, 0), c.keys, 0, qA, qB, topLst);
+    __syncthreads();
+    if ((int)threadIdx.x <= lv) c.st->topLvlOfs[threadIdx.x] = sh.lvlOfs[threadIdx.x];
+    if (threadIdx.x == 0) {
+        c.st->topLevels = (unsigned int)lv;
+        c.st->maxLevel = (unsigned int)lv;
+        c.st->nodeCount = sh.nodeCtr;
+        c.st->leafPtr = sh.leafCtr;
+        c.st->numSub = sh.numSub;
+    }
+}
+
+// One workgroup per range of at most `cap` triangles: keys and queues in LDS, a counting pass, ONE pair of
+// global atomics for the subtree's nodes and leaf storage, the writing pass, then the bottom-up refit.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void lbvh_subtree_kernel(EmitCtx c, int cap)
+{
+    extern __shared__ int smem[];
+    __shared__ EmitShared sh;
+    unsigned int* sKeys = reinterpret_cast<unsigned int*>(smem);  // [cap]
+    const int qInts = 3 * (cap / 2 + 1);
+    int* qA = smem + cap;
+    int* qB = qA + qInts;
+    int* lst = qB + qInts;                                        // [cap]
+    const unsigned int numSub = c.st->numSub;
+    unsigned int deepest = 0;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) sh.item = atomicAdd(&c.st->subNext, 1u);
+        __syncthreads();
+        const unsigned int i = sh.item;
+        if (i >= numSub) break;
+        const int4 root = c.subList[i];
+        for (int k = root.y + threadIdx.x; k < root.z; k += THREADS) sKeys[k - root.y] = c.keys[k];
+        if (threadIdx.x == 0) { sh.nodeCtr = 0; sh.nodeBase = 0; sh.leafCtr = 0ull; sh.leafBase = 0ull; }
+        __syncthreads();
+        emit_subtree<THREADS, false, false, 8>(c, sh, root, sKeys, root.y, qA, qB, lst);
+        if (threadIdx.x == 0) {
+            sh.nodeBase = sh.nodeCtr ? atomicAdd(&c.st->nodeCount, sh.nodeCtr) : 0u;
+            sh.leafBase = sh.leafCtr ? atomicAdd(&c.st->leafPtr, sh.leafCtr) : 0ull;
+            sh.nodeCtr = 0; sh.leafCtr = 0ull;
+        }
+        __syncthreads();
+        const int lv = emit_subtree<THREADS, false, true, 8>(c, sh, root, sKeys, root.y, qA, qB, lst);
+        deepest = max(deepest, (unsigned int)(root.w + lv));
+        __syncthreads();  // the emit's global stores are visible to the whole workgroup from here
+        refit_levels<THREADS>(sh.lvlOfs, lv, lst, c.nodes);
+    }
+    if (threadIdx.x == 0 && deepest) atomicMax(&c.st->maxLevel, deepest);
+}
+
+__global__ __launch_bounds__(TOP_THREADS) void lbvh_top_refit_kernel(const LbvhState* __restrict__ st, const int* __restrict__ topLst,
+                                                                     int* nodes)
+{
+    __shared__ unsigned int ofs[34];
+    const int lv = (int)st->topLevels;
+    if ((int)threadIdx.x <= lv) ofs[threadIdx.x] = st->topLvlOfs[threadIdx.x];
+    __syncthreads();
+    refit_levels<TOP_THREADS>(ofs, lv, topLst, nodes);
+}
+
 }  // namespace ntr
 
 using namespace ntr;
 
 namespace {
-struct Timer {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+// Phase boundaries are recorded as events on the stream and read back after ONE synchronisation at
+// the end of the build, so the timed build has no host round trips inside it.
+struct PhaseEvents {
+    enum { N = 7 };
+    hipEvent_t ev[N] = {};
     hipStream_t s;
-    explicit Timer(hipStream_t st) : s(st) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
-    ~Timer() { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-    void start() { (void)hipEventRecord(e0, s); }
-    float stop_ms() { (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); return ms; }
+    explicit PhaseEvents(hipStream_t st) : s(st) { for (auto& e : ev) (void)hipEventCreate(&e); }
+    ~PhaseEvents() { for (auto& e : ev) (void)hipEventDestroy(e); }
+    void mark(int i) { (void)hipEventRecord(ev[i], s); }
+    float ms(int a, int b) { float v = 0; (void)hipEventElapsedTime(&v, ev[a], ev[b]); return v; }
 };
-struct DevMem {  // frees on scope exit
+
+// Grow-only scratch memory of the builder, kept between builds (one caller per device, as the rest of
+// the C-ABI): a rebuild per frame must not pay nine hipMalloc/hipFree pairs.
+struct Workspace {
     void* p = nullptr;
-    ~DevMem() { if (p) (void)hipFree(p); }
+    size_t bytes = 0;
+    int device = -1;
+    ~Workspace() { /* process exit: the runtime reclaims it */ }
 };
+Workspace g_ws;
+
+int workspace_reserve(size_t bytes, void** out)
+{
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    if (g_ws.p && (g_ws.device != dev || g_ws.bytes < bytes)) {
+        NTR_HIP(hipFree(g_ws.p));
+        g_ws.p = nullptr; g_ws.bytes = 0;
+    }
+    if (!g_ws.p) {
+        NTR_HIP(hipMalloc(&g_ws.p, bytes));
+        g_ws.bytes = bytes; g_ws.device = dev;
+    }
+    *out = g_ws.p;
+    return NTR_OK;
+}
+
+struct Carver {  // 256-byte aligned slices of the workspace
+    size_t off = 0;
+    size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
+};
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
 }  // namespace
 
 extern "C" {
@@ -291,97 +648,150 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     hipStream_t s = (hipStream_t)stream;
     const int n = numTris;
     const int nb = (n + SORT_TILE - 1) / SORT_TILE;
+    const bool levelSync = env_int("NTR_LBVH_LEVELSYNC", 0) != 0;
 
-    DevMem keysA, keysB, idxA, idxB, inWoop, q0, q1, hist, state;
-    NTR_HIP(hipMalloc(&keysA.p, (size_t)n * 4));
-    NTR_HIP(hipMalloc(&keysB.p, (size_t)n * 4));
-    NTR_HIP(hipMalloc(&idxA.p, (size_t)n * 4));
-    NTR_HIP(hipMalloc(&idxB.p, (size_t)n * 4));
-    NTR_HIP(hipMalloc(&inWoop.p, (size_t)n * 48));
-    NTR_HIP(hipMalloc(&q0.p, ((size_t)n + 2) * 12));
-    NTR_HIP(hipMalloc(&q1.p, ((size_t)n + 2) * 12));
-    NTR_HIP(hipMalloc(&hist.p, ((size_t)nb * 256 + 256) * 4));
-    NTR_HIP(hipMalloc(&state.p, sizeof(LbvhState)));
+    Carver cv;
+    const size_t oKeysA = cv.take((size_t)n * 4), oKeysB = cv.take((size_t)n * 4);
+    const size_t oIdxA = cv.take((size_t)n * 4), oIdxB = cv.take((size_t)n * 4);
+    const size_t oWoop = cv.take((size_t)n * 48);
+    const size_t oQ0 = cv.take(((size_t)n + 2) * 12), oQ1 = cv.take(((size_t)n + 2) * 12);
+    const size_t oHist = cv.take(((size_t)nb * 256 + 256) * 4);
+    const size_t oState = cv.take(sizeof(LbvhState));
+    const size_t oSubList = cv.take(((size_t)n / 2 + 2) * 16);
+    const size_t oTopLst = cv.take(((size_t)n + 2) * 4);
+    const size_t oTriBox = cv.take((size_t)n * 24), oTriOut = cv.take((size_t)n * 4);
+    void* wsBase = nullptr;
+    {
+        const int rc = workspace_reserve(cv.off, &wsBase);
+        if (rc != NTR_OK) return rc;
+    }
+    char* ws = (char*)wsBase;
+    LbvhState* state = (LbvhState*)(ws + oState);
 
-    Timer tAll(s), tPhase(s);
-    tAll.start();
+    PhaseEvents pe(s);
+    pe.mark(0);
 
     // L1: Morton codes (step = (max - min) / 1024 on the host, HLBVHBuilder.cpp:76-81)
     F3 lo = {sceneMin[0], sceneMin[1], sceneMin[2]};
     F3 step = {(sceneMax[0] - sceneMin[0]) / 1024.0f, (sceneMax[1] - sceneMin[1]) / 1024.0f, (sceneMax[2] - sceneMin[2]) / 1024.0f};
-    tPhase.start();
     hipLaunchKernelGGL(lbvh_morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, lo, step,
-                       (unsigned int*)keysA.p, (int*)idxA.p);
-    NTR_HIP(hipGetLastError());
-    result->mortonMs = tPhase.stop_ms();
+                       (unsigned int*)(ws + oKeysA), (int*)(ws + oIdxA));
+    pe.mark(1);
 
     // L2: stable radix sort by key, 4 passes of 8 bits (the 30-bit code fits)
-    tPhase.start();
-    unsigned int *kIn = (unsigned int*)keysA.p, *kOut = (unsigned int*)keysB.p;
-    int *vIn = (int*)idxA.p, *vOut = (int*)idxB.p;
+    unsigned int *kIn = (unsigned int*)(ws + oKeysA), *kOut = (unsigned int*)(ws + oKeysB);
+    int *vIn = (int*)(ws + oIdxA), *vOut = (int*)(ws + oIdxB);
+    unsigned int* hist = (unsigned int*)(ws + oHist);
     for (int pass = 0; pass < 4; pass++) {
         const int shift = pass * 8;
-        hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, 1, shift,
-                           (unsigned int*)hist.p, nb);
-        hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(256), dim3(256), 0, s, (unsigned int*)hist.p, nb, (unsigned int*)hist.p + (size_t)nb * 256);
-        hipLaunchKernelGGL(sort_scan_totals_kernel, dim3(1), dim3(256), 0, s, (unsigned int*)hist.p + (size_t)nb * 256);
+        hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, 1, shift, hist, nb);
+        hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(256), dim3(256), 0, s, hist, nb, hist + (size_t)nb * 256);
+        hipLaunchKernelGGL(sort_scan_totals_kernel, dim3(1), dim3(256), 0, s, hist + (size_t)nb * 256);
         hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, kOut, vOut, 1,
-                           shift, (const unsigned int*)hist.p, (const unsigned int*)hist.p + (size_t)nb * 256, nb);
+                           shift, (const unsigned int*)hist, (const unsigned int*)hist + (size_t)nb * 256, nb);
         unsigned int* tk = kIn; kIn = kOut; kOut = tk;
         int* tv = vIn; vIn = vOut; vOut = tv;
     }
-    NTR_HIP(hipGetLastError());
-    result->sortMs = tPhase.stop_ms();
+    pe.mark(2);
     const unsigned int* keys = kIn;  // after 4 passes the sorted data is back in the A buffers
     const int* triSorted = vIn;
 
-    // L4: Woop rows in original triangle order
-    tPhase.start();
-    hipLaunchKernelGGL(lbvh_woop_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, (float4*)inWoop.p);
-    NTR_HIP(hipGetLastError());
-    result->woopMs = tPhase.stop_ms();
+    // L4: Woop rows in original triangle order (per-level path), or the per-triangle box terms (subtree path;
+    // its Woop rows are produced by lbvh_place_kernel once the leaves have their slots)
+    if (levelSync)
+        hipLaunchKernelGGL(lbvh_woop_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, (float4*)(ws + oWoop));
+    else
+        hipLaunchKernelGGL(lbvh_tribox_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted, epsilon,
+                           (float2*)(ws + oTriBox));
+    pe.mark(3);
 
-    // L3: emit, one launch per level, counts stay on the device
-    tPhase.start();
-    NTR_HIP(hipMemsetAsync(state.p, 0, sizeof(LbvhState), s));
-    {
-        const unsigned int one = 1;
-        NTR_HIP(hipMemcpyAsync(&((LbvhState*)state.p)->lvlNodes[0], &one, 4, hipMemcpyHostToDevice, s));
-        const int root[3] = {0, 0, n};
-        NTR_HIP(hipMemcpyAsync(q0.p, root, 12, hipMemcpyHostToDevice, s));
-    }
+    // L3 + L5: emit and refit
+    LbvhState init;
+    memset(&init, 0, sizeof(init));
+    init.lvlNodes[0] = 1;
+    init.nodeCount = 1;
+    NTR_HIP(hipMemcpyAsync(state, &init, sizeof(init), hipMemcpyHostToDevice, s));
     const unsigned int nodeCap = (unsigned int)(nodesCapacity / 64);
-    int emitBlocks = (n / 2 + 255) / 256;
-    if (emitBlocks < 1) emitBlocks = 1;
-    if (emitBlocks > 2048) emitBlocks = 2048;
-    int* qIn = (int*)q0.p;
-    int* qOut = (int*)q1.p;
-    for (int lvl = 0; lvl < 30; lvl++) {  // kernel bit = 29 - lvl (HLBVHBuilder.cpp:344)
-        hipLaunchKernelGGL(lbvh_emit_kernel, dim3(emitBlocks), dim3(256), 0, s, lvl, 29 - lvl, leafSize, (LbvhState*)state.p,
-                           keys, triSorted, (const float4*)inWoop.p, qIn, qOut, (int*)d_nodes, nodeCap, (float4*)d_triWoop,
-                           d_triIndex);
-        int* t = qIn; qIn = qOut; qOut = t;
+    int* q0 = (int*)(ws + oQ0);
+    int* q1 = (int*)(ws + oQ1);
+    LbvhState h;
+    if (levelSync) {
+        const int root[3] = {0, 0, n};
+        NTR_HIP(hipMemcpyAsync(q0, root, 12, hipMemcpyHostToDevice, s));
+        int emitBlocks = (n / 2 + 255) / 256;
+        if (emitBlocks < 1) emitBlocks = 1;
+        if (emitBlocks > 2048) emitBlocks = 2048;
+        int* qIn = q0;
+        int* qOut = q1;
+        for (int lvl = 0; lvl < 30; lvl++) {  // kernel bit = 29 - lvl (HLBVHBuilder.cpp:344)
+            hipLaunchKernelGGL(lbvh_emit_kernel, dim3(emitBlocks), dim3(256), 0, s, lvl, 29 - lvl, leafSize, state, keys, triSorted,
+                               (const float4*)(ws + oWoop), qIn, qOut, (int*)d_nodes, nodeCap, (float4*)d_triWoop, d_triIndex);
+            int* t = qIn; qIn = qOut; qOut = t;
+        }
+        pe.mark(4);
+        // the refit launches are sized from the level counts: one read-back, as the reference does per level
+        NTR_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, s));
+        NTR_HIP(hipStreamSynchronize(s));
+        int numLevels = 0;
+        while (numLevels < 31 && h.lvlNodes[numLevels] > 0) numLevels++;
+        for (int lvl = numLevels - 1; lvl >= 0; lvl--) {
+            int blocks = (int)((h.lvlNodes[lvl] + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(lbvh_refit_kernel, dim3(blocks), dim3(256), 0, s, lvl, epsilon, (const LbvhState*)state, d_triVtxIndex,
+                               d_vtxPos, triSorted, (int*)d_nodes);
+        }
+        pe.mark(5);
+        pe.mark(6);
+    } else {
+        EmitCtx c;
+        c.st = state; c.keys = keys; c.triBox = (const float2*)(ws + oTriBox); c.triOut = (int*)(ws + oTriOut);
+        c.nodes = (int*)d_nodes; c.nodeCap = nodeCap; c.outWoop = (float4*)d_triWoop; c.outIdx = d_triIndex;
+        c.leafSize = leafSize; c.subList = (int4*)(ws + oSubList);
+        // ranges of at most `spill` triangles become one workgroup's subtree: about 1.5 n / spill of them
+        int spill = (int)(1.5 * sqrt((double)n));
+        if (spill < 256) spill = 256;
+        if (spill > 2048) spill = 2048;
+        c.spill = env_int("NTR_LBVH_SPLIT", spill);
+        if (c.spill < 2) c.spill = 2;
+        if (c.spill > 3072) c.spill = 3072;  // 20 bytes of LDS per triangle of a subtree, 64 KB per workgroup
+        hipLaunchKernelGGL(lbvh_top_kernel, dim3(1), dim3(TOP_THREADS), 0, s, c, n, q0, q1, (int*)(ws + oTopLst));
+        pe.mark(4);
+        const int subThreads = env_int("NTR_LBVH_SUB_THREADS", 128);
+        int subBlocks = n / 2 + 1;
+        const int subMax = 256 * (2048 / (subThreads > 0 ? subThreads : 128));
+        if (subBlocks > subMax) subBlocks = subMax;
+        const size_t subLds = ((size_t)c.spill * 2 + 2 * 3 * ((size_t)c.spill / 2 + 1)) * 4;
+        if (subThreads == 64)
+            hipLaunchKernelGGL(lbvh_subtree_kernel<64>, dim3(subBlocks), dim3(64), subLds, s, c, c.spill);
+        else if (subThreads == 256)
+            hipLaunchKernelGGL(lbvh_subtree_kernel<256>, dim3(subBlocks), dim3(256), subLds, s, c, c.spill);
+        else
+            hipLaunchKernelGGL(lbvh_subtree_kernel<128>, dim3(subBlocks), dim3(128), subLds, s, c, c.spill);
+        pe.mark(5);
+        hipLaunchKernelGGL(lbvh_top_refit_kernel, dim3(1), dim3(TOP_THREADS), 0, s, (const LbvhState*)state, (const int*)(ws + oTopLst),
+                           (int*)d_nodes);
+        hipLaunchKernelGGL(lbvh_place_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted,
+                           (const int*)(ws + oTriOut), (float4*)d_triWoop, d_triIndex);
+        pe.mark(6);
     }
     NTR_HIP(hipGetLastError());
-    LbvhState h;
-    NTR_HIP(hipMemcpyAsync(&h, state.p, sizeof(h), hipMemcpyDeviceToHost, s));
-    result->emitMs = tPhase.stop_ms();
+    NTR_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, s));
+    NTR_HIP(hipStreamSynchronize(s));
+    result->mortonMs = pe.ms(0, 1);
+    result->sortMs = pe.ms(1, 2);
+    result->woopMs = pe.ms(2, 3);
+    result->emitMs = pe.ms(3, 4);
+    result->refitMs = pe.ms(4, 6);
+    result->seconds = pe.ms(0, 6) * 1e-3f;
     if (h.overflow) return set_error(NTR_ERR_OVERFLOW, "ntr_lbvh_build: node buffer overflow");
     int numLevels = 0;
     unsigned int numNodes = 0;
-    while (numLevels < 31 && h.lvlNodes[numLevels] > 0) { numNodes += h.lvlNodes[numLevels]; numLevels++; }
-
-    // L5: refit, deepest level first
-    tPhase.start();
-    for (int lvl = numLevels - 1; lvl >= 0; lvl--) {
-        int blocks = (int)((h.lvlNodes[lvl] + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(lbvh_refit_kernel, dim3(blocks), dim3(256), 0, s, lvl, epsilon, (const LbvhState*)state.p,
-                           d_triVtxIndex, d_vtxPos, triSorted, (int*)d_nodes);
+    if (levelSync) {
+        while (numLevels < 31 && h.lvlNodes[numLevels] > 0) { numNodes += h.lvlNodes[numLevels]; numLevels++; }
+    } else {
+        numNodes = h.nodeCount;
+        numLevels = (int)h.maxLevel;
     }
-    NTR_HIP(hipGetLastError());
-    result->refitMs = tPhase.stop_ms();
-    result->seconds = tAll.stop_ms() * 1e-3f;
 
     const unsigned int leafs = (unsigned int)(h.leafPtr & 0xFFFFFFFFull);
     result->numNodes = (int32_t)numNodes;

@@ -13,6 +13,23 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["subtree", "subtree-split16-64t", "subtree-split40-256t", "levelsync"])
+def build_path(request, monkeypatch):
+    """Every test runs on the default emit path (top pass + one workgroup per subtree), on the same path
+    with tiny subtrees (so that small scenes exercise the hand-over too), and on the per-level kernels."""
+    for k in ("NTR_LBVH_LEVELSYNC", "NTR_LBVH_SPLIT", "NTR_LBVH_SUB_THREADS"):
+        monkeypatch.delenv(k, raising=False)
+    if request.param == "levelsync":
+        monkeypatch.setenv("NTR_LBVH_LEVELSYNC", "1")
+    elif request.param == "subtree-split16-64t":
+        monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
+        monkeypatch.setenv("NTR_LBVH_SUB_THREADS", "64")
+    elif request.param == "subtree-split40-256t":
+        monkeypatch.setenv("NTR_LBVH_SPLIT", "40")
+        monkeypatch.setenv("NTR_LBVH_SUB_THREADS", "256")
+    return request.param
+
+
 def gpu_lbvh(tri, pos, leaf_size=8, epsilon=0.001):
     import torch
     from gpu_util import up
