@@ -33,6 +33,25 @@
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
+/* CUDA fminf/fmaxf are the PTX min.f32/max.f32: a NaN operand yields the other operand and, for zeros
+ * of opposite sign, min returns -0 and max returns +0 (PTX ISA, "min"/"max": -0.0 < +0.0).  C's fminf
+ * leaves the zero case to the implementation, so it is spelled out here (it matters only for epsilon = 0,
+ * where a box plane can be a signed zero). */
+static inline float cu_fminf(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return (f2u(a) & 0x80000000u) ? a : b;
+    return a < b ? a : b;
+}
+static inline float cu_fmaxf(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return (f2u(a) & 0x80000000u) ? b : a;
+    return a > b ? a : b;
+}
+
 /* emitTreeKernel.cu:647-653 */
 static inline uint32_t spread(uint32_t n)
 {
@@ -57,8 +76,8 @@ void orc_lbvh_morton(int32_t numTris, const int32_t* tri, const float* pos,
         const float* c = pos + 3 * (size_t)tri[3 * t + 2];
         int cell[3];
         for (int k = 0; k < 3; k++) {
-            float lo = fminf(a[k], fminf(b[k], c[k]));
-            float hi = fmaxf(a[k], fmaxf(b[k], c[k]));
+            float lo = cu_fminf(a[k], cu_fminf(b[k], c[k]));
+            float hi = cu_fmaxf(a[k], cu_fmaxf(b[k], c[k]));
             float mid = lo + (hi - lo) / 2.0f;
             float q = (mid - sceneMin[k]) / step[k];
             cell[k] = clampi((int)floorf(q), 0, 1023);
@@ -167,8 +186,8 @@ static void calc_leaf(const int32_t* tri, const float* pos, const int32_t* triSo
         const float* b = pos + 3 * (size_t)tri[3 * t + 1];
         const float* c = pos + 3 * (size_t)tri[3 * t + 2];
         for (int k = 0; k < 3; k++) {
-            lo[k] = fminf(lo[k], fminf(a[k], fminf(b[k], c[k])) - eps);
-            hi[k] = fmaxf(hi[k], fmaxf(a[k], fmaxf(b[k], c[k])) + eps);
+            lo[k] = cu_fminf(lo[k], cu_fminf(a[k], cu_fminf(b[k], c[k])) - eps);
+            hi[k] = cu_fmaxf(hi[k], cu_fmaxf(a[k], cu_fmaxf(b[k], c[k])) + eps);
         }
     }
 }
@@ -270,9 +289,9 @@ int orc_lbvh_build(int32_t n, const int32_t* tri, int32_t numVerts, const float*
                 } else {
                     const float* cn = (const float*)(nodes + (size_t)(ch[k] / 64) * 16);
                     /* minmax2(childNode[0], childNode[1]) ; min/max of childNode[2] pairs */
-                    box[k][0] = fminf(cn[0], cn[4]); box[k][1] = fmaxf(cn[1], cn[5]);
-                    box[k][2] = fminf(cn[2], cn[6]); box[k][3] = fmaxf(cn[3], cn[7]);
-                    box[k][4] = fminf(cn[8], cn[10]); box[k][5] = fmaxf(cn[9], cn[11]);
+                    box[k][0] = cu_fminf(cn[0], cn[4]); box[k][1] = cu_fmaxf(cn[1], cn[5]);
+                    box[k][2] = cu_fminf(cn[2], cn[6]); box[k][3] = cu_fmaxf(cn[3], cn[7]);
+                    box[k][4] = cu_fminf(cn[8], cn[10]); box[k][5] = cu_fmaxf(cn[9], cn[11]);
                 }
             }
             nf[0] = box[0][0]; nf[1] = box[0][1]; nf[2] = box[0][2]; nf[3] = box[0][3];
@@ -304,6 +323,14 @@ static inline uint64_t mix64(uint64_t h, uint64_t v)
     return h ^ (h >> 29);
 }
 
+/* NaN payload and sign are properties of the machine that produced the NaN (x86 SSE, NVIDIA and AMD
+ * each have their own default NaN), not of the algorithm: every NaN hashes alike.  NaNs appear in Woop
+ * rows of degenerate triangles and where intermediate products overflow or underflow. */
+static inline uint32_t canon_nan(uint32_t u)
+{
+    return ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) ? 0x7FC00000u : u;
+}
+
 typedef struct HashFrame { int32_t node; int stage; uint64_t acc; } HashFrame;
 
 static uint64_t hash_leaf(const uint8_t* woop, const int32_t* triIndex, int32_t child, int hashWoop)
@@ -314,7 +341,7 @@ static uint64_t hash_leaf(const uint8_t* woop, const int32_t* triIndex, int32_t 
         if (w[0] == 0x80000000u) break;
         h = mix64(h, (uint64_t)(uint32_t)triIndex[a]);
         if (hashWoop)
-            for (int k = 0; k < 12; k++) h = mix64(h, w[k]);
+            for (int k = 0; k < 12; k++) h = mix64(h, canon_nan(w[k]));
     }
     return h;
 }
@@ -341,7 +368,7 @@ uint64_t orc_bvh_canonical_hash(const void* nodesv, int64_t nodesBytes, const vo
             continue;
         }
         uint64_t h = 0xABCDEFull;
-        for (int k = 0; k < 12; k++) h = mix64(h, n[k]);
+        for (int k = 0; k < 12; k++) h = mix64(h, canon_nan(n[k]));
         h = mix64(h, n[14]); /* split-axis word */
         uint64_t h1 = ret[--rp], h0 = ret[--rp];
         h = mix64(mix64(h, h0), h1);
