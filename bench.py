@@ -215,6 +215,33 @@ def main():
     extras = {}
     if rank == 0:
         try:
+            # opt-in scheduling hints (ntr_trace_bvh_hinted): block order learned from the previous trace of the
+            # same batch.  NOT used for `value`; the same steps re-timed with one hint object per batch.
+            hints = [nt.SchedHint() for _ in batches]
+            for _ in range(4):
+                for b, hnt in zip(batches, hints):
+                    view.trace(args.kernel, b["n"], b["any_hit"], b["rays"].data_ptr(), b["res"].data_ptr(), stream, False, hint=hnt)
+            torch.cuda.synchronize()
+            hsteps = max(3, min(args.steps, 10))
+            hev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in batches] for _ in range(hsteps)]
+            h0 = time.perf_counter()
+            for s_ in range(hsteps):
+                for bi, (b, hnt) in enumerate(zip(batches, hints)):
+                    hev[s_][bi][0].record()
+                    view.trace(args.kernel, b["n"], b["any_hit"], b["rays"].data_ptr(), b["res"].data_ptr(), stream, False, hint=hnt)
+                    hev[s_][bi][1].record()
+            torch.cuda.synchronize()
+            hwall = time.perf_counter() - h0
+            hms = np.array([[e0.elapsed_time(e1) for (e0, e1) in st_] for st_ in hev])
+            extras["sched_hints"] = {
+                "what": "same batches re-traced with ntr_trace_bvh_hinted (block order from the previous trace of the batch); "
+                        "identical hit records; helps repeated / static batches, not a moving camera (DESIGN.md 4.1)",
+                "mrays_wall": rays_per_step * hsteps / hwall / 1e6,
+                "primary_mrays": n_primary / (float(hms[:, 0].mean()) * 1e-3) / 1e6,
+                "ao_mrays": (sum(b["live"] for b in batches[1:]) / (float(hms[:, 1:].sum(axis=1).mean()) * 1e-3) / 1e6) if len(batches) > 1 else None,
+                "primary_ms": float(hms[:, 0].mean()), "steps": hsteps}
+            for hnt in hints:
+                hnt.close()
             # practical HBM ceiling: device-to-device copy of a buffer larger than the Infinity Cache
             cp_src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
             cp_dst = torch.empty_like(cp_src)

@@ -77,6 +77,11 @@ SYMBOLS = [
     ("ntr_query_config", C.c_int, [C.c_char_p, C.POINTER(KernelConfig)]),
     ("ntr_trace_bvh", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _u32, _vp,
                                 C.POINTER(C.c_float)]),
+    ("ntr_trace_bvh_hinted", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _u32, _vp,
+                                       C.POINTER(C.c_float), _vp]),
+    ("ntr_sched_hint_create", C.c_int, [C.POINTER(_vp)]),
+    ("ntr_sched_hint_destroy", C.c_int, [_vp]),
+    ("ntr_sched_hint_reset", C.c_int, [_vp]),
     ("ntr_selftest_division", C.c_int, [_vp, _i32, _vp, _i32, C.POINTER(_u32), _vp]),
     ("ntr_trace_bvh_stats", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _u32, _vp,
                                       C.POINTER(TraceStats)]),
@@ -139,13 +144,40 @@ def query_config(kernel):
     return cfg
 
 
+class SchedHint:
+    """NtrSchedHint: block-order feedback for repeated traces of one logical batch (include/ntrace_amd.h)."""
+
+    def __init__(self):
+        self._h = _vp()
+        _check(lib().ntr_sched_hint_create(C.byref(self._h)))
+
+    def reset(self):
+        _check(lib().ntr_sched_hint_reset(self._h))
+
+    def close(self):
+        if self._h:
+            lib().ntr_sched_hint_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def trace_bvh(kernel, num_rays, any_hit, d_rays, d_results, d_nodes, nodes_bytes, d_woop, woop_bytes, d_tri_index,
-              layout=4, bvh_flags=0, stream=0, timed=True):
-    """ntr_trace_bvh on raw device pointers (ints).  Returns GPU seconds if timed else None."""
+              layout=4, bvh_flags=0, stream=0, timed=True, hint=None):
+    """ntr_trace_bvh (ntr_trace_bvh_hinted with a SchedHint) on raw device pointers (ints).
+    Returns GPU seconds if timed else None."""
     sec = C.c_float(0.0)
-    _check(lib().ntr_trace_bvh(kernel.encode(), int(num_rays), int(bool(any_hit)), _vp(d_rays), _vp(d_results),
-                               _vp(d_nodes), int(nodes_bytes), _vp(d_woop), int(woop_bytes), _vp(d_tri_index),
-                               int(layout), int(bvh_flags), _vp(stream), C.byref(sec) if timed else None))
+    args = (kernel.encode(), int(num_rays), int(bool(any_hit)), _vp(d_rays), _vp(d_results), _vp(d_nodes), int(nodes_bytes),
+            _vp(d_woop), int(woop_bytes), _vp(d_tri_index), int(layout), int(bvh_flags), _vp(stream),
+            C.byref(sec) if timed else None)
+    if hint is None:
+        _check(lib().ntr_trace_bvh(*args))
+    else:
+        _check(lib().ntr_trace_bvh_hinted(*args, hint._h))
     return float(sec.value) if timed else None
 
 
@@ -271,10 +303,10 @@ class BvhView:
         self.flags = bvh_validate(self.d_nodes, self.nodes_bytes, stream)
         return self.flags
 
-    def trace(self, kernel, num_rays, any_hit, d_rays, d_results, stream=0, timed=True, flags=None):
+    def trace(self, kernel, num_rays, any_hit, d_rays, d_results, stream=0, timed=True, flags=None, hint=None):
         return trace_bvh(kernel, num_rays, any_hit, d_rays, d_results, self.d_nodes, self.nodes_bytes, self.d_woop,
                          self.woop_bytes, self.d_tri_index, self.layout, self.flags if flags is None else flags,
-                         stream, timed)
+                         stream, timed, hint)
 
     def trace_stats(self, kernel, num_rays, any_hit, d_rays, d_results, stream=0):
         return trace_bvh_stats(kernel, num_rays, any_hit, d_rays, d_results, self.d_nodes, self.nodes_bytes,

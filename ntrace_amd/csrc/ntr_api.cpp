@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <new>
 
 #include "ntrace_amd.h"
 #include "ntr_internal.h"
@@ -197,10 +198,28 @@ static int env_int(const char* name, int def)
     return (v && *v) ? atoi(v) : def;
 }
 
+// Scheduling hint (include/ntrace_amd.h): per-block cost of the previous launch -> block order of the next.
+struct NtrSchedHint {
+    unsigned int* order = nullptr;  // device, numBlocks entries
+    unsigned int* cost = nullptr;   // device, numBlocks entries
+    int numBlocks = 0;              // 0 = unbound
+    int device = -1;
+    int uses = 0;                   // launches since the hint was (re)bound
+    bool valid = false;             // order[] holds a permutation
+};
+
+static void sched_hint_release(NtrSchedHint* h)
+{
+    if (h->order) (void)hipFree(h->order);
+    if (h->cost) (void)hipFree(h->cost);
+    h->order = h->cost = nullptr;
+    h->numBlocks = 0; h->uses = 0; h->valid = false;
+}
+
 static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
                       NtrRayResult* d_results, const void* d_nodes, int64_t nodesBytes, const void* d_triWoop,
                       int64_t triWoopBytes, const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags,
-                      void* stream, float* seconds, NtrTraceStats* stats)
+                      void* stream, float* seconds, NtrTraceStats* stats, NtrSchedHint* hint = nullptr)
 {
     if (seconds) *seconds = 0.0f;
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -249,6 +268,12 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         const char* tl = getenv("NTR_TRACE_TIMELINE");
         if (tl && *tl) p.timeline = (unsigned long long*)strtoull(tl, nullptr, 16);
     }
+    p.order = nullptr;
+    p.cost = nullptr;
+    {   // experiment hook: NTR_TRACE_ORDER=<hex device pointer to uint32 block order>
+        const char* od = getenv("NTR_TRACE_ORDER");
+        if (od && *od) p.order = (const unsigned int*)strtoull(od, nullptr, 16);
+    }
     int variant = k->variant;
     if (stats) {
         // RayStats counters (src/rt/bvh/BVH.hpp:44-, filled at CudaBVH.cpp:746-757,1107-1111) are
@@ -279,6 +304,31 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         numBlocks = (numRays + blockThreads - 1) / blockThreads;
     }
 
+    // Scheduling hint: the per-ray kernel dispatches blocks in the hint's order; on refresh launches it
+    // also records per-block costs, from which the next order is derived right after the launch.
+    bool refresh = false;
+    if (hint && variant == NTR_VARIANT_PERRAY) {
+        int dev = 0;
+        NTR_HIP(hipGetDevice(&dev));
+        if (hint->numBlocks != numBlocks || hint->device != dev) {
+            sched_hint_release(hint);
+            NTR_HIP(hipMalloc((void**)&hint->order, (size_t)numBlocks * sizeof(unsigned int)));
+            NTR_HIP(hipMalloc((void**)&hint->cost, (size_t)numBlocks * sizeof(unsigned int)));
+            hint->numBlocks = numBlocks;
+            hint->device = dev;
+        }
+        // costs measured under the natural order differ from those under the derived order, so the first
+        // launches all refresh; afterwards every 8th does (slowly drifting rays keep their schedule)
+        const int every = env_int("NTR_SCHED_REFRESH_EVERY", 8);
+        refresh = hint->uses < 3 || every <= 1 || (hint->uses % every) == 0;
+        hint->uses++;
+        if (hint->valid) p.order = hint->order;
+        if (refresh) {
+            NTR_HIP(hipMemsetAsync(hint->cost, 0, (size_t)numBlocks * sizeof(unsigned int), s));
+            p.cost = hint->cost;
+        }
+    }
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (seconds) {
         NTR_HIP(hipEventCreate(&ev0));
@@ -288,8 +338,13 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     }
     hipError_t le = ntr_launch_trace(variant, &p, numBlocks, s);
     if (le != hipSuccess) return hip_fail(le, "trace_bvh launch");
+    if (seconds) NTR_HIP(hipEventRecord(ev1, s));
+    if (refresh) {
+        le = ntr_launch_sched_order(hint->cost, numBlocks, env_int("NTR_SCHED_CLASSES", 32), hint->order, s);
+        if (le != hipSuccess) return hip_fail(le, "sched_order launch");
+        hint->valid = true;
+    }
     if (seconds) {
-        NTR_HIP(hipEventRecord(ev1, s));
         NTR_HIP(hipEventSynchronize(ev1));
         float ms = 0.0f;
         NTR_HIP(hipEventElapsedTime(&ms, ev0, ev1));
@@ -323,6 +378,38 @@ int ntr_trace_bvh(const char* kernelName, int32_t numRays, int32_t anyHit, const
 {
     return trace_impl(kernelName, numRays, anyHit, d_rays, d_results, d_nodes, nodesBytes, d_triWoop, triWoopBytes,
                       d_triIndex, layout, bvhFlags, stream, seconds, nullptr);
+}
+
+int ntr_trace_bvh_hinted(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
+                         NtrRayResult* d_results, const void* d_nodes, int64_t nodesBytes, const void* d_triWoop,
+                         int64_t triWoopBytes, const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags, void* stream,
+                         float* seconds, NtrSchedHint* hint)
+{
+    return trace_impl(kernelName, numRays, anyHit, d_rays, d_results, d_nodes, nodesBytes, d_triWoop, triWoopBytes,
+                      d_triIndex, layout, bvhFlags, stream, seconds, nullptr, hint);
+}
+
+int ntr_sched_hint_create(NtrSchedHint** out)
+{
+    if (!out) return set_error(NTR_ERR_INVALID, "ntr_sched_hint_create: null out");
+    *out = new (std::nothrow) NtrSchedHint();
+    return *out ? NTR_OK : set_error(NTR_ERR_NOMEM, "ntr_sched_hint_create: out of memory");
+}
+
+int ntr_sched_hint_destroy(NtrSchedHint* hint)
+{
+    if (!hint) return NTR_OK;
+    sched_hint_release(hint);
+    delete hint;
+    return NTR_OK;
+}
+
+int ntr_sched_hint_reset(NtrSchedHint* hint)
+{
+    if (!hint) return set_error(NTR_ERR_INVALID, "ntr_sched_hint_reset: null hint");
+    hint->uses = 0;
+    hint->valid = false;
+    return NTR_OK;
 }
 
 int ntr_trace_bvh_stats(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,

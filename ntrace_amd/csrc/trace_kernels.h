@@ -41,11 +41,15 @@ struct TraceParams {
     int32_t leafSwitchBelow; // serve waiting leaves when fewer lanes than this still hold an inner node
     int32_t coop;            // quad-cooperative LDS-DMA node fetch instead of per-lane loads
     unsigned long long* timeline;  // diagnostic: per-wave realtime stamps (scripts/timeline*.py), or null
+    const unsigned int* order;     // per-ray kernel: workgroup i traces ray block order[i] (null = identity)
+    unsigned int* cost;            // per-ray kernel: cost[block] = max wave lifetime in 10 ns ticks (null = off)
     unsigned long long* stats;  // STATS variant: {innerVisits, triTests, leafVisits, hits}
 };
 
 }  // namespace ntr
 
 extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, int numBlocks, hipStream_t stream);
+extern "C" hipError_t ntr_launch_sched_order(const unsigned int* d_cost, int numBlocks, int classes, unsigned int* d_order,
+                                             hipStream_t stream);
 extern "C" hipError_t ntr_launch_selftest_division(const float* d_x, const float* d_d, int nx, int nd,
                                                    unsigned int* d_mismatches, hipStream_t stream);

@@ -404,13 +404,14 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     __shared__ __attribute__((aligned(16))) char s_stage[WAVES][COOP ? STAGE_BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rayIdx = blockIdx.x * (WAVES * 64) + threadIdx.x;
+    const unsigned int block = p.order ? p.order[blockIdx.x] : blockIdx.x;
+    const int rayIdx = block * (WAVES * 64) + threadIdx.x;
     const bool valid = rayIdx < p.numRays;
     const Rsrc nodes = make_rsrc(p.nodes, p.nodesBytes), woop = make_rsrc(p.woop, p.woopBytes);
     lds_char* stage = (lds_char*)&s_stage[__builtin_amdgcn_readfirstlane(wave)][0];
 
     unsigned long long tl0 = 0;
-    if (p.timeline) tl0 = __builtin_amdgcn_s_memrealtime();  // diagnostic only (NTR_TRACE_TIMELINE)
+    if (p.timeline || p.cost) tl0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz; scheduling feedback / diagnostics
 
     RayRegs r;
     load_ray(p.rays, valid ? rayIdx : 0, r);
@@ -431,11 +432,13 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     else traverse<false, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
 
     if (p.timeline && lane == 0) {
-        const unsigned int w = blockIdx.x * WAVES + wave;
+        const unsigned int w = block * WAVES + wave;
         p.timeline[3 * w + 0] = tl0;
         p.timeline[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
         p.timeline[3 * w + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
     }
+    if (p.cost && lane == 0)  // scheduling feedback: a block's cost is the lifetime of its longest wave
+        atomicMax(&p.cost[block], (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0));
     if (!valid) return;
     store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
     if (STATS) {  // diagnostics variant only: plain per-lane atomics
@@ -579,6 +582,71 @@ __global__ __launch_bounds__(256) void selftest_division_kernel(const float* __r
     if (bad) atomicAdd(mismatches, bad);
 }
 
+
+// ---------------------------------------------------------------------------------
+// Scheduling feedback (ntr_trace_bvh_hinted): turns the per-block costs one launch recorded into
+// the block order of the next launch of the same logical batch -- heaviest cost class first, so
+// that the long-lived waves start early instead of forming the tail of the launch.  Blocks are
+// only CLASSIFIED (NTR_SCHED_CLASSES linear classes of the maximum cost) and keep their original
+// order inside a class: neighbouring blocks trace neighbouring rays, and a full sort by cost was
+// measured slower than the coarse one because it gives that locality up (scripts/order_experiment.py).
+// One workgroup; stable counting sort with a per-thread segment of the block range.
+// ---------------------------------------------------------------------------------
+constexpr int SCHED_THREADS = 128;
+constexpr int SCHED_MAX_CLASSES = 64;
+
+__global__ __launch_bounds__(SCHED_THREADS) void sched_order_kernel(const unsigned int* __restrict__ cost, int numBlocks, int classes,
+                                                                    unsigned int* __restrict__ order)
+{
+    __shared__ unsigned int s_cnt[SCHED_MAX_CLASSES][SCHED_THREADS];
+    __shared__ unsigned int s_red[SCHED_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = (numBlocks + SCHED_THREADS - 1) / SCHED_THREADS;
+    const int b0 = min(tid * seg, numBlocks), b1 = min(b0 + seg, numBlocks);
+
+    unsigned int mx = 0;
+    for (int i = tid; i < numBlocks; i += SCHED_THREADS) mx = max(mx, cost[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, off));
+    if (lane == 0) s_red[wave] = mx;
+    for (int c = 0; c < classes; c++) s_cnt[c][tid] = 0;
+    __syncthreads();
+    mx = 0;
+    for (int w = 0; w < SCHED_THREADS / 64; w++) mx = max(mx, s_red[w]);
+    const unsigned long long scale = (unsigned long long)classes;
+    const unsigned long long denom = (unsigned long long)mx + 1ull;
+    // class 0 = heaviest
+    auto cls = [&](unsigned int c) { return (classes - 1) - (int)(((unsigned long long)c * scale) / denom); };
+
+    for (int i = b0; i < b1; i++) s_cnt[cls(cost[i])][tid]++;
+    __syncthreads();
+    // exclusive scan over (class major, thread minor): one class per iteration, block-wide
+    unsigned int running = 0;
+    for (int c = 0; c < classes; c++) {
+        const unsigned int v = s_cnt[c][tid];
+        unsigned int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int u = (unsigned int)__shfl_up((int)incl, off);
+            if (lane >= off) incl += u;
+        }
+        if (lane == 63) s_red[wave] = incl;
+        __syncthreads();
+        unsigned int before = 0, total = 0;
+        for (int w = 0; w < SCHED_THREADS / 64; w++) {
+            if (w < wave) before += s_red[w];
+            total += s_red[w];
+        }
+        s_cnt[c][tid] = running + before + incl - v;
+        running += total;
+        __syncthreads();
+    }
+    for (int i = b0; i < b1; i++) {
+        const int c = cls(cost[i]);
+        order[s_cnt[c][tid]++] = (unsigned int)i;
+    }
+}
+
 }  // namespace ntr
 
 // ---- host-side launchers (called from ntr_api.cpp) -----------------------------------
@@ -600,6 +668,15 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
     default:
         return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ntr_launch_sched_order(const unsigned int* d_cost, int numBlocks, int classes, unsigned int* d_order,
+                                             hipStream_t stream)
+{
+    if (classes < 1) classes = 1;
+    if (classes > ntr::SCHED_MAX_CLASSES) classes = ntr::SCHED_MAX_CLASSES;
+    hipLaunchKernelGGL(ntr::sched_order_kernel, dim3(1), dim3(ntr::SCHED_THREADS), 0, stream, d_cost, numBlocks, classes, d_order);
     return hipGetLastError();
 }
 

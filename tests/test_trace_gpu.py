@@ -182,3 +182,30 @@ def test_generic_and_fast_paths_agree(soup, kernel):
         a, _ = gpu_trace(kernel, dbvh, rays, any_hit)
         b, _ = gpu_trace(kernel, dbvh, rays, any_hit, flags=0)
         assert_parity(a, b, "fast vs generic %s" % kernel)
+
+
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_sched_hint_changes_order_only(soup, any_hit):
+    """ntr_trace_bvh_hinted: every generation of the hint (cost recording launch, first derived order,
+    refreshed orders), a rebind to another ray count and a reset give the oracle's hit records."""
+    import torch
+    from gpu_util import assert_parity, up
+    dbvh, cam = soup
+    rays = np.concatenate([scenes.primary_rays(cam, 160, 120)[0], scenes.random_rays(30011, seed=12), edge_rays()])
+    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit, threads=8)
+    d_rays = up(rays)
+    hint = nt.SchedHint()
+    for gen in range(12):
+        n = rays.shape[0] if gen != 6 else 777          # generation 6 rebinds the hint to a shorter batch
+        if gen == 9:
+            hint.reset()
+        d_res = torch.full((rays.shape[0] * 16,), 0xCD, dtype=torch.uint8, device="cuda:0")
+        dbvh.view.trace("fermi_speculative_while_while", n, any_hit, d_rays.data_ptr(), d_res.data_ptr(), hint=hint)
+        torch.cuda.synchronize()
+        assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE)[:n], ref[:n], "hint generation %d" % gen)
+    # kernels without a block order accept the hint and ignore it
+    d_res = torch.full((rays.shape[0] * 16,), 0xCD, dtype=torch.uint8, device="cuda:0")
+    dbvh.view.trace("kepler_dynamic_fetch", rays.shape[0], any_hit, d_rays.data_ptr(), d_res.data_ptr(), hint=hint)
+    torch.cuda.synchronize()
+    assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), ref, "hint + persistent kernel")
+    hint.close()
