@@ -56,5 +56,7 @@ extern "C" int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_
     if (!(bad & 1u)) *flags |= NTR_BVH_FINITE;
     if (!(bad & 2u)) *flags |= NTR_BVH_FASTDIV;
     if (!(bad & 4u)) *flags |= NTR_BVH_NOTINY;
+    // hosts validate after every (re)build: refresh the top-of-tree table the dispatch-order prediction uses
+    if (nodesBytes <= 0xFFFFFFFFll) return ntr_top_table_refresh(d_nodes, nodesBytes, stream);
     return NTR_OK;
 }

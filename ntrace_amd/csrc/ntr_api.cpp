@@ -198,6 +198,110 @@ static int env_int(const char* name, int def)
     return (v && *v) ? atoi(v) : def;
 }
 
+// ---- dispatch-order prediction (sched_kernels.hip) ---------------------------------------------------
+// Top-of-tree box tables, one per node buffer seen (keyed by pointer and size; rebuilt by
+// ntr_bvh_validate, which hosts call after every (re)build).  A stale table only costs scheduling quality.
+struct TopTable {
+    const void* nodes = nullptr;
+    int64_t bytes = 0;
+    int device = -1;
+    void* table = nullptr;           // 2 float4 per box
+    unsigned int* count = nullptr;   // boxes in the table
+    unsigned long long lastUse = 0;
+};
+static constexpr int kTopTables = 8;
+static TopTable g_top[kTopTables];
+static unsigned long long g_topClock = 0;
+static constexpr size_t kTopTableBytes = (((size_t)2 << NTR_TOP_DEPTH_MAX) + 16) * 32;  // + padding read by predict_kernel's batches
+
+// Class counters / lists / block order of one prediction, per stream (launches on one stream are ordered;
+// two streams must not share them).
+struct PredictScratch {
+    void* stream = nullptr;
+    int device = -1;
+    unsigned int* classCount = nullptr;  // two sets of NTR_SCHED_PRED_CLASSES counters, used alternately
+    int parity = 0;
+    unsigned int* classList = nullptr;
+    unsigned int* order = nullptr;
+    int capBlocks = 0;
+    unsigned long long lastUse = 0;
+};
+static constexpr int kScratch = 8;
+static PredictScratch g_scratch[kScratch];
+
+static int top_table_get(const void* d_nodes, int64_t nodesBytes, hipStream_t s, bool rebuild, TopTable** out)
+{
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    TopTable* t = nullptr;
+    TopTable* lru = &g_top[0];
+    for (auto& e : g_top) {
+        if (e.nodes == d_nodes && e.bytes == nodesBytes && e.device == dev) { t = &e; break; }
+        if (e.lastUse < lru->lastUse) lru = &e;
+    }
+    bool build = rebuild;
+    if (!t) {
+        t = lru;
+        if (t->table && t->device != dev) { (void)hipFree(t->table); (void)hipFree(t->count); t->table = nullptr; t->count = nullptr; }
+        if (!t->table) {
+            NTR_HIP(hipMalloc(&t->table, kTopTableBytes));
+            NTR_HIP(hipMalloc((void**)&t->count, sizeof(unsigned int)));
+        }
+        t->nodes = d_nodes; t->bytes = nodesBytes; t->device = dev;
+        build = true;
+    }
+    t->lastUse = ++g_topClock;
+    if (build) {
+        const hipError_t e = ntr_launch_top_table(d_nodes, (unsigned int)nodesBytes, env_int("NTR_TRACE_PREDICT_DEPTH", 10), t->table, t->count, s);
+        if (e != hipSuccess) return hip_fail(e, "top_table launch");
+    }
+    *out = t;
+    return NTR_OK;
+}
+
+extern "C" int ntr_top_table_refresh(const void* d_nodes, int64_t nodesBytes, void* stream)
+{
+    TopTable* t = nullptr;
+    return top_table_get(d_nodes, nodesBytes, (hipStream_t)stream, true, &t);
+}
+
+static int predict_scratch_get(hipStream_t s, int numBlocks, PredictScratch** out)
+{
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    PredictScratch* p = nullptr;
+    PredictScratch* lru = &g_scratch[0];
+    for (auto& e : g_scratch) {
+        if (e.classCount && e.stream == (void*)s && e.device == dev) { p = &e; break; }
+        if (e.lastUse < lru->lastUse) lru = &e;
+    }
+    if (!p) {
+        p = lru;
+        if (p->classCount) {
+            NTR_HIP(hipDeviceSynchronize());  // an evicted stream's launches may still read it
+            (void)hipFree(p->classCount); (void)hipFree(p->classList); (void)hipFree(p->order);
+            p->classCount = p->classList = p->order = nullptr; p->capBlocks = 0;
+        }
+        NTR_HIP(hipMalloc((void**)&p->classCount, 2 * NTR_SCHED_PRED_CLASSES * sizeof(unsigned int)));
+        NTR_HIP(hipMemsetAsync(p->classCount, 0, 2 * NTR_SCHED_PRED_CLASSES * sizeof(unsigned int), s));
+        p->stream = (void*)s; p->device = dev; p->parity = 0;
+    }
+    if (p->capBlocks < numBlocks) {
+        if (p->classList) {
+            NTR_HIP(hipStreamSynchronize(s));
+            (void)hipFree(p->classList); (void)hipFree(p->order);
+        }
+        NTR_HIP(hipMalloc((void**)&p->classList, (size_t)NTR_SCHED_PRED_CLASSES * numBlocks * sizeof(unsigned int)));
+        NTR_HIP(hipMalloc((void**)&p->order, (size_t)numBlocks * sizeof(unsigned int)));
+        p->capBlocks = numBlocks;
+    }
+    p->lastUse = ++g_topClock;
+    *out = p;
+    return NTR_OK;
+}
+
 // Scheduling hint (include/ntrace_amd.h): per-block cost of the previous launch -> block order of the next.
 struct NtrSchedHint {
     unsigned int* order = nullptr;  // device, numBlocks entries
@@ -329,12 +433,34 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         }
     }
 
+    // Dispatch-order prediction (sched_kernels.hip): closest-hit launches of the per-ray kernel that are large
+    // enough for the tail to outweigh the two small launches (about 30 us; break-even near 1 M rays).  Any-hit
+    // batches measured no net gain.
+    TopTable* predTable = nullptr;
+    PredictScratch* predScratch = nullptr;
+    if (!hint && !p.order && variant == NTR_VARIANT_PERRAY && !anyHit && numRays >= env_int("NTR_TRACE_PREDICT_MIN_RAYS", 1 << 20) &&
+        env_int("NTR_TRACE_PREDICT", 1) != 0) {
+        rc = top_table_get(d_nodes, nodesBytes, s, false, &predTable);
+        if (rc != NTR_OK) return rc;
+        rc = predict_scratch_get(s, numBlocks, &predScratch);
+        if (rc != NTR_OK) return rc;
+        p.order = predScratch->order;
+    }
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (seconds) {
         NTR_HIP(hipEventCreate(&ev0));
         NTR_HIP(hipEventCreate(&ev1));
         NTR_HIP(hipStreamSynchronize(s));  // launchTimed syncs first (CudaKernel.cpp:193)
         NTR_HIP(hipEventRecord(ev0, s));
+    }
+    if (predScratch) {  // inside the timed bracket: the prediction is part of what the launch costs
+        unsigned int* mine = predScratch->classCount + predScratch->parity * NTR_SCHED_PRED_CLASSES;
+        unsigned int* other = predScratch->classCount + (predScratch->parity ^ 1) * NTR_SCHED_PRED_CLASSES;
+        predScratch->parity ^= 1;
+        const hipError_t pe = ntr_launch_predict(d_rays, numRays, numBlocks, predTable->table, predTable->count, mine, other,
+                                                 predScratch->classList, predScratch->order, s);
+        if (pe != hipSuccess) return hip_fail(pe, "predict launch");
     }
     hipError_t le = ntr_launch_trace(variant, &p, numBlocks, s);
     if (le != hipSuccess) return hip_fail(le, "trace_bvh launch");

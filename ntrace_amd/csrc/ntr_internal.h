@@ -9,6 +9,9 @@ int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3
 int hip_fail(hipError_t e, const char* what);
 }  // namespace ntr
 
+// ntr_api.cpp: (re)build the top-of-tree box table cached for this node buffer (dispatch-order prediction)
+extern "C" int ntr_top_table_refresh(const void* d_nodes, int64_t nodesBytes, void* stream);
+
 #define NTR_HIP(call)                                            \
     do {                                                         \
         hipError_t _e = (call);                                  \

@@ -1,0 +1,185 @@
+// sched_kernels.hip -- dispatch-order prediction for the per-ray trace kernel (gfx950).
+//
+// No counterpart in the reference (its kernels take rays in buffer order).  The launch time of
+// trace_bvh_perray is set by where the long-lived blocks start: started late, they
+// are the tail of the launch.  Before a closest-hit launch the cost of every 256-ray block is
+// therefore PREDICTED and the blocks are dispatched heaviest class first.  The predictor is the
+// number of BVH nodes of depth <= NTR_TOP_DEPTH whose boxes one sample ray of the block
+// intersects -- exactly what a traversal truncated at that depth would visit, evaluated as a dense
+// loop over the top-of-tree box table (no dependent loads).  Prediction only reorders blocks: every
+// ray is traced exactly as without it, so hit records do not depend on anything in this file, and
+// approximate arithmetic (rcp, no division) is fine here.
+//
+//   top_table_kernel   one workgroup, once per BVH: breadth-first walk to depth D, every child box
+//                      of the nodes above D -> table of <= 2^(D+1)-2 boxes (32 B each)
+//   predict_kernel     one lane per block, table boxes as wave-uniform loads: count the boxes hit by the
+//                      block's sample ray, class = min(count, CLASSES-1); blocks are appended to
+//                      their class's list with one global atomic per (workgroup, class), in block
+//                      order inside the workgroup (neighbouring blocks stay neighbours: they share
+//                      BVH nodes, and a finer order by cost was measured slower)
+//   flatten_kernel     class lists -> one block order, heaviest class first (the order[] the per-ray
+//                      kernel already understands)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "trace_kernels.h"
+
+namespace ntr {
+
+// ---- top-of-tree box table -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void top_table_kernel(const float4* __restrict__ nodes, unsigned int nodesBytes, int depth,
+                                                        float4* __restrict__ table, unsigned int* __restrict__ tableCount)
+{
+    // level queues in LDS: a level above `depth` <= NTR_TOP_DEPTH_MAX holds at most 2^(depth-1) inner nodes
+    __shared__ int s_q[2][1 << (NTR_TOP_DEPTH_MAX - 1)];
+    __shared__ unsigned int s_cnt[2], s_out;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_q[0][0] = 0; s_cnt[0] = 1; s_cnt[1] = 0; s_out = 0; }
+    __syncthreads();
+    for (int d = 0; d < depth; d++) {
+        const int cur = d & 1, nxt = cur ^ 1;
+        const unsigned int n = s_cnt[cur];
+        for (unsigned int e = tid; e < n; e += 256) {
+            const unsigned int ofs = (unsigned int)s_q[cur][e];
+            if (ofs + 64u > nodesBytes) continue;  // malformed child pointer: ignore (prediction only)
+            const float4* nd = nodes + (ofs >> 4);
+            const float4 a = nd[0], b = nd[1], c = nd[2];
+            const int4 ch = *reinterpret_cast<const int4*>(nd + 3);
+            const unsigned int o = atomicAdd(&s_out, 2u);
+            table[2 * o + 0] = a;                                  // child 0: lo.x hi.x lo.y hi.y
+            table[2 * o + 1] = make_float4(c.x, c.y, 0.0f, 0.0f);  //          lo.z hi.z
+            table[2 * o + 2] = b;                                  // child 1
+            table[2 * o + 3] = make_float4(c.z, c.w, 0.0f, 0.0f);
+            if (d + 1 < depth) {
+                if (ch.x >= 0) s_q[nxt][atomicAdd(&s_cnt[nxt], 1u)] = ch.x;
+                if (ch.y >= 0) s_q[nxt][atomicAdd(&s_cnt[nxt], 1u)] = ch.y;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_cnt[cur] = 0;
+        __syncthreads();
+    }
+    if (tid == 0) *tableCount = s_out;
+}
+
+// ---- per-block cost class + class lists --------------------------------------------------------------
+// One lane per block (its sample ray in registers); the sixteen waves of a workgroup share 64 blocks and split
+// the table between them: a wave stages its slice in LDS and reads every box back at a wave-uniform address
+// (one LDS broadcast for all 64 lanes).
+constexpr int PRED_WAVES = 16;
+constexpr int PRED_SAMPLE = 100;        // sample ray inside the block (any fixed lane)
+
+__global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* __restrict__ rays, int numRays, int numBlocks,
+                                                                  const float4* __restrict__ table,
+                                                                  const unsigned int* __restrict__ tableCount,
+                                                                  unsigned int* __restrict__ classCount, unsigned int* __restrict__ classList)
+{
+    constexpr int PER_MAX = ((2 << NTR_TOP_DEPTH_MAX) + PRED_WAVES - 1) / PRED_WAVES;  // boxes per wave, at most
+    __shared__ float2 s_tab[PRED_WAVES][PER_MAX * 3];  // per wave: its slice of the table, (lo, hi) per axis
+    __shared__ unsigned int s_cnt[64];
+    __shared__ unsigned int s_hist[NTR_SCHED_PRED_CLASSES], s_base[NTR_SCHED_PRED_CLASSES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int block = blockIdx.x * 64 + lane;
+    if (tid < 64) s_cnt[tid] = 0;
+    if (tid < NTR_SCHED_PRED_CLASSES) s_hist[tid] = 0;
+    const int nBoxes = (int)*tableCount;
+    const int per = min((nBoxes + PRED_WAVES - 1) / PRED_WAVES, PER_MAX);
+    const int b0 = wave * per, n = max(min(b0 + per, nBoxes) - b0, 0);
+    for (int i = lane; i < n; i += 64) {  // stage this wave's slice (coalesced), then read it back with uniform addresses
+        const float4 xy = table[2 * (b0 + i)], z = table[2 * (b0 + i) + 1];
+        s_tab[wave][3 * i + 0] = make_float2(xy.x, xy.y);
+        s_tab[wave][3 * i + 1] = make_float2(xy.z, xy.w);
+        s_tab[wave][3 * i + 2] = make_float2(z.x, z.y);
+    }
+    const int r = min(min(block, numBlocks - 1) * 256 + PRED_SAMPLE, numRays - 1);
+    const float4 o = rays[2 * r], d = rays[2 * r + 1];  // (origin, tmin), (direction, tmax)
+    const float ix = __frcp_rn(d.x), iy = __frcp_rn(d.y), iz = __frcp_rn(d.z);
+    const float ax = -o.x * ix, ay = -o.y * iy, az = -o.z * iz;  // (plane - o) * inv = fma(plane, inv, a)
+    __syncthreads();
+    unsigned int cnt = 0;
+    const float2* tb = &s_tab[wave][0];
+#pragma unroll 8
+    for (int i = 0; i < n; i++) {
+        const float2 bx = tb[3 * i], by = tb[3 * i + 1], bz = tb[3 * i + 2];  // same address in every lane: LDS broadcast
+        const float x0 = fmaf(bx.x, ix, ax), x1 = fmaf(bx.y, ix, ax);
+        const float y0 = fmaf(by.x, iy, ay), y1 = fmaf(by.y, iy, ay);
+        const float z0 = fmaf(bz.x, iz, az), z1 = fmaf(bz.y, iz, az);
+        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), o.w));
+        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), d.w));
+        cnt += (tn <= tf) ? 1u : 0u;
+    }
+    if (cnt) atomicAdd(&s_cnt[lane], cnt);
+    __syncthreads();
+    unsigned int cls = 0;
+    if (tid < 64 && block < numBlocks) {
+        cls = min(s_cnt[lane] >> 1, (unsigned int)(NTR_SCHED_PRED_CLASSES - 1));
+        atomicAdd(&s_hist[cls], 1u);
+        s_cnt[lane] = cls;
+    }
+    __syncthreads();
+    if (tid < NTR_SCHED_PRED_CLASSES && s_hist[tid]) s_base[tid] = atomicAdd(&classCount[tid], s_hist[tid]);
+    __syncthreads();
+    if (tid < 64 && block < numBlocks) {
+        // rank among the workgroup's earlier blocks of the same class: neighbours stay in buffer order
+        unsigned int rank = 0;
+        for (int j = 0; j < lane; j++) rank += (s_cnt[j] == cls) ? 1u : 0u;
+        classList[(size_t)cls * numBlocks + s_base[cls] + rank] = (unsigned int)block;
+    }
+}
+
+// order[e] = e-th block when the class lists are concatenated from the heaviest class down.
+// It also clears the OTHER set of class counters (the two sets alternate between launches, so the set the next
+// prediction adds to is zero without a memset in the stream).
+__global__ __launch_bounds__(256) void flatten_kernel(const unsigned int* __restrict__ classCount, const unsigned int* __restrict__ classList,
+                                                      int numBlocks, unsigned int* __restrict__ order, unsigned int* __restrict__ otherCount)
+{
+    if (blockIdx.x == 0 && threadIdx.x < NTR_SCHED_PRED_CLASSES) otherCount[threadIdx.x] = 0;
+    __shared__ unsigned int s_end[NTR_SCHED_PRED_CLASSES];  // s_end[k] = entries in the k+1 heaviest classes
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        static_assert(NTR_SCHED_PRED_CLASSES == 64, "one class per lane");
+        unsigned int incl = classCount[NTR_SCHED_PRED_CLASSES - 1 - tid];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int u = (unsigned int)__shfl_up((int)incl, off);
+            if (tid >= off) incl += u;
+        }
+        s_end[tid] = incl;
+    }
+    __syncthreads();
+    const int e = blockIdx.x * 256 + tid;
+    if (e >= numBlocks) return;
+    int k = 0;  // first k with e < s_end[k]
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1)
+        if (k + step <= NTR_SCHED_PRED_CLASSES - 1 && s_end[k + step - 1] <= (unsigned int)e) k += step;
+    const unsigned int begin = k ? s_end[k - 1] : 0u;
+    const int cls = NTR_SCHED_PRED_CLASSES - 1 - k;
+    order[e] = classList[(size_t)cls * numBlocks + ((unsigned int)e - begin)];
+}
+
+}  // namespace ntr
+
+extern "C" hipError_t ntr_launch_top_table(const void* d_nodes, unsigned int nodesBytes, int depth, void* d_table,
+                                           unsigned int* d_tableCount, hipStream_t stream)
+{
+    if (depth < 1) depth = 1;
+    if (depth > NTR_TOP_DEPTH_MAX) depth = NTR_TOP_DEPTH_MAX;
+    hipLaunchKernelGGL(ntr::top_table_kernel, dim3(1), dim3(256), 0, stream, (const float4*)d_nodes, nodesBytes, depth, (float4*)d_table,
+                       d_tableCount);
+    return hipGetLastError();
+}
+
+// d_classCount must be zero on entry (NTR_SCHED_PRED_CLASSES words); d_otherCount is zeroed for the next launch.
+extern "C" hipError_t ntr_launch_predict(const void* d_rays, int numRays, int numBlocks, const void* d_table,
+                                         const unsigned int* d_tableCount, unsigned int* d_classCount, unsigned int* d_otherCount,
+                                         unsigned int* d_classList, unsigned int* d_order, hipStream_t stream)
+{
+    const int grid = (numBlocks + 63) / 64;
+    hipLaunchKernelGGL(ntr::predict_kernel, dim3(grid), dim3(ntr::PRED_WAVES * 64), 0, stream, (const float4*)d_rays, numRays, numBlocks,
+                       (const float4*)d_table, d_tableCount, d_classCount, d_classList);
+    hipLaunchKernelGGL(ntr::flatten_kernel, dim3((numBlocks + 255) / 256), dim3(256), 0, stream, (const unsigned int*)d_classCount,
+                       (const unsigned int*)d_classList, numBlocks, d_order, d_otherCount);
+    return hipGetLastError();
+}

@@ -49,6 +49,14 @@ struct TraceParams {
 }  // namespace ntr
 
 extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, int numBlocks, hipStream_t stream);
+// dispatch-order prediction (sched_kernels.hip)
+#define NTR_TOP_DEPTH_MAX 10          // top-of-tree table: child boxes of the nodes above this depth
+#define NTR_SCHED_PRED_CLASSES 64     // cost classes of the predictor (one per lane in the flatten step)
+extern "C" hipError_t ntr_launch_top_table(const void* d_nodes, unsigned int nodesBytes, int depth, void* d_table,
+                                           unsigned int* d_tableCount, hipStream_t stream);
+extern "C" hipError_t ntr_launch_predict(const void* d_rays, int numRays, int numBlocks, const void* d_table,
+                                         const unsigned int* d_tableCount, unsigned int* d_classCount, unsigned int* d_otherCount,
+                                         unsigned int* d_classList, unsigned int* d_order, hipStream_t stream);
 extern "C" hipError_t ntr_launch_sched_order(const unsigned int* d_cost, int numBlocks, int classes, unsigned int* d_order,
                                              hipStream_t stream);
 extern "C" hipError_t ntr_launch_selftest_division(const float* d_x, const float* d_d, int nx, int nd,

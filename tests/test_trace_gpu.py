@@ -209,3 +209,20 @@ def test_sched_hint_changes_order_only(soup, any_hit):
     torch.cuda.synchronize()
     assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), ref, "hint + persistent kernel")
     hint.close()
+
+
+@pytest.mark.parametrize("n", [1, 255, 257, 16385, 70001])
+def test_dispatch_order_prediction_changes_order_only(soup, n, monkeypatch):
+    """Closest-hit launches of the per-ray kernel are dispatched in predicted-cost order (sched_kernels.hip);
+    forced on for small, ragged launches here (block counts that are not multiples of 64, a single block)."""
+    from gpu_util import assert_parity, gpu_trace
+    dbvh, cam = soup
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+    rays = np.concatenate([scenes.primary_rays(cam, 300, 240)[0], edge_rays()])[:n]
+    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
+    for rep in range(3):  # the class counters alternate between two sets
+        got, _ = gpu_trace("fermi_speculative_while_while", dbvh, rays, False)
+        assert_parity(got, ref, "prediction n=%d rep=%d" % (n, rep))
+    monkeypatch.setenv("NTR_TRACE_PREDICT", "0")
+    got, _ = gpu_trace("fermi_speculative_while_while", dbvh, rays, False)
+    assert_parity(got, ref, "prediction off n=%d" % n)
