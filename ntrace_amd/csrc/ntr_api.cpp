@@ -253,7 +253,7 @@ static int top_table_get(const void* d_nodes, int64_t nodesBytes, hipStream_t s,
     }
     t->lastUse = ++g_topClock;
     if (build) {
-        const hipError_t e = ntr_launch_top_table(d_nodes, (unsigned int)nodesBytes, env_int("NTR_TRACE_PREDICT_DEPTH", 10), t->table, t->count, s);
+        const hipError_t e = ntr_launch_top_table(d_nodes, (unsigned int)nodesBytes, env_int("NTR_TRACE_PREDICT_DEPTH", 9), t->table, t->count, s);
         if (e != hipSuccess) return hip_fail(e, "top_table launch");
     }
     *out = t;

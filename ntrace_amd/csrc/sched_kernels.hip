@@ -4,7 +4,7 @@
 // trace_bvh_perray is set by where the long-lived blocks start: started late, they
 // are the tail of the launch.  Before a closest-hit launch the cost of every 256-ray block is
 // therefore PREDICTED and the blocks are dispatched heaviest class first.  The predictor is the
-// number of BVH nodes of depth <= NTR_TOP_DEPTH whose boxes one sample ray of the block
+// number of BVH nodes of depth <= 9 (NTR_TRACE_PREDICT_DEPTH) whose boxes one sample ray of the block
 // intersects -- exactly what a traversal truncated at that depth would visit, evaluated as a dense
 // loop over the top-of-tree box table (no dependent loads).  Prediction only reorders blocks: every
 // ray is traced exactly as without it, so hit records do not depend on anything in this file, and
