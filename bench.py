@@ -65,6 +65,7 @@ def parse():
                     help="NTrace camera signature (CameraControls::encodeSignature) for --scene-obj")
     ap.add_argument("--ao-streams", type=int, default=3,
                     help="HIP streams the independent AO batches of a frame are issued on (1 = one stream, in buffer order)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     return ap.parse_args()
@@ -253,7 +254,7 @@ def main():
 
     # ---- extras (outside the timed region): on-device LBVH build of the same scene, secondary-ray sort ----
     extras = {}
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         try:
             # opt-in scheduling hints (ntr_trace_bvh_hinted): block order learned from the previous trace of the
             # same batch.  NOT used for `value`; the same steps re-timed with one hint object per batch.
@@ -374,6 +375,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(n_primary),
                      "kernel": "trace_bvh (%s), primary batch" % args.kernel,
+                     "launch_ms": prim_ms,
+                     "launch_includes": "predict_kernel + flatten_kernel (dispatch-order prediction, about 30 us) + trace_bvh_perray; "
+                                        "rocprofv3's per-kernel average for trace_bvh_perray alone is in profiles/*_rocprof_summary.txt",
                      "note": "algorithmic bytes (SURVEY 8d accounting) / HIP-event time; > 1 means the bytes are served by L1/L2/"
                              "Infinity Cache: measured HBM-side traffic is in `traffic` (bytes per launch)",
                      "algorithmic_bytes_per_launch": alg_bytes,
