@@ -7,8 +7,8 @@ zero-component directions, origins on vertices, huge / tiny / inf / NaN / degene
 compares hit records bit for bit (id and the 32 bits of t) plus the traversal counters, for every
 kernel name and for closest-hit and any-hit.  LBVH rounds also compare the tree in canonical form.
 
-Usage: python scripts/fuzz_parity.py [--seconds 240] [--seed 1] > log.json   (needs a GPU; the oracle
-is the checker here, exactly as in tests/)."""
+Usage: python tests/fuzz_parity.py [--seconds 240] [--seed 1] > log.json   (needs a GPU).  Test
+infrastructure: the oracle is the checker here, as everywhere under tests/."""
 import argparse
 import json
 import os
@@ -19,7 +19,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch  # noqa: E402
 
 import ntrace_amd as nt  # noqa: E402

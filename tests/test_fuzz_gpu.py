@@ -1,4 +1,4 @@
-"""Short run of the randomised differential test (scripts/fuzz_parity.py): random scenes, SAH and
+"""Short run of the randomised differential test (tests/fuzz_parity.py): random scenes, SAH and
 on-device LBVH trees, ray mixes with zero / tiny / non-finite components, every kernel name, closest-hit
 and any-hit; hit records, traversal counters and LBVH trees must match the CPU oracle exactly."""
 import io
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("seed", [11, 12])
 def test_fuzz_parity_short(seed):
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import fuzz_parity
     buf = io.StringIO()
     with redirect_stdout(buf):
