@@ -124,10 +124,12 @@ def main():
     view = nt.BvhView(d_nodes.data_ptr(), bvh.nodes.nbytes, d_woop.data_ptr(), bvh.woop.nbytes, d_idx.data_ptr())
     view.validate(stream)
 
-    # ---- ray batches: rank r renders its own tile set = the frame seen from camera r ------------
+    # ---- ray batches: rank r renders its own frame of a slow camera move (weak scaling: every rank traces a
+    # full-resolution frame; 2 units per rank in a 3 600-unit hall keeps the frames distinct but equally costly,
+    # so that the slowest rank measures the machine, not the view) ---------------------------------------
     cam = dict(cam)
     eye = np.array(cam["eye"], dtype=np.float64)
-    eye[2] += 35.0 * rank  # weak scaling: every rank traces a full-resolution tile set
+    eye[2] += 2.0 * rank
     cam["eye"] = tuple(eye)
     w, h = args.width, args.height
     n_primary = w * h
