@@ -173,6 +173,14 @@ def main(argv=None):
             # the kernels answer degenerate rays (not tmin < tmax: Ray::degenerate, NaN extents) without
             # traversal, so the traversal counters are defined over the other rays
             live = rays[rays["tmin"] < rays["tmax"]]
+            # scheduling variants only permute blocks: plain, dispatch-order prediction forced on, caller-owned hint
+            sched = int(rng.integers(0, 3))
+            if sched == 1:
+                os.environ["NTR_TRACE_PREDICT_MIN_RAYS"] = "1"
+            else:
+                os.environ.pop("NTR_TRACE_PREDICT_MIN_RAYS", None)
+            hint = nt.SchedHint() if sched == 2 else None
+            tot["sched_%d_rounds" % sched] = tot.get("sched_%d_rounds" % sched, 0) + 1
             for any_hit in (False, True):
                 exp, _ = oracle.trace(nodes, woop, idx, rays, any_hit=any_hit, threads=cores)
                 _, est = oracle.trace(nodes, woop, idx, live, any_hit=any_hit, threads=cores)
@@ -184,11 +192,14 @@ def main(argv=None):
                     cbad = int((st.numInnerVisits, st.numTriTests, st.numLeafVisits, st.numHits) !=
                                (est.numInnerVisits, est.numTriTests, est.numLeafVisits, est.numHits))
                     d_res.fill_(0xCD)
-                    view.trace(kernel, n, any_hit, d_rays.data_ptr(), d_res.data_ptr())
-                    torch.cuda.synchronize()
-                    got2 = d_res.cpu().numpy().view(nt.RESULT_DTYPE)
-                    bad += int(((got2["id"] != exp["id"]) | (got2["t"].view(np.uint32) != exp["t"].view(np.uint32))).sum())
-                    tot["rays_compared"] += 2 * n
+                    for rep in range(3 if hint is not None else 1):  # a hint changes the order from its second use on
+                        d_res.fill_(0xCD)
+                        view.trace(kernel, n, any_hit, d_rays.data_ptr(), d_res.data_ptr(), hint=hint)
+                        torch.cuda.synchronize()
+                        got2 = d_res.cpu().numpy().view(nt.RESULT_DTYPE)
+                        bad += int(((got2["id"] != exp["id"]) | (got2["t"].view(np.uint32) != exp["t"].view(np.uint32))).sum())
+                        tot["rays_compared"] += n
+                    tot["rays_compared"] += n
                     tot["record_mismatches"] += bad
                     tot["counter_mismatches"] += cbad
                     if bad or cbad:
@@ -200,6 +211,7 @@ def main(argv=None):
         tot["rounds"] += 1
         tot["triangles"] += int(tri.shape[0])
         del keep
+        os.environ.pop("NTR_TRACE_PREDICT_MIN_RAYS", None)
     tot["failures"] = [f for f in failures if f["kind"] != "trace"][:20] + [f for f in failures if f["kind"] == "trace"][:6]
     tot["seed"] = args.seed
     tot["seconds"] = args.seconds
