@@ -13,7 +13,7 @@
 //   top_table_kernel   one workgroup, once per BVH: breadth-first walk to depth D, every child box
 //                      of the nodes above D -> table of <= 2^(D+1)-2 boxes (32 B each)
 //   predict_kernel     one lane per block, table boxes as wave-uniform loads: count the boxes hit by the
-//                      block's sample ray, class = min(count, CLASSES-1); blocks are appended to
+//                      block's sample ray, class = min(count / 2, CLASSES-1); blocks are appended to
 //                      their class's list with one global atomic per (workgroup, class), in block
 //                      order inside the workgroup (neighbouring blocks stay neighbours: they share
 //                      BVH nodes, and a finer order by cost was measured slower)
