@@ -686,7 +686,6 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         const int shift = pass * 8;
         hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, 1, shift, hist, nb);
         hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(256), dim3(256), 0, s, hist, nb, hist + (size_t)nb * 256);
-        hipLaunchKernelGGL(sort_scan_totals_kernel, dim3(1), dim3(256), 0, s, hist + (size_t)nb * 256);
         hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, kOut, vOut, 1,
                            shift, (const unsigned int*)hist, (const unsigned int*)hist + (size_t)nb * 256, nb);
         unsigned int* tk = kIn; kIn = kOut; kOut = tk;

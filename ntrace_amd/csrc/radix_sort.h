@@ -2,7 +2,7 @@
 // the LBVH builder (sort_by_key of Morton codes, radixSort.cu:22-50) and the ray sort (192-bit keys,
 // RayBuffer::mortonSort, src/rt/ray/RayBuffer.cpp:103-165).
 //   sort_hist_kernel     per-tile digit histogram in LDS -> hist[digit][tile]
-//   sort_scan_*_kernel   exclusive scan of the histogram array (one workgroup per digit + one for the totals)
+//   sort_scan_rows_kernel exclusive scan of the histogram array, one workgroup per digit
 //   sort_scatter_kernel  stable scatter: each wave ranks 64 keys per round with 8 ballots
 //                        (match-any) + prefix popcount; rounds chain through per-wave LDS counters
 // INDEXED = false: keys[i] is the key of element i, keys and values both move.
@@ -43,8 +43,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(int n, const un
 
 // Scan of the digit-major histogram hist[256][numBlocks] in two small parallel steps:
 //   sort_scan_rows_kernel    one workgroup per digit: exclusive prefix over the tiles, row total out
-//   sort_scan_totals_kernel  exclusive scan of the 256 row totals -> global base of every digit
-// (the scatter adds base[digit] to its tile's row prefix).
+// The exclusive scan of the 256 row totals (global base of every digit) is recomputed by every scatter
+// workgroup in LDS -- 256 words, cheaper than a launch of its own.
 __global__ __launch_bounds__(256) static void sort_scan_rows_kernel(unsigned int* __restrict__ hist, int numBlocks,
                                                                     unsigned int* __restrict__ rowTotal)
 {
@@ -71,34 +71,31 @@ __global__ __launch_bounds__(256) static void sort_scan_rows_kernel(unsigned int
     if (threadIdx.x == 255) rowTotal[blockIdx.x] = s_part[255];
 }
 
-__global__ __launch_bounds__(256) static void sort_scan_totals_kernel(unsigned int* __restrict__ rowTotal)
-{
-    __shared__ unsigned int s_part[256];
-    const unsigned int mine = rowTotal[threadIdx.x];
-    s_part[threadIdx.x] = mine;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const unsigned int v = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    rowTotal[threadIdx.x] = s_part[threadIdx.x] - mine;
-}
-
 template <bool INDEXED>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(int n, const unsigned int* __restrict__ keysIn,
                                                                     const int* __restrict__ valsIn,
                                                                     unsigned int* __restrict__ keysOut, int* __restrict__ valsOut,
                                                                     int stride, int shift, const unsigned int* __restrict__ hist,
-                                                                    const unsigned int* __restrict__ digitBase, int numBlocks)
+                                                                    const unsigned int* __restrict__ rowTotal, int numBlocks)
 {
     constexpr int WAVES = SORT_THREADS / 64;
+    static_assert(SORT_THREADS == 256, "one thread per digit");
     __shared__ unsigned int s_cnt[WAVES][256];
     __shared__ unsigned int s_base[WAVES][256];
+    __shared__ unsigned int s_digit[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < WAVES * 256; i += SORT_THREADS) (&s_cnt[0][0])[i] = 0;
+    // exclusive scan of the digit totals: global base of digit threadIdx.x
+    const unsigned int myTotal = rowTotal[threadIdx.x];
+    s_digit[threadIdx.x] = myTotal;
     __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned int v = (threadIdx.x >= (unsigned)off) ? s_digit[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_digit[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const unsigned int digitBase = s_digit[threadIdx.x] - myTotal;
 
     const int chunk = blockIdx.x * SORT_TILE + wave * (64 * SORT_ITEMS);
     unsigned int key[SORT_ITEMS], rank[SORT_ITEMS];
@@ -125,7 +122,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(int n, const
     __syncthreads();
     {   // digit threadIdx.x: offsets of the waves and the global base of this tile
         const unsigned int d = threadIdx.x;
-        unsigned int run = hist[d * numBlocks + blockIdx.x] + digitBase[d];
+        unsigned int run = hist[d * numBlocks + blockIdx.x] + digitBase;
 #pragma unroll
         for (int w = 0; w < WAVES; w++) {
             s_base[w][d] = run;

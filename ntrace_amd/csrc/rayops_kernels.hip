@@ -210,7 +210,6 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
             hipLaunchKernelGGL(sort_hist_kernel<true>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kw, (const int*)vIn, 6, shift,
                                (unsigned int*)hist.p, nb);
             hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(256), dim3(256), 0, s, (unsigned int*)hist.p, nb, (unsigned int*)hist.p + (size_t)nb * 256);
-        hipLaunchKernelGGL(sort_scan_totals_kernel, dim3(1), dim3(256), 0, s, (unsigned int*)hist.p + (size_t)nb * 256);
             hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kw, (const int*)vIn,
                                (unsigned int*)nullptr, vOut, 6, shift, (const unsigned int*)hist.p, (const unsigned int*)hist.p + (size_t)nb * 256, nb);
             int* t = vIn; vIn = vOut; vOut = t;
