@@ -313,11 +313,12 @@ __device__ __forceinline__ int find_split(const unsigned int* keys, int base, in
 {
     int a = nStart, b = nEnd - 1;
     while (b - a > 1) {
-        const unsigned int len = (unsigned int)(b - a);
+        const int len = b - a;
+        const int step = len / K;  // K is a power of two; any probes strictly inside (a, b) are valid
         int na = a, nb = b;
 #pragma unroll
         for (int j = 1; j < K; j++) {
-            const int p = a + (int)(((unsigned long long)len * j) / K);
+            const int p = step ? a + j * step : min(a + j, b - 1);
             const unsigned int bit = (keys[p - base] >> level) & 1;
             if (bit == startBit) na = max(na, p); else nb = min(nb, p);
         }
@@ -515,43 +516,164 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_kernel(EmitCtx c, int n,
     }
 }
 
-// One workgroup per range of at most `cap` triangles: keys and queues in LDS, a counting pass, ONE pair of
-// global atomics for the subtree's nodes and leaf storage, the writing pass, then the bottom-up refit.
+// Split position as find_split, for ranges of fewer than 2^16 keys held in LDS: 32-bit probe arithmetic.
+template <int LOGK>
+__device__ __forceinline__ int find_split_small(const unsigned int* keys, int nStart, int nEnd, int level, unsigned int startBit)
+{
+    int a = nStart, b = nEnd - 1;
+    while (b - a > 1) {
+        const int len = b - a;
+        int na = a, nb = b;
+#pragma unroll
+        for (int j = 1; j < (1 << LOGK); j++) {
+            const int p = a + ((len * j) >> LOGK);
+            const unsigned int bit = (keys[p] >> level) & 1;
+            if (bit == startBit) na = max(na, p); else nb = min(nb, p);
+        }
+        a = na; b = nb;
+    }
+    return b;
+}
+
+// One entry of a subtree's node list in LDS (positions are relative to the subtree's first triangle, which keeps
+// every field below 2^16 for the subtree sizes a workgroup's LDS can hold).
+struct SubEntry {
+    unsigned int range;   // start | end << 16
+    unsigned int split;   // split | (level + 1) << 16 | leaf0 << 24 | leaf1 << 25
+    unsigned int child;   // entry position of inner child 0 | of inner child 1 << 16
+    unsigned int leaf;    // triangles | leaves << 16 reserved by this subtree before this entry's leaves
+};
+
+// One workgroup per range of at most `cap` triangles.
+//   1. topology, level by level, entirely in LDS (keys, the entry list that doubles as the queue): splits, leaf
+//      decisions, positions of the children in the list, leaf storage offsets;
+//   2. ONE pair of global atomics reserves the subtree's node indices and leaf storage;
+//   3. every entry is written in parallel (node words, leaf boxes and slots): no level dependency any more;
+//   4. bottom-up refit over the levels, children found through the LDS list.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void lbvh_subtree_kernel(EmitCtx c, int cap)
 {
     extern __shared__ int smem[];
     __shared__ EmitShared sh;
-    unsigned int* sKeys = reinterpret_cast<unsigned int*>(smem);  // [cap]
-    const int qInts = 3 * (cap / 2 + 1);
-    int* qA = smem + cap;
-    int* qB = qA + qInts;
-    int* lst = qB + qInts;                                        // [cap]
+    __shared__ unsigned int s_entCount, s_leafCtr;
+    unsigned int* sKeys = reinterpret_cast<unsigned int*>(smem);           // [cap]
+    SubEntry* ent = reinterpret_cast<SubEntry*>(smem + cap);               // [cap]: a subtree over m triangles has < m inner nodes
     const unsigned int numSub = c.st->numSub;
+    const int tid = threadIdx.x;
     unsigned int deepest = 0;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) sh.item = atomicAdd(&c.st->subNext, 1u);
+        if (tid == 0) sh.item = atomicAdd(&c.st->subNext, 1u);
         __syncthreads();
-        const unsigned int i = sh.item;
-        if (i >= numSub) break;
-        const int4 root = c.subList[i];
-        for (int k = root.y + threadIdx.x; k < root.z; k += THREADS) sKeys[k - root.y] = c.keys[k];
-        if (threadIdx.x == 0) { sh.nodeCtr = 0; sh.nodeBase = 0; sh.leafCtr = 0ull; sh.leafBase = 0ull; }
-        __syncthreads();
-        emit_subtree<THREADS, false, false, 8>(c, sh, root, sKeys, root.y, qA, qB, lst);
-        if (threadIdx.x == 0) {
-            sh.nodeBase = sh.nodeCtr ? atomicAdd(&c.st->nodeCount, sh.nodeCtr) : 0u;
-            sh.leafBase = sh.leafCtr ? atomicAdd(&c.st->leafPtr, sh.leafCtr) : 0ull;
-            sh.nodeCtr = 0; sh.leafCtr = 0ull;
+        const unsigned int item = sh.item;
+        if (item >= numSub) break;
+        const int4 root = c.subList[item];
+        const int m = root.z - root.y;
+        for (int k = tid; k < m; k += THREADS) sKeys[k] = c.keys[root.y + k];
+        if (tid == 0) {
+            ent[0].range = (unsigned int)m << 16;  // [0, m)
+            s_entCount = 1; s_leafCtr = 0;
+            sh.lvlOfs[0] = 0;
+        }
+        lds_barrier();
+
+        // ---- 1. topology ------------------------------------------------------------------------------
+        int lv = 0;
+        unsigned int lvlBegin = 0, lvlEnd = 1;
+        for (int lvl = root.w; lvl < 30 && lvlBegin < lvlEnd; lvl++, lv++) {
+            const int levelBit = 29 - lvl;
+            for (unsigned int e = lvlBegin + tid; e < lvlEnd; e += THREADS) {
+                const unsigned int rg = ent[e].range;
+                const int nStart = (int)(rg & 0xFFFFu), nEnd = (int)(rg >> 16);
+                const unsigned int kFirst = sKeys[nStart], kLast = sKeys[nEnd - 1];
+                const unsigned int diff = (kFirst ^ kLast) & ((2u << levelBit) - 1u);
+                const int level = diff ? 31 - __clz((int)diff) : -1;
+                const int split = level >= 0 ? find_split_small<3>(sKeys, nStart, nEnd, level, (kFirst >> level) & 1)
+                                             : (nStart + nEnd) >> 1;  // identical keys: median (:282)
+                const bool leaf0 = (split - nStart) <= c.leafSize || levelBit == 0;
+                const bool leaf1 = (nEnd - split) <= c.leafSize || levelBit == 0;
+                const unsigned int inner = (leaf0 ? 0u : 1u) + (leaf1 ? 0u : 1u);
+                const unsigned int lf = (leaf0 ? ((unsigned int)(split - nStart) + 0x10000u) : 0u) +
+                                        (leaf1 ? ((unsigned int)(nEnd - split) + 0x10000u) : 0u);
+                unsigned int pos = inner ? atomicAdd(&s_entCount, inner) : 0u;
+                const unsigned int leafOfs = lf ? atomicAdd(&s_leafCtr, lf) : 0u;
+                unsigned int child = 0;
+                if (!leaf0) { ent[pos].range = (unsigned int)nStart | ((unsigned int)split << 16); child = pos; pos++; }
+                if (!leaf1) { ent[pos].range = (unsigned int)split | ((unsigned int)nEnd << 16); child |= pos << 16; }
+                ent[e].split = (unsigned int)split | ((unsigned int)(level + 1) << 16) | (leaf0 ? (1u << 24) : 0u) | (leaf1 ? (1u << 25) : 0u);
+                ent[e].child = child;
+                ent[e].leaf = leafOfs;
+            }
+            lds_barrier();
+            lvlBegin = lvlEnd;
+            lvlEnd = s_entCount;
+            if (tid == 0) sh.lvlOfs[lv + 1] = lvlBegin;
+            lds_barrier();  // every thread has read s_entCount before the next level adds to it
+        }
+        const unsigned int numEnt = lvlBegin;  // every entry of the subtree
+        deepest = max(deepest, (unsigned int)(root.w + lv));
+
+        // ---- 2. node indices and leaf storage of the whole subtree ---------------------------------------
+        if (tid == 0) {
+            const unsigned int lc = s_leafCtr;
+            sh.nodeBase = numEnt > 1 ? atomicAdd(&c.st->nodeCount, numEnt - 1) : 0u;
+            sh.leafBase = lc ? atomicAdd(&c.st->leafPtr, ((unsigned long long)(lc & 0xFFFFu) << 32) | (unsigned long long)(lc >> 16)) : 0ull;
         }
         __syncthreads();
-        const int lv = emit_subtree<THREADS, false, true, 8>(c, sh, root, sKeys, root.y, qA, qB, lst);
-        deepest = max(deepest, (unsigned int)(root.w + lv));
-        __syncthreads();  // the emit's global stores are visible to the whole workgroup from here
-        refit_levels<THREADS>(sh.lvlOfs, lv, lst, c.nodes);
+        const unsigned int nodeBase = sh.nodeBase;
+        const unsigned long long leafBase = sh.leafBase;
+        const bool overflow = numEnt > 1 && nodeBase + (numEnt - 1) > c.nodeCap;  // cannot happen with ntr_lbvh_capacity() buffers
+        if (overflow && tid == 0) atomicOr(&c.st->overflow, 1u);
+
+        // ---- 3. all entries at once ------------------------------------------------------------------------
+        for (unsigned int e = tid; e < numEnt && !overflow; e += THREADS) {
+            const SubEntry en = ent[e];
+            const int nIdx = e == 0 ? root.x : (int)(nodeBase + e - 1);
+            const int nStart = root.y + (int)(en.range & 0xFFFFu), nEnd = root.y + (int)(en.range >> 16);
+            const int split = root.y + (int)(en.split & 0xFFFFu);
+            const int level = (int)((en.split >> 16) & 0xFFu) - 1;
+            const bool isLeaf[2] = {((en.split >> 24) & 1u) != 0u, ((en.split >> 25) & 1u) != 0u};
+            const int cs[2] = {nStart, split}, ce[2] = {split, nEnd};
+            const unsigned int cpos[2] = {en.child & 0xFFFFu, en.child >> 16};
+            unsigned long long lp = leafBase + (((unsigned long long)(en.leaf & 0xFFFFu) << 32) | (unsigned long long)(en.leaf >> 16));
+            int* nd = c.nodes + (size_t)nIdx * 16;
+            int ch[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (isLeaf[k]) {
+                    const int out = (int)(lp >> 32) * 3 + (int)(lp & 0xFFFFFFFFull);  // createLeaf (:176-181)
+                    lp += ((unsigned long long)(ce[k] - cs[k]) << 32) + 1ull;
+                    ch[k] = ~out;
+                    emit_leaf(c, out, cs[k], ce[k], nd, k);
+                } else {
+                    ch[k] = (int)(nodeBase + cpos[k] - 1) * 64;
+                }
+            }
+            nd[12] = ch[0]; nd[13] = ch[1]; nd[14] = level % 3; nd[15] = 0;
+        }
+        __syncthreads();  // the leaf boxes are visible to the whole workgroup from here
+
+        // ---- 4. refit, deepest level first: an inner child's box is the union of that child's two boxes ---------
+        for (int l = lv - 1; l >= 0 && !overflow; l--) {
+            const unsigned int b0 = sh.lvlOfs[l], b1 = sh.lvlOfs[l + 1];
+            for (unsigned int e = b0 + tid; e < b1; e += THREADS) {
+                const SubEntry en = ent[e];
+                const int nIdx = e == 0 ? root.x : (int)(nodeBase + e - 1);
+                float* nf = reinterpret_cast<float*>(c.nodes + (size_t)nIdx * 16);
+                const unsigned int cpos[2] = {en.child & 0xFFFFu, en.child >> 16};
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    if ((en.split >> (24 + k)) & 1u) continue;
+                    const float4* cn = reinterpret_cast<const float4*>(c.nodes + (size_t)(nodeBase + cpos[k] - 1) * 16);
+                    const float4 a = cn[0], b = cn[1], cc = cn[2];
+                    reinterpret_cast<float4*>(nf)[k] = make_float4(fminf(a.x, b.x), fmaxf(a.y, b.y), fminf(a.z, b.z), fmaxf(a.w, b.w));
+                    reinterpret_cast<float2*>(nf)[4 + k] = make_float2(fminf(cc.x, cc.z), fmaxf(cc.y, cc.w));
+                }
+            }
+            __syncthreads();  // the level above reads these boxes (same workgroup, same CU)
+        }
     }
-    if (threadIdx.x == 0 && deepest) atomicMax(&c.st->maxLevel, deepest);
+    if (tid == 0 && deepest) atomicMax(&c.st->maxLevel, deepest);
 }
 
 __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_refit_kernel(const LbvhState* __restrict__ st, const int* __restrict__ topLst,
@@ -747,19 +869,23 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         c.nodes = (int*)d_nodes; c.nodeCap = nodeCap; c.outWoop = (float4*)d_triWoop; c.outIdx = d_triIndex;
         c.leafSize = leafSize; c.subList = (int4*)(ws + oSubList);
         // ranges of at most `spill` triangles become one workgroup's subtree: about 1.5 n / spill of them
-        int spill = (int)(1.5 * sqrt((double)n));
-        if (spill < 256) spill = 256;
-        if (spill > 2048) spill = 2048;
-        c.spill = env_int("NTR_LBVH_SPLIT", spill);
+        // as large as a workgroup's LDS entry list allows: the LDS levels of a subtree are cheaper than the top pass's
+        // global ones (sweep: scripts/lbvh_split_sweep.sh)
+        c.spill = env_int("NTR_LBVH_SPLIT", 3072);
         if (c.spill < 2) c.spill = 2;
-        if (c.spill > 3072) c.spill = 3072;  // 20 bytes of LDS per triangle of a subtree, 64 KB per workgroup
+        if (c.spill > 7168) c.spill = 7168;  // 20 bytes of LDS per triangle of a subtree (140 KB), 16-bit positions
         hipLaunchKernelGGL(lbvh_top_kernel, dim3(1), dim3(TOP_THREADS), 0, s, c, n, q0, q1, (int*)(ws + oTopLst));
         pe.mark(4);
         const int subThreads = env_int("NTR_LBVH_SUB_THREADS", 128);
         int subBlocks = n / 2 + 1;
         const int subMax = 256 * (2048 / (subThreads > 0 ? subThreads : 128));
         if (subBlocks > subMax) subBlocks = subMax;
-        const size_t subLds = ((size_t)c.spill * 2 + 2 * 3 * ((size_t)c.spill / 2 + 1)) * 4;
+        const size_t subLds = (size_t)c.spill * (4 + 16);  // keys + entry list
+        if (subLds > 65536) {
+            const void* fn = subThreads == 64 ? (const void*)lbvh_subtree_kernel<64>
+                           : subThreads == 256 ? (const void*)lbvh_subtree_kernel<256> : (const void*)lbvh_subtree_kernel<128>;
+            NTR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)subLds));
+        }
         if (subThreads == 64)
             hipLaunchKernelGGL(lbvh_subtree_kernel<64>, dim3(subBlocks), dim3(64), subLds, s, c, c.spill);
         else if (subThreads == 256)
