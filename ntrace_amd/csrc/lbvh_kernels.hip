@@ -386,55 +386,51 @@ __device__ __forceinline__ void emit_leaf(const EmitCtx& c, int out, int start, 
     reinterpret_cast<float2*>(nf)[4 + k] = make_float2(lo[2], hi[2]);
 }
 
-// Levels [root.w, 30) of the tree below `root`, by all threads of one workgroup.  Every queue entry is
-// split exactly as lbvh_emit_kernel splits it.  Node indices and leaf storage come from LDS counters
-// (sh.nodeCtr / sh.leafCtr, offset by sh.nodeBase / sh.leafBase), so a level costs one barrier and no
-// global atomic.  TOP: the single workgroup that owns the counters of the whole tree; ranges of at most
-// c.spill triangles are appended to c.subList instead of its own queue.  !WRITE: counting pass (only the
-// LDS counters advance).  Returns the number of levels that held inner nodes; with WRITE, lst receives
-// the node indices level by level (offsets in sh.lvlOfs) for the bottom-up refit.
-template <int THREADS, bool TOP, bool WRITE, int K>
-__device__ __forceinline__ int emit_subtree(const EmitCtx& c, EmitShared& sh, int4 root, const unsigned int* keys, int keyBase,
-                                            int* qA, int* qB, int* lst)
+// Top pass: levels 0.. of the tree, by all threads of the ONE workgroup that owns the counters of the whole tree
+// (node indices and leaf storage come from LDS counters: a level costs one barrier and no global atomic).  Every
+// queue entry is split exactly as lbvh_emit_kernel splits it; ranges of at most c.spill triangles are appended to
+// c.subList (for lbvh_subtree_kernel) instead of the next level's queue.  Returns the number of levels that held
+// nodes; lst receives the node indices level by level (offsets in sh.lvlOfs) for lbvh_top_refit_kernel.
+template <int THREADS, int K>
+__device__ __forceinline__ int emit_top(const EmitCtx& c, EmitShared& sh, int n, int* qA, int* qB, int* lst)
 {
     const int tid = threadIdx.x;
     if (tid == 0) {
-        qA[0] = root.x; qA[1] = root.y; qA[2] = root.z;
+        qA[0] = 0; qA[1] = 0; qA[2] = n;  // the root: node 0 over all triangles
         sh.cnt[0] = 1; sh.cnt[1] = 0; sh.cnt[2] = 0;
     }
-    if (TOP) __syncthreads(); else lds_barrier();
+    __syncthreads();
     unsigned int total = 0;
     int lv = 0;
-    for (int lvl = root.w; lvl < 30; lvl++, lv++) {
+    for (int lvl = 0; lvl < 30; lvl++, lv++) {
         const unsigned int inCount = sh.cnt[lv % 3];
         if (inCount == 0) break;
         unsigned int* outCount = &sh.cnt[(lv + 1) % 3];
         if (tid == 0) {
             sh.cnt[(lv + 2) % 3] = 0;  // read one level ago, added to one level ahead
-            if (WRITE) sh.lvlOfs[lv] = total;
+            sh.lvlOfs[lv] = total;
         }
         const int levelBit = 29 - lvl;
         for (unsigned int e = tid; e < inCount; e += THREADS) {
             const int nIdx = qA[3 * e], nStart = qA[3 * e + 1], nEnd = qA[3 * e + 2];
-            const unsigned int kFirst = keys[nStart - keyBase], kLast = keys[nEnd - 1 - keyBase];
+            const unsigned int kFirst = c.keys[nStart], kLast = c.keys[nEnd - 1];
             const unsigned int diff = (kFirst ^ kLast) & ((2u << levelBit) - 1u);
             const int level = diff ? 31 - __clz((int)diff) : -1;  // highest differing bit at or below the level's bit
-            const int split = level >= 0 ? find_split<K>(keys, keyBase, nStart, nEnd, level, (kFirst >> level) & 1)
+            const int split = level >= 0 ? find_split<K>(c.keys, 0, nStart, nEnd, level, (kFirst >> level) & 1)
                                          : (nStart + nEnd) >> 1;  // identical keys: median (:282)
             const int cs[2] = {nStart, split}, ce[2] = {split, nEnd};
             const bool isLeaf[2] = {(split - nStart) <= c.leafSize || levelBit == 0, (nEnd - split) <= c.leafSize || levelBit == 0};
             const unsigned int inner = (isLeaf[0] ? 0u : 1u) + (isLeaf[1] ? 0u : 1u);
             const unsigned long long lf = (isLeaf[0] ? (((unsigned long long)(split - nStart) << 32) + 1ull) : 0ull) +
                                           (isLeaf[1] ? (((unsigned long long)(nEnd - split) << 32) + 1ull) : 0ull);
-            unsigned int childNode = sh.nodeBase + (inner ? atomicAdd(&sh.nodeCtr, inner) : 0u);
-            unsigned long long lp = sh.leafBase + (lf ? atomicAdd(&sh.leafCtr, lf) : 0ull);
-            if (WRITE) {
-                lst[total + e] = nIdx;
-                if (childNode + inner > c.nodeCap) {  // cannot happen with ntr_lbvh_capacity() buffers
-                    atomicOr(&c.st->overflow, 1u);
-                    continue;
-                }
+            unsigned int childNode = inner ? atomicAdd(&sh.nodeCtr, inner) : 0u;
+            unsigned long long lp = lf ? atomicAdd(&sh.leafCtr, lf) : 0ull;
+            lst[total + e] = nIdx;
+            if (childNode + inner > c.nodeCap) {  // cannot happen with ntr_lbvh_capacity() buffers
+                atomicOr(&c.st->overflow, 1u);
+                continue;
             }
+            int* nd = c.nodes + (size_t)nIdx * 16;
             int ch[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -442,9 +438,9 @@ __device__ __forceinline__ int emit_subtree(const EmitCtx& c, EmitShared& sh, in
                     const int out = (int)(lp >> 32) * 3 + (int)(lp & 0xFFFFFFFFull);  // createLeaf (:176-181)
                     lp += ((unsigned long long)(ce[k] - cs[k]) << 32) + 1ull;
                     ch[k] = ~out;
-                    if (WRITE) emit_leaf(c, out, cs[k], ce[k], c.nodes + (size_t)nIdx * 16, k);
+                    emit_leaf(c, out, cs[k], ce[k], nd, k);
                 } else {
-                    if (TOP && (ce[k] - cs[k]) <= c.spill) {
+                    if ((ce[k] - cs[k]) <= c.spill) {
                         const unsigned int si = atomicAdd(&sh.numSub, 1u);
                         c.subList[si] = make_int4((int)childNode, cs[k], ce[k], lvl + 1);
                     } else {
@@ -455,16 +451,13 @@ __device__ __forceinline__ int emit_subtree(const EmitCtx& c, EmitShared& sh, in
                     childNode++;
                 }
             }
-            if (WRITE) {
-                int* nd = c.nodes + (size_t)nIdx * 16;
-                nd[12] = ch[0]; nd[13] = ch[1]; nd[14] = level % 3; nd[15] = 0;
-            }
+            nd[12] = ch[0]; nd[13] = ch[1]; nd[14] = level % 3; nd[15] = 0;
         }
         total += inCount;
-        if (TOP) __syncthreads(); else lds_barrier();
+        __syncthreads();
         int* t = qA; qA = qB; qB = t;
     }
-    if (WRITE && tid == 0) sh.lvlOfs[lv] = total;
+    if (tid == 0) sh.lvlOfs[lv] = total;
     return lv;
 }
 
@@ -504,7 +497,7 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_kernel(EmitCtx c, int n,
         sh.nodeCtr = 1; sh.nodeBase = 0;  // node 0 is the root
         sh.leafCtr = 0ull; sh.leafBase = 0ull; sh.numSub = 0;
     }
-    const int lv = emit_subtree<TOP_THREADS, true, true, 16>(c, sh, make_int4(0, 0, n, 0), c.keys, 0, qA, qB, topLst);
+    const int lv = emit_top<TOP_THREADS, 16>(c, sh, n, qA, qB, topLst);
     __syncthreads();
     if ((int)threadIdx.x <= lv) c.st->topLvlOfs[threadIdx.x] = sh.lvlOfs[threadIdx.x];
     if (threadIdx.x == 0) {
