@@ -73,3 +73,16 @@ def test_no_cpu_fallback_without_device():
                      buf.ctypes.data, 100, buf.ctypes.data, 4096, buf.ctypes.data)
     assert e2.value.code == -1
     assert e.value.code in (-2, -3)
+
+
+def test_sched_hint_object_lifecycle_without_device():
+    """NtrSchedHint is a host object: create / reset / destroy work without a GPU; tracing with it does not."""
+    import ctypes as C
+    L = nt.lib()
+    h = C.c_void_p()
+    assert L.ntr_sched_hint_create(C.byref(h)) == 0 and h.value
+    assert L.ntr_sched_hint_reset(h) == 0
+    assert L.ntr_sched_hint_reset(None) != 0
+    assert L.ntr_sched_hint_create(None) != 0
+    assert L.ntr_sched_hint_destroy(h) == 0
+    assert L.ntr_sched_hint_destroy(None) == 0
