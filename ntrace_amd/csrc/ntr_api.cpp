@@ -219,8 +219,7 @@ static constexpr size_t kTopTableBytes = (((size_t)2 << NTR_TOP_DEPTH_MAX) + 16)
 struct PredictScratch {
     void* stream = nullptr;
     int device = -1;
-    unsigned int* classCount = nullptr;  // two sets of NTR_SCHED_PRED_CLASSES counters, used alternately
-    int parity = 0;
+    unsigned int* classCount = nullptr;  // NTR_SCHED_PRED_CLASSES counters, zero whenever no prediction is in flight
     unsigned int* classList = nullptr;
     unsigned int* order = nullptr;
     int capBlocks = 0;
@@ -284,9 +283,9 @@ static int predict_scratch_get(hipStream_t s, int numBlocks, PredictScratch** ou
             (void)hipFree(p->classCount); (void)hipFree(p->classList); (void)hipFree(p->order);
             p->classCount = p->classList = p->order = nullptr; p->capBlocks = 0;
         }
-        NTR_HIP(hipMalloc((void**)&p->classCount, 2 * NTR_SCHED_PRED_CLASSES * sizeof(unsigned int)));
-        NTR_HIP(hipMemsetAsync(p->classCount, 0, 2 * NTR_SCHED_PRED_CLASSES * sizeof(unsigned int), s));
-        p->stream = (void*)s; p->device = dev; p->parity = 0;
+        NTR_HIP(hipMalloc((void**)&p->classCount, NTR_SCHED_PRED_CLASSES * sizeof(unsigned int)));
+        NTR_HIP(hipMemset(p->classCount, 0, NTR_SCHED_PRED_CLASSES * sizeof(unsigned int)));
+        p->stream = (void*)s; p->device = dev;
     }
     if (p->capBlocks < numBlocks) {
         if (p->classList) {
@@ -401,7 +400,10 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
             p.counter = ds->counters + 8 * 16 * ds->next;
             ds->next = (ds->next + 1) % kNumCounters;
         }
-        NTR_HIP(hipMemsetAsync(p.counter, 0, 8 * 64, s));
+        {   // cleared by a kernel: memset nodes do not survive HIP graph replays (see sched_kernels.hip)
+            const hipError_t ze = ntr_launch_zero_words(p.counter, 8 * 16, s);
+            if (ze != hipSuccess) return hip_fail(ze, "zero_words launch");
+        }
         const int chunksTotal = (numRays + p.chunk - 1) / p.chunk;
         p.shardRays = ((chunksTotal + 7) / 8) * p.chunk;
     } else {
@@ -428,7 +430,8 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         hint->uses++;
         if (hint->valid) p.order = hint->order;
         if (refresh) {
-            NTR_HIP(hipMemsetAsync(hint->cost, 0, (size_t)numBlocks * sizeof(unsigned int), s));
+            const hipError_t ze = ntr_launch_zero_words(hint->cost, numBlocks, s);
+            if (ze != hipSuccess) return hip_fail(ze, "zero_words launch");
             p.cost = hint->cost;
         }
     }
@@ -455,10 +458,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         NTR_HIP(hipEventRecord(ev0, s));
     }
     if (predScratch) {  // inside the timed bracket: the prediction is part of what the launch costs
-        unsigned int* mine = predScratch->classCount + predScratch->parity * NTR_SCHED_PRED_CLASSES;
-        unsigned int* other = predScratch->classCount + (predScratch->parity ^ 1) * NTR_SCHED_PRED_CLASSES;
-        predScratch->parity ^= 1;
-        const hipError_t pe = ntr_launch_predict(d_rays, numRays, numBlocks, predTable->table, predTable->count, mine, other,
+        const hipError_t pe = ntr_launch_predict(d_rays, numRays, numBlocks, predTable->table, predTable->count, predScratch->classCount,
                                                  predScratch->classList, predScratch->order, s);
         if (pe != hipSuccess) return hip_fail(pe, "predict launch");
     }

@@ -18,7 +18,7 @@
 //                      order inside the workgroup (neighbouring blocks stay neighbours: they share
 //                      BVH nodes, and a finer order by cost was measured slower)
 //   flatten_kernel     class lists -> one block order, heaviest class first (the order[] the per-ray
-//                      kernel already understands)
+//                      kernel already understands); clears the class counters for the next prediction
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -128,13 +128,14 @@ __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* 
     }
 }
 
-// order[e] = e-th block when the class lists are concatenated from the heaviest class down.
-// It also clears the OTHER set of class counters (the two sets alternate between launches, so the set the next
-// prediction adds to is zero without a memset in the stream).
-__global__ __launch_bounds__(256) void flatten_kernel(const unsigned int* __restrict__ classCount, const unsigned int* __restrict__ classList,
-                                                      int numBlocks, unsigned int* __restrict__ order, unsigned int* __restrict__ otherCount)
+// order[e] = e-th block when the class lists are concatenated from the heaviest class down.  ONE workgroup, which
+// therefore can also clear the class counters once every thread has read them: the counters are zero whenever no
+// prediction is in flight, without a memset in the stream (hipMemsetAsync nodes were observed not to re-execute
+// when a captured HIP graph is replayed; kernels do).
+constexpr int FLATTEN_THREADS = 1024;
+__global__ __launch_bounds__(FLATTEN_THREADS) void flatten_kernel(unsigned int* __restrict__ classCount, const unsigned int* __restrict__ classList,
+                                                                  int numBlocks, unsigned int* __restrict__ order)
 {
-    if (blockIdx.x == 0 && threadIdx.x < NTR_SCHED_PRED_CLASSES) otherCount[threadIdx.x] = 0;
     __shared__ unsigned int s_end[NTR_SCHED_PRED_CLASSES];  // s_end[k] = entries in the k+1 heaviest classes
     const int tid = threadIdx.x;
     if (tid < 64) {
@@ -146,17 +147,24 @@ __global__ __launch_bounds__(256) void flatten_kernel(const unsigned int* __rest
             if (tid >= off) incl += u;
         }
         s_end[tid] = incl;
+        classCount[NTR_SCHED_PRED_CLASSES - 1 - tid] = 0;  // consumed: ready for the next prediction
     }
     __syncthreads();
-    const int e = blockIdx.x * 256 + tid;
-    if (e >= numBlocks) return;
-    int k = 0;  // first k with e < s_end[k]
+    for (int e = tid; e < numBlocks; e += FLATTEN_THREADS) {
+        int k = 0;  // first k with e < s_end[k]
 #pragma unroll
-    for (int step = 32; step > 0; step >>= 1)
-        if (k + step <= NTR_SCHED_PRED_CLASSES - 1 && s_end[k + step - 1] <= (unsigned int)e) k += step;
-    const unsigned int begin = k ? s_end[k - 1] : 0u;
-    const int cls = NTR_SCHED_PRED_CLASSES - 1 - k;
-    order[e] = classList[(size_t)cls * numBlocks + ((unsigned int)e - begin)];
+        for (int step = 32; step > 0; step >>= 1)
+            if (k + step <= NTR_SCHED_PRED_CLASSES - 1 && s_end[k + step - 1] <= (unsigned int)e) k += step;
+        const unsigned int begin = k ? s_end[k - 1] : 0u;
+        const int cls = NTR_SCHED_PRED_CLASSES - 1 - k;
+        order[e] = classList[(size_t)cls * numBlocks + ((unsigned int)e - begin)];
+    }
+}
+
+// Clears `words` 32-bit words (a kernel, not hipMemsetAsync: see flatten_kernel).
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned int* __restrict__ p, int words)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < words; i += gridDim.x * 256) p[i] = 0;
 }
 
 }  // namespace ntr
@@ -171,15 +179,24 @@ extern "C" hipError_t ntr_launch_top_table(const void* d_nodes, unsigned int nod
     return hipGetLastError();
 }
 
-// d_classCount must be zero on entry (NTR_SCHED_PRED_CLASSES words); d_otherCount is zeroed for the next launch.
+// d_classCount must be zero on entry (NTR_SCHED_PRED_CLASSES words) and is zero again when the launches have run.
 extern "C" hipError_t ntr_launch_predict(const void* d_rays, int numRays, int numBlocks, const void* d_table,
-                                         const unsigned int* d_tableCount, unsigned int* d_classCount, unsigned int* d_otherCount,
-                                         unsigned int* d_classList, unsigned int* d_order, hipStream_t stream)
+                                         const unsigned int* d_tableCount, unsigned int* d_classCount, unsigned int* d_classList,
+                                         unsigned int* d_order, hipStream_t stream)
 {
     const int grid = (numBlocks + 63) / 64;
     hipLaunchKernelGGL(ntr::predict_kernel, dim3(grid), dim3(ntr::PRED_WAVES * 64), 0, stream, (const float4*)d_rays, numRays, numBlocks,
                        (const float4*)d_table, d_tableCount, d_classCount, d_classList);
-    hipLaunchKernelGGL(ntr::flatten_kernel, dim3((numBlocks + 255) / 256), dim3(256), 0, stream, (const unsigned int*)d_classCount,
-                       (const unsigned int*)d_classList, numBlocks, d_order, d_otherCount);
+    hipLaunchKernelGGL(ntr::flatten_kernel, dim3(1), dim3(ntr::FLATTEN_THREADS), 0, stream, d_classCount, (const unsigned int*)d_classList,
+                       numBlocks, d_order);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ntr_launch_zero_words(void* d_ptr, int words, hipStream_t stream)
+{
+    if (words <= 0) return hipSuccess;
+    int grid = (words + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(ntr::zero_words_kernel, dim3(grid), dim3(256), 0, stream, (unsigned int*)d_ptr, words);
     return hipGetLastError();
 }

@@ -55,8 +55,10 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
 extern "C" hipError_t ntr_launch_top_table(const void* d_nodes, unsigned int nodesBytes, int depth, void* d_table,
                                            unsigned int* d_tableCount, hipStream_t stream);
 extern "C" hipError_t ntr_launch_predict(const void* d_rays, int numRays, int numBlocks, const void* d_table,
-                                         const unsigned int* d_tableCount, unsigned int* d_classCount, unsigned int* d_otherCount,
-                                         unsigned int* d_classList, unsigned int* d_order, hipStream_t stream);
+                                         const unsigned int* d_tableCount, unsigned int* d_classCount, unsigned int* d_classList,
+                                         unsigned int* d_order, hipStream_t stream);
+// clears 32-bit words with a kernel (graph-replay safe, unlike a memset node)
+extern "C" hipError_t ntr_launch_zero_words(void* d_ptr, int words, hipStream_t stream);
 extern "C" hipError_t ntr_launch_sched_order(const unsigned int* d_cost, int numBlocks, int classes, unsigned int* d_order,
                                              hipStream_t stream);
 extern "C" hipError_t ntr_launch_selftest_division(const float* d_x, const float* d_d, int nx, int nd,

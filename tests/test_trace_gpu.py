@@ -226,3 +226,33 @@ def test_dispatch_order_prediction_changes_order_only(soup, n, monkeypatch):
     monkeypatch.setenv("NTR_TRACE_PREDICT", "0")
     got, _ = gpu_trace("fermi_speculative_while_while", dbvh, rays, False)
     assert_parity(got, ref, "prediction off n=%d" % n)
+
+
+@pytest.mark.parametrize("kernel", ["fermi_speculative_while_while", "kepler_dynamic_fetch"])
+def test_trace_launch_can_be_captured_in_a_hip_graph_and_replayed(soup, monkeypatch, kernel):
+    """An asynchronous ntr_trace_bvh (dispatch-order prediction forced on; the persistent kernel's ray-pool counters)
+    captured into a HIP graph gives the oracle's records on every replay: all per-launch counters are cleared by
+    kernels inside the captured work (memset nodes were observed not to re-execute on replay)."""
+    import torch
+    from gpu_util import assert_parity, up
+    dbvh, cam = soup
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+    rays = np.concatenate([scenes.primary_rays(cam, 200, 150)[0], scenes.random_rays(5000, seed=3)])
+    n = rays.shape[0]
+    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
+    d_rays = up(rays)
+    d_res = torch.full((n * 16,), 0xCD, dtype=torch.uint8, device="cuda:0")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):  # warm-up: scratch buffers and the top-of-tree table are allocated outside the capture
+            dbvh.view.trace(kernel, n, False, d_rays.data_ptr(), d_res.data_ptr(), s.cuda_stream, False)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        dbvh.view.trace(kernel, n, False, d_rays.data_ptr(), d_res.data_ptr(),
+                        torch.cuda.current_stream().cuda_stream, False)
+    for rep in range(4):
+        d_res.fill_(0xCD)
+        g.replay()
+        torch.cuda.synchronize()
+        assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), ref, "%s graph replay %d" % (kernel, rep))
