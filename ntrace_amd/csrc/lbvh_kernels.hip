@@ -5,18 +5,23 @@
 //   radixSortCuda   radixSort.cu:22-50 (Thrust) -> hand-written LSD radix sort, 4 x 8 bits:
 //                                                  per-tile LDS histograms, one scan, and a stable
 //                                                  scatter ranked with wave64 ballots (match-any)
-//   calcWoopKernel  emitTreeKernel.cu:574-645   -> lbvh_woop_kernel
+//   calcWoopKernel  emitTreeKernel.cu:574-645   -> woop_rows(): computed once per triangle by
+//                                                  lbvh_place_kernel, straight into the slot its leaf
+//                                                  reserved (no intermediate array, no copy)
 //   emitTreeKernel  emitTreeKernel.cu:233-381   -> three launches instead of one per level (the
 //   + createLeaf    :170-231                       reference also reads g_outQueuePtr back to the host
 //   calcAABB        emitTreeKernel.cu:417-562      every level, HLBVHBuilder.cpp:347): lbvh_top_kernel
-//                                                  (one workgroup) splits ranges larger than S triangles
-//                                                  level by level; lbvh_subtree_kernel gives every range
-//                                                  of <= S triangles to one workgroup that emits the
-//                                                  whole subtree below it and refits it bottom-up, with
-//                                                  workgroup barriers only; lbvh_top_refit_kernel closes
-//                                                  the boxes of the top levels.  NTR_LBVH_LEVELSYNC=1
-//                                                  selects the older one-launch-per-level kernels
-//                                                  (lbvh_emit_kernel / lbvh_refit_kernel).
+//   + calcLeaf      :383-408                       (one workgroup) splits ranges larger than S = 3072
+//                                                  triangles level by level; lbvh_subtree_kernel gives
+//                                                  every smaller range to one workgroup: topology of the
+//                                                  whole subtree in an LDS entry list, one pair of global
+//                                                  atomics, all nodes / leaf boxes / slots written in
+//                                                  parallel, bottom-up refit; lbvh_top_refit_kernel closes
+//                                                  the boxes of the top levels.  Leaf boxes are folded from
+//                                                  per-triangle terms (lbvh_tribox_kernel).
+//                                                  NTR_LBVH_LEVELSYNC=1 selects the older one-launch-per-
+//                                                  level kernels (lbvh_emit_kernel / lbvh_refit_kernel /
+//                                                  lbvh_woop_kernel).
 //
 // The tree is the reference's tree: same split rule (highest differing Morton bit at or below the
 // level's bit, median when none), same leaf rule (count <= leafSize, or the level's bit is 0), same
