@@ -121,7 +121,12 @@ NTR_API int ntr_query_config(const char* kernelName, NtrKernelConfig* config);
  *
  * Results follow the reference CPU tracer bit for bit in (id, t): miss =
  * (-1, ray.tmax) (CudaBVH.cpp:273-274).  `bvhFlags`: 0, or hints from
- * ntr_bvh_validate() (hints only select between two exact code paths). */
+ * ntr_bvh_validate() (hints only select between two exact code paths).
+ *
+ * Closest-hit launches of the per-ray kernel with at least 2^20 rays dispatch their 256-ray blocks in
+ * predicted-cost order (two small launches in front of the trace kernel, inside the timed bracket; the
+ * order never changes a result; NTR_TRACE_PREDICT=0 disables it).  An asynchronous call can be captured
+ * into a HIP graph and replayed once a first call on that stream has allocated its scratch buffers. */
 NTR_API int ntr_trace_bvh(const char* kernelName, int32_t numRays, int32_t anyHit,
                           const NtrRay* d_rays, NtrRayResult* d_results,
                           const void* d_nodes, int64_t nodesBytes,

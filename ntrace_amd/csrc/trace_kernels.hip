@@ -38,6 +38,14 @@
 // lets a leaf fetch its triangle and the following terminator word in one round trip).
 // The traversal stack lives in LDS ([entry][lane], conflict-free), spilling to scratch
 // beyond LDS_DEPTH.  No MFMA: there is no dense contraction on this path.
+//
+// SCHEDULING (never a ray's own visiting order, hence never a hit record or a counter):
+//   * a wave leaves its inner-node loop early when few lanes still hold an inner node (leafSwitchBelow);
+//   * trace_bvh_perray maps workgroup i to ray block order[i] when an order is given -- predicted
+//     (sched_kernels.hip, automatic for large closest-hit launches) or learned from the previous launch of
+//     the batch (NtrSchedHint: per-block cost recording here, sched_order_kernel below);
+//   * every per-launch counter is cleared by a kernel, so an asynchronous launch can be captured in a HIP
+//     graph and replayed.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
