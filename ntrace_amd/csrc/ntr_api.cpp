@@ -441,8 +441,9 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     // batches measured no net gain.
     TopTable* predTable = nullptr;
     PredictScratch* predScratch = nullptr;
+    // (a tree of a few hundred nodes is traced faster than it is predicted: Cornell-box class scenes are left alone)
     if (!hint && !p.order && variant == NTR_VARIANT_PERRAY && !anyHit && numRays >= env_int("NTR_TRACE_PREDICT_MIN_RAYS", 1 << 20) &&
-        env_int("NTR_TRACE_PREDICT", 1) != 0) {
+        nodesBytes >= (int64_t)env_int("NTR_TRACE_PREDICT_MIN_NODES", 4096) * 64 && env_int("NTR_TRACE_PREDICT", 1) != 0) {
         rc = top_table_get(d_nodes, nodesBytes, s, false, &predTable);
         if (rc != NTR_OK) return rc;
         rc = predict_scratch_get(s, numBlocks, &predScratch);

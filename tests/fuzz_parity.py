@@ -177,6 +177,7 @@ def main(argv=None):
             sched = int(rng.integers(0, 3))
             if sched == 1:
                 os.environ["NTR_TRACE_PREDICT_MIN_RAYS"] = "1"
+                os.environ["NTR_TRACE_PREDICT_MIN_NODES"] = "1"
             else:
                 os.environ.pop("NTR_TRACE_PREDICT_MIN_RAYS", None)
             hint = nt.SchedHint() if sched == 2 else None

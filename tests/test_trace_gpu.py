@@ -218,6 +218,7 @@ def test_dispatch_order_prediction_changes_order_only(soup, n, monkeypatch):
     from gpu_util import assert_parity, gpu_trace
     dbvh, cam = soup
     monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
     rays = np.concatenate([scenes.primary_rays(cam, 300, 240)[0], edge_rays()])[:n]
     ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
     for rep in range(3):  # the class counters alternate between two sets
@@ -237,6 +238,7 @@ def test_trace_launch_can_be_captured_in_a_hip_graph_and_replayed(soup, monkeypa
     from gpu_util import assert_parity, up
     dbvh, cam = soup
     monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
     rays = np.concatenate([scenes.primary_rays(cam, 200, 150)[0], scenes.random_rays(5000, seed=3)])
     n = rays.shape[0]
     ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
