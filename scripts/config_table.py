@@ -58,3 +58,5 @@ tri, pos, cam = scenes.atrium(); measure("2 Sponza (atrium-262k), SAH", tri, pos
 tri, pos, cam = scenes.conference_room(); measure("3 Conference (room-331k), SAH", tri, pos, cam, "sah")
 tri, pos, cam = scenes.hairball(); measure("4 Hairball (2.8 M), LBVH", tri, pos, cam, "lbvh")
 tri, pos, cam = scenes.courtyard(); measure("5 San Miguel (courtyard-10M), LBVH", tri, pos, cam, "lbvh")
+if "--sah-10m" in sys.argv:
+    measure("5 San Miguel (courtyard-10M), SAH", tri, pos, cam, "sah")
