@@ -360,8 +360,10 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.status = ds->status;
     p.counter = nullptr;
     p.shardRays = 0;
-    p.chunk = env_int("NTR_TRACE_CHUNK", 128);
-    p.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", 40);
+    // persistent kernels (scripts/persist_sweep.py): 64-ray chunks, 6 workgroups per CU; dynamic fetch only for the kernel
+    // named after it (it costs about 10 % here: refilled lanes de-cohere a wave's node fetches)
+    p.chunk = env_int("NTR_TRACE_CHUNK", 64);
+    p.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", strcmp(k->name, "kepler_dynamic_fetch") == 0 ? 24 : 0);
     p.bvhFlags = bvhFlags;
     p.coop = env_int("NTR_TRACE_COOP", 0);
     p.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", 24);  // sweep: flat optimum 16..64 (scripts/trace_sweep.py)
@@ -391,7 +393,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     if (variant == NTR_VARIANT_PERSISTENT) {
         // Persistent grid: CUs x resident blocks per CU (the reference hard-codes
         // 720 warps for GT200/Fermi, CudaBVHTracer.cpp:155-159).
-        const int blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 4);
+        const int blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 6);
         numBlocks = ds->numCUs * blocksPerCU;
         const int needed = (numRays + blockThreads - 1) / blockThreads;
         if (numBlocks > needed) numBlocks = needed;
