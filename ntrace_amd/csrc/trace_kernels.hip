@@ -463,9 +463,12 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
 // empty lanes are refilled from the chunk by ballot + mbcnt prefix
 // (kepler_dynamic_fetch.cu:97-111 on wave64: 64-bit ballot, v_mbcnt_lo/hi).
 // ---------------------------------------------------------------------------------
-template <int WAVES, bool COOP>
+// TL: the diagnostic stamps of NTR_TRACE_TIMELINE are compiled into their own instantiation -- they cost 18 VGPRs,
+// i.e. two waves of occupancy per SIMD, which the production kernel must not pay.
+template <int WAVES, bool COOP, bool TL>
 __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_persistent(TraceParams p)
 {
+    unsigned long long* const timeline = TL ? p.timeline : nullptr;
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     __shared__ __attribute__((aligned(16))) char s_stage[WAVES][COOP ? STAGE_BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
 
     // diagnostic stamps (NTR_TRACE_TIMELINE): wave start, end, cycles spent refilling, refill count
     unsigned long long tlStart = 0, tlRefill = 0, tlCount = 0, tlRays = 0;
-    if (p.timeline) tlStart = __builtin_amdgcn_s_memrealtime();
+    if (timeline) tlStart = __builtin_amdgcn_s_memrealtime();
 
     // Invariant at the top of the loop: a lane either holds a live ray
     // (rayIdx >= 0, node != sentinel) or is empty (rayIdx < 0, node == sentinel).
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
         // ---- refill empty lanes from the wave's chunk ----------------------------
         unsigned long long empty = __ballot(rayIdx < 0);
         unsigned long long tlA = 0;
-        if (p.timeline) { tlA = __builtin_amdgcn_s_memtime(); tlCount++; tlRays += __popcll(empty); }
+        if (timeline) { tlA = __builtin_amdgcn_s_memtime(); tlCount++; tlRays += __popcll(empty); }
         while (empty != 0ull && !poolEmpty) {
             if (chunkNext >= chunkEnd) {  // wave-uniform: grab the next chunk
                 // The ray index space is cut into 8 contiguous ranges with one pool head each
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
             empty = __ballot(rayIdx < 0);
         }
 
-        if (p.timeline) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tlRefill += __builtin_amdgcn_s_memtime() - tlA; }
+        if (timeline) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tlRefill += __builtin_amdgcn_s_memtime() - tlA; }
         // ---- while-while traversal ------------------------------------------------
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
         if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
@@ -558,14 +561,14 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
         }
         if (poolEmpty && __ballot(rayIdx >= 0) == 0ull) break;
     }
-    if (p.timeline && lane == 0) {
+    if (timeline && lane == 0) {
         const unsigned int w = blockIdx.x * WAVES + wave;
-        p.timeline[6 * w + 0] = tlStart;
-        p.timeline[6 * w + 1] = __builtin_amdgcn_s_memrealtime();
-        p.timeline[6 * w + 2] = tlRefill;
-        p.timeline[6 * w + 3] = tlCount;
-        p.timeline[6 * w + 4] = tlRays;
-        p.timeline[6 * w + 5] = __builtin_amdgcn_s_memtime();
+        timeline[6 * w + 0] = tlStart;
+        timeline[6 * w + 1] = __builtin_amdgcn_s_memrealtime();
+        timeline[6 * w + 2] = tlRefill;
+        timeline[6 * w + 3] = tlCount;
+        timeline[6 * w + 4] = tlRays;
+        timeline[6 * w + 5] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -670,8 +673,9 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
         hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERSISTENT:
-        if (p->coop) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
-        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        if (p->coop) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        else if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     default:
         return hipErrorInvalidValue;
