@@ -353,8 +353,8 @@ def main():
             lview.validate(stream)
             lsec = min(lview.trace(args.kernel, n_primary, False, d_rays.data_ptr(), d_res.data_ptr(), stream) for _ in range(5))
             extras["lbvh"] = {"build_ms": best.seconds * 1e3, "mtris_per_s": tri.shape[0] / best.seconds / 1e6,
-                              "phases_ms": {"morton": best.mortonMs, "sort": best.sortMs, "woop": best.woopMs, "emit": best.emitMs,
-                                            "refit": best.refitMs}, "nodes": best.numNodes, "leaves": best.numLeaves,
+                              "phases_ms": {"morton": best.mortonMs, "sort": best.sortMs, "triangle_box_terms": best.woopMs,
+                                            "emit_top_pass": best.emitMs, "emit_subtrees+refit+woop_placement": best.refitMs}, "nodes": best.numNodes, "leaves": best.numLeaves,
                               "primary_mrays_on_lbvh": n_primary / lsec / 1e6}
             # algorithmic bytes of the build (SURVEY 8d accounting, exact from the counts): Morton 48 rd + 8 wr,
             # 4 radix passes x (8 rd + 8 wr + 4 rd histogram), Woop 48 rd + 48 wr per triangle; emit 12 rd + 16 wr per
