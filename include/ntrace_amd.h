@@ -230,7 +230,9 @@ typedef struct NtrLbvhResult {
     int32_t numNodes, numLeaves, numLevels, pad;
     int64_t nodesBytes, triWoopBytes, triIndexBytes;
     float   seconds;                                   /* whole build, GPU time          */
-    float   mortonMs, sortMs, woopMs, emitMs, refitMs; /* L1, L2, L4, L3, L5             */
+    /* phase times: Morton codes; radix sort; per-triangle box terms (per-level path: Woop rows); emit (subtree path:
+     * its top pass); the rest (subtree path: subtree emit + refit + top refit + Woop placement; per-level path: refit) */
+    float   mortonMs, sortMs, woopMs, emitMs, refitMs;
 } NtrLbvhResult;
 
 /* Worst-case output sizes for numTris triangles (what HLBVHBuilder allocates before the build,
