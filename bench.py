@@ -63,6 +63,8 @@ def parse():
                     help="Wavefront OBJ to trace instead of the procedural stand-in (e.g. the real sponza.obj)")
     ap.add_argument("--camera", default=os.environ.get("NTR_CAMERA", ""),
                     help="NTrace camera signature (CameraControls::encodeSignature) for --scene-obj")
+    ap.add_argument("--ao-batch-rays", type=int, default=1 << 20,
+                    help="maxBatchSize of RayGen (the reference constructs it with 1 << 20, Renderer.cpp:45)")
     ap.add_argument("--ao-streams", type=int, default=3,
                     help="HIP streams the independent AO batches of a frame are issued on (1 = one stream, in buffer order)")
     ap.add_argument("--no-graph", action="store_true", help="issue every frame launch by launch instead of replaying a HIP graph of it")
@@ -155,7 +157,7 @@ def main():
     ns = args.ao_samples
     if ns > 0:
         d_nrm = up(scenes.tri_normals(tri, pos))
-        per = (1 << 20) // ns
+        per = max(args.ao_batch_rays // ns, 1)
         ao_seed = 0xFFF2D5E4  # any fixed kernel seed; Raygen.random = false in config.conf
         for lo in range(0, n_primary, per):
             cnt = min(per, n_primary - lo)
