@@ -74,6 +74,12 @@ if __name__ == "__main__":
         cam = bbox_camera(pos)
         rays = np.concatenate([scenes.primary_rays(cam, 48, 48)[0], bbox_rays(pos, 2048, seed=488)])
         make("map_obj_mixed", tri, pos, rays)
+    obj = "/root/reference/data/models/Head/head.obj"  # 18 678 triangles
+    if os.path.exists(obj):
+        tri, pos, _ = nt.obj_load(obj)
+        cam = bbox_camera(pos)
+        rays = np.concatenate([scenes.primary_rays(cam, 40, 40)[0], bbox_rays(pos, 1024, seed=18678)])
+        make("head_obj_mixed", tri, pos, rays)
     tri, pos, cam = scenes.cornell_box()
     make("cornell_primary", tri, pos, scenes.primary_rays(cam, 64, 36)[0])
     tri, pos, cam = scenes.random_soup(1500, seed=77)
