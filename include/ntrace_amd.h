@@ -117,7 +117,8 @@ NTR_API int ntr_query_config(const char* kernelName, NtrKernelConfig* config);
  *
  * nodesBytes / triWoopBytes are the buffer extents the reference binds as texture sizes
  * (setTexRef(..., size), CudaBVHTracer.cpp:142-150); here they bound the kernels' buffer
- * descriptors (< 4 GiB each).
+ * descriptors: triWoopBytes < 4 GiB; nodesBytes <= 0x76543200, because Compact child pointers are signed
+ * 32-bit byte offsets and 0x76543210 is the traversal sentinel (EntrypointSentinel, CudaTracerKernels.hpp:38).
  *
  * Results follow the reference CPU tracer bit for bit in (id, t): miss =
  * (-1, ray.tmax) (CudaBVH.cpp:273-274).  `bvhFlags`: 0, or hints from
@@ -132,6 +133,20 @@ NTR_API int ntr_trace_bvh(const char* kernelName, int32_t numRays, int32_t anyHi
                           const void* d_nodes, int64_t nodesBytes,
                           const void* d_triWoop, int64_t triWoopBytes, const int32_t* d_triIndex,
                           int32_t layout, uint32_t bvhFlags, void* stream, float* seconds);
+
+/* Device status of the launches made since the last check, for callers of the ASYNCHRONOUS form
+ * (seconds == NULL), which cannot report it themselves.  The reference's launches are synchronous and its
+ * kernels silently assume a 64-entry stack (STACK_SIZE, CudaTracerKernels.hpp:37); here a ray whose
+ * traversal stack would exceed 104 entries (LDS + scratch, more than the CPU tracer's 100, CudaBVH.cpp:701)
+ * sets a sticky bit in a per-device status word instead of corrupting memory -- its hit record is then not
+ * to be trusted.  ntr_trace_status waits for `stream`, returns the word in *statusBits (may be NULL), clears
+ * it, and returns NTR_ERR_OVERFLOW if the overflow bit was set (bit 0), NTR_OK otherwise.  Timed calls
+ * (seconds != NULL) perform the same check themselves.  The word is shared by all streams of the device. */
+NTR_API int ntr_trace_status(void* stream, uint32_t* statusBits);
+
+/* Re-reads the NTR_* environment tunables.  They are read once, at first use; sweep scripts
+ * that change a variable inside one process call this afterwards.  Not needed by applications. */
+NTR_API int ntr_tunables_reload(void);
 
 /* Scheduling hint (no counterpart in the reference; its kernels take rays in buffer order).
  *

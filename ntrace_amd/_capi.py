@@ -79,6 +79,8 @@ SYMBOLS = [
                                 C.POINTER(C.c_float)]),
     ("ntr_trace_bvh_hinted", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _u32, _vp,
                                        C.POINTER(C.c_float), _vp]),
+    ("ntr_trace_status", C.c_int, [_vp, C.POINTER(_u32)]),
+    ("ntr_tunables_reload", C.c_int, []),
     ("ntr_sched_hint_create", C.c_int, [C.POINTER(_vp)]),
     ("ntr_sched_hint_destroy", C.c_int, [_vp]),
     ("ntr_sched_hint_reset", C.c_int, [_vp]),
@@ -179,6 +181,35 @@ def trace_bvh(kernel, num_rays, any_hit, d_rays, d_results, d_nodes, nodes_bytes
     else:
         _check(lib().ntr_trace_bvh_hinted(*args, hint._h))
     return float(sec.value) if timed else None
+
+
+def trace_status(stream=0):
+    """ntr_trace_status: waits for `stream`, raises NtrError(NTR_ERR_OVERFLOW) if a launch since the last check
+    overflowed its traversal stack; returns the status bits otherwise."""
+    bits = _u32(0)
+    _check(lib().ntr_trace_status(_vp(stream), C.byref(bits)))
+    return int(bits.value)
+
+
+def set_tunables(**kv):
+    """Sweep helper: set NTR_* environment tunables (None removes one) and make the library re-read them."""
+    for k, v in kv.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    _check(lib().ntr_tunables_reload())
+
+
+def experiment_hooks(timeline=0, order=0):
+    """Diagnostic hooks (per-wave timeline buffer, explicit block order) -- only in builds made with
+    `make -C ntrace_amd/csrc EXPERIMENTS=1`; the shipped library does not export them."""
+    L = lib()
+    if not hasattr(L, "ntr_experiment_hooks"):
+        raise NtrError(-1, "this libntrace_amd.so was built without -DNTR_EXPERIMENTS (make EXPERIMENTS=1)")
+    L.ntr_experiment_hooks.restype = C.c_int
+    L.ntr_experiment_hooks.argtypes = [_vp, _vp]
+    _check(L.ntr_experiment_hooks(_vp(timeline), _vp(order)))
 
 
 def selftest_division(d_x, nx, d_d, nd, stream=0):

@@ -38,8 +38,9 @@ extern "C" int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_
     using namespace ntr;
     if (!flags) return set_error(NTR_ERR_INVALID, "ntr_bvh_validate: null flags");
     *flags = 0;
-    if (!d_nodes || nodesBytes < 64 || (nodesBytes % 64) != 0)
-        return set_error(NTR_ERR_INVALID, "ntr_bvh_validate: node buffer must be a positive multiple of 64 bytes");
+    // the same extent rule as ntr_trace_bvh: child pointers are S32 byte offsets below the sentinel 0x76543210
+    if (!d_nodes || nodesBytes < 64 || (nodesBytes % 64) != 0 || nodesBytes > 0x76543200ll)
+        return set_error(NTR_ERR_INVALID, "ntr_bvh_validate: node buffer size must be a multiple of 64 in [64, 0x76543200]");
     hipStream_t s = (hipStream_t)stream;
     unsigned int* d_bad = nullptr;
     NTR_HIP(hipMalloc((void**)&d_bad, sizeof(unsigned int)));
@@ -57,6 +58,5 @@ extern "C" int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_
     if (!(bad & 2u)) *flags |= NTR_BVH_FASTDIV;
     if (!(bad & 4u)) *flags |= NTR_BVH_NOTINY;
     // hosts validate after every (re)build: refresh the top-of-tree table the dispatch-order prediction uses
-    if (nodesBytes <= 0xFFFFFFFFll) return ntr_top_table_refresh(d_nodes, nodesBytes, stream);
-    return NTR_OK;
+    return ntr_top_table_refresh(d_nodes, nodesBytes, stream);
 }

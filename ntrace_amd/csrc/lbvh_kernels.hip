@@ -36,6 +36,8 @@
 #include <stdlib.h>
 #include <math.h>
 
+#include <mutex>
+
 #include "ntr_internal.h"
 #include "radix_sort.h"
 
@@ -701,29 +703,35 @@ struct PhaseEvents {
     float ms(int a, int b) { float v = 0; (void)hipEventElapsedTime(&v, ev[a], ev[b]); return v; }
 };
 
-// Grow-only scratch memory of the builder, kept between builds (one caller per device, as the rest of
-// the C-ABI): a rebuild per frame must not pay nine hipMalloc/hipFree pairs.
+// Grow-only scratch memory of the builder, kept between builds: a rebuild per frame must not pay nine
+// hipMalloc/hipFree pairs.  One workspace PER DEVICE (one caller per device at a time, as the rest of the
+// C-ABI; host threads driving different devices never touch each other's workspace).  A workspace is only
+// regrown after the device has drained, so a build still in flight on another stream keeps its memory.
 struct Workspace {
     void* p = nullptr;
     size_t bytes = 0;
-    int device = -1;
-    ~Workspace() { /* process exit: the runtime reclaims it */ }
 };
-Workspace g_ws;
+constexpr int kMaxDevices = 64;
+Workspace g_ws[kMaxDevices];
+std::mutex g_wsMu;
 
 int workspace_reserve(size_t bytes, void** out)
 {
     int dev = 0;
     NTR_HIP(hipGetDevice(&dev));
-    if (g_ws.p && (g_ws.device != dev || g_ws.bytes < bytes)) {
-        NTR_HIP(hipFree(g_ws.p));
-        g_ws.p = nullptr; g_ws.bytes = 0;
+    if (dev < 0 || dev >= kMaxDevices) return set_error(NTR_ERR_INVALID, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_wsMu);
+    Workspace& w = g_ws[dev];
+    if (w.p && w.bytes < bytes) {
+        NTR_HIP(hipDeviceSynchronize());
+        NTR_HIP(hipFree(w.p));
+        w.p = nullptr; w.bytes = 0;
     }
-    if (!g_ws.p) {
-        NTR_HIP(hipMalloc(&g_ws.p, bytes));
-        g_ws.bytes = bytes; g_ws.device = dev;
+    if (!w.p) {
+        NTR_HIP(hipMalloc(&w.p, bytes));
+        w.bytes = bytes;
     }
-    *out = g_ws.p;
+    *out = w.p;
     return NTR_OK;
 }
 
@@ -732,11 +740,6 @@ struct Carver {  // 256-byte aligned slices of the workspace
     size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
 };
 
-int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 }  // namespace
 
 extern "C" {
@@ -768,7 +771,8 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     hipStream_t s = (hipStream_t)stream;
     const int n = numTris;
     const int nb = (n + SORT_TILE - 1) / SORT_TILE;
-    const bool levelSync = env_int("NTR_LBVH_LEVELSYNC", 0) != 0;
+    const Tunables tun = tunables();
+    const bool levelSync = tun.lbvhLevelSync != 0;
 
     Carver cv;
     const size_t oKeysA = cv.take((size_t)n * 4), oKeysB = cv.take((size_t)n * 4);
@@ -869,12 +873,12 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         // ranges of at most `spill` triangles become one workgroup's subtree: about 1.5 n / spill of them
         // as large as a workgroup's LDS entry list allows: the LDS levels of a subtree are cheaper than the top pass's
         // global ones (sweep: scripts/lbvh_split_sweep.sh)
-        c.spill = env_int("NTR_LBVH_SPLIT", 3072);
+        c.spill = tun.lbvhSplit;
         if (c.spill < 2) c.spill = 2;
         if (c.spill > 7168) c.spill = 7168;  // 20 bytes of LDS per triangle of a subtree (140 KB), 16-bit positions
         hipLaunchKernelGGL(lbvh_top_kernel, dim3(1), dim3(TOP_THREADS), 0, s, c, n, q0, q1, (int*)(ws + oTopLst));
         pe.mark(4);
-        const int subThreads = env_int("NTR_LBVH_SUB_THREADS", 128);
+        const int subThreads = tun.lbvhSubThreads;
         int subBlocks = n / 2 + 1;
         const int subMax = 256 * (2048 / (subThreads > 0 ? subThreads : 128));
         if (subBlocks > subMax) subBlocks = subMax;

@@ -48,12 +48,22 @@ struct DeviceState {
     unsigned int* status = nullptr;
     unsigned long long* stats = nullptr;  // 4 counters of the stats variant
     int next = 0;
+    int nextPinned = 0;
     int numCUs = 0;
 };
 static constexpr int kNumCounters = 64;  // ring of counter sets (8 heads x 64 B each)
+static constexpr int kPinnedCounters = 192;  // counter sets handed to launches captured into HIP graphs: never reused
 static constexpr int kMaxDevices = 64;
+static constexpr int64_t kMaxNodesBytes = 0x76543200ll;  // largest multiple of 64 below the sentinel 0x76543210
 static DeviceState g_dev[kMaxDevices];
 static std::mutex g_mu;
+
+bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
 
 int get_device_state(DeviceState** out)
 {
@@ -68,7 +78,7 @@ int get_device_state(DeviceState** out)
         NTR_HIP(hipGetDeviceProperties(&prop, dev));
         s.numCUs = prop.multiProcessorCount;
         // Counters sit 64 B apart so concurrent launches never share a line.
-        NTR_HIP(hipMalloc((void**)&s.counters, kNumCounters * 8 * 64));
+        NTR_HIP(hipMalloc((void**)&s.counters, (kNumCounters + kPinnedCounters) * 8 * 64));
         NTR_HIP(hipMalloc((void**)&s.status, 64));
         NTR_HIP(hipMalloc((void**)&s.stats, 256));
         NTR_HIP(hipMemset(s.status, 0, 64));
@@ -107,6 +117,72 @@ static const KernelInfo* find_kernel(const char* name)
 }
 
 }  // namespace ntr
+
+// Tunables.  Environment overrides exist for benchmarking sweeps; they are read ONCE, when the library is first
+// used (and again on ntr_tunables_reload(), which the sweep scripts call after changing a variable), never per
+// launch.  No pointer is ever taken from the environment.
+static int env_int(const char* name, int def)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : def;
+}
+
+namespace ntr {
+static Tunables g_tun;
+static bool g_tunLoaded = false;
+static std::mutex g_tunMu;
+
+static void tunables_load_locked()
+{
+    Tunables t;
+    t.chunk = env_int("NTR_TRACE_CHUNK", 64);
+    t.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", -1);  // -1: 24 for kepler_dynamic_fetch, 0 otherwise
+    t.coop = env_int("NTR_TRACE_COOP", 0);
+    t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", 24);     // sweep: flat optimum 16..64 (scripts/trace_sweep.py)
+    t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 6);
+    t.predict = env_int("NTR_TRACE_PREDICT", 1);
+    t.predictDepth = env_int("NTR_TRACE_PREDICT_DEPTH", 9);
+    t.predictMinRays = env_int("NTR_TRACE_PREDICT_MIN_RAYS", 1 << 20);
+    t.predictMinNodes = env_int("NTR_TRACE_PREDICT_MIN_NODES", 4096);
+    t.schedRefreshEvery = env_int("NTR_SCHED_REFRESH_EVERY", 8);
+    t.schedClasses = env_int("NTR_SCHED_CLASSES", 32);
+    t.lbvhLevelSync = env_int("NTR_LBVH_LEVELSYNC", 0);
+    t.lbvhSplit = env_int("NTR_LBVH_SPLIT", 3072);
+    t.lbvhSubThreads = env_int("NTR_LBVH_SUB_THREADS", 128);
+    t.lbvhLegacyTop = env_int("NTR_LBVH_LEGACY_TOP", 0);
+    t.lbvhLegacySort = env_int("NTR_LBVH_LEGACY_SORT", 0);
+    if (t.chunk < 1) t.chunk = 1;
+    g_tun = t;
+    g_tunLoaded = true;
+}
+
+Tunables tunables()
+{
+    std::lock_guard<std::mutex> lk(g_tunMu);
+    if (!g_tunLoaded) tunables_load_locked();
+    return g_tun;
+}
+}  // namespace ntr
+
+extern "C" int ntr_tunables_reload(void)
+{
+    std::lock_guard<std::mutex> lk(ntr::g_tunMu);
+    ntr::tunables_load_locked();
+    return NTR_OK;
+}
+
+#ifdef NTR_EXPERIMENTS
+// Diagnostic hooks of scripts/timeline*.py and scripts/order_experiment.py; compiled only into experiment builds
+// (make EXPERIMENTS=1).  The shipped library has no way to inject a device pointer into a launch.
+static unsigned long long* g_expTimeline = nullptr;
+static const unsigned int* g_expOrder = nullptr;
+extern "C" NTR_API int ntr_experiment_hooks(void* d_timeline, const void* d_order)
+{
+    g_expTimeline = (unsigned long long*)d_timeline;
+    g_expOrder = (const unsigned int*)d_order;
+    return NTR_OK;
+}
+#endif
 
 using namespace ntr;
 
@@ -191,13 +267,6 @@ int ntr_query_config(const char* kernelName, NtrKernelConfig* config)
     return NTR_OK;
 }
 
-// Tunables (environment overrides are for benchmarking sweeps only).
-static int env_int(const char* name, int def)
-{
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : def;
-}
-
 // ---- dispatch-order prediction (sched_kernels.hip) ---------------------------------------------------
 // Top-of-tree box tables, one per node buffer seen (keyed by pointer and size; rebuilt by
 // ntr_bvh_validate, which hosts call after every (re)build).  A stale table only costs scheduling quality.
@@ -208,8 +277,9 @@ struct TopTable {
     void* table = nullptr;           // 2 float4 per box
     unsigned int* count = nullptr;   // boxes in the table
     unsigned long long lastUse = 0;
+    bool pinned = false;             // referenced by a captured HIP graph: never evicted
 };
-static constexpr int kTopTables = 8;
+static constexpr int kTopTables = 16;
 static TopTable g_top[kTopTables];
 static unsigned long long g_topClock = 0;
 static constexpr size_t kTopTableBytes = (((size_t)2 << NTR_TOP_DEPTH_MAX) + 16) * 32;  // + padding read by predict_kernel's batches
@@ -224,8 +294,9 @@ struct PredictScratch {
     unsigned int* order = nullptr;
     int capBlocks = 0;
     unsigned long long lastUse = 0;
+    bool pinned = false;                 // referenced by a captured HIP graph: never evicted, never regrown
 };
-static constexpr int kScratch = 8;
+static constexpr int kScratch = 32;
 static PredictScratch g_scratch[kScratch];
 
 static int top_table_get(const void* d_nodes, int64_t nodesBytes, hipStream_t s, bool rebuild, TopTable** out)
@@ -233,14 +304,17 @@ static int top_table_get(const void* d_nodes, int64_t nodesBytes, hipStream_t s,
     int dev = 0;
     NTR_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
+    const bool capturing = stream_is_capturing(s);
     TopTable* t = nullptr;
-    TopTable* lru = &g_top[0];
+    TopTable* lru = nullptr;
     for (auto& e : g_top) {
         if (e.nodes == d_nodes && e.bytes == nodesBytes && e.device == dev) { t = &e; break; }
-        if (e.lastUse < lru->lastUse) lru = &e;
+        if (!e.pinned && (!lru || e.lastUse < lru->lastUse)) lru = &e;
     }
     bool build = rebuild;
     if (!t) {
+        if (!lru) return set_error(NTR_ERR_NOMEM, "ntr_trace_bvh: every top-of-tree table is held by a captured HIP graph");
+        if (capturing) return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: first launch on a BVH cannot be captured (trace it once, or call ntr_bvh_validate, before capturing)");
         t = lru;
         if (t->table && t->device != dev) { (void)hipFree(t->table); (void)hipFree(t->count); t->table = nullptr; t->count = nullptr; }
         if (!t->table) {
@@ -251,8 +325,9 @@ static int top_table_get(const void* d_nodes, int64_t nodesBytes, hipStream_t s,
         build = true;
     }
     t->lastUse = ++g_topClock;
+    if (capturing) t->pinned = true;
     if (build) {
-        const hipError_t e = ntr_launch_top_table(d_nodes, (unsigned int)nodesBytes, env_int("NTR_TRACE_PREDICT_DEPTH", 9), t->table, t->count, s);
+        const hipError_t e = ntr_launch_top_table(d_nodes, (unsigned int)nodesBytes, tunables().predictDepth, t->table, t->count, s);
         if (e != hipSuccess) return hip_fail(e, "top_table launch");
     }
     *out = t;
@@ -270,13 +345,18 @@ static int predict_scratch_get(hipStream_t s, int numBlocks, PredictScratch** ou
     int dev = 0;
     NTR_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
+    const bool capturing = stream_is_capturing(s);
     PredictScratch* p = nullptr;
-    PredictScratch* lru = &g_scratch[0];
+    PredictScratch* lru = nullptr;
     for (auto& e : g_scratch) {
-        if (e.classCount && e.stream == (void*)s && e.device == dev) { p = &e; break; }
-        if (e.lastUse < lru->lastUse) lru = &e;
+        // a pinned entry (held by a graph) serves later launches of its stream only while it is large enough
+        if (e.classCount && e.stream == (void*)s && e.device == dev && (!e.pinned || e.capBlocks >= numBlocks)) { p = &e; break; }
+        if (!e.pinned && (!lru || e.lastUse < lru->lastUse)) lru = &e;
     }
+    if (capturing && (!p || p->capBlocks < numBlocks))
+        return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: a launch of this size must run once on the stream before it can be captured");
     if (!p) {
+        if (!lru) return set_error(NTR_ERR_NOMEM, "ntr_trace_bvh: every prediction scratch is held by a captured HIP graph");
         p = lru;
         if (p->classCount) {
             NTR_HIP(hipDeviceSynchronize());  // an evicted stream's launches may still read it
@@ -297,6 +377,7 @@ static int predict_scratch_get(hipStream_t s, int numBlocks, PredictScratch** ou
         p->capBlocks = numBlocks;
     }
     p->lastUse = ++g_topClock;
+    if (capturing) p->pinned = true;
     *out = p;
     return NTR_OK;
 }
@@ -337,8 +418,10 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     if (!d_rays || !d_results) return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: null ray/result buffer");
     // The sizes play the role of the reference's texref extents (setTexRef(..., size),
     // CudaBVHTracer.cpp:142-150); buffer descriptors address at most 4 GiB.
-    if (nodesBytes < 64 || (nodesBytes % 64) != 0 || nodesBytes > 0xFFFFFFFFll)
-        return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: node buffer size must be a multiple of 64 in [64, 4 GiB)");
+    // Compact child pointers are S32 byte offsets and 0x76543210 is the traversal's stack sentinel
+    // (EntrypointSentinel, CudaTracerKernels.hpp:38): a node at or beyond that offset cannot be addressed.
+    if (nodesBytes < 64 || (nodesBytes % 64) != 0 || nodesBytes > kMaxNodesBytes)
+        return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: node buffer size must be a multiple of 64 in [64, 0x76543200]");
     if (triWoopBytes < 16 || (triWoopBytes % 16) != 0 || triWoopBytes > 0xFFFFFFFFll)
         return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: triWoop buffer size must be a multiple of 16 in [16, 4 GiB)");
 
@@ -362,23 +445,20 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.shardRays = 0;
     // persistent kernels (scripts/persist_sweep.py): 64-ray chunks, 6 workgroups per CU; dynamic fetch only for the kernel
     // named after it (it costs about 10 % here: refilled lanes de-cohere a wave's node fetches)
-    p.chunk = env_int("NTR_TRACE_CHUNK", 64);
-    p.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", strcmp(k->name, "kepler_dynamic_fetch") == 0 ? 24 : 0);
+    const Tunables tun = tunables();
+    p.chunk = tun.chunk;
+    p.fetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (strcmp(k->name, "kepler_dynamic_fetch") == 0 ? 24 : 0);
     p.bvhFlags = bvhFlags;
-    p.coop = env_int("NTR_TRACE_COOP", 0);
-    p.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", 24);  // sweep: flat optimum 16..64 (scripts/trace_sweep.py)
+    p.coop = tun.coop;
+    p.leafSwitchBelow = tun.leafSwitchBelow;
     p.stats = ds->stats;
     p.timeline = nullptr;
-    {   // diagnostic: NTR_TRACE_TIMELINE=<hex device pointer> (scripts/timeline*.py)
-        const char* tl = getenv("NTR_TRACE_TIMELINE");
-        if (tl && *tl) p.timeline = (unsigned long long*)strtoull(tl, nullptr, 16);
-    }
     p.order = nullptr;
     p.cost = nullptr;
-    {   // experiment hook: NTR_TRACE_ORDER=<hex device pointer to uint32 block order>
-        const char* od = getenv("NTR_TRACE_ORDER");
-        if (od && *od) p.order = (const unsigned int*)strtoull(od, nullptr, 16);
-    }
+#ifdef NTR_EXPERIMENTS
+    p.timeline = g_expTimeline;
+    p.order = g_expOrder;
+#endif
     int variant = k->variant;
     if (stats) {
         // RayStats counters (src/rt/bvh/BVH.hpp:44-, filled at CudaBVH.cpp:746-757,1107-1111) are
@@ -393,14 +473,22 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     if (variant == NTR_VARIANT_PERSISTENT) {
         // Persistent grid: CUs x resident blocks per CU (the reference hard-codes
         // 720 warps for GT200/Fermi, CudaBVHTracer.cpp:155-159).
-        const int blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 6);
+        const int blocksPerCU = tun.blocksPerCU;
         numBlocks = ds->numCUs * blocksPerCU;
         const int needed = (numRays + blockThreads - 1) / blockThreads;
         if (numBlocks > needed) numBlocks = needed;
         {
+            // a launch that is being captured into a HIP graph keeps its pool heads for the graph's lifetime
+            const bool capturing = stream_is_capturing(s);
             std::lock_guard<std::mutex> lk(g_mu);
-            p.counter = ds->counters + 8 * 16 * ds->next;
-            ds->next = (ds->next + 1) % kNumCounters;
+            if (capturing) {
+                if (ds->nextPinned >= kPinnedCounters)
+                    return set_error(NTR_ERR_NOMEM, "ntr_trace_bvh: more than %d persistent launches captured into HIP graphs", kPinnedCounters);
+                p.counter = ds->counters + 8 * 16 * (kNumCounters + ds->nextPinned++);
+            } else {
+                p.counter = ds->counters + 8 * 16 * ds->next;
+                ds->next = (ds->next + 1) % kNumCounters;
+            }
         }
         {   // cleared by a kernel: memset nodes do not survive HIP graph replays (see sched_kernels.hip)
             const hipError_t ze = ntr_launch_zero_words(p.counter, 8 * 16, s);
@@ -427,7 +515,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         }
         // costs measured under the natural order differ from those under the derived order, so the first
         // launches all refresh; afterwards every 8th does (slowly drifting rays keep their schedule)
-        const int every = env_int("NTR_SCHED_REFRESH_EVERY", 8);
+        const int every = tun.schedRefreshEvery;
         refresh = hint->uses < 3 || every <= 1 || (hint->uses % every) == 0;
         hint->uses++;
         if (hint->valid) p.order = hint->order;
@@ -444,8 +532,8 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     TopTable* predTable = nullptr;
     PredictScratch* predScratch = nullptr;
     // (a tree of a few hundred nodes is traced faster than it is predicted: Cornell-box class scenes are left alone)
-    if (!hint && !p.order && variant == NTR_VARIANT_PERRAY && !anyHit && numRays >= env_int("NTR_TRACE_PREDICT_MIN_RAYS", 1 << 20) &&
-        nodesBytes >= (int64_t)env_int("NTR_TRACE_PREDICT_MIN_NODES", 4096) * 64 && env_int("NTR_TRACE_PREDICT", 1) != 0) {
+    if (!hint && !p.order && variant == NTR_VARIANT_PERRAY && !anyHit && numRays >= tun.predictMinRays &&
+        nodesBytes >= (int64_t)tun.predictMinNodes * 64 && tun.predict != 0) {
         rc = top_table_get(d_nodes, nodesBytes, s, false, &predTable);
         if (rc != NTR_OK) return rc;
         rc = predict_scratch_get(s, numBlocks, &predScratch);
@@ -469,7 +557,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     if (le != hipSuccess) return hip_fail(le, "trace_bvh launch");
     if (seconds) NTR_HIP(hipEventRecord(ev1, s));
     if (refresh) {
-        le = ntr_launch_sched_order(hint->cost, numBlocks, env_int("NTR_SCHED_CLASSES", 32), hint->order, s);
+        le = ntr_launch_sched_order(hint->cost, numBlocks, tun.schedClasses, hint->order, s);
         if (le != hipSuccess) return hip_fail(le, "sched_order launch");
         hint->valid = true;
     }
@@ -516,6 +604,26 @@ int ntr_trace_bvh_hinted(const char* kernelName, int32_t numRays, int32_t anyHit
 {
     return trace_impl(kernelName, numRays, anyHit, d_rays, d_results, d_nodes, nodesBytes, d_triWoop, triWoopBytes,
                       d_triIndex, layout, bvhFlags, stream, seconds, nullptr, hint);
+}
+
+int ntr_trace_status(void* stream, uint32_t* statusBits)
+{
+    if (statusBits) *statusBits = 0;
+    DeviceState* ds = nullptr;
+    const int rc = get_device_state(&ds);
+    if (rc != NTR_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int st = 0;
+    NTR_HIP(hipMemcpyAsync(&st, ds->status, sizeof(st), hipMemcpyDeviceToHost, s));
+    NTR_HIP(hipStreamSynchronize(s));
+    if (statusBits) *statusBits = st;
+    if (st != 0) {
+        NTR_HIP(hipMemsetAsync(ds->status, 0, sizeof(st), s));
+        NTR_HIP(hipStreamSynchronize(s));
+    }
+    if (st & NTR_STATUS_STACK_OVERFLOW)
+        return set_error(NTR_ERR_OVERFLOW, "trace_bvh: traversal stack overflow in a launch since the last status check");
+    return NTR_OK;
 }
 
 int ntr_sched_hint_create(NtrSchedHint** out)

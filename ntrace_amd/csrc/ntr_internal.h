@@ -7,6 +7,19 @@
 namespace ntr {
 int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 int hip_fail(hipError_t e, const char* what);
+
+// Tunables (environment overrides for sweeps), read once at first use -- see ntr_api.cpp.
+struct Tunables {
+    int chunk, fetchThreshold, coop, leafSwitchBelow, blocksPerCU;
+    int predict, predictDepth, predictMinRays, predictMinNodes;
+    int schedRefreshEvery, schedClasses;
+    int lbvhLevelSync, lbvhSplit, lbvhSubThreads, lbvhLegacyTop, lbvhLegacySort;
+};
+Tunables tunables();
+
+// true when `s` is being captured into a HIP graph: scratch handed to such a launch must stay valid for the
+// lifetime of the graph, so it is taken from never-recycled storage.
+bool stream_is_capturing(hipStream_t s);
 }  // namespace ntr
 
 // ntr_api.cpp: (re)build the top-of-tree box table cached for this node buffer (dispatch-order prediction)

@@ -25,9 +25,9 @@ def experiment(name, d_rays, n, any_hit):
     for _ in range(3): view.trace(K, n, any_hit, d_rays.data_ptr(), d_res.data_ptr())
     base = timed()
     ref = d_res.clone()
-    os.environ["NTR_TRACE_TIMELINE"] = "%x" % tl.data_ptr()
+    nt.experiment_hooks(timeline=tl.data_ptr())
     view.trace(K, n, any_hit, d_rays.data_ptr(), d_res.data_ptr())
-    del os.environ["NTR_TRACE_TIMELINE"]
+    nt.experiment_hooks()
     t = tl.cpu().numpy().reshape(-1, 3)
     life = np.zeros(nb * 4); life[:nw] = (t[:, 1] - t[:, 0])
     cost = life.reshape(nb, 4).max(1)
@@ -40,10 +40,10 @@ def experiment(name, d_rays, n, any_hit):
     orders["heavy_first_64_buckets"] = np.argsort(-b, kind="stable")
     for k, o in orders.items():
         d_o = up(o.astype(np.uint32))
-        os.environ["NTR_TRACE_ORDER"] = "%x" % d_o.data_ptr()
+        nt.experiment_hooks(order=d_o.data_ptr())
         view.trace(K, n, any_hit, d_rays.data_ptr(), d_res.data_ptr())
         out[k] = timed()
-        del os.environ["NTR_TRACE_ORDER"]
+        nt.experiment_hooks()
         assert torch.equal(d_res, ref), k
     # second-generation feedback: costs measured under the heavy-first order
     print(name, "rays", n, {k: round(float(v), 1) for k, v in out.items()}, "us; cost ticks p50/p99/max", np.percentile(cost, 50), np.percentile(cost, 99), cost.max())

@@ -19,10 +19,10 @@ nt.raygen_ao(b_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(
 def timed(kernel, m, ah, r, o, reps=7):
     for _ in range(2): view.trace(kernel, m, ah, r.data_ptr(), o.data_ptr())
     return float(np.median([view.trace(kernel, m, ah, r.data_ptr(), o.data_ptr()) for _ in range(reps)])) * 1e6
-os.environ["NTR_TRACE_PREDICT"] = "0"
+nt.set_tunables(NTR_TRACE_PREDICT=0)
 print("per-ray primary %.1f ao %.1f" % (timed("fermi_speculative_while_while", n, False, d_rays, d_res), timed("fermi_speculative_while_while", cnt * ns, True, b_rays, b_res)), flush=True)
 for chunk in (64, 128):
     for bpc in (5, 6, 7, 8):
         for thr in (0, 16, 24, 32):
-            os.environ["NTR_TRACE_CHUNK"] = str(chunk); os.environ["NTR_TRACE_BLOCKS_PER_CU"] = str(bpc); os.environ["NTR_TRACE_FETCH_THRESHOLD"] = str(thr)
+            nt.set_tunables(NTR_TRACE_CHUNK=chunk, NTR_TRACE_BLOCKS_PER_CU=bpc, NTR_TRACE_FETCH_THRESHOLD=thr)
             print("chunk %3d blocks/CU %d threshold %2d: primary %.1f us, AO batch %.1f us" % (chunk, bpc, thr, timed("kepler_dynamic_fetch", n, False, d_rays, d_res), timed("kepler_dynamic_fetch", cnt * ns, True, b_rays, b_res)), flush=True)

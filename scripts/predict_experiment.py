@@ -59,10 +59,10 @@ def experiment(name, rays, d_rays, n, any_hit):
                 b = np.minimum((p / max(p.max(), 1) * C).astype(np.int64), C - 1)
                 o = np.argsort(-b, kind="stable")
                 d_o = up(o.astype(np.uint32))
-                os.environ["NTR_TRACE_ORDER"] = "%x" % d_o.data_ptr()
+                nt.experiment_hooks(order=d_o.data_ptr())
                 view.trace(K, n, any_hit, d_rays.data_ptr(), d_res.data_ptr())
                 out["D%d_%dbox_s%d_c%d" % (D, len(F), len(samples), C)] = timed()
-                del os.environ["NTR_TRACE_ORDER"]
+                nt.experiment_hooks()
                 assert torch.equal(d_res, ref)
     print(name, n, {k: round(float(v), 1) for k, v in out.items()})
 

@@ -22,7 +22,7 @@ def run(name, d_rays, n, any_hit):
     ref = d_res.clone()
     print("%s: %d rays, no hint %.1f us" % (name, n, base))
     for classes in (4, 8, 16, 32, 64):
-        os.environ["NTR_SCHED_CLASSES"] = str(classes)
+        nt.set_tunables(NTR_SCHED_CLASSES=classes)
         h = nt.SchedHint()
         ts = []
         for g in range(20):
@@ -31,7 +31,7 @@ def run(name, d_rays, n, any_hit):
             assert torch.equal(d_res, ref), (classes, g)
         print("  classes %2d: gen0..5 %s | steady median %.1f us (min %.1f)" % (classes, " ".join("%.0f" % t for t in ts[:6]), np.median(ts[6:]), min(ts[6:])))
         h.close()
-    os.environ.pop("NTR_SCHED_CLASSES", None)
+    nt.set_tunables(NTR_SCHED_CLASSES=None)
     # wall-clock per launch, asynchronous launches back to back
     stream = torch.cuda.current_stream().cuda_stream
     for label, hint in (("no hint", None), ("hint", nt.SchedHint())):

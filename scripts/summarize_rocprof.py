@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output directories into text for profiles/.
+
+  summarize_rocprof.py trace <dir>   per kernel x grid size: dispatch count, mean / min / max duration (ns) from
+                                     *_kernel_trace.csv (what `--kernel-trace --stats` aggregates, split by launch shape)
+  summarize_rocprof.py pmc <dir>...  per kernel x grid size x counter: mean per dispatch from *_counter_collection.csv
+Kernel names are shortened to the function name."""
+import collections
+import csv
+import glob
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    name = re.sub(r"^void\s+", "", name)
+    name = name.replace("ntr::", "").replace("(anonymous namespace)::", "")
+    return name[-70:]
+
+
+def trace(d):
+    rows = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            rows[(short(r["Kernel_Name"]), r["Grid_Size_X"], r.get("Workgroup_Size_X", "?"))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    tot = sum(sum(v) for v in rows.values()) or 1
+    print("%-72s %10s %5s %6s %12s %12s %12s %6s" % ("kernel", "grid", "wg", "calls", "mean_ns", "min_ns", "max_ns", "pct"))
+    for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+        print("%-72s %10s %5s %6d %12.0f %12d %12d %6.2f" % (k[0], k[1], k[2], len(v), sum(v) / len(v), min(v), max(v), 100.0 * sum(v) / tot))
+
+
+def pmc(dirs):
+    for d in dirs:
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for f in sorted(glob.glob(d + "/**/*_counter_collection.csv", recursive=True)):
+            for r in csv.DictReader(open(f)):
+                agg[(short(r["Kernel_Name"]), r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in sorted(agg.items()):
+            for c, v in sorted(cs.items()):
+                print("%-72s grid=%10s %-32s n=%4d mean=%.6g" % (k[0], k[1], c, len(v), sum(v) / len(v)))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2])
+    else:
+        pmc(sys.argv[2:])

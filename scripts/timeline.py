@@ -17,9 +17,9 @@ n = rays.shape[0]; d_rays = up(rays); d_res = torch.zeros(n * 16, dtype=torch.ui
 nw = (n + 63) // 64
 tl = torch.zeros(nw * 3, dtype=torch.int64, device=dev)
 for _ in range(3): view.trace("fermi_speculative_while_while", n, False, d_rays.data_ptr(), d_res.data_ptr())
-os.environ["NTR_TRACE_TIMELINE"] = "%x" % tl.data_ptr()
+nt.experiment_hooks(timeline=tl.data_ptr())
 sec = view.trace("fermi_speculative_while_while", n, False, d_rays.data_ptr(), d_res.data_ptr())
-del os.environ["NTR_TRACE_TIMELINE"]
+nt.experiment_hooks()
 t = tl.cpu().numpy().reshape(-1, 3)
 s, e, hw = t[:, 0], t[:, 1], t[:, 2]
 t0 = s.min(); s = (s - t0) / 100.0; e = (e - t0) / 100.0   # us (100 MHz realtime counter)

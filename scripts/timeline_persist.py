@@ -19,9 +19,9 @@ for (c, t, b) in ((64, 0, 7), (64, 40, 7), (32, 48, 7), (64, 56, 4)):
     nw = 256 * b * 4
     tl = torch.zeros(nw * 6, dtype=torch.int64, device=dev)
     for _ in range(2): view.trace("kepler_dynamic_fetch", n, False, d_rays.data_ptr(), d_res.data_ptr())
-    os.environ["NTR_TRACE_TIMELINE"] = "%x" % tl.data_ptr()
+    nt.experiment_hooks(timeline=tl.data_ptr())
     sec = view.trace("kepler_dynamic_fetch", n, False, d_rays.data_ptr(), d_res.data_ptr())
-    del os.environ["NTR_TRACE_TIMELINE"]
+    nt.experiment_hooks()
     t_ = tl.cpu().numpy().reshape(-1, 6)
     t_ = t_[t_[:, 0] > 0]
     s, e = t_[:, 0], t_[:, 1]

@@ -81,6 +81,7 @@ def main():
             for k, v in env.items():
                 if not k.startswith("_"):
                     os.environ[k] = str(v)
+            nt.set_tunables()  # the library reads the environment once: make it re-read
             flags = env.get("_flags", None)
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             e[0].record()

@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _fresh_tunables():
+    """The library reads its NTR_* environment tunables once; tests that change one call nt.set_tunables()
+    themselves, and every test starts from the environment as it is now."""
+    try:
+        import ntrace_amd as nt
+        nt.lib().ntr_tunables_reload()
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built_libraries():
     """Make sure the oracle (gcc) and, when hipcc is present, the product library exist."""

@@ -141,9 +141,9 @@ def main(argv=None):
         try:
             if use_lbvh:
                 if rng.random() < 0.3:
-                    os.environ["NTR_LBVH_SPLIT"] = str(int(rng.choice([2, 16, 100, 3000])))
+                    nt.set_tunables(NTR_LBVH_SPLIT=int(rng.choice([2, 16, 100, 3000])))
                 else:
-                    os.environ.pop("NTR_LBVH_SPLIT", None)
+                    nt.set_tunables(NTR_LBVH_SPLIT=None)
                 nodes, woop, idx, res, keep = gpu_lbvh(tri, pos, leaf, eps)
                 ref = oracle.lbvh_build(tri, pos, leaf, eps)
                 same = (res.numNodes == ref["num_inner"] and res.numLeaves == ref["num_leaves"] and res.numLevels == ref["num_levels"] and
@@ -176,10 +176,9 @@ def main(argv=None):
             # scheduling variants only permute blocks: plain, dispatch-order prediction forced on, caller-owned hint
             sched = int(rng.integers(0, 3))
             if sched == 1:
-                os.environ["NTR_TRACE_PREDICT_MIN_RAYS"] = "1"
-                os.environ["NTR_TRACE_PREDICT_MIN_NODES"] = "1"
+                nt.set_tunables(NTR_TRACE_PREDICT_MIN_RAYS=1, NTR_TRACE_PREDICT_MIN_NODES=1)
             else:
-                os.environ.pop("NTR_TRACE_PREDICT_MIN_RAYS", None)
+                nt.set_tunables(NTR_TRACE_PREDICT_MIN_RAYS=None, NTR_TRACE_PREDICT_MIN_NODES=None)
             hint = nt.SchedHint() if sched == 2 else None
             tot["sched_%d_rounds" % sched] = tot.get("sched_%d_rounds" % sched, 0) + 1
             for any_hit in (False, True):

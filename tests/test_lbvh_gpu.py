@@ -27,6 +27,7 @@ def build_path(request, monkeypatch):
     elif request.param == "subtree-split40-256t":
         monkeypatch.setenv("NTR_LBVH_SPLIT", "40")
         monkeypatch.setenv("NTR_LBVH_SUB_THREADS", "256")
+    nt.set_tunables()  # the library reads the environment once
     return request.param
 
 

@@ -219,12 +219,14 @@ def test_dispatch_order_prediction_changes_order_only(soup, n, monkeypatch):
     dbvh, cam = soup
     monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
     monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
+    nt.set_tunables()
     rays = np.concatenate([scenes.primary_rays(cam, 300, 240)[0], edge_rays()])[:n]
     ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
     for rep in range(3):  # the class counters alternate between two sets
         got, _ = gpu_trace("fermi_speculative_while_while", dbvh, rays, False)
         assert_parity(got, ref, "prediction n=%d rep=%d" % (n, rep))
     monkeypatch.setenv("NTR_TRACE_PREDICT", "0")
+    nt.set_tunables()
     got, _ = gpu_trace("fermi_speculative_while_while", dbvh, rays, False)
     assert_parity(got, ref, "prediction off n=%d" % n)
 
@@ -239,6 +241,7 @@ def test_trace_launch_can_be_captured_in_a_hip_graph_and_replayed(soup, monkeypa
     dbvh, cam = soup
     monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
     monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
+    nt.set_tunables()
     rays = np.concatenate([scenes.primary_rays(cam, 200, 150)[0], scenes.random_rays(5000, seed=3)])
     n = rays.shape[0]
     ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
