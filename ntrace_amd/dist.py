@@ -1,6 +1,13 @@
 """Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo"
-in the CPU tests).  The traced path has no collective: rays are sharded, the BVH is replicated, and
-only hit records / pixels are gathered to rank 0 at the end of a frame."""
+in the CPU tests).  The traced path has no collective: rays are sharded by screen tile, the BVH is
+replicated, and only hit records / pixels are gathered to rank 0 at the end of a frame
+(SURVEY.md section 8(e)).
+
+FramePlan is the partition of ONE frame: the primary-ray index space [0, W*H) -- already 8x8-pixel
+blocks in Morton order (PixelTable, src/rt/ray/PixelTable.cpp:77-122) -- is cut into `world` contiguous
+ranges aligned to 64 rays, so a rank owns a compact set of screen tiles; the rank's AO / diffuse rays
+derive from its OWN primary hits, in batches of at most maxBatchSize output rays as RayGen::ao
+produces them (src/rt/ray/RayGen.cpp:582-602), so no ray or hit ever crosses a rank boundary."""
 import torch
 import torch.distributed as dist
 
@@ -14,6 +21,27 @@ def shard_range(num_rays, rank, world, align=64):
     lo_b = rank * per + min(rank, extra)
     hi_b = lo_b + per + (1 if rank < extra else 0)
     return min(lo_b * align, num_rays), min(hi_b * align, num_rays)
+
+
+class FramePlan:
+    """What `rank` of `world` traces of one frame of `num_primary` primary rays.
+
+    lo, hi       the rank's slice of the primary index space
+    ao_batches   [(first_input_slot, num_inputs)], global primary slots: batch b generates
+                 num_inputs * samples secondary rays from the rank's primary hits (none when samples == 0)"""
+
+    def __init__(self, num_primary, rank, world, samples=8, max_batch_rays=1 << 20, align=64):
+        self.num_primary, self.rank, self.world, self.samples = int(num_primary), int(rank), int(world), int(samples)
+        self.lo, self.hi = shard_range(num_primary, rank, world, align)
+        self.ao_batches = []
+        if samples > 0:
+            per = max(int(max_batch_rays) // samples, 1)
+            for first in range(self.lo, self.hi, per):
+                self.ao_batches.append((first, min(per, self.hi - first)))
+
+    @property
+    def num_own_primary(self):
+        return self.hi - self.lo
 
 
 def gather_hit_records(local, num_rays, align=64, dst=0):
@@ -31,6 +59,30 @@ def gather_hit_records(local, num_rays, align=64, dst=0):
     return torch.cat([o[:s] for o, s in zip(outs, sizes)])
 
 
+def records_checksum(records_u8):
+    """Order-independent 64-bit checksum of a buffer of 16-byte hit records: the wrapping int64 sum of
+    (id, t bits) of every record, each mixed with an odd multiplier.  Sums of the ranks' checksums equal the
+    checksum of the assembled frame (a checksum of checksums)."""
+    if records_u8.numel() == 0:
+        return 0
+    w = records_u8.view(torch.int32).view(-1, 4).to(torch.int64)
+    v = (w[:, 0] * 0x9E3779B1 + w[:, 1] * 0x85EBCA77).sum()
+    return int(v.item())
+
+
+def wrap_i64(x):
+    """Python int -> the signed 64-bit value with the same residue modulo 2^64."""
+    return ((int(x) + (1 << 63)) % (1 << 64)) - (1 << 63)
+
+
+def all_sum_int64(value, device):
+    """Wrapping int64 sum of `value` over the ranks (identity without a process group)."""
+    t = torch.tensor([wrap_i64(value)], dtype=torch.int64, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def job_throughput(units, seconds, device):
     """(sum of units over ranks, max of seconds over ranks): value = units / seconds."""
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
@@ -39,3 +91,15 @@ def job_throughput(units, seconds, device):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(u.item()), float(t.item())
+
+
+def broadcast_bytes(buf_u8, src, device):
+    """Replicates a byte buffer from `src` (BVH replication: built once, broadcast).  `buf_u8` is a
+    uint8 tensor on `src` and may be None elsewhere; returns the tensor on `device` on every rank."""
+    if not dist.is_initialized():
+        return buf_u8.to(device)
+    n = torch.tensor([buf_u8.numel() if dist.get_rank() == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src)
+    out = buf_u8.to(device) if dist.get_rank() == src else torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(out, src)
+    return out

@@ -41,6 +41,82 @@ def _worker(rank, world, port, num_rays, out_path):
     dist.destroy_process_group()
 
 
+def _standin_primary(lo, hi):
+    """Stand-in for the traced primary slice [lo, hi): a deterministic record per global slot."""
+    i = np.arange(lo, hi, dtype=np.int64)
+    rec = np.zeros(hi - lo, dtype=[("id", "<i4"), ("t", "<f4"), ("a", "<i4"), ("b", "<i4")])
+    rec["id"] = np.where((i * 2654435761) % 7 == 0, -1, (i * 40503) % 100000).astype(np.int32)
+    rec["t"] = (i % 1000).astype(np.float32) * 0.25
+    return rec
+
+
+def _standin_ao(primary_rec_of_slot, first, cnt, samples):
+    """Stand-in for one traced AO batch: record of (global input slot s, sample k); missed inputs give degenerate rays."""
+    s_ = np.repeat(np.arange(first, first + cnt, dtype=np.int64), samples)
+    k = np.tile(np.arange(samples, dtype=np.int64), cnt)
+    rec = np.zeros(cnt * samples, dtype=[("id", "<i4"), ("t", "<f4"), ("a", "<i4"), ("b", "<i4")])
+    parent = primary_rec_of_slot(first, first + cnt)
+    miss = np.repeat(parent["id"] == -1, samples)
+    rec["id"] = np.where(miss | ((s_ + k) % 3 == 0), -1, ((s_ * 31 + k) % 5000)).astype(np.int32)
+    rec["t"] = np.where(miss, -1.0, ((s_ * 7 + k) % 640) * 0.0078125).astype(np.float32)
+    return rec
+
+
+def _sharded_frame_worker(rank, world, port, num_primary, samples, max_batch, out_path):
+    """The whole N>1 flow of bench.py on gloo with a stand-in trace: BVH bytes broadcast from rank 0, FramePlan sharding,
+    AO batches from the rank's own primary hits, gather of the primary records, checksum of checksums over the AO
+    records, and rank 0's comparison with the single-rank frame."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cpu = torch.device("cpu")
+    blob = torch.arange(1000, dtype=torch.int64).view(torch.uint8) if rank == 0 else None
+    rep = ntd.broadcast_bytes(blob, 0, cpu)
+    ok = rep.numel() == 8000 and int(rep.view(torch.int64).sum()) == 999 * 1000 // 2
+    plan = ntd.FramePlan(num_primary, rank, world, samples, max_batch)
+    own = _standin_primary(plan.lo, plan.hi)
+    ao_ck = 0
+    for (first, cnt) in plan.ao_batches:
+        ok = ok and plan.lo <= first and first + cnt <= plan.hi and cnt * samples <= max(max_batch, samples)
+        ao_ck += ntd.records_checksum(torch.from_numpy(_standin_ao(_standin_primary, first, cnt, samples).view(np.uint8).copy()))
+    ok = ok and sum(c for _, c in plan.ao_batches) == plan.num_own_primary
+    full = ntd.gather_hit_records(torch.from_numpy(own.view(np.uint8).copy()), num_primary)
+    ao_sum = ntd.all_sum_int64(ao_ck, cpu)
+    units, secs = ntd.job_throughput(plan.num_own_primary * (1 + samples), 0.5 + rank, cpu)
+    if rank == 0:
+        ref = _standin_primary(0, num_primary)
+        ok = ok and torch.equal(full, torch.from_numpy(ref.view(np.uint8).copy()))
+        ref_ao = 0
+        for r in range(world):
+            for (first, cnt) in ntd.FramePlan(num_primary, r, world, samples, max_batch).ao_batches:
+                ref_ao += ntd.records_checksum(torch.from_numpy(_standin_ao(_standin_primary, first, cnt, samples).view(np.uint8).copy()))
+        ok = ok and ntd.wrap_i64(ref_ao) == ntd.wrap_i64(ao_sum)
+        # the single-rank plan (what N = 1 traces) covers the same records in other batches: same checksum
+        one = 0
+        for (first, cnt) in ntd.FramePlan(num_primary, 0, 1, samples, max_batch).ao_batches:
+            one += ntd.records_checksum(torch.from_numpy(_standin_ao(_standin_primary, first, cnt, samples).view(np.uint8).copy()))
+        ok = ok and ntd.wrap_i64(one) == ntd.wrap_i64(ao_sum)
+        ok = ok and units == num_primary * (1 + samples) and secs == 0.5 + (world - 1)
+        open(out_path, "w").write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_frame_plan_batches():
+    p = ntd.FramePlan(1920 * 1080, 3, 8, 8, 1 << 20)
+    assert p.lo % 64 == 0 and p.hi - p.lo == 259200
+    assert p.ao_batches == [(p.lo, 131072), (p.lo + 131072, 128128)]
+    assert ntd.FramePlan(1000, 0, 1, 0).ao_batches == []
+    whole = ntd.FramePlan(1920 * 1080, 0, 1, 8, 1 << 20)
+    assert len(whole.ao_batches) == 16 and sum(c for _, c in whole.ao_batches) == 1920 * 1080
+    assert ntd.wrap_i64((1 << 63) + 5) == -(1 << 63) + 5 and ntd.wrap_i64(-1) == -1
+
+
+def test_two_rank_sharded_frame_gloo(tmp_path):
+    out = str(tmp_path / "frame.txt")
+    mp.spawn(_sharded_frame_worker, args=(2, _free_port(), 20000, 8, 4096, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
 def test_shard_ranges_cover_and_align():
     for n in (1, 63, 64, 65, 1000, 1920 * 1080):
         for world in (1, 2, 3, 8):
@@ -60,3 +136,13 @@ def test_two_rank_gather_gloo(tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, _free_port(), 1000, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def test_bench_refuses_mismatched_world_size():
+    """`bench.py --gpus N` under a launcher that started another number of ranks is an error, not a silent 1-GPU run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 4 but the launcher started WORLD_SIZE=2" in (r.stderr + r.stdout)
