@@ -303,6 +303,15 @@ NTR_API int  ntr_sah_build(int32_t numTris, const int32_t* triVtxIndex /* 3 per 
 NTR_API int  ntr_host_bvh_info(const NtrHostBvh* bvh, NtrHostBvhInfo* info);
 NTR_API void ntr_host_bvh_free(NtrHostBvh* bvh);
 
+/* CudaAS::trace(RayBuffer&, Buffer& visibility) -- the reference's HOST tracer (src/rt/cuda/CudaAS.hpp:62,
+ * CudaBVH::trace, src/rt/cuda/CudaBVH.cpp:213-302; used by its CPURenderer and by BASELINE configuration 1): rays
+ * and results are HOST arrays, visibility (may be NULL / 0) receives 1 at the id of every triangle hit, stats (may
+ * be NULL) the reference's RayStats counters (numLeafVisits / numHits stay 0: the reference does not count them).
+ * Single-threaded, like the reference.  This is an API of its own for host-side callers, NOT a fallback of
+ * ntr_trace_bvh, which never runs on the CPU and fails without a HIP device. */
+NTR_API int ntr_host_bvh_trace(const NtrHostBvh* bvh, int32_t numRays, int32_t anyHit, const NtrRay* rays,
+                               NtrRayResult* results, int32_t* visibility, int32_t numVisibility, NtrTraceStats* stats);
+
 /* ---- scene ingest (host only) ----------------------------------------------- */
 
 /* CameraControls::decodeSignature / encodeSignature (src/framework/3d/CameraControls.cpp:342-399, 471-545):

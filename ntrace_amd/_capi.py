@@ -108,6 +108,7 @@ SYMBOLS = [
     ("ntr_sah_build", C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
     ("ntr_host_bvh_info", C.c_int, [_vp, C.POINTER(_HostBvhInfo)]),
     ("ntr_host_bvh_free", None, [_vp]),
+    ("ntr_host_bvh_trace", C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.POINTER(TraceStats)]),
 ]
 
 
@@ -353,9 +354,36 @@ class HostBvh:
         self.tri_index = tri_index  # int32[]
         self.info = info or {}
         self.layout = 4
+        self._h = None
+
+    def host_trace(self, rays, any_hit=False, num_visibility=0, want_stats=False):
+        """CudaAS::trace (the reference's host tracer, ntr_host_bvh_trace) on numpy rays; needs sah_build(keep_handle=True).
+        Returns (results, visibility or None, TraceStats or None)."""
+        if self._h is None:
+            raise NtrError(-1, "host_trace needs sah_build(..., keep_handle=True)")
+        rays = np.ascontiguousarray(rays)
+        n = rays.shape[0]
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        vis = np.zeros(num_visibility, dtype=np.int32) if num_visibility else None
+        st = TraceStats() if want_stats else None
+        _check(lib().ntr_host_bvh_trace(self._h, n, int(bool(any_hit)), rays.ctypes.data_as(_vp), res.ctypes.data_as(_vp),
+                                        vis.ctypes.data_as(_vp) if vis is not None else None, int(num_visibility),
+                                        C.byref(st) if st is not None else None))
+        return res, vis, st
+
+    def close(self):
+        if self._h is not None:
+            lib().ntr_host_bvh_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-def sah_build(tri_vtx_index, vtx_pos, min_leaf=1, max_leaf=1):
+def sah_build(tri_vtx_index, vtx_pos, min_leaf=1, max_leaf=1, keep_handle=False):
     tri = np.ascontiguousarray(tri_vtx_index, dtype=np.int32).reshape(-1, 3)
     pos = np.ascontiguousarray(vtx_pos, dtype=np.float32).reshape(-1, 3)
     h = _vp()
@@ -369,6 +397,12 @@ def sah_build(tri_vtx_index, vtx_pos, min_leaf=1, max_leaf=1):
         tidx = np.ctypeslib.as_array(C.cast(info.triIndex, C.POINTER(C.c_int32)), (info.triIndexBytes // 4,)).copy()
         meta = dict(numInnerNodes=info.numInnerNodes, numLeafNodes=info.numLeafNodes, maxDepth=info.maxDepth,
                     buildSeconds=float(info.buildSeconds))
-    finally:
+    except Exception:
         lib().ntr_host_bvh_free(h)
-    return HostBvh(nodes, woop, tidx, meta)
+        raise
+    out = HostBvh(nodes, woop, tidx, meta)
+    if keep_handle:
+        out._h = h
+    else:
+        lib().ntr_host_bvh_free(h)
+    return out

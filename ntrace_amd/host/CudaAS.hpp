@@ -23,6 +23,16 @@ enum BVHLayout {
 
 typedef NtrKernelConfig KernelConfig;
 
+// Traversal counters of the host tracer (src/rt/bvh/BVH.hpp:44-70; filled at CudaBVH.cpp:746-749, 1107-1111).
+struct RayStats {
+    RayStats() { clear(); }
+    void clear() { numRays = numTriangleTests = numNodeTests = numTreelets = 0; }
+    S32 numRays;
+    S32 numTriangleTests;
+    S32 numNodeTests;
+    S32 numTreelets;
+};
+
 class CudaAS {
 public:
     virtual ~CudaAS(void) {}
@@ -31,9 +41,10 @@ public:
     virtual Buffer&   getTriIndexBuffer(void) = 0;
     virtual BVHLayout getLayout(void) const = 0;
     virtual void      serialize(std::ostream& out) = 0;
-    // The reference's CudaAS::trace(RayBuffer&, Buffer& visibility) is its *CPU*
-    // tracer (src/rt/cuda/CudaBVH.cpp:213-302).  This backend has no CPU trace
-    // path by design; the CPU tracer is restated only as the test oracle (oracle/).
+    // The reference's HOST tracer (src/rt/cuda/CudaAS.hpp:62, CudaBVH.cpp:213-302): traces `rays` on the CPU
+    // copy of the buffers and sets visibility[id] = 1 for every triangle hit (when `visibility` is not empty).
+    // Never a fallback of the device tracer: CudaBVHTracer::traceBatch fails without a HIP device.
+    virtual void      trace(RayBuffer& rays, Buffer& visibility) = 0;
 };
 
 }  // namespace FW

@@ -27,6 +27,8 @@ public:
     virtual Buffer&   getTriWoopBuffer(void) { return m_triWoop; }
     virtual Buffer&   getTriIndexBuffer(void) { return m_triIndex; }
     virtual void      serialize(std::ostream& out);             // CudaBVH.cpp:118-125
+    virtual void      trace(RayBuffer& rays, Buffer& visibility) { trace(rays, visibility, NULL); }  // CudaBVH.cpp:213-302 (host tracer)
+    void              trace(RayBuffer& rays, Buffer& visibility, RayStats* stats);
 
     // Hint flags for ntr_trace_bvh (NTR_BVH_FINITE), computed once on the device.
     U32 getTraceFlags(void);

@@ -65,6 +65,33 @@ int ntr_host_bvh_info(const NtrHostBvh* bvh, NtrHostBvhInfo* info)
     return NTR_OK;
 }
 
+int ntr_host_bvh_trace(const NtrHostBvh* bvh, int32_t numRays, int32_t anyHit, const NtrRay* rays, NtrRayResult* results,
+                       int32_t* visibility, int32_t numVisibility, NtrTraceStats* stats)
+{
+    if (!bvh || numRays < 0 || (numRays && (!rays || !results)) || numVisibility < 0 || (numVisibility && !visibility))
+        return ntr::set_error(NTR_ERR_INVALID, "ntr_host_bvh_trace: bad argument");
+    try {
+        RayBuffer rb(numRays, anyHit == 0);
+        if (numRays) memcpy(rb.getRayBuffer().getMutablePtr(), rays, (size_t)numRays * sizeof(NtrRay));
+        Buffer vis;
+        if (numVisibility) vis.wrapCPU(visibility, (S64)numVisibility * (S64)sizeof(int32_t));
+        RayStats rs;
+        bvh->cbvh->trace(rb, vis, stats ? &rs : NULL);
+        if (numRays) memcpy(results, rb.getResultBuffer().getPtr(), (size_t)numRays * sizeof(NtrRayResult));
+        if (stats) {
+            memset(stats, 0, sizeof(*stats));
+            stats->numRays = rs.numRays;
+            stats->numInnerVisits = rs.numNodeTests / 2;
+            stats->numTriTests = rs.numTriangleTests;
+        }
+        return NTR_OK;
+    } catch (const FatalError& e) {
+        return ntr::set_error(NTR_ERR_INVALID, "%s", e.message.c_str());
+    } catch (const std::bad_alloc&) {
+        return ntr::set_error(NTR_ERR_NOMEM, "ntr_host_bvh_trace: out of host memory");
+    }
+}
+
 int ntr_camera_decode(const char* signature, float out[16])
 {
     if (!signature || !out) return ntr::set_error(NTR_ERR_INVALID, "ntr_camera_decode: null argument");

@@ -126,6 +126,36 @@ static void cpuTests()
     try { BVH::BuildParams p2; p2.builder = "Nope"; BVH bad(&scene, platform, p2); } catch (const FatalError&) { threw = true; }
     CHECK(threw);
 
+    // CudaAS::trace, the host tracer (CudaBVH.cpp:213-302): rays down the z axis of the closed room hit the far wall
+    // (z = 10.125) or a box in front of it, at exactly representable distances; visibility marks the triangles hit
+    {
+        CudaAS& as = cbvh;
+        RayBuffer rb(4, true);
+        Ray q;
+        q.direction = Vec3f(0.0f, 0.0f, 1.0f);
+        q.tmin = 0.0f;
+        q.tmax = 100.0f;
+        q.origin = Vec3f(-8.0f, 8.0f, -9.0f);  rb.setRay(0, q);   // free path to the far wall: t = 19.125
+        q.origin = Vec3f(-1.5f, -8.0f, -9.0f); rb.setRay(1, q);   // box [-3.5,0.5]x[-10.25,-4]x[1.5,5.25]: t = 10.5
+        q.origin = Vec3f(3.0f, -5.0f, -9.0f);  rb.setRay(2, q);   // box [2.25,5]x[-10.25,-1.5]x[-2,1.75]: t = 7
+        q.tmax = 5.0f;                         rb.setRay(3, q);   // same ray cut short: miss, t = tmax
+        Buffer vis;
+        vis.resize((S64)tris.size() * 4);
+        vis.clear(0);
+        as.trace(rb, vis);
+        CHECK(rb.getResultForSlot(0).hit() && rb.getResultForSlot(0).t == 19.125f);
+        CHECK(rb.getResultForSlot(1).hit() && rb.getResultForSlot(1).t == 10.5f);
+        CHECK(rb.getResultForSlot(2).hit() && rb.getResultForSlot(2).t == 7.0f);
+        CHECK(!rb.getResultForSlot(3).hit() && rb.getResultForSlot(3).t == 5.0f);
+        int marked = 0;
+        for (size_t i = 0; i < tris.size(); i++) marked += ((const S32*)vis.getPtr())[i];
+        CHECK(marked >= 1 && marked <= 3 && ((const S32*)vis.getPtr())[rb.getResultForSlot(0).id] == 1);
+        rb.setNeedClosestHit(false);  // any hit: same rays still hit / miss
+        Buffer none;
+        as.trace(rb, none);
+        CHECK(rb.getResultForSlot(0).hit() && rb.getResultForSlot(2).hit() && !rb.getResultForSlot(3).hit());
+    }
+
     // tracer front end: argument checks that precede device work (CudaBVHTracer.cpp:92-100)
     CudaBVHTracer tracer;
     tracer.setKernel("kepler_dynamic_fetch");
