@@ -303,6 +303,11 @@ NTR_API int  ntr_sah_build(int32_t numTris, const int32_t* triVtxIndex /* 3 per 
 NTR_API int  ntr_host_bvh_info(const NtrHostBvh* bvh, NtrHostBvhInfo* info);
 NTR_API void ntr_host_bvh_free(NtrHostBvh* bvh);
 
+/* A host BVH object over copies of existing BVHLayout_Compact buffers (e.g. the three buffers of a bvhcache file,
+ * CudaBVH::CudaBVH(InputStream&), src/rt/cuda/CudaBVH.cpp:105-116, or a device-built LBVH downloaded to the host). */
+NTR_API int ntr_host_bvh_wrap(const void* nodes, int64_t nodesBytes, const void* triWoop, int64_t triWoopBytes,
+                              const int32_t* triIndex, int64_t triIndexBytes, NtrHostBvh** out);
+
 /* CudaAS::trace(RayBuffer&, Buffer& visibility) -- the reference's HOST tracer (src/rt/cuda/CudaAS.hpp:62,
  * CudaBVH::trace, src/rt/cuda/CudaBVH.cpp:213-302; used by its CPURenderer and by BASELINE configuration 1): rays
  * and results are HOST arrays, visibility (may be NULL / 0) receives 1 at the id of every triangle hit, stats (may

@@ -11,7 +11,7 @@ from ._capi import (BvhView, RAY_DTYPE, RESULT_DTYPE, HostBvh, KernelConfig, Ntr
                     lib_path, query_config, sah_build, trace_bvh, trace_bvh_stats, pixel_table,
                     raygen_primary, raygen_ao, count_hits, selftest_division, lbvh_capacity,
                     lbvh_build, LbvhResult, reconstruct, ray_morton_sort, camera_decode, camera_reencode,
-                    camera_nscreen_to_world, obj_load, SchedHint, trace_status, set_tunables, experiment_hooks)
+                    camera_nscreen_to_world, obj_load, SchedHint, trace_status, set_tunables, experiment_hooks, host_bvh_wrap)
 
 BVHLayout_Compact = 4
 BVH_FINITE, BVH_FASTDIV, BVH_NOTINY = 1, 2, 4
@@ -19,4 +19,4 @@ KERNELS = ("fermi_speculative_while_while", "tesla_persistent_while_while",
            "tesla_persistent_speculative_while_while", "kepler_dynamic_fetch")
 
 __all__ = ["BvhView", "RAY_DTYPE", "RESULT_DTYPE", "HostBvh", "KernelConfig", "NtrError", "bvh_validate", "lib",
-           "lib_path", "query_config", "sah_build", "trace_bvh", "trace_bvh_stats", "TraceStats", "pixel_table", "raygen_primary", "raygen_ao", "count_hits", "selftest_division", "lbvh_capacity", "lbvh_build", "LbvhResult", "reconstruct", "ray_morton_sort", "camera_decode", "camera_reencode", "camera_nscreen_to_world", "obj_load", "SchedHint", "trace_status", "set_tunables", "experiment_hooks", "BVHLayout_Compact", "KERNELS"]
+           "lib_path", "query_config", "sah_build", "trace_bvh", "trace_bvh_stats", "TraceStats", "pixel_table", "raygen_primary", "raygen_ao", "count_hits", "selftest_division", "lbvh_capacity", "lbvh_build", "LbvhResult", "reconstruct", "ray_morton_sort", "camera_decode", "camera_reencode", "camera_nscreen_to_world", "obj_load", "SchedHint", "trace_status", "set_tunables", "experiment_hooks", "host_bvh_wrap", "BVHLayout_Compact", "KERNELS"]

@@ -108,6 +108,7 @@ SYMBOLS = [
     ("ntr_sah_build", C.c_int, [_i32, _vp, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
     ("ntr_host_bvh_info", C.c_int, [_vp, C.POINTER(_HostBvhInfo)]),
     ("ntr_host_bvh_free", None, [_vp]),
+    ("ntr_host_bvh_wrap", C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.POINTER(_vp)]),
     ("ntr_host_bvh_trace", C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.POINTER(TraceStats)]),
 ]
 
@@ -381,6 +382,19 @@ class HostBvh:
             self.close()
         except Exception:
             pass
+
+
+def host_bvh_wrap(nodes, woop, tri_index):
+    """HostBvh (with a live handle, for host_trace) over copies of existing Compact buffers."""
+    nodes = np.ascontiguousarray(nodes).view(np.uint8).reshape(-1)
+    woop = np.ascontiguousarray(woop).view(np.uint8).reshape(-1)
+    tri_index = np.ascontiguousarray(tri_index, dtype=np.int32).reshape(-1)
+    h = _vp()
+    _check(lib().ntr_host_bvh_wrap(nodes.ctypes.data_as(_vp), nodes.nbytes, woop.ctypes.data_as(_vp), woop.nbytes,
+                                   tri_index.ctypes.data_as(_vp), tri_index.nbytes, C.byref(h)))
+    out = HostBvh(nodes.copy(), woop.copy(), tri_index.copy())
+    out._h = h
+    return out
 
 
 def sah_build(tri_vtx_index, vtx_pos, min_leaf=1, max_leaf=1, keep_handle=False):

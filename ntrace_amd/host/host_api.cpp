@@ -65,6 +65,30 @@ int ntr_host_bvh_info(const NtrHostBvh* bvh, NtrHostBvhInfo* info)
     return NTR_OK;
 }
 
+int ntr_host_bvh_wrap(const void* nodes, int64_t nodesBytes, const void* triWoop, int64_t triWoopBytes, const int32_t* triIndex,
+                      int64_t triIndexBytes, NtrHostBvh** out)
+{
+    if (!out) return ntr::set_error(NTR_ERR_INVALID, "ntr_host_bvh_wrap: null out");
+    *out = nullptr;
+    if (!nodes || !triWoop || !triIndex || nodesBytes < 64 || (nodesBytes % 64) != 0 || triWoopBytes < 16 || (triWoopBytes % 16) != 0 ||
+        triIndexBytes * 4 < triWoopBytes)
+        return ntr::set_error(NTR_ERR_INVALID, "ntr_host_bvh_wrap: bad buffer sizes");
+    try {
+        NtrHostBvh* h = new NtrHostBvh();
+        h->scene = nullptr;
+        h->cbvh = new CudaBVH(BVHLayout_Compact);
+        h->cbvh->getNodeBuffer().set(nodes, nodesBytes);
+        h->cbvh->getTriWoopBuffer().set(triWoop, triWoopBytes);
+        h->cbvh->getTriIndexBuffer().set(triIndex, triIndexBytes);
+        *out = h;
+        return NTR_OK;
+    } catch (const FatalError& e) {
+        return ntr::set_error(NTR_ERR_INVALID, "%s", e.message.c_str());
+    } catch (const std::bad_alloc&) {
+        return ntr::set_error(NTR_ERR_NOMEM, "ntr_host_bvh_wrap: out of host memory");
+    }
+}
+
 int ntr_host_bvh_trace(const NtrHostBvh* bvh, int32_t numRays, int32_t anyHit, const NtrRay* rays, NtrRayResult* results,
                        int32_t* visibility, int32_t numVisibility, NtrTraceStats* stats)
 {

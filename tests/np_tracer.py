@@ -29,7 +29,10 @@ def _dot4(a, bx, by, bz, bw):
     return r
 
 
-def trace(nodes, woop, tri_index, rays, any_hit=False, max_stack=100):
+def trace(nodes, woop, tri_index, rays, any_hit=False, max_stack=100, return_stats=False):
+    """Returns (id, t); with return_stats also the counters (inner nodes visited, triangle tests, leaf terminators
+    read, hits) as the reference's RayStats defines them (CudaBVH.cpp:746-749, 1107-1111)."""
+    n_inner = n_tri = n_leaf = 0
     nodes_f = np.frombuffer(np.ascontiguousarray(nodes).tobytes(), dtype=F)
     nodes_i = nodes_f.view(np.int32)
     woop_f = np.frombuffer(np.ascontiguousarray(woop).tobytes(), dtype=F).reshape(-1, 4)
@@ -69,6 +72,7 @@ def trace(nodes, woop, tri_index, rays, any_hit=False, max_stack=100):
                 term = woop_u[ta, 0] == 0x80000000
                 # terminator -> leave leaf, pop
                 tl = inleaf[term]
+                n_leaf += int(tl.size)
                 tri_cur[tl] = -1
                 m = np.zeros(n, dtype=bool)
                 m[tl] = True
@@ -76,6 +80,7 @@ def trace(nodes, woop, tri_index, rays, any_hit=False, max_stack=100):
                 # real triangle
                 ti = inleaf[~term]
                 if ti.size:
+                    n_tri += int(ti.size)
                     a = tri_cur[ti]
                     z, u4, v4 = woop_f[a], woop_f[a + 1], woop_f[a + 2]
                     rx, ry, rz = ox[ti], oy[ti], oz[ti]
@@ -105,6 +110,7 @@ def trace(nodes, woop, tri_index, rays, any_hit=False, max_stack=100):
             # ---- inner step --------------------------------------------------------------
             inner = np.nonzero(~done & (tri_cur < 0) & (node >= 0) & ~enter)[0]
             if inner.size:
+                n_inner += int(inner.size)
                 b = node[inner] // 4                        # byte offset -> float index
                 g = lambda k: nodes_f[b + k]
                 rx, ry, rz = ox[inner], oy[inner], oz[inner]
@@ -140,4 +146,6 @@ def trace(nodes, woop, tri_index, rays, any_hit=False, max_stack=100):
                 m = np.zeros(n, dtype=bool)
                 m[inner[none]] = True
                 pop(m)
+    if return_stats:
+        return res_id, res_t, dict(numInnerVisits=n_inner, numTriTests=n_tri, numLeafVisits=n_leaf, numHits=int((res_id >= 0).sum()))
     return res_id, res_t
