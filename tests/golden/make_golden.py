@@ -1,8 +1,10 @@
 """Generates the golden fixtures under tests/golden/ (inputs + expected outputs).
 
-The reference has no fixtures for this path and cannot run here, so the expected values are
-produced by the CPU oracle and accepted only when the independent numpy restatement
-(tests/np_tracer.py) reproduces them bit for bit.  Re-run: python tests/golden/make_golden.py
+The reference has no fixtures for this path and cannot run here.  The expected values (hit records AND
+traversal counters) are produced by the numpy restatement tests/np_tracer.py -- NOT by the C oracle -- so
+that the tests check both the C oracle and the HIP kernels against a second implementation; the script
+refuses to write a fixture on which the C oracle disagrees.  Hand-derived vectors that depend on neither
+are in tests/kat_vectors.py.  Re-run: python tests/golden/make_golden.py
 """
 import os
 import sys
@@ -17,7 +19,7 @@ import ntrace_amd as nt  # noqa: E402
 import np_tracer  # noqa: E402
 from ntrace_amd import scenes  # noqa: E402
 from oracle import oracle  # noqa: E402
-from test_trace_gpu import edge_rays  # noqa: E402
+from ray_sets import edge_rays  # noqa: E402
 
 
 def make(name, tri, pos, rays):
@@ -25,13 +27,15 @@ def make(name, tri, pos, rays):
     out = dict(nodes=bvh.nodes, woop=bvh.woop, tri_index=bvh.tri_index, rays=rays.view(np.float32).reshape(-1, 8),
                tri=tri, pos=pos)
     for any_hit, key in ((False, "closest"), (True, "any")):
-        ref, st = oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, rays, any_hit=any_hit)
-        nid, ntt = np_tracer.trace(bvh.nodes, bvh.woop, bvh.tri_index, rays, any_hit=any_hit)
-        assert np.array_equal(nid, ref["id"]) and np.array_equal(ntt.view(np.uint32), ref["t"].view(np.uint32)), name
+        nid, ntt, nst = np_tracer.trace(bvh.nodes, bvh.woop, bvh.tri_index, rays, any_hit=any_hit, return_stats=True)
         packed = np.zeros(rays.shape[0], dtype=nt.RESULT_DTYPE)
-        packed["id"], packed["t"] = ref["id"], ref["t"]
+        packed["id"], packed["t"] = nid, ntt
         out["res_" + key] = packed.view(np.int32).reshape(-1, 4)
-        out["stats_" + key] = np.array([st.numInnerVisits, st.numTriTests, st.numLeafVisits, st.numHits], dtype=np.int64)
+        out["stats_" + key] = np.array([nst["numInnerVisits"], nst["numTriTests"], nst["numLeafVisits"], nst["numHits"]], dtype=np.int64)
+        # the C oracle must agree before the fixture is written
+        ref, st = oracle.trace(bvh.nodes, bvh.woop, bvh.tri_index, rays, any_hit=any_hit)
+        assert np.array_equal(nid, ref["id"]) and np.array_equal(ntt.view(np.uint32), ref["t"].view(np.uint32)), name
+        assert [st.numInnerVisits, st.numTriTests, st.numLeafVisits, st.numHits] == list(out["stats_" + key]), (name, key, st.as_dict(), nst)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "tris", tri.shape[0], "rays", rays.shape[0], "hit", float((out["res_closest"][:, 0] >= 0).mean()))
 

@@ -71,7 +71,7 @@ def test_ragged_sizes(soup, kernel, n):
 def test_full_size_properties():
     """BASELINE size (1920x1080 primary on atrium-262k): size-independent properties --
     persistent == per-ray kernel bit for bit, any-hit hits iff closest-hit hits, t within
-    [tmin, tmax], and a bounded sample checked against the oracle."""
+    [tmin, tmax], and EVERY record (closest hit and any hit) checked against the oracle on all host cores."""
     from gpu_util import DeviceBvh, assert_parity, gpu_trace
     tri, pos, cam = scenes.atrium()
     dbvh = DeviceBvh(nt.sah_build(tri, pos))
@@ -84,9 +84,11 @@ def test_full_size_properties():
     hit = a["id"] >= 0
     assert (a["t"][hit] > rays["tmin"][hit]).all() and (a["t"][hit] < rays["tmax"][hit]).all()
     assert np.array_equal(a["t"][~hit].view(np.uint32), rays["tmax"][~hit].view(np.uint32))
-    sel = np.arange(0, rays.shape[0], 17)
-    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays[sel], threads=8)
-    assert_parity(a[sel], ref, "atrium sample")
+    import os
+    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, threads=os.cpu_count() or 8)
+    assert_parity(a, ref, "atrium 1080p primary, every record")
+    refa, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=True, threads=os.cpu_count() or 8)
+    assert_parity(ah, refa, "atrium 1080p any hit, every record")
 
 
 @pytest.mark.parametrize("any_hit", [False, True])
