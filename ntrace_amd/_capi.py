@@ -205,10 +205,10 @@ def set_tunables(**kv):
 
 def experiment_hooks(timeline=0, order=0):
     """Diagnostic hooks (per-wave timeline buffer, explicit block order) -- only in builds made with
-    `make -C ntrace_amd/csrc EXPERIMENTS=1`; the shipped library does not export them."""
+    `make -C ntrace_amd/csrc exp`; the shipped library does not export them."""
     L = lib()
     if not hasattr(L, "ntr_experiment_hooks"):
-        raise NtrError(-1, "this libntrace_amd.so was built without -DNTR_EXPERIMENTS (make EXPERIMENTS=1)")
+        raise NtrError(-1, "this libntrace_amd.so was built without -DNTR_EXPERIMENTS (build `make -C ntrace_amd/csrc exp`, run with NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_exp.so)")
     L.ntr_experiment_hooks.restype = C.c_int
     L.ntr_experiment_hooks.argtypes = [_vp, _vp]
     _check(L.ntr_experiment_hooks(_vp(timeline), _vp(order)))

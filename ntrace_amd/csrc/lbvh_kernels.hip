@@ -54,6 +54,7 @@ struct LbvhState {
     unsigned int maxLevel;       // deepest level holding an inner node, plus one
     unsigned int topLevels;      // levels the top pass processed
     unsigned int topLvlOfs[34];  // per-level offsets into the top pass's node list
+    unsigned int topTrieLevels;  // cell-table top: deepest trie level holding a top node, plus one
 };
 
 // ---- Morton codes ------------------------------------------------------------------------------
@@ -87,6 +88,76 @@ __global__ __launch_bounds__(256) void lbvh_morton_kernel(int n, const int* __re
     }
     keys[t] = spread10(cell[0]) | (spread10(cell[1]) << 1) | (spread10(cell[2]) << 2);
     idx[t] = t;
+}
+
+// Morton codes as lbvh_morton_kernel, fused with everything else that one pass over the mesh can produce:
+//   * the digit histograms of all four radix passes (LDS, then one global add per non-empty bin and workgroup), so
+//     that the sort is four one-sweep launches and nothing else;
+//   * every triangle's term of its leaf's box (calcLeaf, emitTreeKernel.cu:383-408: min/max over the three
+//     vertices, -/+ epsilon) in MESH order -- the vertices are in registers anyway; after the sort one 24-byte
+//     gather per triangle replaces the index -> vertex double gather;
+//   * clearing the one-sweep tile state.
+// Grid-stride over a bounded number of workgroups, so that the histogram flush stays at <= 2048 x 1024 atomics.
+constexpr int MORTON_THREADS = 256;
+constexpr int MORTON_MAX_BLOCKS = 2048;
+constexpr int TOP_CELL_BITS = 14;                      // the top of the tree is derived from the keys' upper 14 bits
+constexpr int TOP_CELLS = 1 << TOP_CELL_BITS;
+
+__global__ __launch_bounds__(MORTON_THREADS) void lbvh_morton_hist_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
+                                                                          F3 lo, F3 step, float eps, unsigned int* __restrict__ keys,
+                                                                          int* __restrict__ idx, float2* __restrict__ boxMesh,
+                                                                          unsigned int* __restrict__ hist /* [4][256] */,
+                                                                          unsigned int* __restrict__ tileState, int tileStateWords)
+{
+    __shared__ unsigned int s_hist[4][256];
+    for (int i = threadIdx.x; i < 1024; i += MORTON_THREADS) (&s_hist[0][0])[i] = 0;
+    const int gtid = blockIdx.x * MORTON_THREADS + threadIdx.x, gstride = gridDim.x * MORTON_THREADS;
+    for (int i = gtid; i < tileStateWords; i += gstride) tileState[i] = 0;
+    __syncthreads();
+    const float l[3] = {lo.x, lo.y, lo.z}, s[3] = {step.x, step.y, step.z};
+    for (int t = gtid; t < n; t += gstride) {
+        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        int cell[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float a = pos[3 * i0 + k], b = pos[3 * i1 + k], c = pos[3 * i2 + k];
+            const float mn = fminf(a, fminf(b, c)), mx = fmaxf(a, fmaxf(b, c));
+            boxMesh[3 * (size_t)t + k] = make_float2(mn - eps, mx + eps);
+            const float mid = mn + (mx - mn) / 2.0f;
+            const int v = (int)floorf((mid - l[k]) / s[k]);
+            cell[k] = min(max(v, 0), 1023);
+        }
+        const unsigned int key = spread10(cell[0]) | (spread10(cell[1]) << 1) | (spread10(cell[2]) << 2);
+        keys[t] = key;
+        idx[t] = t;
+        atomicAdd(&s_hist[0][key & 255], 1u);
+        atomicAdd(&s_hist[1][(key >> 8) & 255], 1u);
+        atomicAdd(&s_hist[2][(key >> 16) & 255], 1u);
+        atomicAdd(&s_hist[3][(key >> 24) & 255], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += MORTON_THREADS) {
+        const unsigned int v = (&s_hist[0][0])[i];
+        if (v) atomicAdd(&hist[i], v);
+    }
+}
+
+// After the sort: box terms in sorted order (one 24-byte gather per triangle) and the cell table of the top pass:
+// cellStart[c] = first sorted position whose key's upper TOP_CELL_BITS bits are >= c (cellStart[TOP_CELLS] = n).
+__global__ __launch_bounds__(256) void lbvh_gather_box_kernel(int n, const unsigned int* __restrict__ keys, const int* __restrict__ triSorted,
+                                                              const float2* __restrict__ boxMesh, float2* __restrict__ triBox,
+                                                              unsigned int* __restrict__ cellStart)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int t = triSorted[j];
+    const float2 a = boxMesh[3 * (size_t)t], b = boxMesh[3 * (size_t)t + 1], c = boxMesh[3 * (size_t)t + 2];
+    triBox[3 * (size_t)j] = a; triBox[3 * (size_t)j + 1] = b; triBox[3 * (size_t)j + 2] = c;
+    const int c1 = (int)(keys[j] >> (30 - TOP_CELL_BITS));
+    const int c0 = j ? (int)(keys[j - 1] >> (30 - TOP_CELL_BITS)) : -1;
+    for (int cc = c0 + 1; cc <= c1; cc++) cellStart[cc] = (unsigned int)j;
+    if (j == n - 1)
+        for (int cc = c1 + 1; cc <= TOP_CELLS; cc++) cellStart[cc] = (unsigned int)n;
 }
 
 // ---- Woop rows (emitTreeKernel.cu:574-635) ---------------------------------------------------------
@@ -351,7 +422,7 @@ struct EmitCtx {
 struct EmitShared {      // LDS bookkeeping of one workgroup
     unsigned long long leafCtr;   // (triangles << 32) | leaves reserved so far, like g_leafsPtr
     unsigned long long leafBase;
-    unsigned int nodeCtr, nodeBase, numSub, item;
+    unsigned int nodeCtr, nodeBase, numSub, item, maxLevel;
     unsigned int cnt[3];          // queue lengths of three consecutive levels, rotating
     unsigned int lvlOfs[34];
 };
@@ -393,33 +464,32 @@ __device__ __forceinline__ void emit_leaf(const EmitCtx& c, int out, int start, 
     reinterpret_cast<float2*>(nf)[4 + k] = make_float2(lo[2], hi[2]);
 }
 
-// Top pass: levels 0.. of the tree, by all threads of the ONE workgroup that owns the counters of the whole tree
-// (node indices and leaf storage come from LDS counters: a level costs one barrier and no global atomic).  Every
-// queue entry is split exactly as lbvh_emit_kernel splits it; ranges of at most c.spill triangles are appended to
-// c.subList (for lbvh_subtree_kernel) instead of the next level's queue.  Returns the number of levels that held
-// nodes; lst receives the node indices level by level (offsets in sh.lvlOfs) for lbvh_top_refit_kernel.
+// Level-by-level emit by all threads of ONE workgroup that owns the node / leaf counters of the whole tree in LDS
+// (a level costs one barrier and no global atomic).  The queue holds (node, start, end, depth) entries -- `inCount` of
+// them are in qA on entry -- and every entry is split exactly as lbvh_emit_kernel splits it (its level bit is
+// 29 - depth); ranges of at most c.spill triangles are appended to c.subList (for lbvh_subtree_kernel) instead of the
+// next round's queue.  Returns the number of rounds that held nodes; lst receives the node indices round by round
+// (offsets in sh.lvlOfs) for the refit; sh.maxLevel = deepest depth that held a node, plus one.
 template <int THREADS, int K>
-__device__ __forceinline__ int emit_top(const EmitCtx& c, EmitShared& sh, int n, int* qA, int* qB, int* lst)
+__device__ __forceinline__ int emit_top(const EmitCtx& c, EmitShared& sh, int4* qA, int4* qB, int* lst, unsigned int firstCount)
 {
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        qA[0] = 0; qA[1] = 0; qA[2] = n;  // the root: node 0 over all triangles
-        sh.cnt[0] = 1; sh.cnt[1] = 0; sh.cnt[2] = 0;
-    }
+    if (tid == 0) { sh.cnt[0] = firstCount; sh.cnt[1] = 0; sh.cnt[2] = 0; }
     __syncthreads();
     unsigned int total = 0;
     int lv = 0;
-    for (int lvl = 0; lvl < 30; lvl++, lv++) {
+    for (; lv < 31; lv++) {
         const unsigned int inCount = sh.cnt[lv % 3];
         if (inCount == 0) break;
         unsigned int* outCount = &sh.cnt[(lv + 1) % 3];
         if (tid == 0) {
-            sh.cnt[(lv + 2) % 3] = 0;  // read one level ago, added to one level ahead
+            sh.cnt[(lv + 2) % 3] = 0;  // read one round ago, added to one round ahead
             sh.lvlOfs[lv] = total;
         }
-        const int levelBit = 29 - lvl;
         for (unsigned int e = tid; e < inCount; e += THREADS) {
-            const int nIdx = qA[3 * e], nStart = qA[3 * e + 1], nEnd = qA[3 * e + 2];
+            const int4 q = qA[e];
+            const int nIdx = q.x, nStart = q.y, nEnd = q.z, lvl = q.w;
+            const int levelBit = 29 - lvl;
             const unsigned int kFirst = c.keys[nStart], kLast = c.keys[nEnd - 1];
             const unsigned int diff = (kFirst ^ kLast) & ((2u << levelBit) - 1u);
             const int level = diff ? 31 - __clz((int)diff) : -1;  // highest differing bit at or below the level's bit
@@ -433,6 +503,7 @@ __device__ __forceinline__ int emit_top(const EmitCtx& c, EmitShared& sh, int n,
             unsigned int childNode = inner ? atomicAdd(&sh.nodeCtr, inner) : 0u;
             unsigned long long lp = lf ? atomicAdd(&sh.leafCtr, lf) : 0ull;
             lst[total + e] = nIdx;
+            atomicMax(&sh.maxLevel, (unsigned int)lvl + 1u);
             if (childNode + inner > c.nodeCap) {  // cannot happen with ntr_lbvh_capacity() buffers
                 atomicOr(&c.st->overflow, 1u);
                 continue;
@@ -452,7 +523,7 @@ __device__ __forceinline__ int emit_top(const EmitCtx& c, EmitShared& sh, int n,
                         c.subList[si] = make_int4((int)childNode, cs[k], ce[k], lvl + 1);
                     } else {
                         const unsigned int slot = atomicAdd(outCount, 1u);
-                        qB[3 * slot] = (int)childNode; qB[3 * slot + 1] = cs[k]; qB[3 * slot + 2] = ce[k];
+                        qB[slot] = make_int4((int)childNode, cs[k], ce[k], lvl + 1);
                     }
                     ch[k] = (int)childNode * 64;
                     childNode++;
@@ -462,7 +533,7 @@ __device__ __forceinline__ int emit_top(const EmitCtx& c, EmitShared& sh, int n,
         }
         total += inCount;
         __syncthreads();
-        int* t = qA; qA = qB; qB = t;
+        int4* t = qA; qA = qB; qB = t;
     }
     if (tid == 0) sh.lvlOfs[lv] = total;
     return lv;
@@ -497,22 +568,178 @@ __device__ __forceinline__ void refit_levels(const unsigned int* lvlOfs, int num
 
 constexpr int TOP_THREADS = 1024;
 
-__global__ __launch_bounds__(TOP_THREADS) void lbvh_top_kernel(EmitCtx c, int n, int* qA, int* qB, int* topLst)
+__global__ __launch_bounds__(TOP_THREADS) void lbvh_top_kernel(EmitCtx c, int n, int4* qA, int4* qB, int* topLst)
 {
     __shared__ EmitShared sh;
     if (threadIdx.x == 0) {
         sh.nodeCtr = 1; sh.nodeBase = 0;  // node 0 is the root
-        sh.leafCtr = 0ull; sh.leafBase = 0ull; sh.numSub = 0;
+        sh.leafCtr = 0ull; sh.leafBase = 0ull; sh.numSub = 0; sh.maxLevel = 0;
+        qA[0] = make_int4(0, 0, n, 0);  // the root: node 0 over all triangles, depth 0
     }
-    const int lv = emit_top<TOP_THREADS, 16>(c, sh, n, qA, qB, topLst);
+    __syncthreads();
+    const int lv = emit_top<TOP_THREADS, 16>(c, sh, qA, qB, topLst, 1u);
     __syncthreads();
     if ((int)threadIdx.x <= lv) c.st->topLvlOfs[threadIdx.x] = sh.lvlOfs[threadIdx.x];
     if (threadIdx.x == 0) {
         c.st->topLevels = (unsigned int)lv;
-        c.st->maxLevel = (unsigned int)lv;
+        c.st->maxLevel = sh.maxLevel;
         c.st->nodeCount = sh.nodeCtr;
         c.st->leafPtr = sh.leafCtr;
         c.st->numSub = sh.numSub;
+    }
+}
+
+// ---- top of the tree from the cell table ---------------------------------------------------------------------------------------
+// Above the cells (the keys' upper TOP_CELL_BITS bits) the tree is a function of the cell table alone: a tree node whose keys
+// first differ in bit 29 - L is the trie node (L, prefix) whose two halves are both non-empty, its range is the trie node's range
+// and its split is the boundary between the halves -- table look-ups, no key probes, no level-by-level dependency.  One workgroup
+// keeps the table and a heap-indexed node-index map in LDS and
+//   1. classifies all 2^(B+1) trie nodes in parallel: TOP NODE (both halves non-empty, more than `spill` triangles), HAND-OVER
+//      ROOT (a child of a top node with at most `spill` triangles: one subtree workgroup each) or OVERSIZE CELL (a single cell
+//      with more than `spill` triangles), and gives each a node index from an LDS counter;
+//   2. writes every top node (children = leaves, or the node indices of step 1) and the hand-over list;
+//   3. splits oversize cells level by level with key probes (emit_top) -- nothing to do for ordinary scenes.
+// The depth of a node (needed for the reference's level-bit-0 leaf rule and its level count) is the number of its trie ancestors
+// with two non-empty halves.  Heap index h = 2^L + prefix; the cells are the heap's last level.
+constexpr int TOP_HEAP = 2 * TOP_CELLS;  // heap indices 1 .. TOP_HEAP-1
+
+struct TopLds {
+    unsigned int cell[TOP_CELLS + 1];
+    unsigned short idx[TOP_HEAP];
+};
+
+__device__ __forceinline__ void trie_range(const unsigned int* cell, unsigned int h, int L, unsigned int& lo, unsigned int& hi)
+{
+    const unsigned int p = h - (1u << L);
+    lo = cell[p << (TOP_CELL_BITS - L)];
+    hi = cell[(p + 1) << (TOP_CELL_BITS - L)];
+}
+__device__ __forceinline__ bool trie_actual(const unsigned int* cell, unsigned int h, int L)  // both halves non-empty (L < TOP_CELL_BITS)
+{
+    const unsigned int p = h - (1u << L);
+    const unsigned int lo = cell[p << (TOP_CELL_BITS - L)], mid = cell[(2 * p + 1) << (TOP_CELL_BITS - L - 1)], hi = cell[(p + 1) << (TOP_CELL_BITS - L)];
+    return lo < mid && mid < hi;
+}
+__device__ __forceinline__ int trie_depth(const unsigned int* cell, unsigned int h, int L)  // trie ancestors with two non-empty halves
+{
+    int d = 0;
+    for (int l = L - 1; l >= 0; l--) {
+        h >>= 1;
+        d += trie_actual(cell, h, l) ? 1 : 0;
+    }
+    return d;
+}
+
+__global__ __launch_bounds__(TOP_THREADS) void lbvh_top_cells_kernel(EmitCtx c, int n, const unsigned int* __restrict__ cellStart,
+                                                                     int* __restrict__ topIdx, int4* qA, int4* qB, int* topLst)
+{
+    extern __shared__ int smem[];
+    TopLds& t = *reinterpret_cast<TopLds*>(smem);
+    __shared__ EmitShared sh;
+    __shared__ unsigned int s_over, s_trieLevels;
+    const int tid = threadIdx.x;
+    for (int i = tid; i <= TOP_CELLS; i += TOP_THREADS) t.cell[i] = cellStart[i];
+    for (int i = tid; i < TOP_HEAP; i += TOP_THREADS) t.idx[i] = 0xFFFFu;
+    if (tid == 0) {
+        sh.nodeCtr = 1; sh.nodeBase = 0;  // node 0 is the root
+        sh.leafCtr = 0ull; sh.leafBase = 0ull; sh.numSub = 0; sh.maxLevel = 0;
+        s_over = 0; s_trieLevels = 0;
+    }
+    __syncthreads();
+    const unsigned int spill = (unsigned int)c.spill, leafSize = (unsigned int)c.leafSize;
+
+    // ---- 1. classify, allocate node indices ------------------------------------------------------------------------------
+    for (unsigned int h = 1 + tid; h < (unsigned int)TOP_HEAP; h += TOP_THREADS) {
+        const int L = 31 - __clz((int)h);
+        unsigned int lo, hi;
+        trie_range(t.cell, h, L, lo, hi);
+        const unsigned int cnt = hi - lo;
+        if (cnt <= leafSize) continue;                                     // a leaf of its parent, or empty
+        const bool isCell = L == TOP_CELL_BITS;
+        if (!isCell && !trie_actual(t.cell, h, L)) continue;               // one empty half: no tree node here
+        // the tree parent: nearest ancestor holding more triangles (its other half is non-empty)
+        unsigned int pcnt = 0xFFFFFFFFu;                                   // none: this is the root
+        {
+            unsigned int a = h;
+            for (int l = L - 1; l >= 0; l--) {
+                a >>= 1;
+                unsigned int alo, ahi;
+                trie_range(t.cell, a, l, alo, ahi);
+                if (ahi - alo != cnt) { pcnt = ahi - alo; break; }
+            }
+        }
+        const bool top = !isCell && cnt > spill;
+        if (!top && pcnt != 0xFFFFFFFFu && pcnt <= spill) continue;       // inside some hand-over root's subtree
+        const unsigned int nIdx = pcnt == 0xFFFFFFFFu ? 0u : atomicAdd(&sh.nodeCtr, 1u);
+        t.idx[h] = (unsigned short)nIdx;
+        if (!top) {
+            const int depth = trie_depth(t.cell, h, L);
+            if (cnt <= spill) {                                            // hand-over root
+                const unsigned int si = atomicAdd(&sh.numSub, 1u);
+                c.subList[si] = make_int4((int)nIdx, (int)lo, (int)hi, depth);
+            } else {                                                       // oversize cell
+                const unsigned int qi = atomicAdd(&s_over, 1u);
+                qA[qi] = make_int4((int)nIdx, (int)lo, (int)hi, depth);
+            }
+        }
+    }
+    __syncthreads();
+    if (sh.nodeCtr > c.nodeCap) {  // cannot happen with ntr_lbvh_capacity() buffers
+        if (tid == 0) atomicOr(&c.st->overflow, 1u);
+        return;
+    }
+
+    // ---- 2. write the top nodes ------------------------------------------------------------------------------------------
+    for (unsigned int h = 1 + tid; h < (unsigned int)TOP_CELLS; h += TOP_THREADS) {
+        const unsigned int nIdx = t.idx[h];
+        const int L = 31 - __clz((int)h);
+        unsigned int lo, hi;
+        trie_range(t.cell, h, L, lo, hi);
+        const bool isTop = nIdx != 0xFFFFu && hi - lo > spill;            // else: nothing, or a hand-over root (its workgroup writes it)
+        topIdx[h] = isTop ? (int)nIdx : -1;                                // every entry of the map is written: no clearing pass
+        if (!isTop) continue;
+        atomicMax(&sh.maxLevel, (unsigned int)trie_depth(t.cell, h, L) + 1u);
+        atomicMax(&s_trieLevels, (unsigned int)L + 1u);
+        int* nd = c.nodes + (size_t)nIdx * 16;
+        int ch[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            unsigned int d = 2 * h + k;
+            int dl = L + 1;
+            unsigned int clo, chi;
+            trie_range(t.cell, d, dl, clo, chi);
+            if (chi - clo <= leafSize) {                                   // createLeaf (:170-231)
+                const unsigned long long lp = atomicAdd(&sh.leafCtr, ((unsigned long long)(chi - clo) << 32) + 1ull);
+                const int out = (int)(lp >> 32) * 3 + (int)(lp & 0xFFFFFFFFull);
+                ch[k] = ~out;
+                emit_leaf(c, out, (int)clo, (int)chi, nd, k);
+                continue;
+            }
+            while (dl < TOP_CELL_BITS && !trie_actual(t.cell, d, dl)) {  // skip trie nodes with an empty half
+                unsigned int llo, lhi;
+                trie_range(t.cell, 2 * d, dl + 1, llo, lhi);
+                d = 2 * d + (lhi > llo ? 0u : 1u);
+                dl++;
+            }
+            ch[k] = (int)t.idx[d] * 64;
+        }
+        nd[12] = ch[0]; nd[13] = ch[1]; nd[14] = (29 - L) % 3; nd[15] = 0;
+    }
+    __syncthreads();
+
+    // ---- 3. oversize cells: level by level with key probes -----------------------------------------------------------------
+    const unsigned int over = s_over;
+    int lv = 0;
+    if (over) lv = emit_top<TOP_THREADS, 16>(c, sh, qA, qB, topLst, over);
+    __syncthreads();
+    if ((int)tid <= lv) c.st->topLvlOfs[tid] = over ? sh.lvlOfs[tid] : 0u;
+    if (tid == 0) {
+        c.st->topLevels = (unsigned int)lv;
+        c.st->maxLevel = sh.maxLevel;
+        c.st->nodeCount = sh.nodeCtr;
+        c.st->leafPtr = sh.leafCtr;
+        c.st->numSub = sh.numSub;
+        c.st->topTrieLevels = s_trieLevels;
     }
 }
 
@@ -686,6 +913,25 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_refit_kernel(const LbvhS
     refit_levels<TOP_THREADS>(ofs, lv, topLst, nodes);
 }
 
+// Refit of the cell-table top: the oversize cells' levels first (deepest first), then the trie levels bottom-up, each
+// level's top nodes found through the heap-indexed map.
+__global__ __launch_bounds__(TOP_THREADS) void lbvh_top_cells_refit_kernel(const LbvhState* __restrict__ st, const int* __restrict__ topLst,
+                                                                           const int* __restrict__ topIdx, int* nodes)
+{
+    __shared__ unsigned int ofs[34];
+    const int lv = (int)st->topLevels;
+    if ((int)threadIdx.x <= lv) ofs[threadIdx.x] = st->topLvlOfs[threadIdx.x];
+    __syncthreads();
+    if (lv) refit_levels<TOP_THREADS>(ofs, lv, topLst, nodes);
+    for (int L = (int)st->topTrieLevels - 1; L >= 0; L--) {
+        for (unsigned int h = (1u << L) + threadIdx.x; h < (2u << L); h += TOP_THREADS) {
+            const int nIdx = topIdx[h];
+            if (nIdx >= 0) refit_node(nodes + (size_t)nIdx * 16, nodes);
+        }
+        __syncthreads();  // the level above reads these boxes (same workgroup, same CU)
+    }
+}
+
 }  // namespace ntr
 
 using namespace ntr;
@@ -770,20 +1016,29 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: output buffers smaller than ntr_lbvh_capacity()");
     hipStream_t s = (hipStream_t)stream;
     const int n = numTris;
+    if (n >= (1 << 28)) return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: at most 2^28 - 1 triangles");
     const int nb = (n + SORT_TILE - 1) / SORT_TILE;
+    const int osTiles = (n + OS_TILE - 1) / OS_TILE;
     const Tunables tun = tunables();
     const bool levelSync = tun.lbvhLevelSync != 0;
+    const bool legacySort = levelSync || tun.lbvhLegacySort != 0;
 
     Carver cv;
     const size_t oKeysA = cv.take((size_t)n * 4), oKeysB = cv.take((size_t)n * 4);
     const size_t oIdxA = cv.take((size_t)n * 4), oIdxB = cv.take((size_t)n * 4);
-    const size_t oWoop = cv.take((size_t)n * 48);
-    const size_t oQ0 = cv.take(((size_t)n + 2) * 12), oQ1 = cv.take(((size_t)n + 2) * 12);
+    const size_t oWoop = cv.take((size_t)n * 48);  // per-level path: Woop rows in mesh order; subtree path: box terms in mesh order (24 B)
+    const size_t oQ0 = cv.take(((size_t)n + 2) * 16), oQ1 = cv.take(((size_t)n + 2) * 16);
     const size_t oHist = cv.take(((size_t)nb * 256 + 256) * 4);
+    // cleared by ONE memset per build: builder state, one-sweep digit histograms, error flag and tickets
     const size_t oState = cv.take(sizeof(LbvhState));
+    const size_t oOsHist = cv.take(4 * 256 * 4);
+    const size_t oOsMisc = cv.take(64);            // [0..3] tickets, [4] error flag
+    const size_t oClearEnd = cv.off;
+    const size_t oOsState = cv.take((size_t)osTiles * 256 * 4);
     const size_t oSubList = cv.take(((size_t)n / 2 + 2) * 16);
     const size_t oTopLst = cv.take(((size_t)n + 2) * 4);
     const size_t oTriBox = cv.take((size_t)n * 24), oTriOut = cv.take((size_t)n * 4);
+    const size_t oCell = cv.take(((size_t)TOP_CELLS + 1) * 4), oTopIdx = cv.take((size_t)TOP_HEAP * 4);
     void* wsBase = nullptr;
     {
         const int rc = workspace_reserve(cv.off, &wsBase);
@@ -791,27 +1046,41 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     }
     char* ws = (char*)wsBase;
     LbvhState* state = (LbvhState*)(ws + oState);
+    unsigned int* osHist = (unsigned int*)(ws + oOsHist);
+    unsigned int* osMisc = (unsigned int*)(ws + oOsMisc);
 
     PhaseEvents pe(s);
     pe.mark(0);
+    NTR_HIP(hipMemsetAsync(ws + oState, 0, oClearEnd - oState, s));
 
     // L1: Morton codes (step = (max - min) / 1024 on the host, HLBVHBuilder.cpp:76-81)
     F3 lo = {sceneMin[0], sceneMin[1], sceneMin[2]};
     F3 step = {(sceneMax[0] - sceneMin[0]) / 1024.0f, (sceneMax[1] - sceneMin[1]) / 1024.0f, (sceneMax[2] - sceneMin[2]) / 1024.0f};
-    hipLaunchKernelGGL(lbvh_morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, lo, step,
-                       (unsigned int*)(ws + oKeysA), (int*)(ws + oIdxA));
+    unsigned int *kIn = (unsigned int*)(ws + oKeysA), *kOut = (unsigned int*)(ws + oKeysB);
+    int *vIn = (int*)(ws + oIdxA), *vOut = (int*)(ws + oIdxB);
+    if (levelSync) {
+        hipLaunchKernelGGL(lbvh_morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, lo, step, kIn, vIn);
+    } else {
+        int mb = (n + MORTON_THREADS * 4 - 1) / (MORTON_THREADS * 4);
+        if (mb > MORTON_MAX_BLOCKS) mb = MORTON_MAX_BLOCKS;
+        hipLaunchKernelGGL(lbvh_morton_hist_kernel, dim3(mb), dim3(MORTON_THREADS), 0, s, n, d_triVtxIndex, d_vtxPos, lo, step, epsilon, kIn, vIn,
+                           (float2*)(ws + oWoop), osHist, (unsigned int*)(ws + oOsState), legacySort ? 0 : osTiles * 256);
+    }
     pe.mark(1);
 
     // L2: stable radix sort by key, 4 passes of 8 bits (the 30-bit code fits)
-    unsigned int *kIn = (unsigned int*)(ws + oKeysA), *kOut = (unsigned int*)(ws + oKeysB);
-    int *vIn = (int*)(ws + oIdxA), *vOut = (int*)(ws + oIdxB);
     unsigned int* hist = (unsigned int*)(ws + oHist);
     for (int pass = 0; pass < 4; pass++) {
         const int shift = pass * 8;
-        hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, 1, shift, hist, nb);
-        hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(256), dim3(256), 0, s, hist, nb, hist + (size_t)nb * 256);
-        hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, kOut, vOut, 1,
-                           shift, (const unsigned int*)hist, (const unsigned int*)hist + (size_t)nb * 256, nb);
+        if (legacySort) {
+            hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, 1, shift, hist, nb);
+            hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(256), dim3(256), 0, s, hist, nb, hist + (size_t)nb * 256);
+            hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, kOut, vOut, 1,
+                               shift, (const unsigned int*)hist, (const unsigned int*)hist + (size_t)nb * 256, nb);
+        } else {
+            hipLaunchKernelGGL(onesweep_pass_kernel, dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
+                               shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
+        }
         unsigned int* tk = kIn; kIn = kOut; kOut = tk;
         int* tv = vIn; vIn = vOut; vOut = tv;
     }
@@ -819,26 +1088,26 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const unsigned int* keys = kIn;  // after 4 passes the sorted data is back in the A buffers
     const int* triSorted = vIn;
 
-    // L4: Woop rows in original triangle order (per-level path), or the per-triangle box terms (subtree path;
-    // its Woop rows are produced by lbvh_place_kernel once the leaves have their slots)
+    // L4: Woop rows in original triangle order (per-level path), or the per-triangle box terms in sorted order plus the
+    // cell table of the top pass (subtree path; its Woop rows are produced by lbvh_place_kernel once the leaves have their slots)
     if (levelSync)
         hipLaunchKernelGGL(lbvh_woop_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, (float4*)(ws + oWoop));
     else
-        hipLaunchKernelGGL(lbvh_tribox_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted, epsilon,
-                           (float2*)(ws + oTriBox));
+        hipLaunchKernelGGL(lbvh_gather_box_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, keys, triSorted, (const float2*)(ws + oWoop),
+                           (float2*)(ws + oTriBox), (unsigned int*)(ws + oCell));
     pe.mark(3);
 
     // L3 + L5: emit and refit
-    LbvhState init;
-    memset(&init, 0, sizeof(init));
-    init.lvlNodes[0] = 1;
-    init.nodeCount = 1;
-    NTR_HIP(hipMemcpyAsync(state, &init, sizeof(init), hipMemcpyHostToDevice, s));
     const unsigned int nodeCap = (unsigned int)(nodesCapacity / 64);
-    int* q0 = (int*)(ws + oQ0);
-    int* q1 = (int*)(ws + oQ1);
     LbvhState h;
     if (levelSync) {
+        LbvhState init;
+        memset(&init, 0, sizeof(init));
+        init.lvlNodes[0] = 1;
+        init.nodeCount = 1;
+        NTR_HIP(hipMemcpyAsync(state, &init, sizeof(init), hipMemcpyHostToDevice, s));
+        int* q0 = (int*)(ws + oQ0);
+        int* q1 = (int*)(ws + oQ1);
         const int root[3] = {0, 0, n};
         NTR_HIP(hipMemcpyAsync(q0, root, 12, hipMemcpyHostToDevice, s));
         int emitBlocks = (n / 2 + 255) / 256;
@@ -876,12 +1145,32 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         c.spill = tun.lbvhSplit;
         if (c.spill < 2) c.spill = 2;
         if (c.spill > 7168) c.spill = 7168;  // 20 bytes of LDS per triangle of a subtree (140 KB), 16-bit positions
-        hipLaunchKernelGGL(lbvh_top_kernel, dim3(1), dim3(TOP_THREADS), 0, s, c, n, q0, q1, (int*)(ws + oTopLst));
+        int4* q0 = (int4*)(ws + oQ0);
+        int4* q1 = (int4*)(ws + oQ1);
+        // 0: the whole tree is one hand-over root; 1: cell-table top (default); 2: level-by-level top with key probes
+        const int topMode = n <= c.spill ? 0 : (tun.lbvhLegacyTop ? 2 : 1);
+        if (topMode == 0) {
+            // node 0 over all triangles at depth 0 goes straight to a subtree workgroup
+            LbvhState init;
+            memset(&init, 0, sizeof(init));
+            init.nodeCount = 1;
+            init.numSub = 1;
+            NTR_HIP(hipMemcpyAsync(state, &init, sizeof(init), hipMemcpyHostToDevice, s));
+            const int root[4] = {0, 0, n, 0};
+            NTR_HIP(hipMemcpyAsync(c.subList, root, 16, hipMemcpyHostToDevice, s));
+        } else if (topMode == 1) {
+            NTR_HIP(hipFuncSetAttribute((const void*)lbvh_top_cells_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopLds)));
+            hipLaunchKernelGGL(lbvh_top_cells_kernel, dim3(1), dim3(TOP_THREADS), sizeof(TopLds), s, c, n, (const unsigned int*)(ws + oCell),
+                               (int*)(ws + oTopIdx), q0, q1, (int*)(ws + oTopLst));
+        } else {
+            hipLaunchKernelGGL(lbvh_top_kernel, dim3(1), dim3(TOP_THREADS), 0, s, c, n, q0, q1, (int*)(ws + oTopLst));
+        }
         pe.mark(4);
         const int subThreads = tun.lbvhSubThreads;
         int subBlocks = n / 2 + 1;
         const int subMax = 256 * (2048 / (subThreads > 0 ? subThreads : 128));
         if (subBlocks > subMax) subBlocks = subMax;
+        if (topMode == 0) subBlocks = 1;
         const size_t subLds = (size_t)c.spill * (4 + 16);  // keys + entry list
         if (subLds > 65536) {
             const void* fn = subThreads == 64 ? (const void*)lbvh_subtree_kernel<64>
@@ -895,14 +1184,20 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         else
             hipLaunchKernelGGL(lbvh_subtree_kernel<128>, dim3(subBlocks), dim3(128), subLds, s, c, c.spill);
         pe.mark(5);
-        hipLaunchKernelGGL(lbvh_top_refit_kernel, dim3(1), dim3(TOP_THREADS), 0, s, (const LbvhState*)state, (const int*)(ws + oTopLst),
-                           (int*)d_nodes);
+        if (topMode == 1)
+            hipLaunchKernelGGL(lbvh_top_cells_refit_kernel, dim3(1), dim3(TOP_THREADS), 0, s, (const LbvhState*)state, (const int*)(ws + oTopLst),
+                               (const int*)(ws + oTopIdx), (int*)d_nodes);
+        else if (topMode == 2)
+            hipLaunchKernelGGL(lbvh_top_refit_kernel, dim3(1), dim3(TOP_THREADS), 0, s, (const LbvhState*)state, (const int*)(ws + oTopLst),
+                               (int*)d_nodes);
         hipLaunchKernelGGL(lbvh_place_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted,
                            (const int*)(ws + oTriOut), (float4*)d_triWoop, d_triIndex);
         pe.mark(6);
     }
     NTR_HIP(hipGetLastError());
+    unsigned int sortErr = 0;
     NTR_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, s));
+    NTR_HIP(hipMemcpyAsync(&sortErr, osMisc + 4, sizeof(sortErr), hipMemcpyDeviceToHost, s));
     NTR_HIP(hipStreamSynchronize(s));
     result->mortonMs = pe.ms(0, 1);
     result->sortMs = pe.ms(1, 2);
@@ -911,6 +1206,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     result->refitMs = pe.ms(4, 6);
     result->seconds = pe.ms(0, 6) * 1e-3f;
     if (h.overflow) return set_error(NTR_ERR_OVERFLOW, "ntr_lbvh_build: node buffer overflow");
+    if (sortErr) return set_error(NTR_ERR_HIP, "ntr_lbvh_build: one-sweep sort timed out waiting for a predecessor tile");
     int numLevels = 0;
     unsigned int numNodes = 0;
     if (levelSync) {

@@ -173,7 +173,7 @@ extern "C" int ntr_tunables_reload(void)
 
 #ifdef NTR_EXPERIMENTS
 // Diagnostic hooks of scripts/timeline*.py and scripts/order_experiment.py; compiled only into experiment builds
-// (make EXPERIMENTS=1).  The shipped library has no way to inject a device pointer into a launch.
+// (`make exp` -> libntrace_amd_exp.so).  The shipped library has no way to inject a device pointer into a launch.
 static unsigned long long* g_expTimeline = nullptr;
 static const unsigned int* g_expOrder = nullptr;
 extern "C" NTR_API int ntr_experiment_hooks(void* d_timeline, const void* d_order)

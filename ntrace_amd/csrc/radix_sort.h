@@ -143,3 +143,155 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(int n, const
 }
 
 }  // namespace ntr
+
+// ------------------------------------------------------------------------------------------------------------
+// One-sweep LSD pass ("onesweep": chained scan with decoupled look-back): ONE launch per 8-bit digit instead of
+// histogram + scan + scatter.  The digit histograms of ALL passes are taken in one earlier read of the keys
+// (lbvh_morton_kernel accumulates them while it produces the keys), so a pass reads every key once and writes it
+// once.
+//
+//   * workgroups take tiles in ticket order (one returning atomic), so every predecessor of a tile is resident
+//     or finished: waiting on predecessors cannot deadlock;
+//   * per tile and digit ONE 32-bit word carries status and count together (4 status bits tagged with the pass,
+//     28 count bits), published and polled with agent-scope atomics: no ordering against other memory is needed,
+//     and the array is cleared once per sort, not per pass;
+//   * ranking inside the tile is the stable wave64 match-any ranking of sort_scatter_kernel; keys are then staged
+//     in LDS in tile-sorted order and written out by consecutive threads, so that every digit's run leaves as
+//     one contiguous store stream;
+//   * every spin is bounded (a poll that never succeeds raises *errFlag instead of hanging the device).
+// Stable; n < 2^28.
+// ------------------------------------------------------------------------------------------------------------
+static constexpr int OS_THREADS = 256;
+static constexpr int OS_ITEMS = 8;
+static constexpr int OS_TILE = OS_THREADS * OS_ITEMS;
+static constexpr unsigned int OS_COUNT_MASK = 0x0FFFFFFFu;
+static constexpr unsigned int OS_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ unsigned int os_status(int pass, bool inclusive) { return (unsigned int)(pass * 2 + (inclusive ? 2 : 1)) << 28; }
+
+__global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n, const unsigned int* __restrict__ keysIn,
+                                                                           const int* __restrict__ valsIn,
+                                                                           unsigned int* __restrict__ keysOut, int* __restrict__ valsOut,
+                                                                           int shift, int pass,
+                                                                           const unsigned int* __restrict__ digitTotals /* [256] of this pass */,
+                                                                           unsigned int* tileState /* [tiles][256] */,
+                                                                           unsigned int* ticket, unsigned int* errFlag)
+{
+    constexpr int WAVES = OS_THREADS / 64;
+    __shared__ unsigned int s_cnt[WAVES][256];   // per wave and digit: keys ranked so far; later the wave's offset inside the digit
+    __shared__ unsigned int s_scan[256];
+    __shared__ unsigned int s_tileStart[256];    // first tile-local position of digit d
+    __shared__ unsigned int s_dst[256];          // global position of tile-local position 0 of digit d's run, minus s_tileStart[d]
+    __shared__ unsigned int s_keys[OS_TILE];
+    __shared__ int s_vals[OS_TILE];
+    __shared__ unsigned int s_tile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    for (int i = tid; i < WAVES * 256; i += OS_THREADS) (&s_cnt[0][0])[i] = 0;
+    // global base of digit `tid`: exclusive scan of the digit totals
+    const unsigned int myTotal = digitTotals[tid];
+    s_scan[tid] = myTotal;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned int v = (tid >= off) ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    const unsigned int digitBase = s_scan[tid] - myTotal;
+    const unsigned int tile = s_tile;
+
+    const long long chunk = (long long)tile * OS_TILE + wave * (64 * OS_ITEMS);
+    unsigned int key[OS_ITEMS], rank[OS_ITEMS];
+    int val[OS_ITEMS];
+    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; r++) {
+        const long long k = chunk + r * 64 + lane;
+        const bool valid = k < n;
+        val[r] = valid ? valsIn[k] : 0;
+        key[r] = valid ? keysIn[k] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; r++) {
+        const bool valid = (chunk + r * 64 + lane) < n;
+        const unsigned int d = (key[r] >> shift) & 255;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const unsigned int before = s_cnt[wave][d];
+        rank[r] = before + __popcll(peers & ltMask);
+        if (valid && (peers & ltMask) == 0ull) s_cnt[wave][d] = before + __popcll(peers);
+    }
+    __syncthreads();
+
+    // digit `tid`: the tile's count, the waves' offsets inside the digit
+    unsigned int cnt = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) {
+        const unsigned int c = s_cnt[w][tid];
+        s_cnt[w][tid] = cnt;
+        cnt += c;
+    }
+    unsigned int* myState = tileState + (size_t)tile * 256 + tid;
+    __hip_atomic_store(myState, (tile == 0 ? os_status(pass, true) : os_status(pass, false)) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // tile-local start of every digit
+    s_scan[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned int v = (tid >= off) ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    const unsigned int tileStart = s_scan[tid] - cnt;
+    s_tileStart[tid] = tileStart;
+
+    // decoupled look-back over the predecessors' words of this digit
+    unsigned int excl = 0;
+    if (tile > 0) {
+        const unsigned int stAgg = os_status(pass, false) >> 28, stInc = os_status(pass, true) >> 28;
+        for (unsigned int t = tile; t-- > 0;) {
+            const unsigned int* p = tileState + (size_t)t * 256 + tid;
+            unsigned int w = 0, spins = 0;
+            for (;;) {
+                w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int st = w >> 28;
+                if (st == stAgg || st == stInc) break;
+                if (++spins > OS_SPIN_LIMIT) { atomicOr(errFlag, 2u); w = stInc << 28; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            excl += w & OS_COUNT_MASK;
+            if ((w >> 28) == stInc) break;
+        }
+        __hip_atomic_store(myState, os_status(pass, true) | ((excl + cnt) & OS_COUNT_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_dst[tid] = digitBase + excl - tileStart;
+    __syncthreads();
+
+    // stage in tile-sorted order, then stream out
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; r++) {
+        if ((chunk + r * 64 + lane) < n) {
+            const unsigned int d = (key[r] >> shift) & 255;
+            const unsigned int pos = s_tileStart[d] + s_cnt[wave][d] + rank[r];
+            s_keys[pos] = key[r];
+            s_vals[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    const long long tileBeg = (long long)tile * OS_TILE;
+    const int tileCount = (int)((n - tileBeg) < (long long)OS_TILE ? (n - tileBeg) : (long long)OS_TILE);
+    for (int i = tid; i < tileCount; i += OS_THREADS) {
+        const unsigned int k = s_keys[i];
+        const unsigned int dst = s_dst[(k >> shift) & 255] + (unsigned int)i;
+        keysOut[dst] = k;
+        valsOut[dst] = s_vals[i];
+    }
+}

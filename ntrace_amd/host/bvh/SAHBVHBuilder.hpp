@@ -1,6 +1,6 @@
-// SAHBVHBuilder.hpp -- full-sweep SAH object-split builder
-// (src/rt/bvh/SAHBVHBuilder.hpp, SAHBVHBuilder.cpp:51-254).  Host-side "prebuilt
-// BVH" producer for the Cornell/Sponza/Conference configurations.
+// SAHBVHBuilder.hpp -- full-sweep SAH object-split builder: the trees of src/rt/bvh/SAHBVHBuilder.cpp:51-254,
+// built in O(n log n) from three presorted primitive orders, subtrees in parallel.  Host-side "prebuilt BVH"
+// producer for the Cornell / Sponza / Conference configurations.
 #pragma once
 #include <vector>
 
@@ -16,36 +16,35 @@ public:
 private:
     enum { MaxDepth = 64 };  // SAHBVHBuilder.hpp:48
 
-    struct Reference {
-        S32  triIdx;
+    struct Job {       // one node to build: the same primitives occupy [begin, end) of all three orders
+        S32  begin, end;
+        S32  level;
+        S32  triBase;   // where this subtree's triangles start in BVH::getTriIndices()
+        S32  order;     // the order (0..2) the primitives were last arranged by when this node is reached
         AABB bounds;
-        Reference(void) : triIdx(-1) {}
     };
-    struct NodeSpec {
-        S32  numRef;
-        AABB bounds;
-        NodeSpec(void) : numRef(0) {}
+    struct Split {
+        F32 sah;
+        S32 dim;
+        S32 numLeft;
+        Split(void) : sah(FW_F32_MAX), dim(0), numLeft(0) {}
     };
-    struct ObjectSplit {
-        F32  sah;
-        S32  sortDim;
-        S32  numLeft;
-        AABB leftBounds;
-        AABB rightBounds;
-        ObjectSplit(void) : sah(FW_F32_MAX), sortDim(0), numLeft(0) {}
+    struct Scratch {   // per thread
+        std::vector<F32> rightArea;
+        std::vector<S32> tmp;
     };
 
-    BVHNode*    buildNode(NodeSpec& spec, int level);
-    BVHNode*    createLeaf(const NodeSpec& spec);
-    ObjectSplit findObjectSplit(const NodeSpec& spec, F32 nodeSAH);
-    void        performObjectSplit(NodeSpec& left, NodeSpec& right, const NodeSpec& spec, const ObjectSplit& split);
-    void        sortTop(int numRef, int dim);
+    BVHNode* build(const Job& job, Scratch& scratch, int spawnDepth);
+    BVHNode* leaf(const Job& job, int order);
+    Split    bestSplit(const Job& job, F32 nodeSAH, Scratch& scratch) const;
 
-    BVH&                   m_bvh;
-    const Platform&        m_platform;
-    BVH::BuildParams       m_params;
-    std::vector<Reference> m_refStack;
-    std::vector<AABB>      m_rightBounds;
+    BVH&              m_bvh;
+    const Platform&   m_platform;
+    BVH::BuildParams  m_params;
+    std::vector<AABB> m_box;       // per triangle
+    std::vector<F32>  m_key[3];    // per triangle and axis: box.min + box.max, the reference's sort key
+    std::vector<S32>  m_order[3];  // the live triangles sorted by (key[axis], triangle index)
+    std::vector<U8>   m_side;      // per triangle: goes to the left child of the node being split
 };
 
 }  // namespace FW

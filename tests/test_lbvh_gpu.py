@@ -13,17 +13,24 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["subtree", "subtree-split16-64t", "subtree-split40-256t", "levelsync"])
+@pytest.fixture(autouse=True, params=["subtree", "subtree-split16-64t", "subtree-split40-256t", "legacy-top-and-sort", "legacy-top-split16", "levelsync"])
 def build_path(request, monkeypatch):
-    """Every test runs on the default emit path (top pass + one workgroup per subtree), on the same path
-    with tiny subtrees (so that small scenes exercise the hand-over too), and on the per-level kernels."""
-    for k in ("NTR_LBVH_LEVELSYNC", "NTR_LBVH_SPLIT", "NTR_LBVH_SUB_THREADS"):
+    """Every test runs on the default path (one-sweep sort, cell-table top pass, one workgroup per subtree), on the same path
+    with tiny subtrees (so that small scenes exercise the hand-over and the oversize-cell fallback too), on the round-1
+    sort / top pass, and on the per-level kernels."""
+    for k in ("NTR_LBVH_LEVELSYNC", "NTR_LBVH_SPLIT", "NTR_LBVH_SUB_THREADS", "NTR_LBVH_LEGACY_TOP", "NTR_LBVH_LEGACY_SORT"):
         monkeypatch.delenv(k, raising=False)
     if request.param == "levelsync":
         monkeypatch.setenv("NTR_LBVH_LEVELSYNC", "1")
     elif request.param == "subtree-split16-64t":
         monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
         monkeypatch.setenv("NTR_LBVH_SUB_THREADS", "64")
+    elif request.param == "legacy-top-and-sort":  # round-1 pipeline: 12-launch sort, level-by-level top pass with key probes
+        monkeypatch.setenv("NTR_LBVH_LEGACY_TOP", "1")
+        monkeypatch.setenv("NTR_LBVH_LEGACY_SORT", "1")
+    elif request.param == "legacy-top-split16":
+        monkeypatch.setenv("NTR_LBVH_LEGACY_TOP", "1")
+        monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
     elif request.param == "subtree-split40-256t":
         monkeypatch.setenv("NTR_LBVH_SPLIT", "40")
         monkeypatch.setenv("NTR_LBVH_SUB_THREADS", "256")
