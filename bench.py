@@ -397,7 +397,7 @@ def main():
                      "note": "SURVEY 8(d) accounting: algorithmic bytes / HIP-event time over 8 TB/s.  frac > 1 means the bytes are served "
                              "by L1/L2/Infinity Cache (the 34 MB BVH is cache-resident; HBM-side bytes per launch are in `traffic`), so "
                              "HBM is not what binds this launch: `binding` holds the fractions of the roofs that do (VALU issue, "
-                             "texture-address unit), and extras.hbm_resident_point the same kernel on a 1.3 GB BVH",
+                             "texture-address unit), and extras.hbm_resident_point the same kernel on a 0.75 GB BVH with coherent and with incoherent rays",
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "binding": binding,
                      "cache_ceilings": {"l2_gather_peak": L2_GATHER_PEAK_GBS, "frac_of_l2_gather": achieved / L2_GATHER_PEAK_GBS,
@@ -591,8 +591,8 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         usec = min(view.trace(args.kernel, b1["n"], True, b1["rays"], b1["res"], stream) for _ in range(5))
         extras["ray_sort"] = {"rays": b1["n"], "sort_ms": ssec * 1e3, "trace_sorted_ms": tsec * 1e3, "trace_unsorted_ms": usec * 1e3}
 
-    # (6) HBM-resident roofline point: the same trace kernel on the 10 M-triangle stand-in for San Miguel.  Its LBVH is 1.3 GB
-    # (nodes + Woop + index), five times the 256 MB Infinity Cache, so node and triangle fetches are served by HBM; SURVEY 8(d)
+    # (6) HBM-resident roofline point: the same trace kernel on the 10 M-triangle stand-in for San Miguel.  Its LBVH is 0.75 GB
+    # (nodes + Woop + index), three times the 256 MB Infinity Cache, so node and triangle fetches are served by HBM; SURVEY 8(d)
     # accounting against 8 TB/s, with the build's own roofline beside it.
     if not args.no_hbm_point:
         tri10, pos10, cam10 = scenes.courtyard()
@@ -605,15 +605,28 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         ts = [lview.trace(args.kernel, w * h, False, d_r10.data_ptr(), d_o10.data_ptr(), stream) for _ in range(5)]
         s10 = lview.trace_stats(args.kernel, w * h, False, d_r10.data_ptr(), d_o10.data_ptr(), stream)
         sec = float(np.mean(ts))
+        # incoherent closest-hit rays (uniform origins in the bounding box, uniform directions): every ray in its own part of
+        # the BVH, so node and triangle fetches miss the caches -- the launch whose bytes HBM really has to deliver
+        nr = 1 << 21
+        d_rr = up(scenes.box_rays(pos10, nr, seed=21))
+        d_ro = torch.zeros(nr * 16, dtype=torch.uint8, device=dev)
+        lview.trace(args.kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream)
+        tr = [lview.trace(args.kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream) for _ in range(5)]
+        sr = lview.trace_stats(args.kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream)
+        secr = float(np.mean(tr))
+
+        def roof(st_, s_):
+            return {"bound": "hbm", "achieved": st_.algorithmic_bytes() / s_ / 1e9, "peak": hbm_peak, "unit": "GB/s",
+                    "frac": st_.algorithmic_bytes() / s_ / 1e9 / hbm_peak, "algorithmic_bytes_per_launch": st_.algorithmic_bytes()}
         extras["hbm_resident_point"] = {
             "scene": "courtyard-10M stand-in for San Miguel, device LBVH (leafSize 8)", "triangles": int(tri10.shape[0]),
-            "bvh_bytes": int(best.nodesBytes + best.triWoopBytes + best.triIndexBytes), "primary_rays": w * h,
-            "primary_ms": sec * 1e3, "primary_mrays": w * h / sec / 1e6, "trace_stats": s10.as_dict(),
-            "roofline": {"bound": "hbm", "achieved": s10.algorithmic_bytes() / sec / 1e9, "peak": hbm_peak, "unit": "GB/s",
-                         "frac": s10.algorithmic_bytes() / sec / 1e9 / hbm_peak, "algorithmic_bytes_per_launch": s10.algorithmic_bytes(),
-                         "note": "PMC traffic (FETCH_SIZE/WRITE_SIZE/TCC hit rate) of this launch: profiles/*hbm* summaries"},
+            "bvh_bytes": int(best.nodesBytes + best.triWoopBytes + best.triIndexBytes),
+            "primary": {"rays": w * h, "ms": sec * 1e3, "mrays": w * h / sec / 1e6, "trace_stats": s10.as_dict(), "roofline": roof(s10, sec)},
+            "incoherent": {"rays": nr, "what": "2^21 closest-hit rays, origins uniform in the bounding box, directions uniform on the sphere",
+                           "ms": secr * 1e3, "mrays": nr / secr / 1e6, "trace_stats": sr.as_dict(), "roofline": roof(sr, secr)},
+            "note": "HBM-side bytes (FETCH_SIZE / WRITE_SIZE / L2 hit rate) of these launches: profiles/*_trace_courtyard_* summaries",
             "lbvh_build": info10}
-        del keep, lview, d_r10, d_o10
+        del keep, lview, d_r10, d_o10, d_rr, d_ro
     view.trace(args.kernel, batches[0]["n"], False, batches[0]["rays"], batches[0]["res"], stream)  # restore the SAH-BVH primary results
     torch.cuda.synchronize()
     return extras

@@ -350,6 +350,24 @@ def random_rays(n, seed, extent=10.0, tmax=1e30):
     return rays
 
 
+def box_rays(pos, n, seed, tmax=None):
+    """Incoherent rays through a scene: origins uniform in its bounding box, directions uniform on the sphere, extent = the
+    box diagonal unless given.  What a diffuse bounce looks like to the memory system: every ray in its own part of the BVH."""
+    rng = np.random.default_rng(seed)
+    lo, hi = pos.min(0).astype(np.float64), pos.max(0).astype(np.float64)
+    o = lo + rng.uniform(0.0, 1.0, size=(n, 3)) * (hi - lo)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros(n, dtype=RAY_DTYPE)
+    for k, a in zip(("ox", "oy", "oz"), o.T):
+        rays[k] = a.astype(np.float32)
+    for k, a in zip(("dx", "dy", "dz"), d.T):
+        rays[k] = a.astype(np.float32)
+    rays["tmin"] = 0.0
+    rays["tmax"] = np.float32(tmax if tmax is not None else np.linalg.norm(hi - lo))
+    return rays
+
+
 def nscreen_to_world(cam, w, h):
     """Row-major 4x4 mapping normalised screen (nx, ny, 0, 1) to a world point on the image plane
     at unit distance: the `nscreenToWorld` input of rayGenPrimaryKernel for this pinhole camera

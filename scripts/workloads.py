@@ -2,8 +2,9 @@
 """Small fixed workloads for rocprofv3 runs (scripts/profile_round.sh), one per sub-command:
 
   lbvh  <scene> [reps]            on-device LBVH builds of atrium (262 k) / hairball (2.8 M) / courtyard (10 M)
-  trace <scene> <kernel> [reps]   1080p primary batch + one 2^20-ray AO batch, SAH BVH for atrium, device LBVH otherwise
-                                  (the 10 M-triangle LBVH is 1.3 GB: larger than the 256 MB Infinity Cache, the
+  trace <scene> <kernel> [reps]   1080p primary batch + one 2^20-ray AO batch + 2^21 incoherent rays (uniform in the
+                                  bounding box), SAH BVH for atrium, device LBVH otherwise
+                                  (the 10 M-triangle LBVH is 0.75 GB: three times the 256 MB Infinity Cache, the
                                   HBM-resident roofline point)
 
 Each prints one JSON line with what the GPU-side counters have to be compared with (algorithmic bytes from the
@@ -95,7 +96,16 @@ def main():
     view.trace(kernel, cnt * ns, True, b_rays.data_ptr(), b_res.data_ptr())
     ta = [view.trace(kernel, cnt * ns, True, b_rays.data_ptr(), b_res.data_ptr()) for _ in range(reps)]
     sa = view.trace_stats(kernel, cnt * ns, True, b_rays.data_ptr(), b_res.data_ptr())
+    # incoherent batch: 2^21 random rays through the bounding box (closest hit) -- every ray in its own part of the BVH
+    nr = 1 << 21
+    d_rr = up(scenes.box_rays(pos, nr, seed=21))
+    d_ro = torch.zeros(nr * 16, dtype=torch.uint8, device=dev)
+    view.trace(kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr())
+    tr = [view.trace(kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr()) for _ in range(reps)]
+    sr = view.trace_stats(kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr())
     print(json.dumps(dict(workload="trace", scene=scene, kernel=kernel, triangles=n, bvh_bytes=bvh_bytes, bvh_flags=view.flags,
+                          incoherent=dict(rays=nr, ms_mean=float(np.mean(tr)) * 1e3, ms_min=float(np.min(tr)) * 1e3, stats=sr.as_dict(),
+                                          algorithmic_bytes=sr.algorithmic_bytes()),
                           primary=dict(rays=npr, ms_mean=float(np.mean(tp)) * 1e3, ms_min=float(np.min(tp)) * 1e3, stats=st.as_dict(),
                                        algorithmic_bytes=st.algorithmic_bytes()),
                           ao=dict(rays=cnt * ns, ms_mean=float(np.mean(ta)) * 1e3, ms_min=float(np.min(ta)) * 1e3, stats=sa.as_dict(),
