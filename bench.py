@@ -436,9 +436,16 @@ def main():
                                             n1 / (c1 - c0) / 1e6),
                                "single_thread_mrays": n1 / (c1 - c0) / 1e6,
                                "parity_mismatches_whole_step": mism, "rays_compared": traced}
-    print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    # RCCL writes a version banner to the C stdout stream; push it out first so that the JSON line is the last line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
 
 
 def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, hbm_peak):
