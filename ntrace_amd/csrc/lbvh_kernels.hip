@@ -932,6 +932,451 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_cells_refit_kernel(const
     }
 }
 
+
+// =====================================================================================================================
+// Bottom-up ("agglomerative") emit + refit in one pass, indices by prefix scan.
+//
+// The reference's tree over distinct keys is the binary radix tree of the sorted keys: a node is a maximal range of keys
+// sharing a prefix, split where the next bit flips (emitTreeKernel.cu:233-381).  Instead of descending level by level it
+// is grown from the leaves: every run of equal keys starts as a cluster; a cluster [l, r) knows which neighbour is its
+// sibling -- the side whose boundary keys share the longer prefix (smaller key[x-1] ^ key[x]) -- and the two siblings
+// meet at their common boundary B: the first to arrive leaves its box there and stops, the second reads it, forms the
+// parent and goes on (one returning atomic per meeting, no spin anywhere, so no ordering between workgroups is assumed).
+// Child boxes are therefore complete when a node is formed: the refit comes for free, and fminf / fmaxf unions are
+// bit-identical in any order.  A merged cluster of at most leafSize triangles is just a bigger leaf candidate; the first
+// merge that exceeds leafSize is an inner node and turns its small children into leaves (the reference's leaf rule).
+//
+// A node is IDENTIFIED by its split position B (the root by 0), a leaf by its first sorted position: nothing is
+// allocated while the tree is formed.  One prefix scan over the node / leaf flags then gives every node its index
+// (rank of its position, root = 0) and every leaf its storage (3 * triangles before + leaves before), with no atomic
+// counter on the critical path and a deterministic numbering.
+//
+// Meetings whose parent range lies inside the workgroup's 512-key tile -- nearly all of them -- use LDS slots and LDS
+// atomics; only the clusters that outgrow their tile meet through memory (agent-scope stores of the 32-byte slot,
+// drained, then the atomic; agent-scope loads after it).
+//
+// Runs of more than leafSize equal keys are the reference's median-split subtrees whose leaf rule depends on the depth
+// (level bit 0, emitTreeKernel.cu:289-292).  They are rare; the pass records them (their positions get no leaf storage
+// here) and the host finishes them with the subtree kernels after the fast path, once depths are known.
+// =====================================================================================================================
+constexpr int AGG_TILE = 512;
+constexpr int AGG_REF_GROUP = 0x7FFFFFFF;   // child reference of a run handed to the subtree kernels (patched later)
+
+struct AggSlot {             // what the first sibling leaves at the meeting point
+    float b[6];              // lo.x hi.x lo.y hi.y lo.z hi.z
+    unsigned int farKind;    // far end of its range | kind << 28
+    unsigned int refH;       // node position (kind 1) | height << 27
+};
+static_assert(sizeof(AggSlot) == 32, "AggSlot must be 32 bytes");
+
+struct AggCtx {
+    const unsigned int* keys;
+    const float2* triBox;
+    int n, leafSize;
+    int* rec;                    // [n + 1][16] node records by split position (0 = root)
+    unsigned char* nodeFlag;     // [n + 1]
+    unsigned char* leafFlag;     // [n + 1] a leaf starts here
+    unsigned char* groupPos;     // [n + 1] position belongs to a run handed to the subtree kernels
+    unsigned int* arrive;        // [n + 1] meeting counters (memory protocol), zeroed
+    AggSlot* slot;               // [n + 1][2]
+    int* parentPos;              // [n + 1] record position of a node's parent
+    int4* groups;                // (parent position or -1, side, start, end)
+    unsigned int* groupCount;
+    LbvhState* st;
+    int useLds;
+};
+
+__device__ __forceinline__ void agg_store_slot(AggSlot* dst, const AggSlot& v)
+{
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&v);
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
+#pragma unroll
+    for (int k = 0; k < 4; k++) __hip_atomic_store(d + k, s[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ AggSlot agg_load_slot(const AggSlot* src)
+{
+    AggSlot v;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(&v);
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
+#pragma unroll
+    for (int k = 0; k < 4; k++) d[k] = __hip_atomic_load(s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+
+__global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
+{
+    __shared__ unsigned int sKeys[AGG_TILE + 2];      // [0] = key before the tile, [AGG_TILE + 1] = key after it
+    __shared__ unsigned int sArrive[AGG_TILE + 1];
+    __shared__ AggSlot sSlot[AGG_TILE + 1][2];
+    const int tid = threadIdx.x;
+    const int n = c.n;
+    const int tileBeg = blockIdx.x * AGG_TILE;
+    const int tileEnd = min(tileBeg + AGG_TILE, n);
+    const int i = tileBeg + tid;
+    sKeys[tid + 1] = i < n ? c.keys[i] : 0u;
+    if (tid == 0) {
+        sKeys[0] = tileBeg > 0 ? c.keys[tileBeg - 1] : 0u;
+        sKeys[AGG_TILE + 1] = (tileBeg + AGG_TILE) < n ? c.keys[tileBeg + AGG_TILE] : 0u;
+    }
+    sArrive[tid] = 0;
+    if (tid == 0) sArrive[AGG_TILE] = 0;
+    __syncthreads();
+    if (i >= n) return;
+
+    auto key = [&](int x) -> unsigned int {   // sorted key at position x (0 <= x < n)
+        const int rel = x - tileBeg + 1;
+        return (rel >= 0 && rel <= AGG_TILE + 1 && x <= tileBeg + AGG_TILE) ? sKeys[rel] : c.keys[x];
+    };
+
+    const unsigned int myKey = sKeys[tid + 1];
+    if (i > 0 && key(i - 1) == myKey) return;         // not the first of its run
+
+    // ---- the run [l, r) of equal keys and its box -------------------------------------------------------------------------
+    int l = i, r = i + 1;
+    while (r < n && key(r) == myKey) r++;
+    float box[6] = {FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX};   // folded from FLT_MAX like calcLeaf (:383-408)
+    for (int j = l; j < r; j++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float2 t = c.triBox[3 * (size_t)j + k];
+            box[2 * k] = fminf(box[2 * k], t.x);
+            box[2 * k + 1] = fmaxf(box[2 * k + 1], t.y);
+        }
+    }
+    int kind = (r - l) <= c.leafSize ? 0 : 2;         // 0 leaf candidate, 1 inner node, 2 run for the subtree kernels
+    int ref = 0;                                      // kind 1: the node's record position
+    int h = kind == 2 ? 1 : 0;                        // levels of inner nodes below and including this cluster
+    if (kind == 2)
+        for (int j = l; j < r; j++) c.groupPos[j] = 1;
+
+    for (;;) {
+        if (l == 0 && r == n) {                       // only a single run can get here unmerged: all keys equal
+            const unsigned int g = atomicAdd(c.groupCount, 1u);
+            c.groups[g] = make_int4(-1, 0, 0, n);
+            break;
+        }
+        const unsigned int dl = l > 0 ? (key(l - 1) ^ key(l)) : 0xFFFFFFFFu;
+        const unsigned int dr = r < n ? (key(r - 1) ^ key(r)) : 0xFFFFFFFFu;
+        const bool sibRight = dr < dl;                // the sibling lies beyond r: this cluster is the left child
+        const int B = sibRight ? r : l;
+        const int hb = 31 - __clz((int)(sibRight ? dr : dl));
+        // the parent's whole range lies inside this tile iff neither neighbour key of the tile shares the parent's prefix
+        bool inTile = false;
+        if (c.useLds && B > tileBeg && B < tileEnd) {
+            const unsigned int pfx = key(B) >> (hb + 1);
+            const bool leftOut = tileBeg == 0 || (sKeys[0] >> (hb + 1)) != pfx;
+            const bool rightOut = tileEnd >= n || (sKeys[AGG_TILE + 1] >> (hb + 1)) != pfx;
+            inTile = leftOut && rightOut;
+        }
+        AggSlot mine;
+#pragma unroll
+        for (int k = 0; k < 6; k++) mine.b[k] = box[k];
+        mine.farKind = (unsigned int)(sibRight ? l : r) | ((unsigned int)kind << 28);
+        mine.refH = (unsigned int)ref | ((unsigned int)h << 27);
+        const int side = sibRight ? 0 : 1;
+        AggSlot sib;
+        if (inTile) {
+            const int bl = B - tileBeg;
+            sSlot[bl][side] = mine;
+            __threadfence_block();
+            const unsigned int old = atomicAdd(&sArrive[bl], 1u);
+            if (old == 0) break;
+            __threadfence_block();
+            sib = sSlot[bl][side ^ 1];
+        } else {
+            agg_store_slot(&c.slot[2 * (size_t)B + side], mine);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slot has reached memory before the arrival is announced
+            const unsigned int old = __hip_atomic_fetch_add(&c.arrive[B], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == 0) break;
+            sib = agg_load_slot(&c.slot[2 * (size_t)B + (side ^ 1)]);
+        }
+        // ---- second to arrive: form the parent ------------------------------------------------------------------------------
+        const int sFar = (int)(sib.farKind & 0x0FFFFFFFu), sKind = (int)(sib.farKind >> 28);
+        const int sRef = (int)(sib.refH & 0x07FFFFFFu), sH = (int)(sib.refH >> 27);
+        const int L = sibRight ? l : sFar, R = sibRight ? sFar : r;
+        // children in tree order: 0 = [L, B), 1 = [B, R)
+        const float* b0 = sibRight ? box : sib.b;
+        const float* b1 = sibRight ? sib.b : box;
+        const int kind0 = sibRight ? kind : sKind, kind1 = sibRight ? sKind : kind;
+        const int ref0 = sibRight ? ref : sRef, ref1 = sibRight ? sRef : ref;
+        const int h0 = sibRight ? h : sH, h1 = sibRight ? sH : h;
+        float ub[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            ub[2 * k] = fminf(b0[2 * k], b1[2 * k]);
+            ub[2 * k + 1] = fmaxf(b0[2 * k + 1], b1[2 * k + 1]);
+        }
+        if (R - L <= c.leafSize) {                    // still a leaf candidate (both children were)
+            l = L; r = R; kind = 0; ref = 0; h = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) box[k] = ub[k];
+            continue;
+        }
+        const int id = (L == 0 && R == n) ? 0 : B;    // record position of the new node
+        int link[2];
+        const int cs[2] = {L, B}, ce[2] = {B, R}, ck[2] = {kind0, kind1}, cr[2] = {ref0, ref1};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (ck[k] == 0) {                          // createLeaf: the child is a leaf starting at cs[k]
+                c.leafFlag[cs[k]] = 1;
+                link[k] = ~cs[k];
+            } else if (ck[k] == 1) {
+                link[k] = cr[k];
+                c.parentPos[cr[k]] = id;
+            } else {
+                link[k] = AGG_REF_GROUP;
+                const unsigned int g = atomicAdd(c.groupCount, 1u);
+                c.groups[g] = make_int4(id, k, cs[k], ce[k]);
+            }
+        }
+        int* nd = c.rec + (size_t)id * 16;
+        float* nf = reinterpret_cast<float*>(nd);
+        reinterpret_cast<float4*>(nf)[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
+        reinterpret_cast<float4*>(nf)[1] = make_float4(b1[0], b1[1], b1[2], b1[3]);
+        reinterpret_cast<float4*>(nf)[2] = make_float4(b0[4], b0[5], b1[4], b1[5]);
+        reinterpret_cast<int4*>(nd)[3] = make_int4(link[0], link[1], hb % 3, 0);
+        c.nodeFlag[id] = 1;
+        l = L; r = R; kind = 1; ref = id; h = 1 + max(h0, h1);
+#pragma unroll
+        for (int k = 0; k < 6; k++) box[k] = ub[k];
+        if (id == 0) {                                 // the root: deepest level that holds an inner node, plus one
+            atomicMax(&c.st->maxLevel, (unsigned int)min(h, 30));
+            break;
+        }
+    }
+}
+
+// Exclusive ranks of the node flags, the leaf-start flags and the positions that keep their leaf storage in the fast path
+// (all but the handed-over runs), by a single-pass chained scan with decoupled look-back (2048 positions per workgroup,
+// tickets as in onesweep_pass_kernel).  Totals go to the builder state: nodeCount, leafPtr = (kept triangles << 32) | leaves.
+constexpr int RANK_THREADS = 256;
+constexpr int RANK_ITEMS = 8;
+constexpr int RANK_TILE = RANK_THREADS * RANK_ITEMS;
+
+__global__ __launch_bounds__(RANK_THREADS) void lbvh_rank_kernel(int n, const unsigned char* __restrict__ nodeFlag,
+                                                                 const unsigned char* __restrict__ leafFlag,
+                                                                 const unsigned char* __restrict__ groupPos, uint4* __restrict__ ranks /* [n + 1] */,
+                                                                 unsigned long long* tileState /* [tiles][2] */, unsigned int* ticket,
+                                                                 LbvhState* st, unsigned int* errFlag)
+{
+    __shared__ unsigned int s_tile;
+    __shared__ unsigned int s_red[3][RANK_THREADS / 64];
+    __shared__ unsigned int s_base[3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const unsigned int tile = s_tile;
+    const int total = n + 1;                           // positions 0 .. n
+    const int base = (int)tile * RANK_TILE + tid * RANK_ITEMS;
+    unsigned int f[3][RANK_ITEMS];
+    unsigned int sum[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < RANK_ITEMS; k++) {
+        const int p = base + k;
+        const bool ok = p < total;
+        f[0][k] = ok ? nodeFlag[p] : 0u;
+        f[1][k] = ok ? leafFlag[p] : 0u;
+        f[2][k] = ok && p < n ? (groupPos[p] ? 0u : 1u) : 0u;
+        sum[0] += f[0][k]; sum[1] += f[1][k]; sum[2] += f[2][k];
+    }
+    // exclusive scan of the per-thread sums inside the workgroup
+    unsigned int excl[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        unsigned int incl = sum[q];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int u = (unsigned int)__shfl_up((int)incl, off);
+            if (lane >= off) incl += u;
+        }
+        if (lane == 63) s_red[q][wave] = incl;
+        excl[q] = incl - sum[q];
+    }
+    __syncthreads();
+    unsigned int tileSum[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        unsigned int before = 0, all = 0;
+        for (int w = 0; w < RANK_THREADS / 64; w++) {
+            if (w < wave) before += s_red[q][w];
+            all += s_red[q][w];
+        }
+        excl[q] += before;
+        tileSum[q] = all;
+    }
+    // chained scan over the tiles: word 0 = status (2 bits) | nodes (31 bits) | leaves (31 bits); word 1 = status | kept positions
+    if (tid == 0) {
+        const unsigned long long agg0 = ((unsigned long long)tileSum[0] << 31) | tileSum[1];
+        const unsigned long long agg1 = tileSum[2];
+        unsigned long long* my = tileState + 2 * (size_t)tile;
+        const unsigned long long ST_AGG = 1ull << 62, ST_INC = 2ull << 62, MASK = (1ull << 62) - 1ull;
+        if (tile == 0) {
+            __hip_atomic_store(my + 1, ST_INC | agg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(my, ST_INC | agg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base[0] = s_base[1] = s_base[2] = 0;
+        } else {
+            __hip_atomic_store(my + 1, ST_AGG | agg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(my, ST_AGG | agg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long e0 = 0, e1 = 0;
+            for (unsigned int t = tile; t-- > 0;) {
+                const unsigned long long* p = tileState + 2 * (size_t)t;
+                unsigned long long w0 = 0, w1 = 0;
+                unsigned int spins = 0;
+                for (;;) {   // a tile's two words are published one after the other (word 1 first): accept a pair with equal status
+                    w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((w0 >> 62) != 0 && (w1 >> 62) == (w0 >> 62)) break;
+                    if (++spins > (1u << 22)) { atomicOr(errFlag, 4u); w0 = ST_INC; w1 = ST_INC; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                e0 += w0 & MASK;
+                e1 += w1 & MASK;
+                if ((w0 >> 62) == 2) break;
+            }
+            __hip_atomic_store(my + 1, ST_INC | ((e1 + agg1) & MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(my, ST_INC | ((e0 + agg0) & MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base[0] = (unsigned int)(e0 >> 31);
+            s_base[1] = (unsigned int)(e0 & 0x7FFFFFFFull);
+            s_base[2] = (unsigned int)e1;
+        }
+        if ((int)((tile + 1) * RANK_TILE) >= total) {   // the last tile knows the totals
+            st->nodeCount = s_base[0] + tileSum[0];
+            st->leafPtr = ((unsigned long long)(s_base[2] + tileSum[2]) << 32) | (unsigned long long)(s_base[1] + tileSum[1]);
+        }
+    }
+    __syncthreads();
+    unsigned int run[3] = {s_base[0] + excl[0], s_base[1] + excl[1], s_base[2] + excl[2]};
+#pragma unroll
+    for (int k = 0; k < RANK_ITEMS; k++) {
+        const int p = base + k;
+        if (p < total) ranks[p] = make_uint4(run[0], run[1], run[2], 0u);
+        run[0] += f[0][k]; run[1] += f[1][k]; run[2] += f[2][k];
+    }
+}
+
+// Final pass, one thread per sorted position j: the node recorded at j (if any) goes to its ranked index with its child references
+// translated, triangle j's Woop rows and index go to its leaf's storage (calcWoopKernel, emitTreeKernel.cu:574-645), and the leaf
+// that ends before j gets its terminator.  Positions of handed-over runs are left to the subtree kernels.
+__global__ __launch_bounds__(256) void lbvh_finalize_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
+                                                            const int* __restrict__ triSorted, const int* __restrict__ rec,
+                                                            const unsigned char* __restrict__ nodeFlag, const unsigned char* __restrict__ leafFlag,
+                                                            const unsigned char* __restrict__ groupPos, const uint4* __restrict__ ranks,
+                                                            int* __restrict__ nodes, unsigned int nodeCap, float4* __restrict__ outWoop,
+                                                            int* __restrict__ outIdx, int* __restrict__ triOut, LbvhState* st)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    const uint4 rk = ranks[j];
+    if (nodeFlag[j]) {
+        if (rk.x >= nodeCap) { atomicOr(&st->overflow, 1u); }
+        else {
+            const int4* src = reinterpret_cast<const int4*>(rec + (size_t)j * 16);
+            int4* dst = reinterpret_cast<int4*>(nodes + (size_t)rk.x * 16);
+            const int4 a = src[0], b = src[1], cc = src[2];
+            int4 d = src[3];
+            int* lk = &d.x;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int ref = k ? d.y : d.x;
+                int out = ref;
+                if (ref < 0) {                                   // leaf starting at ~ref: storage = 3 * kept triangles before + leaves before
+                    const uint4 lr = ranks[~ref];
+                    out = ~(int)(3u * lr.z + lr.y);
+                } else if (ref != AGG_REF_GROUP) {
+                    out = (int)(ranks[ref].x * 64u);             // inner child recorded at position ref
+                }
+                lk[k] = out;
+            }
+            dst[0] = a; dst[1] = b; dst[2] = cc; dst[3] = d;
+        }
+    }
+    const float nz = __uint_as_float(0x80000000u);
+    if (j == n) {                                                // terminator of the last leaf of the fast path
+        if (rk.y > 0) {
+            const unsigned int tp = 3u * rk.z + rk.y - 1u;
+            outWoop[tp] = make_float4(nz, nz, nz, nz);
+            outIdx[tp] = 0;
+        }
+        return;
+    }
+    if (groupPos[j]) return;
+    const unsigned int lf = leafFlag[j];
+    if (lf && rk.y > 0) {                                        // a leaf starts here: close the one before it
+        const unsigned int tp = 3u * rk.z + rk.y - 1u;
+        outWoop[tp] = make_float4(nz, nz, nz, nz);
+        outIdx[tp] = 0;
+    }
+    const int o = (int)(3u * rk.z + rk.y + lf) - 1;              // 3 * kept triangles before + leaves up to and including this one - 1
+    const int t = triSorted[j];
+    float4 r0, r1, r2;
+    woop_rows(tri, pos, t, r0, r1, r2);
+    outWoop[o + 0] = r0;
+    outWoop[o + 1] = r1;
+    outWoop[o + 2] = r2;
+    outIdx[o + 0] = t;
+    outIdx[o + 1] = 0;
+    outIdx[o + 2] = 0;
+    triOut[j] = o;
+}
+
+// Slow path for the handed-over runs (equal keys, more than leafSize triangles), after the fast path: depth of each run's root by
+// walking the parent positions, its node index / forced leaf, the parent's link patched in the final node array, and the hand-over
+// list for lbvh_subtree_kernel / the oversize queue for emit_top.  One workgroup (the counters live in LDS like lbvh_top_kernel).
+__global__ __launch_bounds__(TOP_THREADS) void lbvh_groups_kernel(EmitCtx c, int n, const int4* __restrict__ groups, unsigned int numGroups,
+                                                                  const int* __restrict__ parentPos, const uint4* __restrict__ ranks,
+                                                                  int4* qA, int4* qB, int* topLst)
+{
+    __shared__ EmitShared sh;
+    __shared__ unsigned int s_over;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        sh.nodeCtr = c.st->nodeCount; sh.nodeBase = 0;
+        sh.leafCtr = c.st->leafPtr; sh.leafBase = 0ull; sh.numSub = 0; sh.maxLevel = c.st->maxLevel;
+        s_over = 0;
+    }
+    __syncthreads();
+    for (unsigned int g = tid; g < numGroups; g += TOP_THREADS) {
+        const int4 q = groups[g];
+        int depth = 0;
+        if (q.x >= 0) {
+            depth = 1;
+            for (int p = q.x; p != 0; p = parentPos[p]) depth++;
+        }
+        int* nd = q.x >= 0 ? c.nodes + (size_t)ranks[q.x].x * 16 : nullptr;
+        if (depth >= 30) {  // the parent's level bit is 0: the run is a leaf whatever its size (emitTreeKernel.cu:289-292)
+            const unsigned long long lp = atomicAdd(&sh.leafCtr, ((unsigned long long)(q.w - q.z) << 32) + 1ull);
+            const int out = (int)(lp >> 32) * 3 + (int)(lp & 0xFFFFFFFFull);
+            emit_leaf(c, out, q.z, q.w, nd, q.y);
+            nd[12 + q.y] = ~out;
+            continue;
+        }
+        if (q.x < 0) atomicMax(&sh.nodeCtr, 1u);  // all keys equal: the run is the root, node 0
+        const unsigned int nIdx = q.x >= 0 ? atomicAdd(&sh.nodeCtr, 1u) : 0u;
+        if (nd) nd[12 + q.y] = (int)nIdx * 64;
+        if (q.w - q.z <= c.spill) {
+            const unsigned int si = atomicAdd(&sh.numSub, 1u);
+            c.subList[si] = make_int4((int)nIdx, q.z, q.w, depth);
+        } else {
+            const unsigned int qi = atomicAdd(&s_over, 1u);
+            qA[qi] = make_int4((int)nIdx, q.z, q.w, depth);
+        }
+    }
+    __syncthreads();
+    const unsigned int over = s_over;
+    int lv = 0;
+    if (over) lv = emit_top<TOP_THREADS, 16>(c, sh, qA, qB, topLst, over);
+    __syncthreads();
+    if ((int)tid <= lv) c.st->topLvlOfs[tid] = over ? sh.lvlOfs[tid] : 0u;
+    if (tid == 0) {
+        c.st->topLevels = (unsigned int)lv;
+        c.st->maxLevel = sh.maxLevel;
+        c.st->nodeCount = sh.nodeCtr;
+        c.st->leafPtr = sh.leafCtr;
+        c.st->numSub = sh.numSub;
+        c.st->subNext = 0;
+    }
+}
+
 }  // namespace ntr
 
 using namespace ntr;
@@ -1022,6 +1467,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const Tunables tun = tunables();
     const bool levelSync = tun.lbvhLevelSync != 0;
     const bool legacySort = levelSync || tun.lbvhLegacySort != 0;
+    if (n >= (1 << 27)) return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: at most 2^27 - 1 triangles");
 
     Carver cv;
     const size_t oKeysA = cv.take((size_t)n * 4), oKeysB = cv.take((size_t)n * 4);
@@ -1039,6 +1485,17 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oTopLst = cv.take(((size_t)n + 2) * 4);
     const size_t oTriBox = cv.take((size_t)n * 24), oTriOut = cv.take((size_t)n * 4);
     const size_t oCell = cv.take(((size_t)TOP_CELLS + 1) * 4), oTopIdx = cv.take((size_t)TOP_HEAP * 4);
+    // bottom-up emit: zeroed region (flags, meeting counters, scan state) first, then records, slots, ranks
+    const int rankTiles = (n + 1 + RANK_TILE - 1) / RANK_TILE;
+    const size_t oAggZero = cv.off;
+    const size_t oNodeFlag = cv.take((size_t)n + 1), oLeafFlag = cv.take((size_t)n + 1), oGroupPos = cv.take((size_t)n + 1);
+    const size_t oArrive = cv.take(((size_t)n + 1) * 4);
+    const size_t oRankState = cv.take((size_t)rankTiles * 16);
+    const size_t oAggMisc = cv.take(64);           // [0] group count, [1] rank ticket
+    const size_t oAggZeroEnd = cv.off;
+    const size_t oRec = cv.take(((size_t)n + 1) * 64), oSlot = cv.take(((size_t)n + 1) * 64);
+    const size_t oParentPos = cv.take(((size_t)n + 1) * 4), oRanks = cv.take(((size_t)n + 1) * 16);
+    const size_t oGroups = cv.take(((size_t)n / 2 + 2) * 16);
     void* wsBase = nullptr;
     {
         const int rc = workspace_reserve(cv.off, &wsBase);
@@ -1147,8 +1604,61 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         if (c.spill > 7168) c.spill = 7168;  // 20 bytes of LDS per triangle of a subtree (140 KB), 16-bit positions
         int4* q0 = (int4*)(ws + oQ0);
         int4* q1 = (int4*)(ws + oQ1);
-        // 0: the whole tree is one hand-over root; 1: cell-table top (default); 2: level-by-level top with key probes
-        const int topMode = n <= c.spill ? 0 : (tun.lbvhLegacyTop ? 2 : 1);
+        // 0: the whole tree is one hand-over root; 1: cell-table top; 2: level-by-level top with key probes;
+        // 3: bottom-up emit with scanned indices (default)
+        const int topMode = n <= c.spill ? 0 : (tun.lbvhLegacyTop ? 2 : (tun.lbvhEmit == 1 ? 1 : 3));
+        unsigned int* aggMisc = (unsigned int*)(ws + oAggMisc);
+        auto launch_subtrees = [&](int blocks) -> int {
+            const int subThreads = tun.lbvhSubThreads;
+            const size_t subLds = (size_t)c.spill * (4 + 16);  // keys + entry list
+            if (subLds > 65536) {
+                const void* fn = subThreads == 64 ? (const void*)lbvh_subtree_kernel<64>
+                               : subThreads == 256 ? (const void*)lbvh_subtree_kernel<256> : (const void*)lbvh_subtree_kernel<128>;
+                NTR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)subLds));
+            }
+            if (subThreads == 64)
+                hipLaunchKernelGGL(lbvh_subtree_kernel<64>, dim3(blocks), dim3(64), subLds, s, c, c.spill);
+            else if (subThreads == 256)
+                hipLaunchKernelGGL(lbvh_subtree_kernel<256>, dim3(blocks), dim3(256), subLds, s, c, c.spill);
+            else
+                hipLaunchKernelGGL(lbvh_subtree_kernel<128>, dim3(blocks), dim3(128), subLds, s, c, c.spill);
+            return NTR_OK;
+        };
+        if (topMode == 3) {
+            AggCtx a;
+            a.keys = keys; a.triBox = c.triBox; a.n = n; a.leafSize = leafSize;
+            a.rec = (int*)(ws + oRec);
+            a.nodeFlag = (unsigned char*)(ws + oNodeFlag); a.leafFlag = (unsigned char*)(ws + oLeafFlag); a.groupPos = (unsigned char*)(ws + oGroupPos);
+            a.arrive = (unsigned int*)(ws + oArrive); a.slot = (AggSlot*)(ws + oSlot); a.parentPos = (int*)(ws + oParentPos);
+            a.groups = (int4*)(ws + oGroups); a.groupCount = aggMisc; a.st = state; a.useLds = tun.lbvhAggLds;
+            NTR_HIP(hipMemsetAsync(ws + oAggZero, 0, oAggZeroEnd - oAggZero, s));
+            hipLaunchKernelGGL(lbvh_agglomerate_kernel, dim3((n + AGG_TILE - 1) / AGG_TILE), dim3(AGG_TILE), 0, s, a);
+            pe.mark(4);
+            hipLaunchKernelGGL(lbvh_rank_kernel, dim3(rankTiles), dim3(RANK_THREADS), 0, s, n, (const unsigned char*)a.nodeFlag, (const unsigned char*)a.leafFlag,
+                               (const unsigned char*)a.groupPos, (uint4*)(ws + oRanks), (unsigned long long*)(ws + oRankState), aggMisc + 1, state, osMisc + 4);
+            pe.mark(5);
+            hipLaunchKernelGGL(lbvh_finalize_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted, (const int*)a.rec,
+                               (const unsigned char*)a.nodeFlag, (const unsigned char*)a.leafFlag, (const unsigned char*)a.groupPos,
+                               (const uint4*)(ws + oRanks), (int*)d_nodes, nodeCap, (float4*)d_triWoop, d_triIndex, c.triOut, state);
+            pe.mark(6);
+            // runs of more than leafSize equal keys (rare) are finished by the subtree kernels once the fast path is through: that
+            // costs them one more synchronisation, and ordinary scenes nothing
+            unsigned int numGroups = 0;
+            NTR_HIP(hipMemcpyAsync(&numGroups, aggMisc, sizeof(numGroups), hipMemcpyDeviceToHost, s));
+            NTR_HIP(hipStreamSynchronize(s));
+            if (numGroups) {
+                hipLaunchKernelGGL(lbvh_groups_kernel, dim3(1), dim3(TOP_THREADS), 0, s, c, n, (const int4*)a.groups, numGroups, (const int*)a.parentPos,
+                                   (const uint4*)(ws + oRanks), q0, q1, (int*)(ws + oTopLst));
+                int blocks = (int)numGroups * 2 + 64;   // hand-over roots: the runs themselves and what the oversize fallback cuts off
+                if (blocks > 2048) blocks = 2048;
+                const int rc = launch_subtrees(blocks);
+                if (rc != NTR_OK) return rc;
+                hipLaunchKernelGGL(lbvh_top_refit_kernel, dim3(1), dim3(TOP_THREADS), 0, s, (const LbvhState*)state, (const int*)(ws + oTopLst), (int*)d_nodes);
+                hipLaunchKernelGGL(lbvh_place_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted,
+                                   (const int*)(ws + oTriOut), (float4*)d_triWoop, d_triIndex);
+                pe.mark(6);
+            }
+        } else {
         if (topMode == 0) {
             // node 0 over all triangles at depth 0 goes straight to a subtree workgroup
             LbvhState init;
@@ -1166,23 +1676,14 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             hipLaunchKernelGGL(lbvh_top_kernel, dim3(1), dim3(TOP_THREADS), 0, s, c, n, q0, q1, (int*)(ws + oTopLst));
         }
         pe.mark(4);
-        const int subThreads = tun.lbvhSubThreads;
         int subBlocks = n / 2 + 1;
-        const int subMax = 256 * (2048 / (subThreads > 0 ? subThreads : 128));
+        const int subMax = 256 * (2048 / (tun.lbvhSubThreads > 0 ? tun.lbvhSubThreads : 128));
         if (subBlocks > subMax) subBlocks = subMax;
         if (topMode == 0) subBlocks = 1;
-        const size_t subLds = (size_t)c.spill * (4 + 16);  // keys + entry list
-        if (subLds > 65536) {
-            const void* fn = subThreads == 64 ? (const void*)lbvh_subtree_kernel<64>
-                           : subThreads == 256 ? (const void*)lbvh_subtree_kernel<256> : (const void*)lbvh_subtree_kernel<128>;
-            NTR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)subLds));
+        {
+            const int rc = launch_subtrees(subBlocks);
+            if (rc != NTR_OK) return rc;
         }
-        if (subThreads == 64)
-            hipLaunchKernelGGL(lbvh_subtree_kernel<64>, dim3(subBlocks), dim3(64), subLds, s, c, c.spill);
-        else if (subThreads == 256)
-            hipLaunchKernelGGL(lbvh_subtree_kernel<256>, dim3(subBlocks), dim3(256), subLds, s, c, c.spill);
-        else
-            hipLaunchKernelGGL(lbvh_subtree_kernel<128>, dim3(subBlocks), dim3(128), subLds, s, c, c.spill);
         pe.mark(5);
         if (topMode == 1)
             hipLaunchKernelGGL(lbvh_top_cells_refit_kernel, dim3(1), dim3(TOP_THREADS), 0, s, (const LbvhState*)state, (const int*)(ws + oTopLst),
@@ -1193,6 +1694,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         hipLaunchKernelGGL(lbvh_place_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted,
                            (const int*)(ws + oTriOut), (float4*)d_triWoop, d_triIndex);
         pe.mark(6);
+        }
     }
     NTR_HIP(hipGetLastError());
     unsigned int sortErr = 0;
@@ -1206,7 +1708,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     result->refitMs = pe.ms(4, 6);
     result->seconds = pe.ms(0, 6) * 1e-3f;
     if (h.overflow) return set_error(NTR_ERR_OVERFLOW, "ntr_lbvh_build: node buffer overflow");
-    if (sortErr) return set_error(NTR_ERR_HIP, "ntr_lbvh_build: one-sweep sort timed out waiting for a predecessor tile");
+    if (sortErr) return set_error(NTR_ERR_HIP, "ntr_lbvh_build: a chained scan timed out waiting for a predecessor tile (status %u)", sortErr);
     int numLevels = 0;
     unsigned int numNodes = 0;
     if (levelSync) {

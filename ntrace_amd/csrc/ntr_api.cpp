@@ -152,6 +152,8 @@ static void tunables_load_locked()
     t.lbvhSubThreads = env_int("NTR_LBVH_SUB_THREADS", 128);
     t.lbvhLegacyTop = env_int("NTR_LBVH_LEGACY_TOP", 0);
     t.lbvhLegacySort = env_int("NTR_LBVH_LEGACY_SORT", 0);
+    t.lbvhEmit = env_int("NTR_LBVH_EMIT", 0);          // 0: bottom-up emit with scanned indices; 1: cell-table top + subtree workgroups
+    t.lbvhAggLds = env_int("NTR_LBVH_AGG_LDS", 1);     // bottom-up emit: meetings inside a tile through LDS
     if (t.chunk < 1) t.chunk = 1;
     g_tun = t;
     g_tunLoaded = true;

@@ -13,16 +13,28 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["subtree", "subtree-split16-64t", "subtree-split40-256t", "legacy-top-and-sort", "legacy-top-split16", "levelsync"])
+@pytest.fixture(autouse=True, params=["default", "split16-64t", "split40-256t", "bottom-up-no-lds", "bottom-up-no-lds-split16", "cells-top", "cells-top-split16",
+                                       "legacy-top-and-sort", "legacy-top-split16", "levelsync"])
 def build_path(request, monkeypatch):
-    """Every test runs on the default path (one-sweep sort, cell-table top pass, one workgroup per subtree), on the same path
-    with tiny subtrees (so that small scenes exercise the hand-over and the oversize-cell fallback too), on the round-1
-    sort / top pass, and on the per-level kernels."""
-    for k in ("NTR_LBVH_LEVELSYNC", "NTR_LBVH_SPLIT", "NTR_LBVH_SUB_THREADS", "NTR_LBVH_LEGACY_TOP", "NTR_LBVH_LEGACY_SORT"):
+    """Every test runs on the default path (one-sweep sort, bottom-up emit with scanned indices; scenes of at most `split`
+    triangles are one subtree workgroup), on the same path with a tiny `split` (so that small scenes take the bottom-up emit, and
+    runs of equal keys its slow path with hand-over roots and the oversize fallback), with every meeting through memory, on the
+    cell-table top pass + subtree workgroups, on the round-1 sort / top pass, and on the per-level kernels."""
+    for k in ("NTR_LBVH_LEVELSYNC", "NTR_LBVH_SPLIT", "NTR_LBVH_SUB_THREADS", "NTR_LBVH_LEGACY_TOP", "NTR_LBVH_LEGACY_SORT", "NTR_LBVH_EMIT", "NTR_LBVH_AGG_LDS"):
         monkeypatch.delenv(k, raising=False)
     if request.param == "levelsync":
         monkeypatch.setenv("NTR_LBVH_LEVELSYNC", "1")
-    elif request.param == "subtree-split16-64t":
+    elif request.param == "bottom-up-no-lds":  # every meeting of the bottom-up emit through memory
+        monkeypatch.setenv("NTR_LBVH_AGG_LDS", "0")
+    elif request.param == "bottom-up-no-lds-split16":
+        monkeypatch.setenv("NTR_LBVH_AGG_LDS", "0")
+        monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
+    elif request.param == "cells-top":  # cell-table top pass + one workgroup per subtree
+        monkeypatch.setenv("NTR_LBVH_EMIT", "1")
+    elif request.param == "cells-top-split16":
+        monkeypatch.setenv("NTR_LBVH_EMIT", "1")
+        monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
+    elif request.param == "split16-64t":
         monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
         monkeypatch.setenv("NTR_LBVH_SUB_THREADS", "64")
     elif request.param == "legacy-top-and-sort":  # round-1 pipeline: 12-launch sort, level-by-level top pass with key probes
@@ -31,7 +43,7 @@ def build_path(request, monkeypatch):
     elif request.param == "legacy-top-split16":
         monkeypatch.setenv("NTR_LBVH_LEGACY_TOP", "1")
         monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
-    elif request.param == "subtree-split40-256t":
+    elif request.param == "split40-256t":
         monkeypatch.setenv("NTR_LBVH_SPLIT", "40")
         monkeypatch.setenv("NTR_LBVH_SUB_THREADS", "256")
     nt.set_tunables()  # the library reads the environment once
