@@ -1204,44 +1204,65 @@ __global__ __launch_bounds__(RANK_THREADS) void lbvh_rank_kernel(int n, const un
         excl[q] += before;
         tileSum[q] = all;
     }
-    // chained scan over the tiles: word 0 = status (2 bits) | nodes (31 bits) | leaves (31 bits); word 1 = status | kept positions
-    if (tid == 0) {
+    // chained scan over the tiles: word 0 = status (2 bits) | nodes (31 bits) | leaves (31 bits); word 1 = status | kept positions.
+    // The first wave looks back 64 predecessors per round trip (lane L reads tile t - L): the sums of the lanes up to the nearest
+    // inclusive word -- or up to the first unpublished one, which is then polled again -- are reduced across the wave.
+    if (wave == 0) {
         const unsigned long long agg0 = ((unsigned long long)tileSum[0] << 31) | tileSum[1];
         const unsigned long long agg1 = tileSum[2];
         unsigned long long* my = tileState + 2 * (size_t)tile;
         const unsigned long long ST_AGG = 1ull << 62, ST_INC = 2ull << 62, MASK = (1ull << 62) - 1ull;
-        if (tile == 0) {
-            __hip_atomic_store(my + 1, ST_INC | agg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(my, ST_INC | agg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_base[0] = s_base[1] = s_base[2] = 0;
-        } else {
-            __hip_atomic_store(my + 1, ST_AGG | agg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(my, ST_AGG | agg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long e0 = 0, e1 = 0;
-            for (unsigned int t = tile; t-- > 0;) {
-                const unsigned long long* p = tileState + 2 * (size_t)t;
-                unsigned long long w0 = 0, w1 = 0;
-                unsigned int spins = 0;
-                for (;;) {   // a tile's two words are published one after the other (word 1 first): accept a pair with equal status
+        unsigned int e[3] = {0, 0, 0};
+        if (tile > 0) {
+            if (lane == 0) {
+                __hip_atomic_store(my + 1, ST_AGG | agg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(my, ST_AGG | agg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int t = (int)tile - 1;
+            unsigned int spins = 0;
+            for (;;) {
+                const int tt = t - lane;
+                unsigned long long w0 = ST_INC, w1 = ST_INC;   // before the first tile: an inclusive zero
+                if (tt >= 0) {
+                    const unsigned long long* p = tileState + 2 * (size_t)tt;
                     w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((w0 >> 62) != 0 && (w1 >> 62) == (w0 >> 62)) break;
-                    if (++spins > (1u << 22)) { atomicOr(errFlag, 4u); w0 = ST_INC; w1 = ST_INC; break; }
-                    __builtin_amdgcn_s_sleep(2);
                 }
-                e0 += w0 & MASK;
-                e1 += w1 & MASK;
-                if ((w0 >> 62) == 2) break;
+                // a tile's two words are published one after the other (word 1 first): a pair counts when both carry the same status
+                const unsigned int st = ((w0 >> 62) == (w1 >> 62)) ? (unsigned int)(w0 >> 62) : 0u;
+                const unsigned long long ready = __ballot(st != 0u), incl = __ballot(st == 2u);
+                const int firstWait = ready == ~0ull ? 64 : __builtin_ctzll(~ready);
+                const int firstInc = incl ? __builtin_ctzll(incl) : 64;
+                const int take = min(firstWait, firstInc + 1);
+                unsigned int v[3] = {0, 0, 0};
+                if (lane < take) {
+                    v[0] = (unsigned int)((w0 & MASK) >> 31);
+                    v[1] = (unsigned int)(w0 & 0x7FFFFFFFull);
+                    v[2] = (unsigned int)(w1 & MASK);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) v[q] += (unsigned int)__shfl_xor((int)v[q], off);
+                    e[q] += v[q];
+                }
+                if (firstInc < firstWait) break;               // the consumed lanes end in an inclusive prefix
+                t -= take;
+                if (take < 64) {
+                    if (++spins > (1u << 22)) { if (lane == 0) atomicOr(errFlag, 4u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
-            __hip_atomic_store(my + 1, ST_INC | ((e1 + agg1) & MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(my, ST_INC | ((e0 + agg0) & MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_base[0] = (unsigned int)(e0 >> 31);
-            s_base[1] = (unsigned int)(e0 & 0x7FFFFFFFull);
-            s_base[2] = (unsigned int)e1;
         }
-        if ((int)((tile + 1) * RANK_TILE) >= total) {   // the last tile knows the totals
-            st->nodeCount = s_base[0] + tileSum[0];
-            st->leafPtr = ((unsigned long long)(s_base[2] + tileSum[2]) << 32) | (unsigned long long)(s_base[1] + tileSum[1]);
+        if (lane == 0) {
+            const unsigned long long inc0 = ((((unsigned long long)(e[0] + tileSum[0])) << 31) | (unsigned long long)(e[1] + tileSum[1])) & MASK;
+            __hip_atomic_store(my + 1, ST_INC | ((unsigned long long)(e[2] + tileSum[2]) & MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(my, ST_INC | inc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base[0] = e[0]; s_base[1] = e[1]; s_base[2] = e[2];
+            if ((int)((tile + 1) * RANK_TILE) >= total) {      // the last tile knows the totals
+                st->nodeCount = e[0] + tileSum[0];
+                st->leafPtr = ((unsigned long long)(e[2] + tileSum[2]) << 32) | (unsigned long long)(e[1] + tileSum[1]);
+            }
         }
     }
     __syncthreads();

@@ -253,22 +253,36 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
     const unsigned int tileStart = s_scan[tid] - cnt;
     s_tileStart[tid] = tileStart;
 
-    // decoupled look-back over the predecessors' words of this digit
+    // decoupled look-back over the predecessors' words of this digit, OS_LOOK of them per round trip (the loads of a round are
+    // independent; they are consumed nearest tile first, up to the first inclusive word, or re-read from the first unpublished one)
     unsigned int excl = 0;
     if (tile > 0) {
+        constexpr int OS_LOOK = 8;
         const unsigned int stAgg = os_status(pass, false) >> 28, stInc = os_status(pass, true) >> 28;
-        for (unsigned int t = tile; t-- > 0;) {
-            const unsigned int* p = tileState + (size_t)t * 256 + tid;
-            unsigned int w = 0, spins = 0;
-            for (;;) {
-                w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned int st = w >> 28;
-                if (st == stAgg || st == stInc) break;
-                if (++spins > OS_SPIN_LIMIT) { atomicOr(errFlag, 2u); w = stInc << 28; break; }
-                __builtin_amdgcn_s_sleep(2);
+        int t = (int)tile - 1;
+        unsigned int spins = 0;
+        bool done = false;
+        while (!done) {
+            unsigned int w[OS_LOOK];
+#pragma unroll
+            for (int j = 0; j < OS_LOOK; j++)
+                w[j] = (t - j) >= 0 ? __hip_atomic_load(tileState + (size_t)(t - j) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : (stInc << 28);  // before the first tile: nothing
+            int used = 0;
+#pragma unroll
+            for (int j = 0; j < OS_LOOK; j++) {
+                if (done || used != j) continue;
+                const unsigned int st = w[j] >> 28;
+                if (st != stAgg && st != stInc) continue;   // not published yet: stop consuming here
+                excl += w[j] & OS_COUNT_MASK;
+                used = j + 1;
+                if (st == stInc) done = true;
             }
-            excl += w & OS_COUNT_MASK;
-            if ((w >> 28) == stInc) break;
+            t -= used;
+            if (!done && used < OS_LOOK) {
+                if (++spins > OS_SPIN_LIMIT) { atomicOr(errFlag, 2u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
         }
         __hip_atomic_store(myState, os_status(pass, true) | ((excl + cnt) & OS_COUNT_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -1,8 +1,11 @@
 // CudaBVH.cpp -- host BVH -> BVHLayout_Compact buffers (+ bvhcache (de)serialisation).
 #include "CudaBVH.hpp"
 
+#include <cstring>
 #include <istream>
 #include <ostream>
+#include <thread>
+#include <utility>
 #include <vector>
 
 namespace FW {
@@ -55,59 +58,98 @@ U32 CudaBVH::getTraceFlags(void)
 // Emission order of CudaBVH::createCompact (CudaBVH.cpp:594-652): explicit stack,
 // pop -> for child 0 then child 1: an inner child takes the next 64-B slot at once
 // (so siblings are adjacent) and is pushed; a leaf child appends its triangles and
-// a terminator.
+// a terminator.  The layout (which slot every node and every leaf gets) is fixed by that
+// walk, which only chases pointers: it is done first and records where everything goes;
+// the contents -- child boxes, Woop rows (a 4x4 cofactor inverse per triangle), indices --
+// are then written by all host threads, every record being independent of the others.
 void CudaBVH::createCompact(const BVH& bvh, int nodeOffsetSizeDiv)
 {
-    struct StackEntry {
-        const BVHNode* node;
-        S32            idx;  // index of the node's first int4
-    };
     struct Int4 { S32 x, y, z, w; };
+    struct InnerRec { const BVHNode* node; S32 idx, c0, c1; };  // idx = index of the node's first int4
+    struct LeafRec { const LeafNode* leaf; S32 ofs; };           // ofs = float4 index of the leaf's first Woop row
 
-    std::vector<Int4> nodeData(4);
-    std::vector<Int4> triWoopData;
-    std::vector<S32>  triIndexData;
-    std::vector<StackEntry> stack(1, StackEntry{bvh.getRoot(), 0});
-
+    // ---- 1. layout ---------------------------------------------------------------------------------------------
+    std::vector<InnerRec> inner;
+    std::vector<LeafRec> leaves;
+    std::vector<std::pair<const BVHNode*, S32> > stack(1, std::make_pair((const BVHNode*)bvh.getRoot(), (S32)0));
+    S64 numNodeInt4 = 4, numWoop = 0;
     while (!stack.empty()) {
-        StackEntry e = stack.back();
+        const std::pair<const BVHNode*, S32> e = stack.back();
         stack.pop_back();
-        if (e.node->getNumChildNodes() != 2) fail("CudaBVH::createCompact: inner node without 2 children");
-        const AABB* cbox[2];
-        int cidx[2];
-
+        if (e.first->getNumChildNodes() != 2) fail("CudaBVH::createCompact: inner node without 2 children");
+        InnerRec rec = {e.first, e.second, 0, 0};
         for (int i = 0; i < 2; i++) {
-            const BVHNode* child = e.node->getChildNode(i);
-            cbox[i] = &child->m_bounds;
+            const BVHNode* child = e.first->getChildNode(i);
+            S32 cidx;
             if (!child->isLeaf()) {
-                cidx[i] = (int)(nodeData.size() * sizeof(Int4)) / nodeOffsetSizeDiv;
-                stack.push_back(StackEntry{child, (S32)nodeData.size()});
-                nodeData.resize(nodeData.size() + 4);
-                continue;
+                cidx = (S32)((numNodeInt4 * (S64)sizeof(Int4)) / nodeOffsetSizeDiv);
+                stack.push_back(std::make_pair(child, (S32)numNodeInt4));
+                numNodeInt4 += 4;
+            } else {
+                const LeafNode* leaf = static_cast<const LeafNode*>(child);
+                cidx = ~(S32)numWoop;
+                leaves.push_back(LeafRec{leaf, (S32)numWoop});
+                numWoop += (S64)(leaf->m_hi - leaf->m_lo) * 3 + 1;  // three rows per triangle + the terminator
             }
-            const LeafNode* leaf = static_cast<const LeafNode*>(child);
-            cidx[i] = ~(int)triWoopData.size();
-            for (int j = leaf->m_lo; j < leaf->m_hi; j++) {
-                woopifyTri(bvh, j);
-                if (m_woop[0].x == 0.0f) m_woop[0].x = 0.0f;  // -0 would alias the terminator (:627-628)
-                Int4 w[3];
-                memcpy(w, m_woop, sizeof(w));
-                triWoopData.insert(triWoopData.end(), w, w + 3);
-                triIndexData.push_back(bvh.getTriIndices()[j]);
-                triIndexData.push_back(0);
-                triIndexData.push_back(0);
+            (i ? rec.c1 : rec.c0) = cidx;
+        }
+        inner.push_back(rec);
+        if (numNodeInt4 * (S64)sizeof(Int4) > 0x7FFFFFFFll || numWoop > 0x7FFFFFFFll) fail("CudaBVH::createCompact: BVH too large for 32-bit offsets");
+    }
+
+    // ---- 2. contents, in parallel ------------------------------------------------------------------------------
+    std::vector<Int4> nodeData((size_t)numNodeInt4);
+    std::vector<Int4> triWoopData((size_t)numWoop);
+    std::vector<S32>  triIndexData((size_t)numWoop);
+    const Vec3i* triVtxIndex = (const Vec3i*)bvh.getScene()->getTriVtxIndexBuffer().getPtr();
+    const Vec3f* vtxPos = (const Vec3f*)bvh.getScene()->getVtxPosBuffer().getPtr();
+    const std::vector<S32>& triIndices = bvh.getTriIndices();
+
+    auto fillInner = [&](size_t b, size_t e) {
+        for (size_t k = b; k < e; k++) {
+            const InnerRec& r = inner[k];
+            const AABB& b0 = r.node->getChildNode(0)->m_bounds;
+            const AABB& b1 = r.node->getChildNode(1)->m_bounds;
+            Int4* dst = &nodeData[(size_t)r.idx];
+            dst[0] = Int4{(S32)floatToBits(b0.min().x), (S32)floatToBits(b0.max().x), (S32)floatToBits(b0.min().y), (S32)floatToBits(b0.max().y)};
+            dst[1] = Int4{(S32)floatToBits(b1.min().x), (S32)floatToBits(b1.max().x), (S32)floatToBits(b1.min().y), (S32)floatToBits(b1.max().y)};
+            dst[2] = Int4{(S32)floatToBits(b0.min().z), (S32)floatToBits(b0.max().z), (S32)floatToBits(b1.min().z), (S32)floatToBits(b1.max().z)};
+            dst[3] = Int4{r.c0, r.c1, (S32)static_cast<const InnerNode*>(r.node)->getSplitInfo().getBitCode(), 0};
+        }
+    };
+    auto fillLeaves = [&](size_t b, size_t e) {
+        for (size_t k = b; k < e; k++) {
+            const LeafRec& r = leaves[k];
+            S32 o = r.ofs;
+            for (int j = r.leaf->m_lo; j < r.leaf->m_hi; j++, o += 3) {
+                Vec4f w[3];
+                woopify(triVtxIndex, vtxPos, triIndices[j], w);
+                if (w[0].x == 0.0f) w[0].x = 0.0f;  // -0 would alias the terminator (:627-628)
+                memcpy(&triWoopData[(size_t)o], w, sizeof(w));
+                triIndexData[(size_t)o] = triIndices[j];
+                triIndexData[(size_t)o + 1] = 0;
+                triIndexData[(size_t)o + 2] = 0;
             }
             const S32 nz = (S32)0x80000000;
-            triWoopData.push_back(Int4{nz, nz, nz, nz});  // Array<Vec4i>::add(0x80000000) -> Vec4i(a) sets all four (:641)
-            triIndexData.push_back(0);
+            triWoopData[(size_t)o] = Int4{nz, nz, nz, nz};  // Array<Vec4i>::add(0x80000000) -> Vec4i(a) sets all four (:641)
+            triIndexData[(size_t)o] = 0;
         }
-
-        const InnerNode* eN = static_cast<const InnerNode*>(e.node);
-        Int4* dst = &nodeData[e.idx];
-        dst[0] = Int4{(S32)floatToBits(cbox[0]->min().x), (S32)floatToBits(cbox[0]->max().x), (S32)floatToBits(cbox[0]->min().y), (S32)floatToBits(cbox[0]->max().y)};
-        dst[1] = Int4{(S32)floatToBits(cbox[1]->min().x), (S32)floatToBits(cbox[1]->max().x), (S32)floatToBits(cbox[1]->min().y), (S32)floatToBits(cbox[1]->max().y)};
-        dst[2] = Int4{(S32)floatToBits(cbox[0]->min().z), (S32)floatToBits(cbox[0]->max().z), (S32)floatToBits(cbox[1]->min().z), (S32)floatToBits(cbox[1]->max().z)};
-        dst[3] = Int4{cidx[0], cidx[1], (S32)eN->getSplitInfo().getBitCode(), 0};
+    };
+    unsigned threads = std::thread::hardware_concurrency();
+    if (threads == 0) threads = 1;
+    if (threads > 64) threads = 64;
+    if (inner.size() < 50000) threads = 1;
+    if (threads == 1) {
+        fillInner(0, inner.size());
+        fillLeaves(0, leaves.size());
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; t++)
+            pool.emplace_back([&, t]() {
+                fillInner(inner.size() * t / threads, inner.size() * (t + 1) / threads);
+                fillLeaves(leaves.size() * t / threads, leaves.size() * (t + 1) / threads);
+            });
+        for (std::thread& th : pool) th.join();
     }
 
     m_nodes.set(nodeData.data(), (S64)(nodeData.size() * sizeof(Int4)));
@@ -157,11 +199,10 @@ M4 inverted(const M4& a)
 }
 }  // namespace
 
-void CudaBVH::woopifyTri(const BVH& bvh, int idx)
+// Woop rows of scene triangle `tri` (CudaBVH::woopifyTri, CudaBVH.cpp:668-687).
+void CudaBVH::woopify(const Vec3i* triVtxIndex, const Vec3f* vtxPos, S32 tri, Vec4f (&out)[3])
 {
-    const Vec3i* triVtxIndex = (const Vec3i*)bvh.getScene()->getTriVtxIndexBuffer().getPtr();
-    const Vec3f* vtxPos = (const Vec3f*)bvh.getScene()->getVtxPosBuffer().getPtr();
-    const Vec3i& inds = triVtxIndex[bvh.getTriIndices()[idx]];
+    const Vec3i& inds = triVtxIndex[tri];
     const Vec3f& v0 = vtxPos[inds.x];
     const Vec3f& v1 = vtxPos[inds.y];
     const Vec3f& v2 = vtxPos[inds.z];
@@ -177,9 +218,9 @@ void CudaBVH::woopifyTri(const BVH& bvh, int idx)
     }
     mtx = inverted(mtx);
 
-    m_woop[0] = Vec4f(mtx.m[2][0], mtx.m[2][1], mtx.m[2][2], -mtx.m[2][3]);
-    m_woop[1] = Vec4f(mtx.m[0][0], mtx.m[0][1], mtx.m[0][2], mtx.m[0][3]);
-    m_woop[2] = Vec4f(mtx.m[1][0], mtx.m[1][1], mtx.m[1][2], mtx.m[1][3]);
+    out[0] = Vec4f(mtx.m[2][0], mtx.m[2][1], mtx.m[2][2], -mtx.m[2][3]);
+    out[1] = Vec4f(mtx.m[0][0], mtx.m[0][1], mtx.m[0][2], mtx.m[0][3]);
+    out[2] = Vec4f(mtx.m[1][0], mtx.m[1][1], mtx.m[1][2], mtx.m[1][3]);
 }
 
 }  // namespace FW

@@ -36,13 +36,12 @@ public:
 
 protected:
     void createCompact(const BVH& bvh, int nodeOffsetSizeDiv);  // CudaBVH.cpp:579-664
-    void woopifyTri(const BVH& bvh, int idx);                   // CudaBVH.cpp:668-687
+    static void woopify(const Vec3i* triVtxIndex, const Vec3f* vtxPos, S32 tri, Vec4f (&out)[3]);  // CudaBVH.cpp:668-687
 
     BVHLayout m_layout;
     Buffer    m_nodes;
     Buffer    m_triWoop;
     Buffer    m_triIndex;
-    Vec4f     m_woop[3];
     U32       m_flags;
     bool      m_flagsValid;
 };
