@@ -934,33 +934,34 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_cells_refit_kernel(const
 
 
 // =====================================================================================================================
-// Bottom-up ("agglomerative") emit + refit in one pass, indices by prefix scan.
+// Bottom-up ("agglomerative") emit + refit in one pass, indices by prefix counts.
 //
 // The reference's tree over distinct keys is the binary radix tree of the sorted keys: a node is a maximal range of keys
-// sharing a prefix, split where the next bit flips (emitTreeKernel.cu:233-381).  Instead of descending level by level it
-// is grown from the leaves: every run of equal keys starts as a cluster; a cluster [l, r) knows which neighbour is its
-// sibling -- the side whose boundary keys share the longer prefix (smaller key[x-1] ^ key[x]) -- and the two siblings
-// meet at their common boundary B: the first to arrive leaves its box there and stops, the second reads it, forms the
-// parent and goes on (one returning atomic per meeting, no spin anywhere, so no ordering between workgroups is assumed).
-// Child boxes are therefore complete when a node is formed: the refit comes for free, and fminf / fmaxf unions are
-// bit-identical in any order.  A merged cluster of at most leafSize triangles is just a bigger leaf candidate; the first
-// merge that exceeds leafSize is an inner node and turns its small children into leaves (the reference's leaf rule).
+// sharing a prefix, split where the next bit flips (emitTreeKernel.cu:233-381); a child becomes a leaf as soon as it holds at
+// most leafSize triangles (:289-292).  Instead of descending level by level the tree is grown from its leaves:
 //
-// A node is IDENTIFIED by its split position B (the root by 0), a leaf by its first sorted position: nothing is
-// allocated while the tree is formed.  One prefix scan over the node / leaf flags then gives every node its index
-// (rank of its position, root = 0) and every leaf its storage (3 * triangles before + leaves before), with no atomic
-// counter on the critical path and a deterministic numbering.
-//
-// Meetings whose parent range lies inside the workgroup's 512-key tile -- nearly all of them -- use LDS slots and LDS
-// atomics; only the clusters that outgrow their tile meet through memory (agent-scope stores of the 32-byte slot,
-// drained, then the atomic; agent-scope loads after it).
-//
-// Runs of more than leafSize equal keys are the reference's median-split subtrees whose leaf rule depends on the depth
-// (level bit 0, emitTreeKernel.cu:289-292).  They are rare; the pass records them (their positions get no leaf storage
-// here) and the host finishes them with the subtree kernels after the fast path, once depths are known.
+//   * LEAVES come straight from the keys: the leaf of position i is the largest prefix group around i with at most leafSize
+//     members, which only depends on the highest differing bits between key[i] and its leafSize neighbours on either side.
+//   * A cluster [l, r) knows which neighbour is its sibling -- the side whose boundary keys share the longer prefix (smaller
+//     key[x-1] ^ key[x]) -- and the two siblings MEET at their common boundary B: the first to arrive leaves its box there and
+//     stops, the second reads it, forms the parent and goes on (one returning atomic per meeting, no spin anywhere, so no
+//     ordering between workgroups is assumed).  Child boxes are complete when a node is formed: the refit comes for free, and
+//     fminf / fmaxf unions are bit-identical in any order.
+//   * A node is IDENTIFIED by its split position B (the root by 0), a leaf by its first sorted position: nothing is allocated
+//     while the tree is formed.  Prefix counts over the node / leaf bit masks then give every node its index (rank of its
+//     position, root = 0) and every leaf its storage (3 * start + leaves before), with no atomic counter on the critical path and
+//     a deterministic numbering.
+//   * Meetings whose parent range lies inside the workgroup's 512-key tile -- nearly all of them -- use LDS slots and LDS
+//     atomics; only clusters that outgrow their tile meet through memory (agent-scope stores of the 32-byte slot, drained, then
+//     the atomic; agent-scope loads after it).
+//   * RUNS of more than leafSize equal keys are the reference's median-split subtrees (:282), whose leaf rule depends on the
+//     depth (level bit 0, :289-292).  The bottom-up pass treats such a run as one opaque cluster; lbvh_runs_kernel then walks
+//     the parent positions for its depth and records its median nodes and leaves under the same position scheme.
+// Kernels: lbvh_agglomerate_kernel -> lbvh_runs_kernel -> lbvh_count_kernel -> lbvh_tilescan_kernel -> lbvh_finalize_kernel.
 // =====================================================================================================================
 constexpr int AGG_TILE = 512;
-constexpr int AGG_REF_GROUP = 0x7FFFFFFF;   // child reference of a run handed to the subtree kernels (patched later)
+constexpr int AGG_HALO = 32;                // neighbour keys kept on either side of the tile (leafSize <= AGG_HALO)
+constexpr int AGG_REF_RUN = 0x7FFFFFFF;     // child reference of a run of equal keys until lbvh_runs_kernel has patched it
 
 struct AggSlot {             // what the first sibling leaves at the meeting point
     float b[6];              // lo.x hi.x lo.y hi.y lo.z hi.z
@@ -971,17 +972,17 @@ static_assert(sizeof(AggSlot) == 32, "AggSlot must be 32 bytes");
 
 struct AggCtx {
     const unsigned int* keys;
-    const float2* triBox;
+    const int* triSorted;        // sorted position -> triangle
+    const float2* boxMesh;       // per triangle (mesh order): (lo, hi) per axis, epsilon applied
     int n, leafSize;
     int* rec;                    // [n + 1][16] node records by split position (0 = root)
     unsigned char* nodeFlag;     // [n + 1]
     unsigned char* leafFlag;     // [n + 1] a leaf starts here
-    unsigned char* groupPos;     // [n + 1] position belongs to a run handed to the subtree kernels
     unsigned int* arrive;        // [n + 1] meeting counters (memory protocol), zeroed
     AggSlot* slot;               // [n + 1][2]
     int* parentPos;              // [n + 1] record position of a node's parent
-    int4* groups;                // (parent position or -1, side, start, end)
-    unsigned int* groupCount;
+    int4* runs;                  // (parent position or -1, side, start, end) of the runs of more than leafSize equal keys
+    unsigned int* runCount;
     LbvhState* st;
     int useLds;
 };
@@ -1003,56 +1004,118 @@ __device__ __forceinline__ AggSlot agg_load_slot(const AggSlot* src)
     return v;
 }
 
+// box of the sorted positions [a, b), folded from FLT_MAX like calcLeaf (emitTreeKernel.cu:383-408)
+__device__ __forceinline__ void agg_fold_box(const AggCtx& c, int a, int b, float (&box)[6])
+{
+    box[0] = box[2] = box[4] = FLT_MAX;
+    box[1] = box[3] = box[5] = -FLT_MAX;
+    for (int j = a; j < b; j++) {
+        const int t = c.triSorted[j];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float2 v = c.boxMesh[3 * (size_t)t + k];
+            box[2 * k] = fminf(box[2 * k], v.x);
+            box[2 * k + 1] = fmaxf(box[2 * k + 1], v.y);
+        }
+    }
+}
+
+__device__ __forceinline__ void agg_write_record(int* rec, int id, const float* b0, const float* b1, int link0, int link1, int splitBit)
+{
+    int* nd = rec + (size_t)id * 16;
+    float* nf = reinterpret_cast<float*>(nd);
+    reinterpret_cast<float4*>(nf)[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
+    reinterpret_cast<float4*>(nf)[1] = make_float4(b1[0], b1[1], b1[2], b1[3]);
+    reinterpret_cast<float4*>(nf)[2] = make_float4(b0[4], b0[5], b1[4], b1[5]);
+    reinterpret_cast<int4*>(nd)[3] = make_int4(link0, link1, splitBit, 0);
+}
+
 __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
 {
-    __shared__ unsigned int sKeys[AGG_TILE + 2];      // [0] = key before the tile, [AGG_TILE + 1] = key after it
+    __shared__ unsigned int sKeys[AGG_TILE + 2 * AGG_HALO];   // sKeys[AGG_HALO + k] = key of position tileBeg + k
     __shared__ unsigned int sArrive[AGG_TILE + 1];
     __shared__ AggSlot sSlot[AGG_TILE + 1][2];
-    const int tid = threadIdx.x;
-    const int n = c.n;
+    __shared__ int sWalker[AGG_TILE];                         // start positions of the tile's clusters, compacted; bit 31 = run of equal keys
+    __shared__ int sWalkerEnd[AGG_TILE];
+    __shared__ unsigned int sWaveCount[AGG_TILE / 64], sNumWalkers;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = c.n, leafSize = c.leafSize;
     const int tileBeg = blockIdx.x * AGG_TILE;
     const int tileEnd = min(tileBeg + AGG_TILE, n);
-    const int i = tileBeg + tid;
-    sKeys[tid + 1] = i < n ? c.keys[i] : 0u;
-    if (tid == 0) {
-        sKeys[0] = tileBeg > 0 ? c.keys[tileBeg - 1] : 0u;
-        sKeys[AGG_TILE + 1] = (tileBeg + AGG_TILE) < n ? c.keys[tileBeg + AGG_TILE] : 0u;
+    for (int k = tid; k < AGG_TILE + 2 * AGG_HALO; k += AGG_TILE) {
+        const int x = tileBeg - AGG_HALO + k;
+        sKeys[k] = (x >= 0 && x < n) ? c.keys[x] : 0u;
     }
     sArrive[tid] = 0;
     if (tid == 0) sArrive[AGG_TILE] = 0;
     __syncthreads();
-    if (i >= n) return;
 
     auto key = [&](int x) -> unsigned int {   // sorted key at position x (0 <= x < n)
-        const int rel = x - tileBeg + 1;
-        return (rel >= 0 && rel <= AGG_TILE + 1 && x <= tileBeg + AGG_TILE) ? sKeys[rel] : c.keys[x];
+        const int rel = x - tileBeg + AGG_HALO;
+        return (rel >= 0 && rel < AGG_TILE + 2 * AGG_HALO) ? sKeys[rel] : c.keys[x];
     };
+    auto hbit = [](unsigned int x) -> int { return x ? 31 - __clz((int)x) : -1; };   // highest set bit, -1 for equal keys
 
-    const unsigned int myKey = sKeys[tid + 1];
-    if (i > 0 && key(i - 1) == myKey) return;         // not the first of its run
-
-    // ---- the run [l, r) of equal keys and its box -------------------------------------------------------------------------
-    int l = i, r = i + 1;
-    while (r < n && key(r) == myKey) r++;
-    float box[6] = {FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX};   // folded from FLT_MAX like calcLeaf (:383-408)
-    for (int j = l; j < r; j++) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float2 t = c.triBox[3 * (size_t)j + k];
-            box[2 * k] = fminf(box[2 * k], t.x);
-            box[2 * k + 1] = fmaxf(box[2 * k + 1], t.y);
+    // ---- the cluster every position starts in ---------------------------------------------------------------------------------
+    // leaf of position i = the largest prefix group around i with at most leafSize members: with the neighbours' highest differing
+    // bits sorted, T = the leafSize-th smallest, the leaf is i plus every neighbour below T.  T == -1: at least leafSize neighbours
+    // carry the same key -- position i is inside a run of more than leafSize equal keys.
+    const int i = tileBeg + tid;
+    bool starts = false, isRun = false;
+    int cEnd = 0;
+    if (i < n) {
+        const unsigned int myKey = sKeys[AGG_HALO + tid];
+        int a = 1, b = 1, T = 64;
+        for (int step = 0; step < leafSize; step++) {
+            const int hl = (i - a >= 0) ? hbit(key(i - a) ^ myKey) : 64;
+            const int hr = (i + b < n) ? hbit(key(i + b) ^ myKey) : 64;
+            if (hl <= hr) { T = hl; a++; } else { T = hr; b++; }
+        }
+        if (T == -1) {
+            isRun = true;
+            starts = i == 0 || key(i - 1) != myKey;
+            if (starts) {
+                int r = i + 1;
+                while (r < n && key(r) == myKey) r++;
+                cEnd = r;
+            }
+        } else {
+            int ls = i, le = i + 1;
+            while (ls - 1 >= 0 && (i - (ls - 1)) <= leafSize && hbit(key(ls - 1) ^ myKey) < T) ls--;
+            while (le < n && (le - i) <= leafSize && hbit(key(le) ^ myKey) < T) le++;
+            starts = ls == i;
+            cEnd = le;
         }
     }
-    int kind = (r - l) <= c.leafSize ? 0 : 2;         // 0 leaf candidate, 1 inner node, 2 run for the subtree kernels
+    // compact the starting clusters so that they occupy the first lanes of the workgroup
+    const unsigned long long m = __ballot(starts);
+    if (lane == 0) sWaveCount[wave] = (unsigned int)__popcll(m);
+    __syncthreads();
+    unsigned int before = 0, all = 0;
+    for (int w = 0; w < AGG_TILE / 64; w++) {
+        if (w < wave) before += sWaveCount[w];
+        all += sWaveCount[w];
+    }
+    if (starts) {
+        const unsigned int wi = before + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+        sWalker[wi] = i | (isRun ? (int)0x80000000u : 0);
+        sWalkerEnd[wi] = cEnd;
+    }
+    if (tid == 0) sNumWalkers = all;
+    __syncthreads();
+    if ((unsigned int)tid >= sNumWalkers) return;
+
+    int l = sWalker[tid] & 0x7FFFFFFF, r = sWalkerEnd[tid];
+    int kind = (sWalker[tid] < 0) ? 2 : 0;            // 0 leaf, 1 inner node, 2 run of equal keys
     int ref = 0;                                      // kind 1: the node's record position
     int h = kind == 2 ? 1 : 0;                        // levels of inner nodes below and including this cluster
-    if (kind == 2)
-        for (int j = l; j < r; j++) c.groupPos[j] = 1;
+    float box[6];
+    agg_fold_box(c, l, r, box);
 
     for (;;) {
         if (l == 0 && r == n) {                       // only a single run can get here unmerged: all keys equal
-            const unsigned int g = atomicAdd(c.groupCount, 1u);
-            c.groups[g] = make_int4(-1, 0, 0, n);
+            const unsigned int g = atomicAdd(c.runCount, 1u);
+            c.runs[g] = make_int4(-1, 0, 0, n);
             break;
         }
         const unsigned int dl = l > 0 ? (key(l - 1) ^ key(l)) : 0xFFFFFFFFu;
@@ -1064,8 +1127,8 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
         bool inTile = false;
         if (c.useLds && B > tileBeg && B < tileEnd) {
             const unsigned int pfx = key(B) >> (hb + 1);
-            const bool leftOut = tileBeg == 0 || (sKeys[0] >> (hb + 1)) != pfx;
-            const bool rightOut = tileEnd >= n || (sKeys[AGG_TILE + 1] >> (hb + 1)) != pfx;
+            const bool leftOut = tileBeg == 0 || (sKeys[AGG_HALO - 1] >> (hb + 1)) != pfx;
+            const bool rightOut = tileEnd >= n || (sKeys[AGG_HALO + AGG_TILE] >> (hb + 1)) != pfx;
             inTile = leftOut && rightOut;
         }
         AggSlot mine;
@@ -1097,24 +1160,12 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
         // children in tree order: 0 = [L, B), 1 = [B, R)
         const float* b0 = sibRight ? box : sib.b;
         const float* b1 = sibRight ? sib.b : box;
-        const int kind0 = sibRight ? kind : sKind, kind1 = sibRight ? sKind : kind;
-        const int ref0 = sibRight ? ref : sRef, ref1 = sibRight ? sRef : ref;
-        const int h0 = sibRight ? h : sH, h1 = sibRight ? sH : h;
-        float ub[6];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            ub[2 * k] = fminf(b0[2 * k], b1[2 * k]);
-            ub[2 * k + 1] = fmaxf(b0[2 * k + 1], b1[2 * k + 1]);
-        }
-        if (R - L <= c.leafSize) {                    // still a leaf candidate (both children were)
-            l = L; r = R; kind = 0; ref = 0; h = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) box[k] = ub[k];
-            continue;
-        }
+        const int ck[2] = {sibRight ? kind : sKind, sibRight ? sKind : kind};
+        const int cr[2] = {sibRight ? ref : sRef, sibRight ? sRef : ref};
+        const int hmax = max(h, sH);
         const int id = (L == 0 && R == n) ? 0 : B;    // record position of the new node
+        const int cs[2] = {L, B}, ce[2] = {B, R};
         int link[2];
-        const int cs[2] = {L, B}, ce[2] = {B, R}, ck[2] = {kind0, kind1}, cr[2] = {ref0, ref1};
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             if (ck[k] == 0) {                          // createLeaf: the child is a leaf starting at cs[k]
@@ -1124,19 +1175,20 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
                 link[k] = cr[k];
                 c.parentPos[cr[k]] = id;
             } else {
-                link[k] = AGG_REF_GROUP;
-                const unsigned int g = atomicAdd(c.groupCount, 1u);
-                c.groups[g] = make_int4(id, k, cs[k], ce[k]);
+                link[k] = AGG_REF_RUN;
+                const unsigned int g = atomicAdd(c.runCount, 1u);
+                c.runs[g] = make_int4(id, k, cs[k], ce[k]);
             }
         }
-        int* nd = c.rec + (size_t)id * 16;
-        float* nf = reinterpret_cast<float*>(nd);
-        reinterpret_cast<float4*>(nf)[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
-        reinterpret_cast<float4*>(nf)[1] = make_float4(b1[0], b1[1], b1[2], b1[3]);
-        reinterpret_cast<float4*>(nf)[2] = make_float4(b0[4], b0[5], b1[4], b1[5]);
-        reinterpret_cast<int4*>(nd)[3] = make_int4(link[0], link[1], hb % 3, 0);
+        agg_write_record(c.rec, id, b0, b1, link[0], link[1], hb % 3);
         c.nodeFlag[id] = 1;
-        l = L; r = R; kind = 1; ref = id; h = 1 + max(h0, h1);
+        float ub[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            ub[2 * k] = fminf(b0[2 * k], b1[2 * k]);
+            ub[2 * k + 1] = fmaxf(b0[2 * k + 1], b1[2 * k + 1]);
+        }
+        l = L; r = R; kind = 1; ref = id; h = 1 + hmax;
 #pragma unroll
         for (int k = 0; k < 6; k++) box[k] = ub[k];
         if (id == 0) {                                 // the root: deepest level that holds an inner node, plus one
@@ -1146,165 +1198,163 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
     }
 }
 
-// Exclusive ranks of the node flags, the leaf-start flags and the positions that keep their leaf storage in the fast path
-// (all but the handed-over runs), by a single-pass chained scan with decoupled look-back (2048 positions per workgroup,
-// tickets as in onesweep_pass_kernel).  Totals go to the builder state: nodeCount, leafPtr = (kept triangles << 32) | leaves.
-constexpr int RANK_THREADS = 256;
-constexpr int RANK_ITEMS = 8;
-constexpr int RANK_TILE = RANK_THREADS * RANK_ITEMS;
-
-__global__ __launch_bounds__(RANK_THREADS) void lbvh_rank_kernel(int n, const unsigned char* __restrict__ nodeFlag,
-                                                                 const unsigned char* __restrict__ leafFlag,
-                                                                 const unsigned char* __restrict__ groupPos, uint4* __restrict__ ranks /* [n + 1] */,
-                                                                 unsigned long long* tileState /* [tiles][2] */, unsigned int* ticket,
-                                                                 LbvhState* st, unsigned int* errFlag)
+// Runs of more than leafSize equal keys: the reference splits them at the median (emitTreeKernel.cu:282) until a part holds at
+// most leafSize triangles or the level bit reaches 0 (:289-292), so the subtree depends on the run's depth -- the number of its
+// ancestors, found by walking the parent positions.  One thread per run records the median nodes (identified by their split
+// position, which lies strictly inside the run) and flags the leaves, exactly like the bottom-up pass does for the rest of the tree,
+// and patches the reference its parent holds.  Boxes are folded per child range.
+__global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
 {
-    __shared__ unsigned int s_tile;
-    __shared__ unsigned int s_red[3][RANK_THREADS / 64];
-    __shared__ unsigned int s_base[3];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const unsigned int tile = s_tile;
-    const int total = n + 1;                           // positions 0 .. n
-    const int base = (int)tile * RANK_TILE + tid * RANK_ITEMS;
-    unsigned int f[3][RANK_ITEMS];
-    unsigned int sum[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < RANK_ITEMS; k++) {
-        const int p = base + k;
-        const bool ok = p < total;
-        f[0][k] = ok ? nodeFlag[p] : 0u;
-        f[1][k] = ok ? leafFlag[p] : 0u;
-        f[2][k] = ok && p < n ? (groupPos[p] ? 0u : 1u) : 0u;
-        sum[0] += f[0][k]; sum[1] += f[1][k]; sum[2] += f[2][k];
-    }
-    // exclusive scan of the per-thread sums inside the workgroup
-    unsigned int excl[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        unsigned int incl = sum[q];
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int u = (unsigned int)__shfl_up((int)incl, off);
-            if (lane >= off) incl += u;
+    const unsigned int numRuns = *c.runCount;
+    for (unsigned int g = blockIdx.x * blockDim.x + threadIdx.x; g < numRuns; g += gridDim.x * blockDim.x) {
+        const int4 q = c.runs[g];
+        int depth = 0;
+        if (q.x >= 0) {
+            depth = 1;
+            for (int p = q.x; p != 0; p = c.parentPos[p]) depth++;
         }
-        if (lane == 63) s_red[q][wave] = incl;
-        excl[q] = incl - sum[q];
-    }
-    __syncthreads();
-    unsigned int tileSum[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        unsigned int before = 0, all = 0;
-        for (int w = 0; w < RANK_THREADS / 64; w++) {
-            if (w < wave) before += s_red[q][w];
-            all += s_red[q][w];
+        int* parentLink = q.x >= 0 ? c.rec + (size_t)q.x * 16 + 12 + q.y : nullptr;
+        if (depth >= 30) {                              // the parent's level bit is 0: a leaf whatever its size
+            c.leafFlag[q.z] = 1;
+            *parentLink = ~q.z;
+            continue;
         }
-        excl[q] += before;
-        tileSum[q] = all;
-    }
-    // chained scan over the tiles: word 0 = status (2 bits) | nodes (31 bits) | leaves (31 bits); word 1 = status | kept positions.
-    // The first wave looks back 64 predecessors per round trip (lane L reads tile t - L): the sums of the lanes up to the nearest
-    // inclusive word -- or up to the first unpublished one, which is then polled again -- are reduced across the wave.
-    if (wave == 0) {
-        const unsigned long long agg0 = ((unsigned long long)tileSum[0] << 31) | tileSum[1];
-        const unsigned long long agg1 = tileSum[2];
-        unsigned long long* my = tileState + 2 * (size_t)tile;
-        const unsigned long long ST_AGG = 1ull << 62, ST_INC = 2ull << 62, MASK = (1ull << 62) - 1ull;
-        unsigned int e[3] = {0, 0, 0};
-        if (tile > 0) {
-            if (lane == 0) {
-                __hip_atomic_store(my + 1, ST_AGG | agg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(my, ST_AGG | agg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            int t = (int)tile - 1;
-            unsigned int spins = 0;
-            for (;;) {
-                const int tt = t - lane;
-                unsigned long long w0 = ST_INC, w1 = ST_INC;   // before the first tile: an inclusive zero
-                if (tt >= 0) {
-                    const unsigned long long* p = tileState + 2 * (size_t)tt;
-                    w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                // a tile's two words are published one after the other (word 1 first): a pair counts when both carry the same status
-                const unsigned int st = ((w0 >> 62) == (w1 >> 62)) ? (unsigned int)(w0 >> 62) : 0u;
-                const unsigned long long ready = __ballot(st != 0u), incl = __ballot(st == 2u);
-                const int firstWait = ready == ~0ull ? 64 : __builtin_ctzll(~ready);
-                const int firstInc = incl ? __builtin_ctzll(incl) : 64;
-                const int take = min(firstWait, firstInc + 1);
-                unsigned int v[3] = {0, 0, 0};
-                if (lane < take) {
-                    v[0] = (unsigned int)((w0 & MASK) >> 31);
-                    v[1] = (unsigned int)(w0 & 0x7FFFFFFFull);
-                    v[2] = (unsigned int)(w1 & MASK);
-                }
+        // explicit stack of (start, end, depth, record position); a node at depth 29 only has leaf children
+        int stS[32], stE[32], stD[32], stP[32];
+        int sp = 0;
+        const int top = q.x >= 0 ? ((q.z + q.w) >> 1) : 0;
+        if (parentLink) *parentLink = top;
+        stS[0] = q.z; stE[0] = q.w; stD[0] = depth; stP[0] = top;
+        sp = 1;
+        unsigned int deepest = 0;
+        while (sp > 0) {
+            sp--;
+            const int a = stS[sp], b = stE[sp], d = stD[sp], id = stP[sp];
+            const int mid = (a + b) >> 1;
+            deepest = max(deepest, (unsigned int)d + 1u);
+            float b0[6], b1[6];
+            agg_fold_box(c, a, mid, b0);
+            agg_fold_box(c, mid, b, b1);
+            const int cs[2] = {a, mid}, ce[2] = {mid, b};
+            int link[2];
 #pragma unroll
-                for (int q = 0; q < 3; q++) {
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) v[q] += (unsigned int)__shfl_xor((int)v[q], off);
-                    e[q] += v[q];
-                }
-                if (firstInc < firstWait) break;               // the consumed lanes end in an inclusive prefix
-                t -= take;
-                if (take < 64) {
-                    if (++spins > (1u << 22)) { if (lane == 0) atomicOr(errFlag, 4u); break; }
-                    __builtin_amdgcn_s_sleep(1);
+            for (int k = 0; k < 2; k++) {
+                if ((ce[k] - cs[k]) <= c.leafSize || d == 29) {
+                    c.leafFlag[cs[k]] = 1;
+                    link[k] = ~cs[k];
+                } else {
+                    const int cm = (cs[k] + ce[k]) >> 1;
+                    link[k] = cm;
+                    stS[sp] = cs[k]; stE[sp] = ce[k]; stD[sp] = d + 1; stP[sp] = cm;
+                    sp++;
                 }
             }
+            // split word of a median split: level = -1 in the reference (no differing bit), and -1 % 3 == -1
+            agg_write_record(c.rec, id, b0, b1, link[0], link[1], -1);
+            c.nodeFlag[id] = 1;
         }
-        if (lane == 0) {
-            const unsigned long long inc0 = ((((unsigned long long)(e[0] + tileSum[0])) << 31) | (unsigned long long)(e[1] + tileSum[1])) & MASK;
-            __hip_atomic_store(my + 1, ST_INC | ((unsigned long long)(e[2] + tileSum[2]) & MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(my, ST_INC | inc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_base[0] = e[0]; s_base[1] = e[1]; s_base[2] = e[2];
-            if ((int)((tile + 1) * RANK_TILE) >= total) {      // the last tile knows the totals
-                st->nodeCount = e[0] + tileSum[0];
-                st->leafPtr = ((unsigned long long)(e[2] + tileSum[2]) << 32) | (unsigned long long)(e[1] + tileSum[1]);
-            }
-        }
-    }
-    __syncthreads();
-    unsigned int run[3] = {s_base[0] + excl[0], s_base[1] + excl[1], s_base[2] + excl[2]};
-#pragma unroll
-    for (int k = 0; k < RANK_ITEMS; k++) {
-        const int p = base + k;
-        if (p < total) ranks[p] = make_uint4(run[0], run[1], run[2], 0u);
-        run[0] += f[0][k]; run[1] += f[1][k]; run[2] += f[2][k];
+        atomicMax(&c.st->maxLevel, min(deepest, 30u));
     }
 }
 
-// Final pass, one thread per sorted position j: the node recorded at j (if any) goes to its ranked index with its child references
-// translated, triangle j's Woop rows and index go to its leaf's storage (calcWoopKernel, emitTreeKernel.cu:574-645), and the leaf
-// that ends before j gets its terminator.  Positions of handed-over runs are left to the subtree kernels.
-__global__ __launch_bounds__(256) void lbvh_finalize_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
-                                                            const int* __restrict__ triSorted, const int* __restrict__ rec,
-                                                            const unsigned char* __restrict__ nodeFlag, const unsigned char* __restrict__ leafFlag,
-                                                            const unsigned char* __restrict__ groupPos, const uint4* __restrict__ ranks,
-                                                            int* __restrict__ nodes, unsigned int nodeCap, float4* __restrict__ outWoop,
-                                                            int* __restrict__ outIdx, int* __restrict__ triOut, LbvhState* st)
+// Node / leaf-start flags -> bit masks (one 64-bit word per wave) and counts per 256 positions.
+constexpr int CNT_TILE = 256;
+
+__global__ __launch_bounds__(CNT_TILE) void lbvh_count_kernel(int n, const unsigned char* __restrict__ nodeFlag, const unsigned char* __restrict__ leafFlag,
+                                                              unsigned long long* __restrict__ nodeBits, unsigned long long* __restrict__ leafBits,
+                                                              uint2* __restrict__ tileCount)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned int s_n[CNT_TILE / 64], s_l[CNT_TILE / 64];
+    const int p = blockIdx.x * CNT_TILE + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool ok = p <= n;
+    const unsigned long long nb = __ballot(ok && nodeFlag[ok ? p : 0] != 0), lb = __ballot(ok && leafFlag[ok ? p : 0] != 0);
+    if (lane == 0) {
+        nodeBits[(size_t)blockIdx.x * (CNT_TILE / 64) + wave] = nb;
+        leafBits[(size_t)blockIdx.x * (CNT_TILE / 64) + wave] = lb;
+        s_n[wave] = (unsigned int)__popcll(nb);
+        s_l[wave] = (unsigned int)__popcll(lb);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int a = 0, b = 0;
+        for (int w = 0; w < CNT_TILE / 64; w++) { a += s_n[w]; b += s_l[w]; }
+        tileCount[blockIdx.x] = make_uint2(a, b);
+    }
+}
+
+// Exclusive scan of the per-tile counts (one workgroup); the totals become the builder state's nodeCount and leafPtr.
+__global__ __launch_bounds__(1024) void lbvh_tilescan_kernel(int numTiles, int n, const uint2* __restrict__ tileCount, uint2* __restrict__ tileBase,
+                                                             LbvhState* st)
+{
+    __shared__ unsigned int s_a[1024], s_b[1024];
+    const int tid = threadIdx.x;
+    const int per = (numTiles + 1023) / 1024;
+    const int beg = min(tid * per, numTiles), end = min(beg + per, numTiles);
+    unsigned int a = 0, b = 0;
+    for (int k = beg; k < end; k++) { const uint2 v = tileCount[k]; a += v.x; b += v.y; }
+    s_a[tid] = a; s_b[tid] = b;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned int va = tid >= off ? s_a[tid - off] : 0u, vb = tid >= off ? s_b[tid - off] : 0u;
+        __syncthreads();
+        s_a[tid] += va; s_b[tid] += vb;
+        __syncthreads();
+    }
+    unsigned int ra = s_a[tid] - a, rb = s_b[tid] - b;
+    for (int k = beg; k < end; k++) {
+        const uint2 v = tileCount[k];
+        tileBase[k] = make_uint2(ra, rb);
+        ra += v.x; rb += v.y;
+    }
+    if (tid == 1023) {
+        st->nodeCount = s_a[1023];
+        st->leafPtr = ((unsigned long long)n << 32) | (unsigned long long)s_b[1023];
+    }
+}
+
+// exclusive rank of position p: set bits before p
+__device__ __forceinline__ unsigned int agg_rank(const unsigned long long* __restrict__ bits, unsigned int tileBaseValue, int p)
+{
+    const int w = p >> 6;
+    unsigned int acc = tileBaseValue;
+    for (int k = (p >> 8) << 2; k < w; k++) acc += (unsigned int)__popcll(bits[k]);
+    return acc + (unsigned int)__popcll(bits[w] & ((1ull << (p & 63)) - 1ull));
+}
+
+// Final pass, one thread per sorted position j: the node recorded at j (if any) goes to its ranked index with its child references
+// translated, triangle j's Woop rows and index go to its leaf's storage (calcWoopKernel, emitTreeKernel.cu:574-645; leaf storage
+// = 3 * first position + leaves before, createLeaf :176-181 with the leaves numbered in sorted order), and the leaf that ends
+// before j gets its terminator.
+__global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
+                                                                 const int* __restrict__ triSorted, const int* __restrict__ rec,
+                                                                 const unsigned long long* __restrict__ nodeBits,
+                                                                 const unsigned long long* __restrict__ leafBits, const uint2* __restrict__ tileBase,
+                                                                 int* __restrict__ nodes, unsigned int nodeCap, float4* __restrict__ outWoop,
+                                                                 int* __restrict__ outIdx, LbvhState* st)
+{
+    const int j = blockIdx.x * CNT_TILE + threadIdx.x;
     if (j > n) return;
-    const uint4 rk = ranks[j];
-    if (nodeFlag[j]) {
-        if (rk.x >= nodeCap) { atomicOr(&st->overflow, 1u); }
+    const uint2 tb = tileBase[blockIdx.x];
+    const unsigned int rkN = agg_rank(nodeBits, tb.x, j), rkL = agg_rank(leafBits, tb.y, j);
+    const bool isNode = (nodeBits[j >> 6] >> (j & 63)) & 1ull, isLeafStart = (leafBits[j >> 6] >> (j & 63)) & 1ull;
+    if (isNode) {
+        if (rkN >= nodeCap) atomicOr(&st->overflow, 1u);
         else {
             const int4* src = reinterpret_cast<const int4*>(rec + (size_t)j * 16);
-            int4* dst = reinterpret_cast<int4*>(nodes + (size_t)rk.x * 16);
+            int4* dst = reinterpret_cast<int4*>(nodes + (size_t)rkN * 16);
             const int4 a = src[0], b = src[1], cc = src[2];
             int4 d = src[3];
             int* lk = &d.x;
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int ref = k ? d.y : d.x;
-                int out = ref;
-                if (ref < 0) {                                   // leaf starting at ~ref: storage = 3 * kept triangles before + leaves before
-                    const uint4 lr = ranks[~ref];
-                    out = ~(int)(3u * lr.z + lr.y);
-                } else if (ref != AGG_REF_GROUP) {
-                    out = (int)(ranks[ref].x * 64u);             // inner child recorded at position ref
+                int out;
+                if (ref < 0) {                                   // leaf starting at s = ~ref: float4 index 3 * s + leaves before s
+                    const int sPos = ~ref;
+                    out = ~(int)(3u * (unsigned int)sPos + agg_rank(leafBits, tileBase[sPos >> 8].y, sPos));
+                } else {                                         // inner child recorded at position ref
+                    out = (int)(agg_rank(nodeBits, tileBase[ref >> 8].x, ref) * 64u);
                 }
                 lk[k] = out;
             }
@@ -1312,22 +1362,13 @@ __global__ __launch_bounds__(256) void lbvh_finalize_kernel(int n, const int* __
         }
     }
     const float nz = __uint_as_float(0x80000000u);
-    if (j == n) {                                                // terminator of the last leaf of the fast path
-        if (rk.y > 0) {
-            const unsigned int tp = 3u * rk.z + rk.y - 1u;
-            outWoop[tp] = make_float4(nz, nz, nz, nz);
-            outIdx[tp] = 0;
-        }
-        return;
-    }
-    if (groupPos[j]) return;
-    const unsigned int lf = leafFlag[j];
-    if (lf && rk.y > 0) {                                        // a leaf starts here: close the one before it
-        const unsigned int tp = 3u * rk.z + rk.y - 1u;
+    if ((isLeafStart || j == n) && rkL > 0) {                     // a leaf starts here (or the array ends): close the one before it
+        const unsigned int tp = 3u * (unsigned int)j + rkL - 1u;
         outWoop[tp] = make_float4(nz, nz, nz, nz);
         outIdx[tp] = 0;
     }
-    const int o = (int)(3u * rk.z + rk.y + lf) - 1;              // 3 * kept triangles before + leaves up to and including this one - 1
+    if (j == n) return;
+    const int o = (int)(3u * (unsigned int)j + rkL + (isLeafStart ? 1u : 0u)) - 1;   // 3 j + leaves up to and including this one - 1
     const int t = triSorted[j];
     float4 r0, r1, r2;
     woop_rows(tri, pos, t, r0, r1, r2);
@@ -1337,65 +1378,6 @@ __global__ __launch_bounds__(256) void lbvh_finalize_kernel(int n, const int* __
     outIdx[o + 0] = t;
     outIdx[o + 1] = 0;
     outIdx[o + 2] = 0;
-    triOut[j] = o;
-}
-
-// Slow path for the handed-over runs (equal keys, more than leafSize triangles), after the fast path: depth of each run's root by
-// walking the parent positions, its node index / forced leaf, the parent's link patched in the final node array, and the hand-over
-// list for lbvh_subtree_kernel / the oversize queue for emit_top.  One workgroup (the counters live in LDS like lbvh_top_kernel).
-__global__ __launch_bounds__(TOP_THREADS) void lbvh_groups_kernel(EmitCtx c, int n, const int4* __restrict__ groups, unsigned int numGroups,
-                                                                  const int* __restrict__ parentPos, const uint4* __restrict__ ranks,
-                                                                  int4* qA, int4* qB, int* topLst)
-{
-    __shared__ EmitShared sh;
-    __shared__ unsigned int s_over;
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        sh.nodeCtr = c.st->nodeCount; sh.nodeBase = 0;
-        sh.leafCtr = c.st->leafPtr; sh.leafBase = 0ull; sh.numSub = 0; sh.maxLevel = c.st->maxLevel;
-        s_over = 0;
-    }
-    __syncthreads();
-    for (unsigned int g = tid; g < numGroups; g += TOP_THREADS) {
-        const int4 q = groups[g];
-        int depth = 0;
-        if (q.x >= 0) {
-            depth = 1;
-            for (int p = q.x; p != 0; p = parentPos[p]) depth++;
-        }
-        int* nd = q.x >= 0 ? c.nodes + (size_t)ranks[q.x].x * 16 : nullptr;
-        if (depth >= 30) {  // the parent's level bit is 0: the run is a leaf whatever its size (emitTreeKernel.cu:289-292)
-            const unsigned long long lp = atomicAdd(&sh.leafCtr, ((unsigned long long)(q.w - q.z) << 32) + 1ull);
-            const int out = (int)(lp >> 32) * 3 + (int)(lp & 0xFFFFFFFFull);
-            emit_leaf(c, out, q.z, q.w, nd, q.y);
-            nd[12 + q.y] = ~out;
-            continue;
-        }
-        if (q.x < 0) atomicMax(&sh.nodeCtr, 1u);  // all keys equal: the run is the root, node 0
-        const unsigned int nIdx = q.x >= 0 ? atomicAdd(&sh.nodeCtr, 1u) : 0u;
-        if (nd) nd[12 + q.y] = (int)nIdx * 64;
-        if (q.w - q.z <= c.spill) {
-            const unsigned int si = atomicAdd(&sh.numSub, 1u);
-            c.subList[si] = make_int4((int)nIdx, q.z, q.w, depth);
-        } else {
-            const unsigned int qi = atomicAdd(&s_over, 1u);
-            qA[qi] = make_int4((int)nIdx, q.z, q.w, depth);
-        }
-    }
-    __syncthreads();
-    const unsigned int over = s_over;
-    int lv = 0;
-    if (over) lv = emit_top<TOP_THREADS, 16>(c, sh, qA, qB, topLst, over);
-    __syncthreads();
-    if ((int)tid <= lv) c.st->topLvlOfs[tid] = over ? sh.lvlOfs[tid] : 0u;
-    if (tid == 0) {
-        c.st->topLevels = (unsigned int)lv;
-        c.st->maxLevel = sh.maxLevel;
-        c.st->nodeCount = sh.nodeCtr;
-        c.st->leafPtr = sh.leafCtr;
-        c.st->numSub = sh.numSub;
-        c.st->subNext = 0;
-    }
 }
 
 }  // namespace ntr
@@ -1507,16 +1489,17 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oTriBox = cv.take((size_t)n * 24), oTriOut = cv.take((size_t)n * 4);
     const size_t oCell = cv.take(((size_t)TOP_CELLS + 1) * 4), oTopIdx = cv.take((size_t)TOP_HEAP * 4);
     // bottom-up emit: zeroed region (flags, meeting counters, scan state) first, then records, slots, ranks
-    const int rankTiles = (n + 1 + RANK_TILE - 1) / RANK_TILE;
+    const int cntTiles = (n + 1 + CNT_TILE - 1) / CNT_TILE;
     const size_t oAggZero = cv.off;
-    const size_t oNodeFlag = cv.take((size_t)n + 1), oLeafFlag = cv.take((size_t)n + 1), oGroupPos = cv.take((size_t)n + 1);
+    const size_t oNodeFlag = cv.take((size_t)n + 1), oLeafFlag = cv.take((size_t)n + 1);
     const size_t oArrive = cv.take(((size_t)n + 1) * 4);
-    const size_t oRankState = cv.take((size_t)rankTiles * 16);
-    const size_t oAggMisc = cv.take(64);           // [0] group count, [1] rank ticket
+    const size_t oAggMisc = cv.take(64);           // [0] number of runs of more than leafSize equal keys
     const size_t oAggZeroEnd = cv.off;
     const size_t oRec = cv.take(((size_t)n + 1) * 64), oSlot = cv.take(((size_t)n + 1) * 64);
-    const size_t oParentPos = cv.take(((size_t)n + 1) * 4), oRanks = cv.take(((size_t)n + 1) * 16);
-    const size_t oGroups = cv.take(((size_t)n / 2 + 2) * 16);
+    const size_t oParentPos = cv.take(((size_t)n + 1) * 4);
+    const size_t oRuns = cv.take(((size_t)n / 2 + 2) * 16);
+    const size_t oNodeBits = cv.take((size_t)cntTiles * (CNT_TILE / 8)), oLeafBits = cv.take((size_t)cntTiles * (CNT_TILE / 8));
+    const size_t oTileCount = cv.take((size_t)cntTiles * 8), oTileBase = cv.take((size_t)cntTiles * 8);
     void* wsBase = nullptr;
     {
         const int rc = workspace_reserve(cv.off, &wsBase);
@@ -1568,9 +1551,15 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
 
     // L4: Woop rows in original triangle order (per-level path), or the per-triangle box terms in sorted order plus the
     // cell table of the top pass (subtree path; its Woop rows are produced by lbvh_place_kernel once the leaves have their slots)
+    int spillSize = tun.lbvhSplit;
+    if (spillSize < 2) spillSize = 2;
+    if (spillSize > 7168) spillSize = 7168;  // 20 bytes of LDS per triangle of a subtree (140 KB), 16-bit positions
+    // 0: the whole tree is one hand-over root; 1: cell-table top + subtree workgroups; 2: level-by-level top with key probes;
+    // 3: bottom-up emit with ranked indices (default; it gathers the box terms itself)
+    const int topMode = n <= spillSize ? 0 : (tun.lbvhLegacyTop ? 2 : (tun.lbvhEmit == 1 ? 1 : 3));
     if (levelSync)
         hipLaunchKernelGGL(lbvh_woop_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, (float4*)(ws + oWoop));
-    else
+    else if (topMode != 3)
         hipLaunchKernelGGL(lbvh_gather_box_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, keys, triSorted, (const float2*)(ws + oWoop),
                            (float2*)(ws + oTriBox), (unsigned int*)(ws + oCell));
     pe.mark(3);
@@ -1620,14 +1609,9 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         // ranges of at most `spill` triangles become one workgroup's subtree: about 1.5 n / spill of them
         // as large as a workgroup's LDS entry list allows: the LDS levels of a subtree are cheaper than the top pass's
         // global ones (sweep: scripts/lbvh_split_sweep.sh)
-        c.spill = tun.lbvhSplit;
-        if (c.spill < 2) c.spill = 2;
-        if (c.spill > 7168) c.spill = 7168;  // 20 bytes of LDS per triangle of a subtree (140 KB), 16-bit positions
+        c.spill = spillSize;
         int4* q0 = (int4*)(ws + oQ0);
         int4* q1 = (int4*)(ws + oQ1);
-        // 0: the whole tree is one hand-over root; 1: cell-table top; 2: level-by-level top with key probes;
-        // 3: bottom-up emit with scanned indices (default)
-        const int topMode = n <= c.spill ? 0 : (tun.lbvhLegacyTop ? 2 : (tun.lbvhEmit == 1 ? 1 : 3));
         unsigned int* aggMisc = (unsigned int*)(ws + oAggMisc);
         auto launch_subtrees = [&](int blocks) -> int {
             const int subThreads = tun.lbvhSubThreads;
@@ -1647,38 +1631,23 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         };
         if (topMode == 3) {
             AggCtx a;
-            a.keys = keys; a.triBox = c.triBox; a.n = n; a.leafSize = leafSize;
+            a.keys = keys; a.triSorted = triSorted; a.boxMesh = (const float2*)(ws + oWoop); a.n = n; a.leafSize = leafSize;
             a.rec = (int*)(ws + oRec);
-            a.nodeFlag = (unsigned char*)(ws + oNodeFlag); a.leafFlag = (unsigned char*)(ws + oLeafFlag); a.groupPos = (unsigned char*)(ws + oGroupPos);
+            a.nodeFlag = (unsigned char*)(ws + oNodeFlag); a.leafFlag = (unsigned char*)(ws + oLeafFlag);
             a.arrive = (unsigned int*)(ws + oArrive); a.slot = (AggSlot*)(ws + oSlot); a.parentPos = (int*)(ws + oParentPos);
-            a.groups = (int4*)(ws + oGroups); a.groupCount = aggMisc; a.st = state; a.useLds = tun.lbvhAggLds;
+            a.runs = (int4*)(ws + oRuns); a.runCount = aggMisc; a.st = state; a.useLds = tun.lbvhAggLds;
             NTR_HIP(hipMemsetAsync(ws + oAggZero, 0, oAggZeroEnd - oAggZero, s));
             hipLaunchKernelGGL(lbvh_agglomerate_kernel, dim3((n + AGG_TILE - 1) / AGG_TILE), dim3(AGG_TILE), 0, s, a);
+            hipLaunchKernelGGL(lbvh_runs_kernel, dim3(64), dim3(64), 0, s, a);
             pe.mark(4);
-            hipLaunchKernelGGL(lbvh_rank_kernel, dim3(rankTiles), dim3(RANK_THREADS), 0, s, n, (const unsigned char*)a.nodeFlag, (const unsigned char*)a.leafFlag,
-                               (const unsigned char*)a.groupPos, (uint4*)(ws + oRanks), (unsigned long long*)(ws + oRankState), aggMisc + 1, state, osMisc + 4);
+            hipLaunchKernelGGL(lbvh_count_kernel, dim3(cntTiles), dim3(CNT_TILE), 0, s, n, (const unsigned char*)a.nodeFlag, (const unsigned char*)a.leafFlag,
+                               (unsigned long long*)(ws + oNodeBits), (unsigned long long*)(ws + oLeafBits), (uint2*)(ws + oTileCount));
+            hipLaunchKernelGGL(lbvh_tilescan_kernel, dim3(1), dim3(1024), 0, s, cntTiles, n, (const uint2*)(ws + oTileCount), (uint2*)(ws + oTileBase), state);
             pe.mark(5);
-            hipLaunchKernelGGL(lbvh_finalize_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted, (const int*)a.rec,
-                               (const unsigned char*)a.nodeFlag, (const unsigned char*)a.leafFlag, (const unsigned char*)a.groupPos,
-                               (const uint4*)(ws + oRanks), (int*)d_nodes, nodeCap, (float4*)d_triWoop, d_triIndex, c.triOut, state);
+            hipLaunchKernelGGL(lbvh_finalize_kernel, dim3(cntTiles), dim3(CNT_TILE), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted, (const int*)a.rec,
+                               (const unsigned long long*)(ws + oNodeBits), (const unsigned long long*)(ws + oLeafBits), (const uint2*)(ws + oTileBase),
+                               (int*)d_nodes, nodeCap, (float4*)d_triWoop, d_triIndex, state);
             pe.mark(6);
-            // runs of more than leafSize equal keys (rare) are finished by the subtree kernels once the fast path is through: that
-            // costs them one more synchronisation, and ordinary scenes nothing
-            unsigned int numGroups = 0;
-            NTR_HIP(hipMemcpyAsync(&numGroups, aggMisc, sizeof(numGroups), hipMemcpyDeviceToHost, s));
-            NTR_HIP(hipStreamSynchronize(s));
-            if (numGroups) {
-                hipLaunchKernelGGL(lbvh_groups_kernel, dim3(1), dim3(TOP_THREADS), 0, s, c, n, (const int4*)a.groups, numGroups, (const int*)a.parentPos,
-                                   (const uint4*)(ws + oRanks), q0, q1, (int*)(ws + oTopLst));
-                int blocks = (int)numGroups * 2 + 64;   // hand-over roots: the runs themselves and what the oversize fallback cuts off
-                if (blocks > 2048) blocks = 2048;
-                const int rc = launch_subtrees(blocks);
-                if (rc != NTR_OK) return rc;
-                hipLaunchKernelGGL(lbvh_top_refit_kernel, dim3(1), dim3(TOP_THREADS), 0, s, (const LbvhState*)state, (const int*)(ws + oTopLst), (int*)d_nodes);
-                hipLaunchKernelGGL(lbvh_place_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted,
-                                   (const int*)(ws + oTriOut), (float4*)d_triWoop, d_triIndex);
-                pe.mark(6);
-            }
         } else {
         if (topMode == 0) {
             // node 0 over all triangles at depth 0 goes straight to a subtree workgroup
