@@ -1038,6 +1038,7 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
     __shared__ int sWalker[AGG_TILE];                         // start positions of the tile's clusters, compacted; bit 31 = run of equal keys
     __shared__ int sWalkerEnd[AGG_TILE];
     __shared__ unsigned int sWaveCount[AGG_TILE / 64], sNumWalkers;
+    __shared__ float sBox[AGG_TILE][6];                       // box terms of the tile's positions, gathered by all threads at once
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = c.n, leafSize = c.leafSize;
     const int tileBeg = blockIdx.x * AGG_TILE;
@@ -1045,6 +1046,15 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
     for (int k = tid; k < AGG_TILE + 2 * AGG_HALO; k += AGG_TILE) {
         const int x = tileBeg - AGG_HALO + k;
         sKeys[k] = (x >= 0 && x < n) ? c.keys[x] : 0u;
+    }
+    if (tileBeg + tid < n) {   // one index -> box-term gather per position, all in flight together
+        const int t = c.triSorted[tileBeg + tid];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float2 v = c.boxMesh[3 * (size_t)t + k];
+            sBox[tid][2 * k] = v.x;
+            sBox[tid][2 * k + 1] = v.y;
+        }
     }
     sArrive[tid] = 0;
     if (tid == 0) sArrive[AGG_TILE] = 0;
@@ -1110,7 +1120,27 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
     int ref = 0;                                      // kind 1: the node's record position
     int h = kind == 2 ? 1 : 0;                        // levels of inner nodes below and including this cluster
     float box[6];
-    agg_fold_box(c, l, r, box);
+    {   // the cluster's box, folded from FLT_MAX like calcLeaf (:383-408): tile positions from LDS, the few beyond it from memory
+        box[0] = box[2] = box[4] = FLT_MAX;
+        box[1] = box[3] = box[5] = -FLT_MAX;
+        const int inTileEnd = min(r, tileEnd);
+        for (int j = l; j < inTileEnd; j++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                box[2 * k] = fminf(box[2 * k], sBox[j - tileBeg][2 * k]);
+                box[2 * k + 1] = fmaxf(box[2 * k + 1], sBox[j - tileBeg][2 * k + 1]);
+            }
+        }
+        if (r > inTileEnd) {
+            float rest[6];
+            agg_fold_box(c, inTileEnd, r, rest);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                box[2 * k] = fminf(box[2 * k], rest[2 * k]);
+                box[2 * k + 1] = fmaxf(box[2 * k + 1], rest[2 * k + 1]);
+            }
+        }
+    }
 
     for (;;) {
         if (l == 0 && r == n) {                       // only a single run can get here unmerged: all keys equal
@@ -1203,10 +1233,36 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
 // ancestors, found by walking the parent positions.  One thread per run records the median nodes (identified by their split
 // position, which lies strictly inside the run) and flags the leaves, exactly like the bottom-up pass does for the rest of the tree,
 // and patches the reference its parent holds.  Boxes are folded per child range.
+// box of the sorted positions [a, b) by a whole wave: lanes stride over the range, min / max across the lanes by shuffles
+__device__ __forceinline__ void agg_fold_box_wave(const AggCtx& c, int a, int b, float (&box)[6])
+{
+    const int lane = threadIdx.x & 63;
+    box[0] = box[2] = box[4] = FLT_MAX;
+    box[1] = box[3] = box[5] = -FLT_MAX;
+    for (int j = a + lane; j < b; j += 64) {
+        const int t = c.triSorted[j];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float2 v = c.boxMesh[3 * (size_t)t + k];
+            box[2 * k] = fminf(box[2 * k], v.x);
+            box[2 * k + 1] = fmaxf(box[2 * k + 1], v.y);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            box[2 * k] = fminf(box[2 * k], __shfl_xor(box[2 * k], off));
+            box[2 * k + 1] = fmaxf(box[2 * k + 1], __shfl_xor(box[2 * k + 1], off));
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
 {
     const unsigned int numRuns = *c.runCount;
-    for (unsigned int g = blockIdx.x * blockDim.x + threadIdx.x; g < numRuns; g += gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x;
+    for (unsigned int g = blockIdx.x; g < numRuns; g += gridDim.x) {   // one wave per run; control flow is wave-uniform
         const int4 q = c.runs[g];
         int depth = 0;
         if (q.x >= 0) {
@@ -1215,15 +1271,17 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
         }
         int* parentLink = q.x >= 0 ? c.rec + (size_t)q.x * 16 + 12 + q.y : nullptr;
         if (depth >= 30) {                              // the parent's level bit is 0: a leaf whatever its size
-            c.leafFlag[q.z] = 1;
-            *parentLink = ~q.z;
+            if (lane == 0) {
+                c.leafFlag[q.z] = 1;
+                *parentLink = ~q.z;
+            }
             continue;
         }
         // explicit stack of (start, end, depth, record position); a node at depth 29 only has leaf children
         int stS[32], stE[32], stD[32], stP[32];
         int sp = 0;
         const int top = q.x >= 0 ? ((q.z + q.w) >> 1) : 0;
-        if (parentLink) *parentLink = top;
+        if (parentLink && lane == 0) *parentLink = top;
         stS[0] = q.z; stE[0] = q.w; stD[0] = depth; stP[0] = top;
         sp = 1;
         unsigned int deepest = 0;
@@ -1233,14 +1291,14 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
             const int mid = (a + b) >> 1;
             deepest = max(deepest, (unsigned int)d + 1u);
             float b0[6], b1[6];
-            agg_fold_box(c, a, mid, b0);
-            agg_fold_box(c, mid, b, b1);
+            agg_fold_box_wave(c, a, mid, b0);
+            agg_fold_box_wave(c, mid, b, b1);
             const int cs[2] = {a, mid}, ce[2] = {mid, b};
             int link[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 if ((ce[k] - cs[k]) <= c.leafSize || d == 29) {
-                    c.leafFlag[cs[k]] = 1;
+                    if (lane == 0) c.leafFlag[cs[k]] = 1;
                     link[k] = ~cs[k];
                 } else {
                     const int cm = (cs[k] + ce[k]) >> 1;
@@ -1249,11 +1307,13 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
                     sp++;
                 }
             }
-            // split word of a median split: level = -1 in the reference (no differing bit), and -1 % 3 == -1
-            agg_write_record(c.rec, id, b0, b1, link[0], link[1], -1);
-            c.nodeFlag[id] = 1;
+            if (lane == 0) {
+                // split word of a median split: level = -1 in the reference (no differing bit), and -1 % 3 == -1
+                agg_write_record(c.rec, id, b0, b1, link[0], link[1], -1);
+                c.nodeFlag[id] = 1;
+            }
         }
-        atomicMax(&c.st->maxLevel, min(deepest, 30u));
+        if (lane == 0) atomicMax(&c.st->maxLevel, min(deepest, 30u));
     }
 }
 
@@ -1283,33 +1343,40 @@ __global__ __launch_bounds__(CNT_TILE) void lbvh_count_kernel(int n, const unsig
     }
 }
 
-// Exclusive scan of the per-tile counts (one workgroup); the totals become the builder state's nodeCount and leafPtr.
+// Exclusive scan of the per-tile counts (one workgroup, 1024 tiles per round with the next round's loads already in flight);
+// the totals become the builder state's nodeCount and leafPtr.
 __global__ __launch_bounds__(1024) void lbvh_tilescan_kernel(int numTiles, int n, const uint2* __restrict__ tileCount, uint2* __restrict__ tileBase,
                                                              LbvhState* st)
 {
-    __shared__ unsigned int s_a[1024], s_b[1024];
-    const int tid = threadIdx.x;
-    const int per = (numTiles + 1023) / 1024;
-    const int beg = min(tid * per, numTiles), end = min(beg + per, numTiles);
-    unsigned int a = 0, b = 0;
-    for (int k = beg; k < end; k++) { const uint2 v = tileCount[k]; a += v.x; b += v.y; }
-    s_a[tid] = a; s_b[tid] = b;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const unsigned int va = tid >= off ? s_a[tid - off] : 0u, vb = tid >= off ? s_b[tid - off] : 0u;
+    __shared__ unsigned int s_wa[16], s_wb[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned int carryA = 0, carryB = 0;
+    uint2 next = tid < numTiles ? tileCount[tid] : make_uint2(0u, 0u);
+    for (int base = 0; base < numTiles; base += 1024) {
+        const uint2 v = next;
+        const int nk = base + 1024 + tid;
+        next = nk < numTiles ? tileCount[nk] : make_uint2(0u, 0u);
+        unsigned int ia = v.x, ib = v.y;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int ua = (unsigned int)__shfl_up((int)ia, off), ub = (unsigned int)__shfl_up((int)ib, off);
+            if (lane >= off) { ia += ua; ib += ub; }
+        }
+        if (lane == 63) { s_wa[wave] = ia; s_wb[wave] = ib; }
         __syncthreads();
-        s_a[tid] += va; s_b[tid] += vb;
+        unsigned int beforeA = 0, beforeB = 0, allA = 0, allB = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) { beforeA += s_wa[w]; beforeB += s_wb[w]; }
+            allA += s_wa[w]; allB += s_wb[w];
+        }
+        if (base + tid < numTiles) tileBase[base + tid] = make_uint2(carryA + beforeA + ia - v.x, carryB + beforeB + ib - v.y);
+        carryA += allA; carryB += allB;
         __syncthreads();
     }
-    unsigned int ra = s_a[tid] - a, rb = s_b[tid] - b;
-    for (int k = beg; k < end; k++) {
-        const uint2 v = tileCount[k];
-        tileBase[k] = make_uint2(ra, rb);
-        ra += v.x; rb += v.y;
-    }
-    if (tid == 1023) {
-        st->nodeCount = s_a[1023];
-        st->leafPtr = ((unsigned long long)n << 32) | (unsigned long long)s_b[1023];
+    if (tid == 0) {
+        st->nodeCount = carryA;
+        st->leafPtr = ((unsigned long long)n << 32) | (unsigned long long)carryB;
     }
 }
 
@@ -1466,7 +1533,9 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const int n = numTris;
     if (n >= (1 << 28)) return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: at most 2^28 - 1 triangles");
     const int nb = (n + SORT_TILE - 1) / SORT_TILE;
-    const int osTiles = (n + OS_TILE - 1) / OS_TILE;
+    // one-sweep tiles: 2048 keys while the launch is latency-bound, 4096 (longer runs per digit in the scatter) for large inputs
+    const int osItems = n >= (1 << 21) ? 16 : 8;
+    const int osTiles = (n + OS_THREADS * osItems - 1) / (OS_THREADS * osItems);
     const Tunables tun = tunables();
     const bool levelSync = tun.lbvhLevelSync != 0;
     const bool legacySort = levelSync || tun.lbvhLegacySort != 0;
@@ -1539,8 +1608,12 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, kOut, vOut, 1,
                                shift, (const unsigned int*)hist, (const unsigned int*)hist + (size_t)nb * 256, nb);
         } else {
-            hipLaunchKernelGGL(onesweep_pass_kernel, dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
-                               shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
+            if (osItems == 16)
+                hipLaunchKernelGGL(onesweep_pass_kernel<16>, dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
+                                   shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
+            else
+                hipLaunchKernelGGL(onesweep_pass_kernel<8>, dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
+                                   shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
         }
         unsigned int* tk = kIn; kIn = kOut; kOut = tk;
         int* tv = vIn; vIn = vOut; vOut = tv;
@@ -1638,7 +1711,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             a.runs = (int4*)(ws + oRuns); a.runCount = aggMisc; a.st = state; a.useLds = tun.lbvhAggLds;
             NTR_HIP(hipMemsetAsync(ws + oAggZero, 0, oAggZeroEnd - oAggZero, s));
             hipLaunchKernelGGL(lbvh_agglomerate_kernel, dim3((n + AGG_TILE - 1) / AGG_TILE), dim3(AGG_TILE), 0, s, a);
-            hipLaunchKernelGGL(lbvh_runs_kernel, dim3(64), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(lbvh_runs_kernel, dim3(2048), dim3(64), 0, s, a);
             pe.mark(4);
             hipLaunchKernelGGL(lbvh_count_kernel, dim3(cntTiles), dim3(CNT_TILE), 0, s, n, (const unsigned char*)a.nodeFlag, (const unsigned char*)a.leafFlag,
                                (unsigned long long*)(ws + oNodeBits), (unsigned long long*)(ws + oLeafBits), (uint2*)(ws + oTileCount));

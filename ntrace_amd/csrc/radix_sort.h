@@ -162,13 +162,31 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(int n, const
 // Stable; n < 2^28.
 // ------------------------------------------------------------------------------------------------------------
 static constexpr int OS_THREADS = 256;
-static constexpr int OS_ITEMS = 8;
-static constexpr int OS_TILE = OS_THREADS * OS_ITEMS;
 static constexpr unsigned int OS_COUNT_MASK = 0x0FFFFFFFu;
 static constexpr unsigned int OS_SPIN_LIMIT = 1u << 22;
 
 __device__ __forceinline__ unsigned int os_status(int pass, bool inclusive) { return (unsigned int)(pass * 2 + (inclusive ? 2 : 1)) << 28; }
 
+// exclusive prefix over the 256 threads of a workgroup (one value each): wave scans by lane shuffles, one barrier
+__device__ __forceinline__ unsigned int os_excl_scan_256(unsigned int v, unsigned int* s_waveTotals /* [4] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int u = (unsigned int)__shfl_up((int)incl, off);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) s_waveTotals[wave] = incl;
+    __syncthreads();
+    unsigned int before = 0;
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+        if (w < wave) before += s_waveTotals[w];
+    return before + incl - v;
+}
+
+template <int ITEMS>
 __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n, const unsigned int* __restrict__ keysIn,
                                                                            const int* __restrict__ valsIn,
                                                                            unsigned int* __restrict__ keysOut, int* __restrict__ valsOut,
@@ -178,43 +196,35 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
                                                                            unsigned int* ticket, unsigned int* errFlag)
 {
     constexpr int WAVES = OS_THREADS / 64;
+    constexpr int TILE = OS_THREADS * ITEMS;
     __shared__ unsigned int s_cnt[WAVES][256];   // per wave and digit: keys ranked so far; later the wave's offset inside the digit
-    __shared__ unsigned int s_scan[256];
+    __shared__ unsigned int s_wt[2][WAVES];
     __shared__ unsigned int s_tileStart[256];    // first tile-local position of digit d
     __shared__ unsigned int s_dst[256];          // global position of tile-local position 0 of digit d's run, minus s_tileStart[d]
-    __shared__ unsigned int s_keys[OS_TILE];
-    __shared__ int s_vals[OS_TILE];
+    __shared__ unsigned int s_keys[TILE];
+    __shared__ int s_vals[TILE];
     __shared__ unsigned int s_tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     for (int i = tid; i < WAVES * 256; i += OS_THREADS) (&s_cnt[0][0])[i] = 0;
     // global base of digit `tid`: exclusive scan of the digit totals
-    const unsigned int myTotal = digitTotals[tid];
-    s_scan[tid] = myTotal;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const unsigned int v = (tid >= off) ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
-    }
-    const unsigned int digitBase = s_scan[tid] - myTotal;
+    const unsigned int digitBase = os_excl_scan_256(digitTotals[tid], s_wt[0]);   // (its barrier also publishes s_tile and s_cnt)
     const unsigned int tile = s_tile;
 
-    const long long chunk = (long long)tile * OS_TILE + wave * (64 * OS_ITEMS);
-    unsigned int key[OS_ITEMS], rank[OS_ITEMS];
-    int val[OS_ITEMS];
+    const long long chunk = (long long)tile * TILE + wave * (64 * ITEMS);
+    unsigned int key[ITEMS], rank[ITEMS];
+    int val[ITEMS];
     const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const long long k = chunk + r * 64 + lane;
         const bool valid = k < n;
         val[r] = valid ? valsIn[k] : 0;
         key[r] = valid ? keysIn[k] : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const bool valid = (chunk + r * 64 + lane) < n;
         const unsigned int d = (key[r] >> shift) & 255;
         unsigned long long peers = __ballot(valid);
@@ -242,15 +252,7 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
     __hip_atomic_store(myState, (tile == 0 ? os_status(pass, true) : os_status(pass, false)) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // tile-local start of every digit
-    s_scan[tid] = cnt;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const unsigned int v = (tid >= off) ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
-    }
-    const unsigned int tileStart = s_scan[tid] - cnt;
+    const unsigned int tileStart = os_excl_scan_256(cnt, s_wt[1]);
     s_tileStart[tid] = tileStart;
 
     // decoupled look-back over the predecessors' words of this digit, OS_LOOK of them per round trip (the loads of a round are
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
 
     // stage in tile-sorted order, then stream out
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         if ((chunk + r * 64 + lane) < n) {
             const unsigned int d = (key[r] >> shift) & 255;
             const unsigned int pos = s_tileStart[d] + s_cnt[wave][d] + rank[r];
@@ -300,8 +302,8 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
         }
     }
     __syncthreads();
-    const long long tileBeg = (long long)tile * OS_TILE;
-    const int tileCount = (int)((n - tileBeg) < (long long)OS_TILE ? (n - tileBeg) : (long long)OS_TILE);
+    const long long tileBeg = (long long)tile * TILE;
+    const int tileCount = (int)((n - tileBeg) < (long long)TILE ? (n - tileBeg) : (long long)TILE);
     for (int i = tid; i < tileCount; i += OS_THREADS) {
         const unsigned int k = s_keys[i];
         const unsigned int dst = s_dst[(k >> shift) & 255] + (unsigned int)i;
