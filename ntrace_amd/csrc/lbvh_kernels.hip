@@ -970,6 +970,23 @@ struct AggSlot {             // what the first sibling leaves at the meeting poi
 };
 static_assert(sizeof(AggSlot) == 32, "AggSlot must be 32 bytes");
 
+struct AggSlotG {            // meeting slot of the second stage: the cluster also carries the key difference at its far end
+    float b[6];
+    unsigned int farKind, refH, dFar, pad[3];
+};
+static_assert(sizeof(AggSlotG) == 48, "AggSlotG must be 48 bytes");
+
+struct AggExport {           // a cluster that has outgrown its tile, handed to the second stage
+    float b[6];
+    int l;
+    unsigned int rKind;      // r | kind << 28
+    unsigned int refH;
+    unsigned int dl, dr;     // key[l-1] ^ key[l], key[r-1] ^ key[r] (0xFFFFFFFF at the ends of the array)
+    unsigned int pad;
+};
+static_assert(sizeof(AggExport) == 48, "AggExport must be 48 bytes");
+constexpr int AGG_EXPORT_CAP = 64;   // a tile's clusters with a parent outside it are children of the <= 2 x 30 nodes that cross its two borders
+
 struct AggCtx {
     const unsigned int* keys;
     const int* triSorted;        // sorted position -> triangle
@@ -985,6 +1002,9 @@ struct AggCtx {
     unsigned int* runCount;
     LbvhState* st;
     int useLds;
+    AggExport* exports;          // [tiles][AGG_EXPORT_CAP] (two-stage mode)
+    unsigned int* exportCount;   // [tiles], zeroed
+    AggSlotG* slotG;             // [n + 1][2] (two-stage mode)
 };
 
 __device__ __forceinline__ void agg_store_slot(AggSlot* dst, const AggSlot& v)
@@ -1030,6 +1050,59 @@ __device__ __forceinline__ void agg_write_record(int* rec, int id, const float* 
     reinterpret_cast<int4*>(nd)[3] = make_int4(link0, link1, splitBit, 0);
 }
 
+// The second sibling to arrive forms the parent of the clusters [l, r) (its own) and the sibling's: children become leaves / keep
+// their node / are recorded as runs, the node record goes to its split position, and the caller's cluster becomes the parent.
+// Returns true when the parent is the root.
+__device__ __forceinline__ bool agg_form_parent(const AggCtx& c, bool sibRight, int B, int hb, int& l, int& r, int& kind, int& ref, int& h,
+                                                float (&box)[6], int sFar, int sKind, int sRef, int sH, const float* sibBox)
+{
+    const int n = c.n;
+    const int L = sibRight ? l : sFar, R = sibRight ? sFar : r;
+    // children in tree order: 0 = [L, B), 1 = [B, R)
+    const float* b0 = sibRight ? box : sibBox;
+    const float* b1 = sibRight ? sibBox : box;
+    const int ck[2] = {sibRight ? kind : sKind, sibRight ? sKind : kind};
+    const int cr[2] = {sibRight ? ref : sRef, sibRight ? sRef : ref};
+    const int hmax = max(h, sH);
+    const int id = (L == 0 && R == n) ? 0 : B;    // record position of the new node
+    const int cs[2] = {L, B}, ce[2] = {B, R};
+    int link[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (ck[k] == 0) {                          // createLeaf: the child is a leaf starting at cs[k]
+            c.leafFlag[cs[k]] = 1;
+            link[k] = ~cs[k];
+        } else if (ck[k] == 1) {
+            link[k] = cr[k];
+            c.parentPos[cr[k]] = id;
+        } else {
+            link[k] = AGG_REF_RUN;
+            const unsigned int g = atomicAdd(c.runCount, 1u);
+            c.runs[g] = make_int4(id, k, cs[k], ce[k]);
+        }
+    }
+    agg_write_record(c.rec, id, b0, b1, link[0], link[1], hb % 3);
+    c.nodeFlag[id] = 1;
+    float ub[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        ub[2 * k] = fminf(b0[2 * k], b1[2 * k]);
+        ub[2 * k + 1] = fmaxf(b0[2 * k + 1], b1[2 * k + 1]);
+    }
+    l = L; r = R; kind = 1; ref = id; h = 1 + hmax;
+#pragma unroll
+    for (int k = 0; k < 6; k++) box[k] = ub[k];
+    if (id == 0) {                                 // the root: deepest level that holds an inner node, plus one
+        atomicMax(&c.st->maxLevel, (unsigned int)min(h, 30));
+        return true;
+    }
+    return false;
+}
+
+// EXPORT = false: clusters that outgrow their tile go on meeting through memory in this launch (small inputs: one launch less).
+// EXPORT = true : they are handed to lbvh_agglomerate_top_kernel instead, so that a workgroup -- and its LDS -- is released as soon as
+//                 the work inside its tile is done; the chains of meetings along the tile borders then run as plain threads.
+template <bool EXPORT>
 __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
 {
     __shared__ unsigned int sKeys[AGG_TILE + 2 * AGG_HALO];   // sKeys[AGG_HALO + k] = key of position tileBeg + k
@@ -1037,7 +1110,7 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
     __shared__ AggSlot sSlot[AGG_TILE + 1][2];
     __shared__ int sWalker[AGG_TILE];                         // start positions of the tile's clusters, compacted; bit 31 = run of equal keys
     __shared__ int sWalkerEnd[AGG_TILE];
-    __shared__ unsigned int sWaveCount[AGG_TILE / 64], sNumWalkers;
+    __shared__ unsigned int sWaveCount[AGG_TILE / 64], sNumWalkers, sExports;
     __shared__ float sBox[AGG_TILE][6];                       // box terms of the tile's positions, gathered by all threads at once
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = c.n, leafSize = c.leafSize;
@@ -1057,7 +1130,7 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
         }
     }
     sArrive[tid] = 0;
-    if (tid == 0) sArrive[AGG_TILE] = 0;
+    if (tid == 0) { sArrive[AGG_TILE] = 0; sExports = 0; }
     __syncthreads();
 
     auto key = [&](int x) -> unsigned int {   // sorted key at position x (0 <= x < n)
@@ -1170,61 +1243,96 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
         AggSlot sib;
         if (inTile) {
             const int bl = B - tileBeg;
+            // LDS executes a wave's operations in order and the atomic serialises the two siblings, so the slot only has to be
+            // written before the atomic is issued and read after it has returned: LDS counters, not vmcnt -- the global stores of
+            // the node just formed stay in flight
             sSlot[bl][side] = mine;
-            __threadfence_block();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const unsigned int old = atomicAdd(&sArrive[bl], 1u);
             if (old == 0) break;
-            __threadfence_block();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             sib = sSlot[bl][side ^ 1];
+        } else if (EXPORT) {
+            const unsigned int k = atomicAdd(&sExports, 1u);
+            if (k < (unsigned int)AGG_EXPORT_CAP) {
+                AggExport e;
+#pragma unroll
+                for (int q = 0; q < 6; q++) e.b[q] = box[q];
+                e.l = l; e.rKind = (unsigned int)r | ((unsigned int)kind << 28); e.refH = mine.refH; e.dl = dl; e.dr = dr; e.pad = 0;
+                c.exports[(size_t)blockIdx.x * AGG_EXPORT_CAP + k] = e;
+                atomicAdd(&c.exportCount[blockIdx.x], 1u);
+            } else {
+                atomicOr(&c.st->overflow, 2u);   // cannot happen: at most 2 x 30 nodes cross a tile's borders
+            }
+            break;
         } else {
-            agg_store_slot(&c.slot[2 * (size_t)B + side], mine);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slot has reached memory before the arrival is announced
-            const unsigned int old = __hip_atomic_fetch_add(&c.arrive[B], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == 0) break;
+            // Peek first: along a tile border the siblings of a growing cluster are usually waiting already (their arrival was
+            // announced after their slot had reached memory), and then this cluster is the second for certain -- it neither
+            // publishes its own slot nor touches the counter, it just reads the sibling's: two round trips instead of four.
+            if (__hip_atomic_load(&c.arrive[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                agg_store_slot(&c.slot[2 * (size_t)B + side], mine);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slot has reached memory before the arrival is announced
+                const unsigned int old = __hip_atomic_fetch_add(&c.arrive[B], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == 0) break;
+            }
+            asm volatile("" ::: "memory");
             sib = agg_load_slot(&c.slot[2 * (size_t)B + (side ^ 1)]);
         }
         // ---- second to arrive: form the parent ------------------------------------------------------------------------------
-        const int sFar = (int)(sib.farKind & 0x0FFFFFFFu), sKind = (int)(sib.farKind >> 28);
-        const int sRef = (int)(sib.refH & 0x07FFFFFFu), sH = (int)(sib.refH >> 27);
-        const int L = sibRight ? l : sFar, R = sibRight ? sFar : r;
-        // children in tree order: 0 = [L, B), 1 = [B, R)
-        const float* b0 = sibRight ? box : sib.b;
-        const float* b1 = sibRight ? sib.b : box;
-        const int ck[2] = {sibRight ? kind : sKind, sibRight ? sKind : kind};
-        const int cr[2] = {sibRight ? ref : sRef, sibRight ? sRef : ref};
-        const int hmax = max(h, sH);
-        const int id = (L == 0 && R == n) ? 0 : B;    // record position of the new node
-        const int cs[2] = {L, B}, ce[2] = {B, R};
-        int link[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            if (ck[k] == 0) {                          // createLeaf: the child is a leaf starting at cs[k]
-                c.leafFlag[cs[k]] = 1;
-                link[k] = ~cs[k];
-            } else if (ck[k] == 1) {
-                link[k] = cr[k];
-                c.parentPos[cr[k]] = id;
-            } else {
-                link[k] = AGG_REF_RUN;
-                const unsigned int g = atomicAdd(c.runCount, 1u);
-                c.runs[g] = make_int4(id, k, cs[k], ce[k]);
-            }
-        }
-        agg_write_record(c.rec, id, b0, b1, link[0], link[1], hb % 3);
-        c.nodeFlag[id] = 1;
-        float ub[6];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            ub[2 * k] = fminf(b0[2 * k], b1[2 * k]);
-            ub[2 * k + 1] = fmaxf(b0[2 * k + 1], b1[2 * k + 1]);
-        }
-        l = L; r = R; kind = 1; ref = id; h = 1 + hmax;
-#pragma unroll
-        for (int k = 0; k < 6; k++) box[k] = ub[k];
-        if (id == 0) {                                 // the root: deepest level that holds an inner node, plus one
-            atomicMax(&c.st->maxLevel, (unsigned int)min(h, 30));
+        if (agg_form_parent(c, sibRight, B, hb, l, r, kind, ref, h, box, (int)(sib.farKind & 0x0FFFFFFFu), (int)(sib.farKind >> 28),
+                            (int)(sib.refH & 0x07FFFFFFu), (int)(sib.refH >> 27), sib.b))
             break;
+    }
+}
+
+// Second stage of the two-stage mode: one thread per cluster that outgrew its tile; the same meetings, all through memory, with the
+// key differences at the cluster's two ends carried along (no key is read any more).
+__global__ __launch_bounds__(256) void lbvh_agglomerate_top_kernel(AggCtx c, int numTiles)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tile = g / AGG_EXPORT_CAP, k = g % AGG_EXPORT_CAP;
+    if (tile >= numTiles || (unsigned int)k >= min(c.exportCount[tile], (unsigned int)AGG_EXPORT_CAP)) return;
+    const AggExport e = c.exports[(size_t)tile * AGG_EXPORT_CAP + k];
+    int l = e.l, r = (int)(e.rKind & 0x0FFFFFFFu), kind = (int)(e.rKind >> 28), ref = (int)(e.refH & 0x07FFFFFFu), h = (int)(e.refH >> 27);
+    unsigned int dl = e.dl, dr = e.dr;
+    float box[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) box[q] = e.b[q];
+    for (;;) {
+        const bool sibRight = dr < dl;
+        const int B = sibRight ? r : l;
+        const int hb = 31 - __clz((int)(sibRight ? dr : dl));
+        const int side = sibRight ? 0 : 1;
+        AggSlotG sib;
+        if (__hip_atomic_load(&c.arrive[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            AggSlotG mine;
+#pragma unroll
+            for (int q = 0; q < 6; q++) mine.b[q] = box[q];
+            mine.farKind = (unsigned int)(sibRight ? l : r) | ((unsigned int)kind << 28);
+            mine.refH = (unsigned int)ref | ((unsigned int)h << 27);
+            mine.dFar = sibRight ? dl : dr;
+            mine.pad[0] = mine.pad[1] = mine.pad[2] = 0;
+            {
+                const unsigned long long* sp = reinterpret_cast<const unsigned long long*>(&mine);
+                unsigned long long* dp = reinterpret_cast<unsigned long long*>(&c.slotG[2 * (size_t)B + side]);
+#pragma unroll
+                for (int q = 0; q < 5; q++) __hip_atomic_store(dp + q, sp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slot has reached memory before the arrival is announced
+            const unsigned int old = __hip_atomic_fetch_add(&c.arrive[B], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == 0) return;
         }
+        asm volatile("" ::: "memory");
+        {
+            unsigned long long* dp = reinterpret_cast<unsigned long long*>(&sib);
+            const unsigned long long* sp = reinterpret_cast<const unsigned long long*>(&c.slotG[2 * (size_t)B + (side ^ 1)]);
+#pragma unroll
+            for (int q = 0; q < 5; q++) dp[q] = __hip_atomic_load(sp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (sibRight) dr = sib.dFar; else dl = sib.dFar;
+        if (agg_form_parent(c, sibRight, B, hb, l, r, kind, ref, h, box, (int)(sib.farKind & 0x0FFFFFFFu), (int)(sib.farKind >> 28),
+                            (int)(sib.refH & 0x07FFFFFFu), (int)(sib.refH >> 27), sib.b))
+            return;
     }
 }
 
@@ -1562,9 +1670,12 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oAggZero = cv.off;
     const size_t oNodeFlag = cv.take((size_t)n + 1), oLeafFlag = cv.take((size_t)n + 1);
     const size_t oArrive = cv.take(((size_t)n + 1) * 4);
+    const int aggTiles = (n + AGG_TILE - 1) / AGG_TILE;
+    const size_t oExportCount = cv.take((size_t)aggTiles * 4);
     const size_t oAggMisc = cv.take(64);           // [0] number of runs of more than leafSize equal keys
     const size_t oAggZeroEnd = cv.off;
-    const size_t oRec = cv.take(((size_t)n + 1) * 64), oSlot = cv.take(((size_t)n + 1) * 64);
+    const size_t oRec = cv.take(((size_t)n + 1) * 64), oSlot = cv.take(((size_t)n + 1) * 96);
+    const size_t oExports = cv.take((size_t)aggTiles * AGG_EXPORT_CAP * sizeof(AggExport));
     const size_t oParentPos = cv.take(((size_t)n + 1) * 4);
     const size_t oRuns = cv.take(((size_t)n / 2 + 2) * 16);
     const size_t oNodeBits = cv.take((size_t)cntTiles * (CNT_TILE / 8)), oLeafBits = cv.take((size_t)cntTiles * (CNT_TILE / 8));
@@ -1709,8 +1820,17 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             a.nodeFlag = (unsigned char*)(ws + oNodeFlag); a.leafFlag = (unsigned char*)(ws + oLeafFlag);
             a.arrive = (unsigned int*)(ws + oArrive); a.slot = (AggSlot*)(ws + oSlot); a.parentPos = (int*)(ws + oParentPos);
             a.runs = (int4*)(ws + oRuns); a.runCount = aggMisc; a.st = state; a.useLds = tun.lbvhAggLds;
+            a.exports = (AggExport*)(ws + oExports); a.exportCount = (unsigned int*)(ws + oExportCount); a.slotG = (AggSlotG*)(ws + oSlot);
             NTR_HIP(hipMemsetAsync(ws + oAggZero, 0, oAggZeroEnd - oAggZero, s));
-            hipLaunchKernelGGL(lbvh_agglomerate_kernel, dim3((n + AGG_TILE - 1) / AGG_TILE), dim3(AGG_TILE), 0, s, a);
+            // two stages for large inputs (a workgroup leaves as soon as its tile is done, the chains along the tile borders run as plain
+            // threads of a second launch); one launch for small ones, where the extra launch costs more than it saves
+            const bool staged = tun.lbvhAggStaged < 0 ? n >= (1 << 20) : tun.lbvhAggStaged != 0;
+            if (staged && a.useLds) {
+                hipLaunchKernelGGL(lbvh_agglomerate_kernel<true>, dim3(aggTiles), dim3(AGG_TILE), 0, s, a);
+                hipLaunchKernelGGL(lbvh_agglomerate_top_kernel, dim3((aggTiles * AGG_EXPORT_CAP + 255) / 256), dim3(256), 0, s, a, aggTiles);
+            } else {
+                hipLaunchKernelGGL(lbvh_agglomerate_kernel<false>, dim3(aggTiles), dim3(AGG_TILE), 0, s, a);
+            }
             hipLaunchKernelGGL(lbvh_runs_kernel, dim3(2048), dim3(64), 0, s, a);
             pe.mark(4);
             hipLaunchKernelGGL(lbvh_count_kernel, dim3(cntTiles), dim3(CNT_TILE), 0, s, n, (const unsigned char*)a.nodeFlag, (const unsigned char*)a.leafFlag,

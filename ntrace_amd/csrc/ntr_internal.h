@@ -13,7 +13,7 @@ struct Tunables {
     int chunk, fetchThreshold, coop, leafSwitchBelow, blocksPerCU, ageShift;
     int predict, predictDepth, predictMinRays, predictMinNodes;
     int schedRefreshEvery, schedClasses;
-    int lbvhLevelSync, lbvhSplit, lbvhSubThreads, lbvhLegacyTop, lbvhLegacySort, lbvhEmit, lbvhAggLds;
+    int lbvhLevelSync, lbvhSplit, lbvhSubThreads, lbvhLegacyTop, lbvhLegacySort, lbvhEmit, lbvhAggLds, lbvhAggStaged;
 };
 Tunables tunables();
 

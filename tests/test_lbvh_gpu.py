@@ -13,14 +13,14 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "split16-64t", "split40-256t", "bottom-up-no-lds", "bottom-up-no-lds-split16", "cells-top", "cells-top-split16",
+@pytest.fixture(autouse=True, params=["default", "split16-64t", "split40-256t", "bottom-up-no-lds", "bottom-up-no-lds-split16", "bottom-up-staged", "bottom-up-staged-split16", "cells-top", "cells-top-split16",
                                        "legacy-top-and-sort", "legacy-top-split16", "levelsync"])
 def build_path(request, monkeypatch):
     """Every test runs on the default path (one-sweep sort, bottom-up emit with scanned indices; scenes of at most `split`
     triangles are one subtree workgroup), on the same path with a tiny `split` (so that small scenes take the bottom-up emit, and
     runs of equal keys its slow path with hand-over roots and the oversize fallback), with every meeting through memory, on the
     cell-table top pass + subtree workgroups, on the round-1 sort / top pass, and on the per-level kernels."""
-    for k in ("NTR_LBVH_LEVELSYNC", "NTR_LBVH_SPLIT", "NTR_LBVH_SUB_THREADS", "NTR_LBVH_LEGACY_TOP", "NTR_LBVH_LEGACY_SORT", "NTR_LBVH_EMIT", "NTR_LBVH_AGG_LDS"):
+    for k in ("NTR_LBVH_LEVELSYNC", "NTR_LBVH_SPLIT", "NTR_LBVH_SUB_THREADS", "NTR_LBVH_LEGACY_TOP", "NTR_LBVH_LEGACY_SORT", "NTR_LBVH_EMIT", "NTR_LBVH_AGG_LDS", "NTR_LBVH_AGG_STAGED"):
         monkeypatch.delenv(k, raising=False)
     if request.param == "levelsync":
         monkeypatch.setenv("NTR_LBVH_LEVELSYNC", "1")
@@ -28,6 +28,11 @@ def build_path(request, monkeypatch):
         monkeypatch.setenv("NTR_LBVH_AGG_LDS", "0")
     elif request.param == "bottom-up-no-lds-split16":
         monkeypatch.setenv("NTR_LBVH_AGG_LDS", "0")
+        monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
+    elif request.param == "bottom-up-staged":  # clusters that outgrow their tile go to a second launch (default only from 2^20 triangles)
+        monkeypatch.setenv("NTR_LBVH_AGG_STAGED", "1")
+    elif request.param == "bottom-up-staged-split16":
+        monkeypatch.setenv("NTR_LBVH_AGG_STAGED", "1")
         monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
     elif request.param == "cells-top":  # cell-table top pass + one workgroup per subtree
         monkeypatch.setenv("NTR_LBVH_EMIT", "1")
