@@ -1740,7 +1740,8 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     if (spillSize > 7168) spillSize = 7168;  // 20 bytes of LDS per triangle of a subtree (140 KB), 16-bit positions
     // 0: the whole tree is one hand-over root; 1: cell-table top + subtree workgroups; 2: level-by-level top with key probes;
     // 3: bottom-up emit with ranked indices (default; it gathers the box terms itself)
-    const int topMode = n <= spillSize ? 0 : (tun.lbvhLegacyTop ? 2 : (tun.lbvhEmit == 1 ? 1 : 3));
+    // (a scene of at most leafSize triangles is a root over two leaves: the table / bottom-up paths expect more than one leaf's worth)
+    const int topMode = n <= spillSize ? 0 : ((tun.lbvhLegacyTop || n <= leafSize) ? 2 : (tun.lbvhEmit == 1 ? 1 : 3));
     if (levelSync)
         hipLaunchKernelGGL(lbvh_woop_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, (float4*)(ws + oWoop));
     else if (topMode != 3)

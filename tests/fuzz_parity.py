@@ -145,6 +145,9 @@ def main(argv=None):
                 nt.set_tunables(NTR_LBVH_SPLIT=int(rng.choice([2, 16, 100, 3000])) if rng.random() < 0.3 else None,
                                 NTR_LBVH_EMIT=int(rng.choice([0, 0, 1])), NTR_LBVH_AGG_LDS=int(rng.choice([1, 1, 0])),
                                 NTR_LBVH_AGG_STAGED=int(rng.choice([-1, 0, 1])))
+                if os.environ.get("NTR_FUZZ_VERBOSE"):
+                    print("lbvh n=%d leaf=%d eps=%g %s" % (tri.shape[0], leaf, eps, {k: v for k, v in os.environ.items() if k.startswith("NTR_LBVH")}),
+                          file=sys.stderr, flush=True)
                 nodes, woop, idx, res, keep = gpu_lbvh(tri, pos, leaf, eps)
                 ref = oracle.lbvh_build(tri, pos, leaf, eps)
                 same = (res.numNodes == ref["num_inner"] and res.numLeaves == ref["num_leaves"] and res.numLevels == ref["num_levels"] and
