@@ -140,7 +140,6 @@ static void tunables_load_locked()
     t.coop = env_int("NTR_TRACE_COOP", 0);
     t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", 24);     // sweep: flat optimum 16..64 (scripts/trace_sweep.py)
     t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 6);
-    t.ageShift = env_int("NTR_TRACE_AGE_SHIFT", 0);
     t.predict = env_int("NTR_TRACE_PREDICT", 1);
     t.predictDepth = env_int("NTR_TRACE_PREDICT_DEPTH", 9);
     t.predictMinRays = env_int("NTR_TRACE_PREDICT_MIN_RAYS", 1 << 20);
@@ -455,7 +454,6 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.bvhFlags = bvhFlags;
     p.coop = tun.coop;
     p.leafSwitchBelow = tun.leafSwitchBelow;
-    p.ageShift = tun.ageShift;
     p.stats = ds->stats;
     p.timeline = nullptr;
     p.order = nullptr;

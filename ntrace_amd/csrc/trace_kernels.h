@@ -40,7 +40,6 @@ struct TraceParams {
     uint32_t bvhFlags;
     int32_t leafSwitchBelow; // serve waiting leaves when fewer lanes than this still hold an inner node
     int32_t coop;            // quad-cooperative LDS-DMA node fetch instead of per-lane loads
-    int32_t ageShift;        // per-ray kernel: a wave raises its issue priority every 2^ageShift inner steps (0 = never)
     unsigned long long* timeline;  // diagnostic: per-wave realtime stamps (scripts/timeline*.py), or null
     const unsigned int* order;     // per-ray kernel: workgroup i traces ray block order[i] (null = identity)
     unsigned int* cost;            // per-ray kernel: cost[block] = max wave lifetime in 10 ns ticks (null = off)

@@ -377,14 +377,9 @@ template <bool FAST, bool STATS, bool DYNAMIC_FETCH, bool COOP>
 __device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, lds_char* stage, int lane, RayRegs& r, int& node,
                                          LaneStack& st, int (&spill)[SPILL_DEPTH], bool anyHit,
                                          int& hitAddr, float& hitU, float& hitV, LaneStats& ls, unsigned int* status,
-                                         bool poolEmpty, int fetchThreshold, int leafSwitchBelow, int ageShift)
+                                         bool poolEmpty, int fetchThreshold, int leafSwitchBelow)
 {
     unsigned long long live = __ballot(node != kSentinel);
-    // Ageing priority (scheduling only): the launch ends with its longest-lived waves, and a wave that shares its SIMD with six
-    // others gets a seventh of the issue slots however old it is.  A wave therefore raises its own issue priority after
-    // 2^ageShift, 2 * 2^ageShift and 3 * 2^ageShift inner-node steps: old waves finish sooner, young ones fill the gaps.
-    unsigned int steps = 0;
-    const unsigned int age1 = ageShift > 0 ? (1u << ageShift) : 0xFFFFFFFFu;
     while (live != 0ull) {
         for (;;) {
             const bool inner = (unsigned)node < (unsigned)kSentinel;
@@ -396,12 +391,6 @@ __device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, lds_char* stage,
             if (__popcll(innerMask) < leafSwitchBelow && __ballot(node < 0) != 0ull) break;
             inner_step<FAST, COOP>(nodes, stage, lane, inner, r, node, st, spill, status);
             if (STATS && inner) ls.inner++;
-            if (!DYNAMIC_FETCH) {
-                steps++;
-                if (steps == age1) __builtin_amdgcn_s_setprio(1);
-                else if (steps == 2u * age1) __builtin_amdgcn_s_setprio(2);
-                else if (steps == 3u * age1) __builtin_amdgcn_s_setprio(3);
-            }
         }
         if (node < 0) {
             if (leaf_step<STATS>(woop, r, node, anyHit, hitAddr, hitU, hitV, ls)) node = kSentinel;
@@ -447,8 +436,8 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     LaneStats ls = {0u, 0u, 0u};
 
     const bool fastWave = (p.bvhFlags & NTR_BVH_FASTDIV) && __ballot(node != kSentinel && !ray_is_nice(r, p.bvhFlags)) == 0ull;
-    if (fastWave) traverse<true, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow, p.ageShift);
-    else traverse<false, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow, p.ageShift);
+    if (fastWave) traverse<true, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
+    else traverse<false, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
 
     if (p.timeline && lane == 0) {
         const unsigned int w = block * WAVES + wave;
@@ -562,8 +551,8 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
         if (timeline) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tlRefill += __builtin_amdgcn_s_memtime() - tlA; }
         // ---- while-while traversal ------------------------------------------------
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
-        if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow, 0);
-        else traverse<false, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow, 0);
+        if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
+        else traverse<false, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
 
         // ---- retire finished rays ---------------------------------------------------
         if (rayIdx >= 0 && node == kSentinel) {
