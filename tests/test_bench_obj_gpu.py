@@ -1,0 +1,47 @@
+"""The real-asset path of bench.py (`--scene-obj` / `--camera`, what a supplied sponza.obj would take) on fixture-sized
+geometry: the triangles of the reference's Map.obj (tests/golden/map_obj_mixed.npz, read through this repo's importer when
+the fixture was made) written back as a Wavefront OBJ, traced once from the bounding-box camera and once from the camera
+signature of the reference's config.conf.  The bench compares every hit record of the step with the oracle itself
+(cpu_baseline.parity_mismatches_whole_step)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SIGNATURE = "GBSvz1V04qy/Ju69/21iChCz/idyKy10A0Kfx1pzUoy/DuY2/0aNqY10sZpuu/5/5f/0/"  # config.conf of the reference
+
+
+def _write_obj(path, tri, pos):
+    with open(path, "w") as f:
+        for p in pos:
+            f.write("v %.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
+        for t in tri:
+            f.write("f %d %d %d\n" % (t[0] + 1, t[1] + 1, t[2] + 1))
+
+
+def _bench(args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("camera", ["bounding-box", "config.conf signature"])
+def test_bench_scene_obj_path(tmp_path, camera):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "map_obj_mixed.npz"))
+    obj = str(tmp_path / "map.obj")
+    _write_obj(obj, g["tri"], g["pos"])
+    args = ["--scene-obj", obj, "--width", "320", "--height", "200", "--steps", "2", "--warmup", "1", "--no-extras"]
+    if camera != "bounding-box":
+        args += ["--camera", REF_SIGNATURE]
+    out = _bench(args)
+    assert out["data"].startswith("OBJ map.obj") and out["config"]["triangles"] == g["tri"].shape[0]
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
+    assert out["cpu_baseline"]["parity_mismatches_whole_step"] == 0
+    assert out["cpu_baseline"]["rays_compared"] >= 320 * 200
+    if camera == "bounding-box":
+        assert out["config"]["primary_hits_rank0"] > 1000   # looking down the long axis from inside the box
