@@ -1,7 +1,4 @@
 // host_api.cpp -- C-ABI entry points that are pure host work (no device).
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -34,21 +31,15 @@ int ntr_sah_build(int32_t numTris, const int32_t* triVtxIndex, int32_t numVerts,
             return ntr::set_error(NTR_ERR_INVALID, "ntr_sah_build: vertex index out of range at triangle %lld", (long long)(i / 3));
     try {
         NtrHostBvh* h = new NtrHostBvh();
-        auto T0 = std::chrono::steady_clock::now();
-        auto lap = [&](const char* what) { if (getenv("NTR_SAH_TIMING")) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  %s %.2f s\n", what, std::chrono::duration<double>(t - T0).count()); T0 = t; } };
         h->scene = new Scene(numTris, (const Vec3i*)triVtxIndex, numVerts, (const Vec3f*)vtxPos);
-        lap("scene");
         Platform platform("GPU");  // Renderer.cpp:88-89
         platform.setLeafPreferences(minLeafSize, maxLeafSize);
         BVH::BuildParams params;
         params.stats = &h->stats;
         {
         BVH bvh(h->scene, platform, params);
-        lap("bvh ctor");
         h->cbvh = new CudaBVH(bvh, BVHLayout_Compact);
-        lap("compact");
         }
-        lap("bvh dtor");
         *out = h;
         return NTR_OK;
     } catch (const FatalError& e) {
