@@ -105,7 +105,8 @@ constexpr int TOP_CELLS = 1 << TOP_CELL_BITS;
 
 __global__ __launch_bounds__(MORTON_THREADS) void lbvh_morton_hist_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
                                                                           F3 lo, F3 step, float eps, unsigned int* __restrict__ keys,
-                                                                          int* __restrict__ idx, float2* __restrict__ boxMesh,
+                                                                          int* __restrict__ idx, float2* __restrict__ boxMesh /* or null */,
+                                                                          float* __restrict__ triVerts /* 9 per triangle, or null */,
                                                                           unsigned int* __restrict__ hist /* [4][256] */,
                                                                           unsigned int* __restrict__ tileState, int tileStateWords)
 {
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(MORTON_THREADS) void lbvh_morton_hist_kernel(int n,
         for (int k = 0; k < 3; k++) {
             const float a = pos[3 * i0 + k], b = pos[3 * i1 + k], c = pos[3 * i2 + k];
             const float mn = fminf(a, fminf(b, c)), mx = fmaxf(a, fmaxf(b, c));
-            boxMesh[3 * (size_t)t + k] = make_float2(mn - eps, mx + eps);
+            if (boxMesh) boxMesh[3 * (size_t)t + k] = make_float2(mn - eps, mx + eps);
+            if (triVerts) { triVerts[9 * (size_t)t + k] = a; triVerts[9 * (size_t)t + 3 + k] = b; triVerts[9 * (size_t)t + 6 + k] = c; }
             const float mid = mn + (mx - mn) / 2.0f;
             const int v = (int)floorf((mid - l[k]) / s[k]);
             cell[k] = min(max(v, 0), 1023);
@@ -161,13 +163,9 @@ __global__ __launch_bounds__(256) void lbvh_gather_box_kernel(int n, const unsig
 }
 
 // ---- Woop rows (emitTreeKernel.cu:574-635) ---------------------------------------------------------
-__device__ __forceinline__ void woop_rows(const int* __restrict__ tri, const float* __restrict__ pos, int t, float4& r0, float4& r1,
-                                          float4& r2)
+__device__ __forceinline__ void woop_rows_verts(float v0x, float v0y, float v0z, float v1x, float v1y, float v1z, float v2x, float v2y,
+                                                float v2z, float4& r0, float4& r1, float4& r2)
 {
-    const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-    const float v0x = pos[3 * i0], v0y = pos[3 * i0 + 1], v0z = pos[3 * i0 + 2];
-    const float v1x = pos[3 * i1], v1y = pos[3 * i1 + 1], v1z = pos[3 * i1 + 2];
-    const float v2x = pos[3 * i2], v2y = pos[3 * i2 + 1], v2z = pos[3 * i2 + 2];
     const float c0x = v0x - v2x, c0y = v0y - v2y, c0z = v0z - v2z;
     const float c1x = v1x - v2x, c1y = v1y - v2y, c1z = v1z - v2z;
     const float c2x = c0y * c1z - c0z * c1y, c2y = c0z * c1x - c0x * c1z, c2z = c0x * c1y - c0y * c1x;
@@ -185,6 +183,14 @@ __device__ __forceinline__ void woop_rows(const int* __restrict__ tri, const flo
     r0 = make_float4(o0x, i2y, i2z, o0w);
     r1 = make_float4(i0x, i0y, i0z, o1w);
     r2 = make_float4(i1x, i1y, i1z, o2w);
+}
+
+__device__ __forceinline__ void woop_rows(const int* __restrict__ tri, const float* __restrict__ pos, int t, float4& r0, float4& r1,
+                                          float4& r2)
+{
+    const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+    woop_rows_verts(pos[3 * i0], pos[3 * i0 + 1], pos[3 * i0 + 2], pos[3 * i1], pos[3 * i1 + 1], pos[3 * i1 + 2], pos[3 * i2],
+                    pos[3 * i2 + 1], pos[3 * i2 + 2], r0, r1, r2);
 }
 
 __global__ __launch_bounds__(256) void lbvh_woop_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
@@ -990,7 +996,9 @@ constexpr int AGG_EXPORT_CAP = 64;   // a tile's clusters with a parent outside 
 struct AggCtx {
     const unsigned int* keys;
     const int* triSorted;        // sorted position -> triangle
-    const float2* boxMesh;       // per triangle (mesh order): (lo, hi) per axis, epsilon applied
+    const float* triVerts;       // per triangle (mesh order): the three vertex positions, 36 B -- ONE random access per triangle
+    float* vertsSorted;          // the same per sorted position: written here, read in order by lbvh_finalize_kernel
+    float eps;
     int n, leafSize;
     int* rec;                    // [n + 1][16] node records by split position (0 = root)
     unsigned char* nodeFlag;     // [n + 1]
@@ -1024,18 +1032,29 @@ __device__ __forceinline__ AggSlot agg_load_slot(const AggSlot* src)
     return v;
 }
 
+// the term triangle t contributes to its leaf's box (calcLeaf, emitTreeKernel.cu:383-408): min / max over the vertices, -/+ epsilon
+__device__ __forceinline__ void agg_tri_terms(const float* __restrict__ v /* 9 floats */, float eps, float (&term)[6])
+{
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float a = v[k], b = v[3 + k], c = v[6 + k];
+        term[2 * k] = fminf(a, fminf(b, c)) - eps;
+        term[2 * k + 1] = fmaxf(a, fmaxf(b, c)) + eps;
+    }
+}
+
 // box of the sorted positions [a, b), folded from FLT_MAX like calcLeaf (emitTreeKernel.cu:383-408)
 __device__ __forceinline__ void agg_fold_box(const AggCtx& c, int a, int b, float (&box)[6])
 {
     box[0] = box[2] = box[4] = FLT_MAX;
     box[1] = box[3] = box[5] = -FLT_MAX;
     for (int j = a; j < b; j++) {
-        const int t = c.triSorted[j];
+        float term[6];
+        agg_tri_terms(c.triVerts + 9 * (size_t)c.triSorted[j], c.eps, term);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float2 v = c.boxMesh[3 * (size_t)t + k];
-            box[2 * k] = fminf(box[2 * k], v.x);
-            box[2 * k + 1] = fmaxf(box[2 * k + 1], v.y);
+            box[2 * k] = fminf(box[2 * k], term[2 * k]);
+            box[2 * k + 1] = fmaxf(box[2 * k + 1], term[2 * k + 1]);
         }
     }
 }
@@ -1120,14 +1139,18 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
         const int x = tileBeg - AGG_HALO + k;
         sKeys[k] = (x >= 0 && x < n) ? c.keys[x] : 0u;
     }
-    if (tileBeg + tid < n) {   // one index -> box-term gather per position, all in flight together
-        const int t = c.triSorted[tileBeg + tid];
+    if (tileBeg + tid < n) {   // one index -> vertex gather (36 contiguous bytes) per position, all in flight together
+        const float* src = c.triVerts + 9 * (size_t)c.triSorted[tileBeg + tid];
+        float v[9];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float2 v = c.boxMesh[3 * (size_t)t + k];
-            sBox[tid][2 * k] = v.x;
-            sBox[tid][2 * k + 1] = v.y;
-        }
+        for (int k = 0; k < 9; k++) v[k] = src[k];
+        float* dst = c.vertsSorted + 9 * (size_t)(tileBeg + tid);   // in sorted order for the final pass (coalesced there)
+#pragma unroll
+        for (int k = 0; k < 9; k++) dst[k] = v[k];
+        float term[6];
+        agg_tri_terms(v, c.eps, term);
+#pragma unroll
+        for (int k = 0; k < 6; k++) sBox[tid][k] = term[k];
     }
     sArrive[tid] = 0;
     if (tid == 0) { sArrive[AGG_TILE] = 0; sExports = 0; }
@@ -1348,12 +1371,12 @@ __device__ __forceinline__ void agg_fold_box_wave(const AggCtx& c, int a, int b,
     box[0] = box[2] = box[4] = FLT_MAX;
     box[1] = box[3] = box[5] = -FLT_MAX;
     for (int j = a + lane; j < b; j += 64) {
-        const int t = c.triSorted[j];
+        float term[6];
+        agg_tri_terms(c.triVerts + 9 * (size_t)c.triSorted[j], c.eps, term);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float2 v = c.boxMesh[3 * (size_t)t + k];
-            box[2 * k] = fminf(box[2 * k], v.x);
-            box[2 * k + 1] = fmaxf(box[2 * k + 1], v.y);
+            box[2 * k] = fminf(box[2 * k], term[2 * k]);
+            box[2 * k + 1] = fmaxf(box[2 * k + 1], term[2 * k + 1]);
         }
     }
 #pragma unroll
@@ -1501,7 +1524,7 @@ __device__ __forceinline__ unsigned int agg_rank(const unsigned long long* __res
 // translated, triangle j's Woop rows and index go to its leaf's storage (calcWoopKernel, emitTreeKernel.cu:574-645; leaf storage
 // = 3 * first position + leaves before, createLeaf :176-181 with the leaves numbered in sorted order), and the leaf that ends
 // before j gets its terminator.
-__global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
+__global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const float* __restrict__ vertsSorted,
                                                                  const int* __restrict__ triSorted, const int* __restrict__ rec,
                                                                  const unsigned long long* __restrict__ nodeBits,
                                                                  const unsigned long long* __restrict__ leafBits, const uint2* __restrict__ tileBase,
@@ -1545,8 +1568,9 @@ __global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const in
     if (j == n) return;
     const int o = (int)(3u * (unsigned int)j + rkL + (isLeafStart ? 1u : 0u)) - 1;   // 3 j + leaves up to and including this one - 1
     const int t = triSorted[j];
+    const float* v = vertsSorted + 9 * (size_t)j;
     float4 r0, r1, r2;
-    woop_rows(tri, pos, t, r0, r1, r2);
+    woop_rows_verts(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], r0, r1, r2);
     outWoop[o + 0] = r0;
     outWoop[o + 1] = r1;
     outWoop[o + 2] = r2;
@@ -1676,6 +1700,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oAggZeroEnd = cv.off;
     const size_t oRec = cv.take(((size_t)n + 1) * 64), oSlot = cv.take(((size_t)n + 1) * 96);
     const size_t oExports = cv.take((size_t)aggTiles * AGG_EXPORT_CAP * sizeof(AggExport));
+    const size_t oTriVerts = cv.take((size_t)n * 36), oVertsSorted = cv.take((size_t)n * 36);
     const size_t oParentPos = cv.take(((size_t)n + 1) * 4);
     const size_t oRuns = cv.take(((size_t)n / 2 + 2) * 16);
     const size_t oNodeBits = cv.take((size_t)cntTiles * (CNT_TILE / 8)), oLeafBits = cv.take((size_t)cntTiles * (CNT_TILE / 8));
@@ -1694,6 +1719,15 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     pe.mark(0);
     NTR_HIP(hipMemsetAsync(ws + oState, 0, oClearEnd - oState, s));
 
+    int spillSize = tun.lbvhSplit;
+    if (spillSize < 2) spillSize = 2;
+    if (spillSize > 7168) spillSize = 7168;  // 20 bytes of LDS per triangle of a subtree (140 KB), 16-bit positions
+    // 0: the whole tree is one hand-over root; 1: cell-table top + subtree workgroups; 2: level-by-level top with key probes;
+    // 3: bottom-up emit with ranked indices (default; it gathers the box terms itself)
+    // (a scene of at most leafSize triangles is a root over two leaves: the table / bottom-up paths expect more than one leaf's worth)
+    const int topMode = n <= spillSize ? 0 : ((tun.lbvhLegacyTop || n <= leafSize) ? 2 : (tun.lbvhEmit == 1 ? 1 : 3));
+    const bool bottomUp = !levelSync && topMode == 3;
+
     // L1: Morton codes (step = (max - min) / 1024 on the host, HLBVHBuilder.cpp:76-81)
     F3 lo = {sceneMin[0], sceneMin[1], sceneMin[2]};
     F3 step = {(sceneMax[0] - sceneMin[0]) / 1024.0f, (sceneMax[1] - sceneMin[1]) / 1024.0f, (sceneMax[2] - sceneMin[2]) / 1024.0f};
@@ -1705,7 +1739,8 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         int mb = (n + MORTON_THREADS * 4 - 1) / (MORTON_THREADS * 4);
         if (mb > MORTON_MAX_BLOCKS) mb = MORTON_MAX_BLOCKS;
         hipLaunchKernelGGL(lbvh_morton_hist_kernel, dim3(mb), dim3(MORTON_THREADS), 0, s, n, d_triVtxIndex, d_vtxPos, lo, step, epsilon, kIn, vIn,
-                           (float2*)(ws + oWoop), osHist, (unsigned int*)(ws + oOsState), legacySort ? 0 : osTiles * 256);
+                           bottomUp ? (float2*)nullptr : (float2*)(ws + oWoop), bottomUp ? (float*)(ws + oTriVerts) : (float*)nullptr, osHist,
+                           (unsigned int*)(ws + oOsState), legacySort ? 0 : osTiles * 256);
     }
     pe.mark(1);
 
@@ -1735,13 +1770,6 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
 
     // L4: Woop rows in original triangle order (per-level path), or the per-triangle box terms in sorted order plus the
     // cell table of the top pass (subtree path; its Woop rows are produced by lbvh_place_kernel once the leaves have their slots)
-    int spillSize = tun.lbvhSplit;
-    if (spillSize < 2) spillSize = 2;
-    if (spillSize > 7168) spillSize = 7168;  // 20 bytes of LDS per triangle of a subtree (140 KB), 16-bit positions
-    // 0: the whole tree is one hand-over root; 1: cell-table top + subtree workgroups; 2: level-by-level top with key probes;
-    // 3: bottom-up emit with ranked indices (default; it gathers the box terms itself)
-    // (a scene of at most leafSize triangles is a root over two leaves: the table / bottom-up paths expect more than one leaf's worth)
-    const int topMode = n <= spillSize ? 0 : ((tun.lbvhLegacyTop || n <= leafSize) ? 2 : (tun.lbvhEmit == 1 ? 1 : 3));
     if (levelSync)
         hipLaunchKernelGGL(lbvh_woop_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, (float4*)(ws + oWoop));
     else if (topMode != 3)
@@ -1816,7 +1844,8 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         };
         if (topMode == 3) {
             AggCtx a;
-            a.keys = keys; a.triSorted = triSorted; a.boxMesh = (const float2*)(ws + oWoop); a.n = n; a.leafSize = leafSize;
+            a.keys = keys; a.triSorted = triSorted; a.triVerts = (const float*)(ws + oTriVerts); a.vertsSorted = (float*)(ws + oVertsSorted);
+            a.eps = epsilon; a.n = n; a.leafSize = leafSize;
             a.rec = (int*)(ws + oRec);
             a.nodeFlag = (unsigned char*)(ws + oNodeFlag); a.leafFlag = (unsigned char*)(ws + oLeafFlag);
             a.arrive = (unsigned int*)(ws + oArrive); a.slot = (AggSlot*)(ws + oSlot); a.parentPos = (int*)(ws + oParentPos);
@@ -1838,7 +1867,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
                                (unsigned long long*)(ws + oNodeBits), (unsigned long long*)(ws + oLeafBits), (uint2*)(ws + oTileCount));
             hipLaunchKernelGGL(lbvh_tilescan_kernel, dim3(1), dim3(1024), 0, s, cntTiles, n, (const uint2*)(ws + oTileCount), (uint2*)(ws + oTileBase), state);
             pe.mark(5);
-            hipLaunchKernelGGL(lbvh_finalize_kernel, dim3(cntTiles), dim3(CNT_TILE), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted, (const int*)a.rec,
+            hipLaunchKernelGGL(lbvh_finalize_kernel, dim3(cntTiles), dim3(CNT_TILE), 0, s, n, (const float*)a.vertsSorted, triSorted, (const int*)a.rec,
                                (const unsigned long long*)(ws + oNodeBits), (const unsigned long long*)(ws + oLeafBits), (const uint2*)(ws + oTileBase),
                                (int*)d_nodes, nodeCap, (float4*)d_triWoop, d_triIndex, state);
             pe.mark(6);
