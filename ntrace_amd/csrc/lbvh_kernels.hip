@@ -68,6 +68,10 @@ __device__ __forceinline__ unsigned int spread10(unsigned int n)  // emitTreeKer
 }
 
 struct F3 { float x, y, z; };
+// a triangle's vertex record: three packed float3 (36 B, 4-byte aligned) moved as three 12-byte accesses
+struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
+struct __attribute__((packed, aligned(4))) TriVerts { V3 v[3]; };
+static_assert(sizeof(TriVerts) == 36, "TriVerts must be 36 bytes");
 
 __global__ __launch_bounds__(256) void lbvh_morton_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
                                                           F3 lo, F3 step, unsigned int* __restrict__ keys,
@@ -106,7 +110,7 @@ constexpr int TOP_CELLS = 1 << TOP_CELL_BITS;
 __global__ __launch_bounds__(MORTON_THREADS) void lbvh_morton_hist_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
                                                                           F3 lo, F3 step, float eps, unsigned int* __restrict__ keys,
                                                                           int* __restrict__ idx, float2* __restrict__ boxMesh /* or null */,
-                                                                          float* __restrict__ triVerts /* 9 per triangle, or null */,
+                                                                          TriVerts* __restrict__ triVerts /* mesh order, or null */,
                                                                           unsigned int* __restrict__ hist /* [4][256] */,
                                                                           unsigned int* __restrict__ tileState, int tileStateWords)
 {
@@ -119,12 +123,15 @@ __global__ __launch_bounds__(MORTON_THREADS) void lbvh_morton_hist_kernel(int n,
     for (int t = gtid; t < n; t += gstride) {
         const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
         int cell[3];
+        const V3 p0 = *reinterpret_cast<const V3*>(pos + 3 * (size_t)i0), p1 = *reinterpret_cast<const V3*>(pos + 3 * (size_t)i1),
+                 p2 = *reinterpret_cast<const V3*>(pos + 3 * (size_t)i2);
+        if (triVerts) { triVerts[t].v[0] = p0; triVerts[t].v[1] = p1; triVerts[t].v[2] = p2; }
+        const float va[3] = {p0.x, p0.y, p0.z}, vb[3] = {p1.x, p1.y, p1.z}, vc[3] = {p2.x, p2.y, p2.z};
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float a = pos[3 * i0 + k], b = pos[3 * i1 + k], c = pos[3 * i2 + k];
+            const float a = va[k], b = vb[k], c = vc[k];
             const float mn = fminf(a, fminf(b, c)), mx = fmaxf(a, fmaxf(b, c));
             if (boxMesh) boxMesh[3 * (size_t)t + k] = make_float2(mn - eps, mx + eps);
-            if (triVerts) { triVerts[9 * (size_t)t + k] = a; triVerts[9 * (size_t)t + 3 + k] = b; triVerts[9 * (size_t)t + 6 + k] = c; }
             const float mid = mn + (mx - mn) / 2.0f;
             const int v = (int)floorf((mid - l[k]) / s[k]);
             cell[k] = min(max(v, 0), 1023);
@@ -996,8 +1003,8 @@ constexpr int AGG_EXPORT_CAP = 64;   // a tile's clusters with a parent outside 
 struct AggCtx {
     const unsigned int* keys;
     const int* triSorted;        // sorted position -> triangle
-    const float* triVerts;       // per triangle (mesh order): the three vertex positions, 36 B -- ONE random access per triangle
-    float* vertsSorted;          // the same per sorted position: written here, read in order by lbvh_finalize_kernel
+    const TriVerts* triVerts;    // per triangle (mesh order): the three vertex positions, 36 B -- ONE random access per triangle
+    TriVerts* vertsSorted;       // the same per sorted position: written here, read in order by lbvh_finalize_kernel
     float eps;
     int n, leafSize;
     int* rec;                    // [n + 1][16] node records by split position (0 = root)
@@ -1033,8 +1040,9 @@ __device__ __forceinline__ AggSlot agg_load_slot(const AggSlot* src)
 }
 
 // the term triangle t contributes to its leaf's box (calcLeaf, emitTreeKernel.cu:383-408): min / max over the vertices, -/+ epsilon
-__device__ __forceinline__ void agg_tri_terms(const float* __restrict__ v /* 9 floats */, float eps, float (&term)[6])
+__device__ __forceinline__ void agg_tri_terms(const TriVerts& tv, float eps, float (&term)[6])
 {
+    const float v[9] = {tv.v[0].x, tv.v[0].y, tv.v[0].z, tv.v[1].x, tv.v[1].y, tv.v[1].z, tv.v[2].x, tv.v[2].y, tv.v[2].z};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float a = v[k], b = v[3 + k], c = v[6 + k];
@@ -1050,7 +1058,7 @@ __device__ __forceinline__ void agg_fold_box(const AggCtx& c, int a, int b, floa
     box[1] = box[3] = box[5] = -FLT_MAX;
     for (int j = a; j < b; j++) {
         float term[6];
-        agg_tri_terms(c.triVerts + 9 * (size_t)c.triSorted[j], c.eps, term);
+        agg_tri_terms(c.triVerts[c.triSorted[j]], c.eps, term);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             box[2 * k] = fminf(box[2 * k], term[2 * k]);
@@ -1140,15 +1148,10 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
         sKeys[k] = (x >= 0 && x < n) ? c.keys[x] : 0u;
     }
     if (tileBeg + tid < n) {   // one index -> vertex gather (36 contiguous bytes) per position, all in flight together
-        const float* src = c.triVerts + 9 * (size_t)c.triSorted[tileBeg + tid];
-        float v[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) v[k] = src[k];
-        float* dst = c.vertsSorted + 9 * (size_t)(tileBeg + tid);   // in sorted order for the final pass (coalesced there)
-#pragma unroll
-        for (int k = 0; k < 9; k++) dst[k] = v[k];
+        const TriVerts tv = c.triVerts[c.triSorted[tileBeg + tid]];
+        c.vertsSorted[tileBeg + tid] = tv;                            // in sorted order for the final pass
         float term[6];
-        agg_tri_terms(v, c.eps, term);
+        agg_tri_terms(tv, c.eps, term);
 #pragma unroll
         for (int k = 0; k < 6; k++) sBox[tid][k] = term[k];
     }
@@ -1372,7 +1375,7 @@ __device__ __forceinline__ void agg_fold_box_wave(const AggCtx& c, int a, int b,
     box[1] = box[3] = box[5] = -FLT_MAX;
     for (int j = a + lane; j < b; j += 64) {
         float term[6];
-        agg_tri_terms(c.triVerts + 9 * (size_t)c.triSorted[j], c.eps, term);
+        agg_tri_terms(c.triVerts[c.triSorted[j]], c.eps, term);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             box[2 * k] = fminf(box[2 * k], term[2 * k]);
@@ -1524,7 +1527,7 @@ __device__ __forceinline__ unsigned int agg_rank(const unsigned long long* __res
 // translated, triangle j's Woop rows and index go to its leaf's storage (calcWoopKernel, emitTreeKernel.cu:574-645; leaf storage
 // = 3 * first position + leaves before, createLeaf :176-181 with the leaves numbered in sorted order), and the leaf that ends
 // before j gets its terminator.
-__global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const float* __restrict__ vertsSorted,
+__global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const TriVerts* __restrict__ vertsSorted,
                                                                  const int* __restrict__ triSorted, const int* __restrict__ rec,
                                                                  const unsigned long long* __restrict__ nodeBits,
                                                                  const unsigned long long* __restrict__ leafBits, const uint2* __restrict__ tileBase,
@@ -1568,9 +1571,9 @@ __global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const fl
     if (j == n) return;
     const int o = (int)(3u * (unsigned int)j + rkL + (isLeafStart ? 1u : 0u)) - 1;   // 3 j + leaves up to and including this one - 1
     const int t = triSorted[j];
-    const float* v = vertsSorted + 9 * (size_t)j;
+    const TriVerts tv = vertsSorted[j];
     float4 r0, r1, r2;
-    woop_rows_verts(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], r0, r1, r2);
+    woop_rows_verts(tv.v[0].x, tv.v[0].y, tv.v[0].z, tv.v[1].x, tv.v[1].y, tv.v[1].z, tv.v[2].x, tv.v[2].y, tv.v[2].z, r0, r1, r2);
     outWoop[o + 0] = r0;
     outWoop[o + 1] = r1;
     outWoop[o + 2] = r2;
@@ -1739,7 +1742,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         int mb = (n + MORTON_THREADS * 4 - 1) / (MORTON_THREADS * 4);
         if (mb > MORTON_MAX_BLOCKS) mb = MORTON_MAX_BLOCKS;
         hipLaunchKernelGGL(lbvh_morton_hist_kernel, dim3(mb), dim3(MORTON_THREADS), 0, s, n, d_triVtxIndex, d_vtxPos, lo, step, epsilon, kIn, vIn,
-                           bottomUp ? (float2*)nullptr : (float2*)(ws + oWoop), bottomUp ? (float*)(ws + oTriVerts) : (float*)nullptr, osHist,
+                           bottomUp ? (float2*)nullptr : (float2*)(ws + oWoop), bottomUp ? (TriVerts*)(ws + oTriVerts) : (TriVerts*)nullptr, osHist,
                            (unsigned int*)(ws + oOsState), legacySort ? 0 : osTiles * 256);
     }
     pe.mark(1);
@@ -1844,7 +1847,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         };
         if (topMode == 3) {
             AggCtx a;
-            a.keys = keys; a.triSorted = triSorted; a.triVerts = (const float*)(ws + oTriVerts); a.vertsSorted = (float*)(ws + oVertsSorted);
+            a.keys = keys; a.triSorted = triSorted; a.triVerts = (const TriVerts*)(ws + oTriVerts); a.vertsSorted = (TriVerts*)(ws + oVertsSorted);
             a.eps = epsilon; a.n = n; a.leafSize = leafSize;
             a.rec = (int*)(ws + oRec);
             a.nodeFlag = (unsigned char*)(ws + oNodeFlag); a.leafFlag = (unsigned char*)(ws + oLeafFlag);
@@ -1867,7 +1870,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
                                (unsigned long long*)(ws + oNodeBits), (unsigned long long*)(ws + oLeafBits), (uint2*)(ws + oTileCount));
             hipLaunchKernelGGL(lbvh_tilescan_kernel, dim3(1), dim3(1024), 0, s, cntTiles, n, (const uint2*)(ws + oTileCount), (uint2*)(ws + oTileBase), state);
             pe.mark(5);
-            hipLaunchKernelGGL(lbvh_finalize_kernel, dim3(cntTiles), dim3(CNT_TILE), 0, s, n, (const float*)a.vertsSorted, triSorted, (const int*)a.rec,
+            hipLaunchKernelGGL(lbvh_finalize_kernel, dim3(cntTiles), dim3(CNT_TILE), 0, s, n, (const TriVerts*)a.vertsSorted, triSorted, (const int*)a.rec,
                                (const unsigned long long*)(ws + oNodeBits), (const unsigned long long*)(ws + oLeafBits), (const uint2*)(ws + oTileBase),
                                (int*)d_nodes, nodeCap, (float4*)d_triWoop, d_triIndex, state);
             pe.mark(6);
