@@ -1133,8 +1133,8 @@ template <bool EXPORT>
 __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
 {
     __shared__ unsigned int sKeys[AGG_TILE + 2 * AGG_HALO];   // sKeys[AGG_HALO + k] = key of position tileBeg + k
-    __shared__ unsigned int sArrive[AGG_TILE + 1];
-    __shared__ AggSlot sSlot[AGG_TILE + 1][2];
+    __shared__ unsigned int sMeet[AGG_TILE + 1];               // per boundary: 0, or 1 + the compacted index of the cluster waiting there
+    __shared__ AggSlot sOwn[AGG_TILE];                        // per cluster (compacted index): what it shows to its sibling
     __shared__ int sWalker[AGG_TILE];                         // start positions of the tile's clusters, compacted; bit 31 = run of equal keys
     __shared__ int sWalkerEnd[AGG_TILE];
     __shared__ unsigned int sWaveCount[AGG_TILE / 64], sNumWalkers, sExports;
@@ -1155,8 +1155,8 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
 #pragma unroll
         for (int k = 0; k < 6; k++) sBox[tid][k] = term[k];
     }
-    sArrive[tid] = 0;
-    if (tid == 0) { sArrive[AGG_TILE] = 0; sExports = 0; }
+    sMeet[tid] = 0;
+    if (tid == 0) { sMeet[AGG_TILE] = 0; sExports = 0; }
     __syncthreads();
 
     auto key = [&](int x) -> unsigned int {   // sorted key at position x (0 <= x < n)
@@ -1269,15 +1269,16 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
         AggSlot sib;
         if (inTile) {
             const int bl = B - tileBeg;
-            // LDS executes a wave's operations in order and the atomic serialises the two siblings, so the slot only has to be
-            // written before the atomic is issued and read after it has returned: LDS counters, not vmcnt -- the global stores of
-            // the node just formed stay in flight
-            sSlot[bl][side] = mine;
+            // Every cluster keeps its record in its own LDS slot and the two siblings exchange slot numbers at the boundary: the
+            // first finds 0 and stops (its record stays put), the second finds the first's number.  LDS executes a wave's operations
+            // in order and the exchange serialises the two, so only LDS counters are waited for -- the global stores of the node just
+            // formed stay in flight.
+            sOwn[tid] = mine;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned int old = atomicAdd(&sArrive[bl], 1u);
+            const unsigned int old = atomicExch(&sMeet[bl], (unsigned int)tid + 1u);
             if (old == 0) break;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            sib = sSlot[bl][side ^ 1];
+            sib = sOwn[old - 1u];
         } else if (EXPORT) {
             const unsigned int k = atomicAdd(&sExports, 1u);
             if (k < (unsigned int)AGG_EXPORT_CAP) {
@@ -1451,24 +1452,31 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
     }
 }
 
-// Node / leaf-start flags -> bit masks (one 64-bit word per wave) and counts per 256 positions.
-constexpr int CNT_TILE = 256;
+// Node / leaf-start flags -> bit masks (one 64-bit word per 64 positions) and counts per RANK_BLOCK positions.
+constexpr int CNT_TILE = 256;                  // threads of the count / finalize workgroups
+constexpr int RANK_SHIFT = 10;
+constexpr int RANK_BLOCK = 1 << RANK_SHIFT;    // positions per prefix-count entry (16 mask words)
 
 __global__ __launch_bounds__(CNT_TILE) void lbvh_count_kernel(int n, const unsigned char* __restrict__ nodeFlag, const unsigned char* __restrict__ leafFlag,
                                                               unsigned long long* __restrict__ nodeBits, unsigned long long* __restrict__ leafBits,
                                                               uint2* __restrict__ tileCount)
 {
     __shared__ unsigned int s_n[CNT_TILE / 64], s_l[CNT_TILE / 64];
-    const int p = blockIdx.x * CNT_TILE + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool ok = p <= n;
-    const unsigned long long nb = __ballot(ok && nodeFlag[ok ? p : 0] != 0), lb = __ballot(ok && leafFlag[ok ? p : 0] != 0);
-    if (lane == 0) {
-        nodeBits[(size_t)blockIdx.x * (CNT_TILE / 64) + wave] = nb;
-        leafBits[(size_t)blockIdx.x * (CNT_TILE / 64) + wave] = lb;
-        s_n[wave] = (unsigned int)__popcll(nb);
-        s_l[wave] = (unsigned int)__popcll(lb);
+    unsigned int cn = 0, cl = 0;
+#pragma unroll
+    for (int r = 0; r < RANK_BLOCK / CNT_TILE; r++) {
+        const int p = blockIdx.x * RANK_BLOCK + r * CNT_TILE + threadIdx.x;
+        const bool ok = p <= n;
+        const unsigned long long nb = __ballot(ok && nodeFlag[ok ? p : 0] != 0), lb = __ballot(ok && leafFlag[ok ? p : 0] != 0);
+        if (lane == 0) {
+            nodeBits[(size_t)(p >> 6)] = nb;
+            leafBits[(size_t)(p >> 6)] = lb;
+        }
+        cn += (unsigned int)__popcll(nb);
+        cl += (unsigned int)__popcll(lb);
     }
+    if (lane == 0) { s_n[wave] = cn; s_l[wave] = cl; }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int a = 0, b = 0;
@@ -1519,7 +1527,7 @@ __device__ __forceinline__ unsigned int agg_rank(const unsigned long long* __res
 {
     const int w = p >> 6;
     unsigned int acc = tileBaseValue;
-    for (int k = (p >> 8) << 2; k < w; k++) acc += (unsigned int)__popcll(bits[k]);
+    for (int k = (p >> RANK_SHIFT) << (RANK_SHIFT - 6); k < w; k++) acc += (unsigned int)__popcll(bits[k]);
     return acc + (unsigned int)__popcll(bits[w] & ((1ull << (p & 63)) - 1ull));
 }
 
@@ -1536,7 +1544,7 @@ __global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const Tr
 {
     const int j = blockIdx.x * CNT_TILE + threadIdx.x;
     if (j > n) return;
-    const uint2 tb = tileBase[blockIdx.x];
+    const uint2 tb = tileBase[j >> RANK_SHIFT];
     const unsigned int rkN = agg_rank(nodeBits, tb.x, j), rkL = agg_rank(leafBits, tb.y, j);
     const bool isNode = (nodeBits[j >> 6] >> (j & 63)) & 1ull, isLeafStart = (leafBits[j >> 6] >> (j & 63)) & 1ull;
     if (isNode) {
@@ -1553,9 +1561,9 @@ __global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const Tr
                 int out;
                 if (ref < 0) {                                   // leaf starting at s = ~ref: float4 index 3 * s + leaves before s
                     const int sPos = ~ref;
-                    out = ~(int)(3u * (unsigned int)sPos + agg_rank(leafBits, tileBase[sPos >> 8].y, sPos));
+                    out = ~(int)(3u * (unsigned int)sPos + agg_rank(leafBits, tileBase[sPos >> RANK_SHIFT].y, sPos));
                 } else {                                         // inner child recorded at position ref
-                    out = (int)(agg_rank(nodeBits, tileBase[ref >> 8].x, ref) * 64u);
+                    out = (int)(agg_rank(nodeBits, tileBase[ref >> RANK_SHIFT].x, ref) * 64u);
                 }
                 lk[k] = out;
             }
@@ -1693,7 +1701,8 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oTriBox = cv.take((size_t)n * 24), oTriOut = cv.take((size_t)n * 4);
     const size_t oCell = cv.take(((size_t)TOP_CELLS + 1) * 4), oTopIdx = cv.take((size_t)TOP_HEAP * 4);
     // bottom-up emit: zeroed region (flags, meeting counters, scan state) first, then records, slots, ranks
-    const int cntTiles = (n + 1 + CNT_TILE - 1) / CNT_TILE;
+    const int cntTiles = (n + 1 + RANK_BLOCK - 1) / RANK_BLOCK;    // prefix-count entries
+    const int finTiles = (n + 1 + CNT_TILE - 1) / CNT_TILE;       // workgroups of the final pass
     const size_t oAggZero = cv.off;
     const size_t oNodeFlag = cv.take((size_t)n + 1), oLeafFlag = cv.take((size_t)n + 1);
     const size_t oArrive = cv.take(((size_t)n + 1) * 4);
@@ -1706,7 +1715,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oTriVerts = cv.take((size_t)n * 36), oVertsSorted = cv.take((size_t)n * 36);
     const size_t oParentPos = cv.take(((size_t)n + 1) * 4);
     const size_t oRuns = cv.take(((size_t)n / 2 + 2) * 16);
-    const size_t oNodeBits = cv.take((size_t)cntTiles * (CNT_TILE / 8)), oLeafBits = cv.take((size_t)cntTiles * (CNT_TILE / 8));
+    const size_t oNodeBits = cv.take((size_t)cntTiles * (RANK_BLOCK / 8)), oLeafBits = cv.take((size_t)cntTiles * (RANK_BLOCK / 8));
     const size_t oTileCount = cv.take((size_t)cntTiles * 8), oTileBase = cv.take((size_t)cntTiles * 8);
     void* wsBase = nullptr;
     {
@@ -1870,7 +1879,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
                                (unsigned long long*)(ws + oNodeBits), (unsigned long long*)(ws + oLeafBits), (uint2*)(ws + oTileCount));
             hipLaunchKernelGGL(lbvh_tilescan_kernel, dim3(1), dim3(1024), 0, s, cntTiles, n, (const uint2*)(ws + oTileCount), (uint2*)(ws + oTileBase), state);
             pe.mark(5);
-            hipLaunchKernelGGL(lbvh_finalize_kernel, dim3(cntTiles), dim3(CNT_TILE), 0, s, n, (const TriVerts*)a.vertsSorted, triSorted, (const int*)a.rec,
+            hipLaunchKernelGGL(lbvh_finalize_kernel, dim3(finTiles), dim3(CNT_TILE), 0, s, n, (const TriVerts*)a.vertsSorted, triSorted, (const int*)a.rec,
                                (const unsigned long long*)(ws + oNodeBits), (const unsigned long long*)(ws + oLeafBits), (const uint2*)(ws + oTileBase),
                                (int*)d_nodes, nodeCap, (float4*)d_triWoop, d_triIndex, state);
             pe.mark(6);
