@@ -1459,29 +1459,32 @@ constexpr int RANK_BLOCK = 1 << RANK_SHIFT;    // positions per prefix-count ent
 
 __global__ __launch_bounds__(CNT_TILE) void lbvh_count_kernel(int n, const unsigned char* __restrict__ nodeFlag, const unsigned char* __restrict__ leafFlag,
                                                               unsigned long long* __restrict__ nodeBits, unsigned long long* __restrict__ leafBits,
-                                                              uint2* __restrict__ tileCount)
+                                                              uint2* __restrict__ blockCount /* per RANK_BLOCK positions */,
+                                                              uint2* __restrict__ subBase /* per 256 positions: count inside its block before it */)
 {
-    __shared__ unsigned int s_n[CNT_TILE / 64], s_l[CNT_TILE / 64];
+    constexpr int ROUNDS = RANK_BLOCK / CNT_TILE;
+    __shared__ unsigned int s_n[ROUNDS][CNT_TILE / 64], s_l[ROUNDS][CNT_TILE / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned int cn = 0, cl = 0;
 #pragma unroll
-    for (int r = 0; r < RANK_BLOCK / CNT_TILE; r++) {
+    for (int r = 0; r < ROUNDS; r++) {
         const int p = blockIdx.x * RANK_BLOCK + r * CNT_TILE + threadIdx.x;
         const bool ok = p <= n;
         const unsigned long long nb = __ballot(ok && nodeFlag[ok ? p : 0] != 0), lb = __ballot(ok && leafFlag[ok ? p : 0] != 0);
         if (lane == 0) {
             nodeBits[(size_t)(p >> 6)] = nb;
             leafBits[(size_t)(p >> 6)] = lb;
+            s_n[r][wave] = (unsigned int)__popcll(nb);
+            s_l[r][wave] = (unsigned int)__popcll(lb);
         }
-        cn += (unsigned int)__popcll(nb);
-        cl += (unsigned int)__popcll(lb);
     }
-    if (lane == 0) { s_n[wave] = cn; s_l[wave] = cl; }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int a = 0, b = 0;
-        for (int w = 0; w < CNT_TILE / 64; w++) { a += s_n[w]; b += s_l[w]; }
-        tileCount[blockIdx.x] = make_uint2(a, b);
+        for (int r = 0; r < ROUNDS; r++) {
+            subBase[(size_t)blockIdx.x * ROUNDS + r] = make_uint2(a, b);
+            for (int w = 0; w < CNT_TILE / 64; w++) { a += s_n[r][w]; b += s_l[r][w]; }
+        }
+        blockCount[blockIdx.x] = make_uint2(a, b);
     }
 }
 
@@ -1522,12 +1525,13 @@ __global__ __launch_bounds__(1024) void lbvh_tilescan_kernel(int numTiles, int n
     }
 }
 
-// exclusive rank of position p: set bits before p
-__device__ __forceinline__ unsigned int agg_rank(const unsigned long long* __restrict__ bits, unsigned int tileBaseValue, int p)
+// exclusive rank of position p (set bits before p) = count before its 1024-block + count inside the block before its 256-tile
+// (both passed in as `base`) + set bits of the tile's words before p
+__device__ __forceinline__ unsigned int agg_rank(const unsigned long long* __restrict__ bits, unsigned int base, int p)
 {
     const int w = p >> 6;
-    unsigned int acc = tileBaseValue;
-    for (int k = (p >> RANK_SHIFT) << (RANK_SHIFT - 6); k < w; k++) acc += (unsigned int)__popcll(bits[k]);
+    unsigned int acc = base;
+    for (int k = (p >> 8) << 2; k < w; k++) acc += (unsigned int)__popcll(bits[k]);
     return acc + (unsigned int)__popcll(bits[w] & ((1ull << (p & 63)) - 1ull));
 }
 
@@ -1539,13 +1543,14 @@ __global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const Tr
                                                                  const int* __restrict__ triSorted, const int* __restrict__ rec,
                                                                  const unsigned long long* __restrict__ nodeBits,
                                                                  const unsigned long long* __restrict__ leafBits, const uint2* __restrict__ tileBase,
+                                                                 const uint2* __restrict__ subBase,
                                                                  int* __restrict__ nodes, unsigned int nodeCap, float4* __restrict__ outWoop,
                                                                  int* __restrict__ outIdx, LbvhState* st)
 {
     const int j = blockIdx.x * CNT_TILE + threadIdx.x;
     if (j > n) return;
-    const uint2 tb = tileBase[j >> RANK_SHIFT];
-    const unsigned int rkN = agg_rank(nodeBits, tb.x, j), rkL = agg_rank(leafBits, tb.y, j);
+    const uint2 tb = tileBase[j >> RANK_SHIFT], sb = subBase[j >> 8];
+    const unsigned int rkN = agg_rank(nodeBits, tb.x + sb.x, j), rkL = agg_rank(leafBits, tb.y + sb.y, j);
     const bool isNode = (nodeBits[j >> 6] >> (j & 63)) & 1ull, isLeafStart = (leafBits[j >> 6] >> (j & 63)) & 1ull;
     if (isNode) {
         if (rkN >= nodeCap) atomicOr(&st->overflow, 1u);
@@ -1561,9 +1566,9 @@ __global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const Tr
                 int out;
                 if (ref < 0) {                                   // leaf starting at s = ~ref: float4 index 3 * s + leaves before s
                     const int sPos = ~ref;
-                    out = ~(int)(3u * (unsigned int)sPos + agg_rank(leafBits, tileBase[sPos >> RANK_SHIFT].y, sPos));
+                    out = ~(int)(3u * (unsigned int)sPos + agg_rank(leafBits, tileBase[sPos >> RANK_SHIFT].y + subBase[sPos >> 8].y, sPos));
                 } else {                                         // inner child recorded at position ref
-                    out = (int)(agg_rank(nodeBits, tileBase[ref >> RANK_SHIFT].x, ref) * 64u);
+                    out = (int)(agg_rank(nodeBits, tileBase[ref >> RANK_SHIFT].x + subBase[ref >> 8].x, ref) * 64u);
                 }
                 lk[k] = out;
             }
@@ -1717,6 +1722,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oRuns = cv.take(((size_t)n / 2 + 2) * 16);
     const size_t oNodeBits = cv.take((size_t)cntTiles * (RANK_BLOCK / 8)), oLeafBits = cv.take((size_t)cntTiles * (RANK_BLOCK / 8));
     const size_t oTileCount = cv.take((size_t)cntTiles * 8), oTileBase = cv.take((size_t)cntTiles * 8);
+    const size_t oSubBase = cv.take((size_t)cntTiles * (RANK_BLOCK / CNT_TILE) * 8);
     void* wsBase = nullptr;
     {
         const int rc = workspace_reserve(cv.off, &wsBase);
@@ -1876,11 +1882,12 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             hipLaunchKernelGGL(lbvh_runs_kernel, dim3(2048), dim3(64), 0, s, a);
             pe.mark(4);
             hipLaunchKernelGGL(lbvh_count_kernel, dim3(cntTiles), dim3(CNT_TILE), 0, s, n, (const unsigned char*)a.nodeFlag, (const unsigned char*)a.leafFlag,
-                               (unsigned long long*)(ws + oNodeBits), (unsigned long long*)(ws + oLeafBits), (uint2*)(ws + oTileCount));
+                               (unsigned long long*)(ws + oNodeBits), (unsigned long long*)(ws + oLeafBits), (uint2*)(ws + oTileCount), (uint2*)(ws + oSubBase));
             hipLaunchKernelGGL(lbvh_tilescan_kernel, dim3(1), dim3(1024), 0, s, cntTiles, n, (const uint2*)(ws + oTileCount), (uint2*)(ws + oTileBase), state);
             pe.mark(5);
             hipLaunchKernelGGL(lbvh_finalize_kernel, dim3(finTiles), dim3(CNT_TILE), 0, s, n, (const TriVerts*)a.vertsSorted, triSorted, (const int*)a.rec,
                                (const unsigned long long*)(ws + oNodeBits), (const unsigned long long*)(ws + oLeafBits), (const uint2*)(ws + oTileBase),
+                               (const uint2*)(ws + oSubBase),
                                (int*)d_nodes, nodeCap, (float4*)d_triWoop, d_triIndex, state);
             pe.mark(6);
         } else {
