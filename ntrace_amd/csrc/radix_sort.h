@@ -186,11 +186,13 @@ __device__ __forceinline__ unsigned int os_excl_scan_256(unsigned int v, unsigne
     return before + incl - v;
 }
 
-template <int ITEMS>
+// INDEXED = false: keysIn[i] is the key of element i; keys and values both move.
+// INDEXED = true : the key word of element i is keysIn[valsIn[i] * stride] (multi-word keys stay in place, only the index array moves).
+template <int ITEMS, bool INDEXED>
 __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n, const unsigned int* __restrict__ keysIn,
                                                                            const int* __restrict__ valsIn,
                                                                            unsigned int* __restrict__ keysOut, int* __restrict__ valsOut,
-                                                                           int shift, int pass,
+                                                                           int stride, int shift, int pass,
                                                                            const unsigned int* __restrict__ digitTotals /* [256] of this pass */,
                                                                            unsigned int* tileState /* [tiles][256] */,
                                                                            unsigned int* ticket, unsigned int* errFlag)
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
         const long long k = chunk + r * 64 + lane;
         const bool valid = k < n;
         val[r] = valid ? valsIn[k] : 0;
-        key[r] = valid ? keysIn[k] : 0xFFFFFFFFu;
+        key[r] = valid ? (INDEXED ? keysIn[(size_t)val[r] * stride] : keysIn[k]) : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
     for (int i = tid; i < tileCount; i += OS_THREADS) {
         const unsigned int k = s_keys[i];
         const unsigned int dst = s_dst[(k >> shift) & 255] + (unsigned int)i;
-        keysOut[dst] = k;
+        if (!INDEXED) keysOut[dst] = k;
         valsOut[dst] = s_vals[i];
     }
 }

@@ -3,8 +3,9 @@
 //                        textured, path-traced and VPL shading are out of scope)
 //   secondary-ray sort   src/rt/ray/RayBuffer.cpp:103-165 + RayBufferKernels.cu:70-197:
 //                        findAABB -> 192-bit Morton keys -> sort -> reorder.  The reference sorts the
-//                        keys on the CPU (RayBuffer.cpp:149); here the sort is the LSD radix sort of
-//                        radix_sort.h over an index array (19 passes cover the 150 significant bits).
+//                        keys on the CPU (RayBuffer.cpp:149); here the sort is the one-sweep LSD radix sort of
+//                        radix_sort.h over an index array: 19 digit passes cover the 150 significant bits, one
+//                        launch each, their histograms taken while the keys are produced.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
@@ -100,11 +101,16 @@ __global__ void ray_aabb_decode_kernel(const unsigned int* __restrict__ box, flo
 }
 
 // genMortonKeysKernel (RayBufferKernels.cu:140-175): 6 x 32 bits interleaved (component c, bit i -> bit c + 6 i).
+constexpr int RAY_KEY_DIGITS = 19;   // 8-bit digits of the 150 significant key bits: words 0..3 fully, word 4 bits 0..23
+
 __global__ __launch_bounds__(256) void ray_keys_kernel(int n, const NtrRay* __restrict__ rays, const float* __restrict__ box,
-                                                       unsigned int* __restrict__ keys /* 6 words per ray */, int* __restrict__ idx)
+                                                       unsigned int* __restrict__ keys /* 6 words per ray */, int* __restrict__ idx,
+                                                       unsigned int* __restrict__ hist /* [RAY_KEY_DIGITS][256], zeroed */)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+    __shared__ unsigned int s_hist[RAY_KEY_DIGITS][256];
+    for (int i = threadIdx.x; i < RAY_KEY_DIGITS * 256; i += 256) (&s_hist[0][0])[i] = 0;
+    __syncthreads();
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     const float4 o = reinterpret_cast<const float4*>(rays)[2 * t], d = reinterpret_cast<const float4*>(rays)[2 * t + 1];
     const float ax = (o.x - box[0]) / (box[3] - box[0]), ay = (o.y - box[1]) / (box[4] - box[1]), az = (o.z - box[2]) / (box[5] - box[2]);
     // normalize(v) = v * (1 * rcp(length(v)))  (Math.hpp:141-142)
@@ -124,6 +130,14 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(int n, const NtrRay* __re
 #pragma unroll
     for (int k = 0; k < 6; k++) keys[6 * t + k] = h[k];
     idx[t] = t;
+#pragma unroll
+    for (int p = 0; p < RAY_KEY_DIGITS; p++) atomicAdd(&s_hist[p][(h[p >> 2] >> ((p & 3) * 8)) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RAY_KEY_DIGITS * 256; i += 256) {
+        const unsigned int v = (&s_hist[0][0])[i];
+        if (v) atomicAdd(&hist[i], v);
+    }
 }
 
 // reorderRaysKernel (RayBufferKernels.cu:179-197)
@@ -181,15 +195,24 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
     if (!d_inRays || !d_inSlotToID || !d_outRays || !d_outIDToSlot || !d_outSlotToID || d_inRays == d_outRays)
         return set_error(NTR_ERR_INVALID, "ntr_ray_morton_sort: null or aliased buffer");
     hipStream_t s = (hipStream_t)stream;
-    const int n = numRays, nb = (n + SORT_TILE - 1) / SORT_TILE;
-    DevMem keys, idxA, idxB, hist, box;
+    const int n = numRays;
+    if (n >= (1 << 28)) return set_error(NTR_ERR_INVALID, "ntr_ray_morton_sort: at most 2^28 - 1 rays");
+    constexpr int ITEMS = 8;
+    const int tiles = (n + OS_THREADS * ITEMS - 1) / (OS_THREADS * ITEMS);
+    DevMem keys, idxA, idxB, scratch, box;
     NTR_HIP(hipMalloc(&keys.p, (size_t)n * 24));
     NTR_HIP(hipMalloc(&idxA.p, (size_t)n * 4));
     NTR_HIP(hipMalloc(&idxB.p, (size_t)n * 4));
-    NTR_HIP(hipMalloc(&hist.p, ((size_t)nb * 256 + 256) * 4));
+    // one zeroed block: digit histograms, per-pass tickets, error flag, then the tile state of the chained scans
+    const size_t histWords = (size_t)RAY_KEY_DIGITS * 256, miscWords = 32, stateWords = (size_t)tiles * 256;
+    NTR_HIP(hipMalloc(&scratch.p, (histWords + miscWords + stateWords) * 4));
     NTR_HIP(hipMalloc(&box.p, 64));
+    unsigned int* histp = (unsigned int*)scratch.p;
+    unsigned int* misc = histp + histWords;      // [0..18] tickets, [31] error flag
+    unsigned int* state = misc + miscWords;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (seconds) { NTR_HIP(hipEventCreate(&e0)); NTR_HIP(hipEventCreate(&e1)); NTR_HIP(hipEventRecord(e0, s)); }
+    NTR_HIP(hipMemsetAsync(scratch.p, 0, (histWords + miscWords + stateWords) * 4, s));
 
     unsigned int* ubox = (unsigned int*)box.p;
     float* fbox = (float*)box.p + 8;
@@ -199,21 +222,21 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(ray_aabb_kernel, dim3(blocks), dim3(256), 0, s, n, d_inRays, ubox);
     hipLaunchKernelGGL(ray_aabb_decode_kernel, dim3(1), dim3(64), 0, s, (const unsigned int*)ubox, fbox);
-    hipLaunchKernelGGL(ray_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_inRays, (const float*)fbox,
-                       (unsigned int*)keys.p, (int*)idxA.p);
+    int kblocks = (n + 1023) / 1024;
+    if (kblocks > 512) kblocks = 512;
+    hipLaunchKernelGGL(ray_keys_kernel, dim3(kblocks), dim3(256), 0, s, n, d_inRays, (const float*)fbox, (unsigned int*)keys.p, (int*)idxA.p, histp);
     // stable LSD sort of the index array by the 192-bit key: words 0..3 fully, word 4 bits 0..23
     // (the highest set bit is 5 + 6*24 = 149: a* < 2^25, b* < 2^22); word 5 is always zero.
+    // The tile-state words carry the pass number in their status bits, so one clearing serves all passes (pass p uses status 2p+1, 2p+2
+    // of a 4-bit field: the passes are numbered modulo 7 and the state is cleared again every 7 passes).
     int *vIn = (int*)idxA.p, *vOut = (int*)idxB.p;
-    for (int word = 0; word < 5; word++)
-        for (int shift = 0; shift < (word == 4 ? 24 : 32); shift += 8) {
-            const unsigned int* kw = (const unsigned int*)keys.p + word;
-            hipLaunchKernelGGL(sort_hist_kernel<true>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kw, (const int*)vIn, 6, shift,
-                               (unsigned int*)hist.p, nb);
-            hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(256), dim3(256), 0, s, (unsigned int*)hist.p, nb, (unsigned int*)hist.p + (size_t)nb * 256);
-            hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kw, (const int*)vIn,
-                               (unsigned int*)nullptr, vOut, 6, shift, (const unsigned int*)hist.p, (const unsigned int*)hist.p + (size_t)nb * 256, nb);
-            int* t = vIn; vIn = vOut; vOut = t;
-        }
+    for (int p = 0; p < RAY_KEY_DIGITS; p++) {
+        if (p > 0 && (p % 7) == 0) NTR_HIP(hipMemsetAsync(state, 0, stateWords * 4, s));
+        const unsigned int* kw = (const unsigned int*)keys.p + (p >> 2);
+        hipLaunchKernelGGL((onesweep_pass_kernel<ITEMS, true>), dim3(tiles), dim3(OS_THREADS), 0, s, n, kw, (const int*)vIn, (unsigned int*)nullptr, vOut, 6,
+                           (p & 3) * 8, p % 7, (const unsigned int*)(histp + (size_t)p * 256), state, misc + p, misc + 31);
+        int* t = vIn; vIn = vOut; vOut = t;
+    }
     hipLaunchKernelGGL(ray_reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, (const int*)vIn, d_inRays, d_inSlotToID,
                        d_outRays, d_outIDToSlot, d_outSlotToID);
     NTR_HIP(hipGetLastError());
@@ -226,7 +249,10 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
     }
+    unsigned int sortErr = 0;
+    NTR_HIP(hipMemcpyAsync(&sortErr, misc + 31, sizeof(sortErr), hipMemcpyDeviceToHost, s));
     NTR_HIP(hipStreamSynchronize(s));  // temporaries are freed on return
+    if (sortErr) return set_error(NTR_ERR_HIP, "ntr_ray_morton_sort: a chained scan timed out waiting for a predecessor tile");
     return NTR_OK;
 }
 
