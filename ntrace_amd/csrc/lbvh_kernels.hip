@@ -1773,10 +1773,10 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
                                shift, (const unsigned int*)hist, (const unsigned int*)hist + (size_t)nb * 256, nb);
         } else {
             if (osItems == 16)
-                hipLaunchKernelGGL((onesweep_pass_kernel<16, false>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
+                hipLaunchKernelGGL((onesweep_pass_kernel<16, 0>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
                                    1, shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
             else
-                hipLaunchKernelGGL((onesweep_pass_kernel<8, false>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
+                hipLaunchKernelGGL((onesweep_pass_kernel<8, 0>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
                                    1, shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
         }
         unsigned int* tk = kIn; kIn = kOut; kOut = tk;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(int n, const
         const int k = chunk + r * 64 + lane;
         const bool valid = k < n;
         val[r] = valid ? valsIn[k] : 0;
-        key[r] = valid ? (INDEXED ? keysIn[(size_t)val[r] * stride] : keysIn[k]) : 0xFFFFFFFFu;
+        key[r] = valid ? (MODE != 0 ? keysIn[(size_t)val[r] * stride] : keysIn[k]) : 0xFFFFFFFFu;
         const unsigned int d = (key[r] >> shift) & 255;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -186,9 +186,11 @@ __device__ __forceinline__ unsigned int os_excl_scan_256(unsigned int v, unsigne
     return before + incl - v;
 }
 
-// INDEXED = false: keysIn[i] is the key of element i; keys and values both move.
-// INDEXED = true : the key word of element i is keysIn[valsIn[i] * stride] (multi-word keys stay in place, only the index array moves).
-template <int ITEMS, bool INDEXED>
+// MODE 0: keysIn[i] is the key of element i; keys and values both move.
+// MODE 1: the key word of element i is keysIn[valsIn[i] * stride] (multi-word keys stay in place, only the index array moves).
+// MODE 2: the key word is fetched as in MODE 1 and moves with the value from here on (first pass over a word of a multi-word key;
+//         the following passes over that word run in MODE 0 on the dense (word, value) pairs).
+template <int ITEMS, int MODE>
 __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n, const unsigned int* __restrict__ keysIn,
                                                                            const int* __restrict__ valsIn,
                                                                            unsigned int* __restrict__ keysOut, int* __restrict__ valsOut,
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
     for (int i = tid; i < tileCount; i += OS_THREADS) {
         const unsigned int k = s_keys[i];
         const unsigned int dst = s_dst[(k >> shift) & 255] + (unsigned int)i;
-        if (!INDEXED) keysOut[dst] = k;
+        if (MODE != 1) keysOut[dst] = k;
         valsOut[dst] = s_vals[i];
     }
 }
