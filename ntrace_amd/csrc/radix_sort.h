@@ -106,7 +106,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(int n, const
         const int k = chunk + r * 64 + lane;
         const bool valid = k < n;
         val[r] = valid ? valsIn[k] : 0;
-        key[r] = valid ? (MODE != 0 ? keysIn[(size_t)val[r] * stride] : keysIn[k]) : 0xFFFFFFFFu;
+        key[r] = valid ? (INDEXED ? keysIn[(size_t)val[r] * stride] : keysIn[k]) : 0xFFFFFFFFu;
         const unsigned int d = (key[r] >> shift) & 255;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
         const long long k = chunk + r * 64 + lane;
         const bool valid = k < n;
         val[r] = valid ? valsIn[k] : 0;
-        key[r] = valid ? (INDEXED ? keysIn[(size_t)val[r] * stride] : keysIn[k]) : 0xFFFFFFFFu;
+        key[r] = valid ? (MODE != 0 ? keysIn[(size_t)val[r] * stride] : keysIn[k]) : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
