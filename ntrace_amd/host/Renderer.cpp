@@ -1,11 +1,18 @@
 #include "Renderer.hpp"
 
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <fstream>
+
+#include "Hash.hpp"
+
 namespace FW {
 
 // Renderer::Renderer (Renderer.cpp:44-94): m_raygen(1 << 20), Platform("GPU") with leaf preferences (1,1).
 Renderer::Renderer(const String& builder)
     : m_builder(builder), m_raygen(1 << 20), m_enableRandom(false), m_scene(NULL), m_cameraFar(0.0f), m_newBatch(true),
-      m_batchRays(NULL), m_batchStart(0), m_accelStruct(NULL)
+      m_batchRays(NULL), m_batchStart(0), m_accelStruct(NULL), m_cachePath("bvhcache"), m_cacheDataStructure(false)
 {
     m_cudaTracer = new CudaBVHTracer();
     m_cudaTracer->setScene(NULL);
@@ -34,13 +41,34 @@ void Renderer::setParams(const Params& params)  // Renderer.cpp:138-143
     m_cudaTracer->setKernel(params.kernelName);
 }
 
-// Renderer::getCudaBVH (Renderer.cpp:147-305) without the cache-file and OcclusionBVH branches.
+// "<cachePath>/<hash>_<builder>.dat" with the hash over scene, platform, build parameters, layout and data structure name
+// (Renderer.cpp:173-180); this backend's only data structure is "BVH".
+String Renderer::getCacheFileName(void)
+{
+    char name[64];
+    const U32 h = hashBits(m_scene ? m_scene->hash() : 0u, m_platform.computeHash(), m_buildParams.computeHash(),
+                           (U32)m_cudaTracer->getDesiredBVHLayout(), hashString("BVH"));
+    snprintf(name, sizeof(name), "/%08x_", h);
+    return m_cachePath + name + m_builder + ".dat";
+}
+
+// Renderer::getCudaBVH (Renderer.cpp:147-305) without the OcclusionBVH branch.
 CudaAS* Renderer::getCudaBVH(void)
 {
     BVHLayout layout = m_cudaTracer->getDesiredBVHLayout();
     if (!m_scene || (m_accelStruct && m_accelStruct->getLayout() == layout)) return m_accelStruct;
     delete m_accelStruct;
     m_accelStruct = NULL;
+    const String cacheFile = getCacheFileName();
+    if (m_cacheDataStructure) {  // cache file exists => import (:184-191)
+        std::ifstream in(cacheFile.c_str(), std::ios::binary);
+        if (in) {
+            CudaBVH* cached = new CudaBVH(in);
+            if (!hasError() && cached->getLayout() == layout) { m_accelStruct = cached; return m_accelStruct; }
+            clearError();
+            delete cached;
+        }
+    }
     if (m_builder == "HLBVH") {
         HLBVHParams params;  // Renderer.cpp:203-207 asks for hlbvh = true, hlbvhBits = 4; this backend
         params.hlbvh = false;  // provides the plain LBVH pipeline of the same builder
@@ -51,6 +79,11 @@ CudaAS* Renderer::getCudaBVH(void)
         BVH bvh(m_scene, m_platform, m_buildParams);
         m_accelStruct = new CudaBVH(bvh, layout);
         failIfError();
+    }
+    if (m_cacheDataStructure) {  // write to cache (:293-299); a failure to write is not an error
+        ::mkdir(m_cachePath.c_str(), 0777);
+        std::ofstream out(cacheFile.c_str(), std::ios::binary);
+        if (out) m_accelStruct->serialize(out);
     }
     return m_accelStruct;
 }

@@ -30,11 +30,17 @@ public:
     void   setScene(Scene* scene);  // replaces setMesh(): the Scene is built by the caller
     Scene* getScene(void) const { return m_scene; }
     void   setBuildParams(const BVH::BuildParams& params) { invalidateBVH(); m_buildParams = params; }
+    BVH::BuildParams& getBuildParams(void) { return m_buildParams; }
     void   invalidateBVH(void) { delete m_accelStruct; m_accelStruct = NULL; }
     void   setParams(const Params& params);
     void   setEnableRandom(bool enable) { m_enableRandom = enable; }
     CudaVirtualTracer& getCudaTracer(void) { return *m_cudaTracer; }
     CudaAS* getCudaBVH(void);
+    // BVH cache files, "<cachePath>/<hash>_<builder>.dat" (Renderer.cpp:173-191, 293-299; format of CudaBVH::serialize).  Off by
+    // default, like Renderer.cacheDataStructure in the reference's environment.
+    void   setCachePath(const String& path) { m_cachePath = path; }
+    void   setCacheDataStructure(bool enable) { m_cacheDataStructure = enable; }
+    String getCacheFileName(void);
 
     void beginFrame(const CameraView& camera);
     bool nextBatch(void);
@@ -64,6 +70,8 @@ private:
     RayBuffer*         m_batchRays;
     S32                m_batchStart;
     CudaAS*            m_accelStruct;
+    String             m_cachePath;
+    bool               m_cacheDataStructure;
     CudaVirtualTracer* m_cudaTracer;
 };
 

@@ -1,5 +1,7 @@
 #include "Scene.hpp"
 
+#include "Hash.hpp"
+
 #include <cmath>
 
 namespace FW {
@@ -27,15 +29,14 @@ Scene::Scene(S32 numTris, const Vec3i* triVtxIndex, S32 numVerts, const Vec3f* v
     }
 }
 
+// Scene::hash (src/rt/Scene.cpp:171-179): hashBits over the hashes of the scene's buffers.  The reference also hashes its per-triangle
+// material / shaded colour buffers, which this mirror does not hold (shading is out of scope): their slots hash an empty buffer, so
+// a cache file NAME matches the reference's only for scenes without them; the file FORMAT is the reference's either way.
 U32 Scene::hash(void)
 {
-    // FNV-1a over the geometry; only used to key BVH cache files.
-    U32 h = 2166136261u;
-    const U8* p = m_triVtxIndex.getPtr();
-    for (S64 i = 0; i < m_triVtxIndex.getSize(); i++) h = (h ^ p[i]) * 16777619u;
-    p = m_vtxPos.getPtr();
-    for (S64 i = 0; i < m_vtxPos.getSize(); i++) h = (h ^ p[i]) * 16777619u;
-    return h;
+    const U32 empty = hashBuffer(NULL, 0);
+    return hashBits(hashBuffer(m_triVtxIndex.getPtr(), m_triVtxIndex.getSize()), hashBuffer(m_triNormal.getPtr(), m_triNormal.getSize()), empty, empty,
+                    hashBuffer(m_vtxPos.getPtr(), m_vtxPos.getSize()));
 }
 
 }  // namespace FW

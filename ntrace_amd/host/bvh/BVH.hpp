@@ -4,6 +4,7 @@
 #pragma once
 #include <vector>
 
+#include "../Hash.hpp"
 #include "../Scene.hpp"
 #include "BVHNode.hpp"
 #include "Platform.hpp"
@@ -32,7 +33,7 @@ public:
         F32    splitAlpha;
         String builder;  // "SAHBVH" (Renderer.builder in config.conf)
         BuildParams(void) : stats(NULL), enablePrints(false), splitAlpha(1.0e-5f), builder("SAHBVH") {}
-        U32 computeHash(void) const { return floatToBits(splitAlpha) * 31u + (U32)builder.size(); }
+        U32 computeHash(void) const { return hashBits(floatToBits(splitAlpha)); }  // src/rt/bvh/BVH.hpp:143
     };
 
     BVH(Scene* scene, const Platform& platform, const BuildParams& params);

@@ -1,6 +1,7 @@
 // Platform.hpp -- SAH cost / batching / leaf-size settings (src/rt/bvh/Platform.hpp:45-160).
 #pragma once
 #include "../Defs.hpp"
+#include "../Hash.hpp"
 
 namespace FW {
 
@@ -37,13 +38,11 @@ private:
     S32    m_maxLeafSize;
 };
 
+// src/rt/bvh/Platform.hpp:162
 inline U32 Platform::computeHash() const
 {
-    U32 h = 2166136261u;
-    for (char c : m_name) h = (h ^ (U8)c) * 16777619u;
-    const U32 v[6] = {floatToBits(m_SAHNodeCost), floatToBits(m_SAHTriangleCost), (U32)m_triBatchSize, (U32)m_nodeBatchSize, (U32)m_minLeafSize, (U32)m_maxLeafSize};
-    for (U32 x : v) h = (h ^ x) * 16777619u;
-    return h;
+    return hashBits(hashString(m_name), floatToBits(m_SAHNodeCost), floatToBits(m_SAHTriangleCost),
+                    hashBits((U32)m_triBatchSize, (U32)m_nodeBatchSize, (U32)m_minLeafSize, (U32)m_maxLeafSize));
 }
 
 }  // namespace FW

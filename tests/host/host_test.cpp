@@ -1,10 +1,13 @@
 // host_test.cpp -- exercises the C++ host mirror (ntrace_amd/host) the way NTrace's own code uses
 // the reference classes.  `host_test cpu` needs no GPU; `host_test gpu` runs the device paths.
 // Compiled with plain g++ against libntrace_amd.so: the mirror's headers contain no HIP types.
+#include <unistd.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <sstream>
 #include <vector>
 
@@ -168,6 +171,56 @@ static void cpuTests()
     threw = false;
     try { tracer.setKernel("no_such_kernel"); } catch (const FatalError&) { threw = true; }
     CHECK(threw);
+    // BVH cache files (Renderer.cpp:173-191, 293-299): "<path>/<hash>_<builder>.dat"; the second Renderer imports what the first wrote
+    {
+        CHECK(hashBits(1u) != hashBits(2u) && hashBuffer("abc", 3) != hashBuffer("abd", 3));
+        CHECK(hashBuffer("0123456789abcdef", 16) != hashBuffer("0123456789abcdeg", 16));
+        std::vector<Vec3i> tris;
+        std::vector<Vec3f> verts;
+        makeScene(tris, verts, 6);
+        Renderer::Params params;
+        params.kernelName = "fermi_speculative_while_while";
+        Scene scene((S32)tris.size(), tris.data(), (S32)verts.size(), verts.data());
+        char dir[] = "/tmp/ntr_bvhcache_XXXXXX";
+        CHECK(mkdtemp(dir) != NULL);
+        Renderer first("SAHBVH");
+        first.setScene(&scene);
+        first.setParams(params);
+        first.setCachePath(dir);
+        first.setCacheDataStructure(true);
+        const String name = first.getCacheFileName();
+        CHECK(name.find(String(dir) + "/") == 0 && name.size() == std::strlen(dir) + 1 + 8 + 1 + 6 + 4 && name.find("_SAHBVH.dat") != String::npos);
+        CudaAS* built = first.getCudaBVH();
+        std::ifstream probe(name.c_str(), std::ios::binary);
+        CHECK(built && probe.good());
+        // poison the builder name: a second Renderer can only get a BVH out of the cache file
+        Renderer second("SAHBVH");
+        second.setScene(&scene);
+        second.setParams(params);
+        second.setCachePath(dir);
+        second.setCacheDataStructure(true);
+        CHECK(second.getCacheFileName() == name);
+        second.getBuildParams().builder = "no_such_builder";
+        CudaAS* cached = second.getCudaBVH();
+        CHECK(cached && cached->getNodeBuffer().getSize() == built->getNodeBuffer().getSize() &&
+              std::memcmp(cached->getNodeBuffer().getPtr(), built->getNodeBuffer().getPtr(), (size_t)built->getNodeBuffer().getSize()) == 0);
+        CHECK(cached && cached->getTriWoopBuffer().getSize() == built->getTriWoopBuffer().getSize() &&
+              std::memcmp(cached->getTriIndexBuffer().getPtr(), built->getTriIndexBuffer().getPtr(), (size_t)built->getTriIndexBuffer().getSize()) == 0);
+        // a different scene or build parameter names a different file
+        Renderer third("SAHBVH");
+        third.setScene(&scene);
+        third.setParams(params);
+        third.setCachePath(dir);
+        third.getBuildParams().splitAlpha = 0.5f;
+        CHECK(third.getCacheFileName() != name);
+        verts[0].x += 1.0f;
+        Scene moved((S32)tris.size(), tris.data(), (S32)verts.size(), verts.data());
+        third.getBuildParams().splitAlpha = first.getBuildParams().splitAlpha;
+        third.setScene(&moved);
+        CHECK(third.getCacheFileName() != name);
+        std::remove(name.c_str());
+        rmdir(dir);
+    }
     // sticky error model (Defs.hpp:142-151)
     clearError();
     setError("first %d", 1);
