@@ -4,10 +4,13 @@
   summarize_rocprof.py trace <dir>   per kernel x grid size: dispatch count, mean / min / max duration (ns) from
                                      *_kernel_trace.csv (what `--kernel-trace --stats` aggregates, split by launch shape)
   summarize_rocprof.py pmc <dir>...  per kernel x grid size x counter: mean per dispatch from *_counter_collection.csv
+  summarize_rocprof.py json <pmc.txt>...  the `pmc` text of several workloads -> one {"kernel|grid|counter": mean} object
+                                     (profiles/*_pmc_summary.json, which bench.py reads for roofline.binding)
 Kernel names are shortened to the function name."""
 import collections
 import csv
 import glob
+import json
 import re
 import sys
 
@@ -41,8 +44,21 @@ def pmc(dirs):
                 print("%-72s grid=%10s %-32s n=%4d mean=%.6g" % (k[0], k[1], c, len(v), sum(v) / len(v)))
 
 
+def to_json(files):
+    out = {}
+    pat = re.compile(r"^(.*?)\s+grid=\s*(\d+)\s+(\S+)\s+n=\s*\d+\s+mean=(\S+)$")
+    for f in files:
+        for line in open(f):
+            m = pat.match(line.rstrip())
+            if m and not m.group(1).startswith(("__amd", "l<", "void at::")):
+                out["%s|%s|%s" % (m.group(1).strip(), m.group(2), m.group(3))] = float(m.group(4))
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "trace":
+    if sys.argv[1] == "json":
+        to_json(sys.argv[2:])
+    elif sys.argv[1] == "trace":
         trace(sys.argv[2])
     else:
         pmc(sys.argv[2:])
