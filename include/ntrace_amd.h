@@ -245,8 +245,10 @@ typedef struct NtrLbvhResult {
     int32_t numNodes, numLeaves, numLevels, pad;
     int64_t nodesBytes, triWoopBytes, triIndexBytes;
     float   seconds;                                   /* whole build, GPU time          */
-    /* phase times: Morton codes; radix sort; per-triangle box terms (per-level path: Woop rows); emit (subtree path:
-     * its top pass); the rest (subtree path: subtree emit + refit + top refit + Woop placement; per-level path: refit) */
+    /* phase times.  Default (bottom-up) path: Morton codes + digit histograms; the four sort passes; woopMs ~ 0; emitMs =
+     * bottom-up emit with boxes (agglomerate kernels + equal-key runs); refitMs = ranking + finalize (node words, Woop rows).
+     * Legacy paths: per-triangle box terms (per-level path: Woop rows) in woopMs; emitMs = top pass (per-level: all levels);
+     * refitMs = subtree emit + refit + top refit + Woop placement (per-level: refit). */
     float   mortonMs, sortMs, woopMs, emitMs, refitMs;
 } NtrLbvhResult;
 

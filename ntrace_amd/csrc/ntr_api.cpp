@@ -51,7 +51,8 @@ struct DeviceState {
     int nextPinned = 0;
     int numCUs = 0;
 };
-static constexpr int kNumCounters = 64;  // ring of counter sets (8 heads x 64 B each)
+static constexpr int kPoolHeadsMax = 1024;
+static constexpr int kNumCounters = 64;  // ring of counter sets (kPoolHeadsMax heads x 64 B each)
 static constexpr int kPinnedCounters = 192;  // counter sets handed to launches captured into HIP graphs: never reused
 static constexpr int kMaxDevices = 64;
 static constexpr int64_t kMaxNodesBytes = 0x76543200ll;  // largest multiple of 64 below the sentinel 0x76543210
@@ -78,7 +79,7 @@ int get_device_state(DeviceState** out)
         NTR_HIP(hipGetDeviceProperties(&prop, dev));
         s.numCUs = prop.multiProcessorCount;
         // Counters sit 64 B apart so concurrent launches never share a line.
-        NTR_HIP(hipMalloc((void**)&s.counters, (kNumCounters + kPinnedCounters) * 8 * 64));
+        NTR_HIP(hipMalloc((void**)&s.counters, (kNumCounters + kPinnedCounters) * kPoolHeadsMax * 64));
         NTR_HIP(hipMalloc((void**)&s.status, 64));
         NTR_HIP(hipMalloc((void**)&s.stats, 256));
         NTR_HIP(hipMemset(s.status, 0, 64));
@@ -140,6 +141,7 @@ static void tunables_load_locked()
     t.coop = env_int("NTR_TRACE_COOP", 0);
     t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", 24);     // sweep: flat optimum 16..64 (scripts/trace_sweep.py)
     t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 6);
+    t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/persist_diag.py)
     t.predict = env_int("NTR_TRACE_PREDICT", 1);
     t.predictDepth = env_int("NTR_TRACE_PREDICT_DEPTH", 9);
     t.predictMinRays = env_int("NTR_TRACE_PREDICT_MIN_RAYS", 1 << 20);
@@ -446,6 +448,8 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.status = ds->status;
     p.counter = nullptr;
     p.shardRays = 0;
+    p.numHeads = 8;
+    p.numBlocks = 0;
     // persistent kernels (scripts/persist_sweep.py): 64-ray chunks, 6 workgroups per CU; dynamic fetch only for the kernel
     // named after it (it costs about 10 % here: refilled lanes de-cohere a wave's node fetches)
     const Tunables tun = tunables();
@@ -487,18 +491,21 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
             if (capturing) {
                 if (ds->nextPinned >= kPinnedCounters)
                     return set_error(NTR_ERR_NOMEM, "ntr_trace_bvh: more than %d persistent launches captured into HIP graphs", kPinnedCounters);
-                p.counter = ds->counters + 8 * 16 * (kNumCounters + ds->nextPinned++);
+                p.counter = ds->counters + kPoolHeadsMax * 16 * (kNumCounters + ds->nextPinned++);
             } else {
-                p.counter = ds->counters + 8 * 16 * ds->next;
+                p.counter = ds->counters + kPoolHeadsMax * 16 * ds->next;
                 ds->next = (ds->next + 1) % kNumCounters;
             }
         }
         {   // cleared by a kernel: memset nodes do not survive HIP graph replays (see sched_kernels.hip)
-            const hipError_t ze = ntr_launch_zero_words(p.counter, 8 * 16, s);
+            const hipError_t ze = ntr_launch_zero_words(p.counter, kPoolHeadsMax * 16, s);
             if (ze != hipSuccess) return hip_fail(ze, "zero_words launch");
         }
         const int chunksTotal = (numRays + p.chunk - 1) / p.chunk;
-        p.shardRays = ((chunksTotal + 7) / 8) * p.chunk;
+        int heads = tun.poolHeads < 8 ? 8 : (tun.poolHeads > kPoolHeadsMax ? kPoolHeadsMax : tun.poolHeads & ~7);
+        p.numHeads = heads;
+        p.numBlocks = numBlocks;
+        p.shardRays = ((chunksTotal + heads - 1) / heads) * p.chunk;
     } else {
         numBlocks = (numRays + blockThreads - 1) / blockThreads;
     }

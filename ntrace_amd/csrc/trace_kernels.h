@@ -32,10 +32,12 @@ struct TraceParams {
     uint32_t nodesBytes;  // buffer-descriptor ranges (out-of-range loads return 0)
     uint32_t woopBytes;
     const int32_t* triIndex;
-    int32_t* counter;        // persistent: 8 pool heads 64 B apart (zeroed on the stream before launch)
+    int32_t* counter;        // persistent: numHeads pool heads 64 B apart (zeroed on the stream before launch)
     unsigned int* status;    // sticky error bits
     int32_t chunk;           // persistent: rays per pool grab
-    int32_t shardRays;       // persistent: rays per pool shard (8 shards, a multiple of chunk)
+    int32_t shardRays;       // persistent: rays per pool shard (numHeads shards, a multiple of chunk)
+    int32_t numHeads;        // persistent: pool heads, a multiple of 8 (one group per XCD), <= 1024
+    int32_t numBlocks;       // persistent: grid size (the statically assigned first chunks are counted from it)
     int32_t fetchThreshold;  // persistent: refill when fewer lanes are live
     uint32_t bvhFlags;
     int32_t leafSwitchBelow; // serve waiting leaves when fewer lanes than this still hold an inner node

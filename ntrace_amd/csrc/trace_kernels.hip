@@ -459,9 +459,17 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
 
 // ---------------------------------------------------------------------------------
 // Variant 2: persistent waves.  Each wave owns a chunk [next,end) of the ray index
-// space taken from one global counter (one returning atomic per chunk, lane 0);
-// empty lanes are refilled from the chunk by ballot + mbcnt prefix
+// space; empty lanes are refilled from the chunk by ballot + mbcnt prefix
 // (kepler_dynamic_fetch.cu:97-111 on wave64: 64-bit ballot, v_mbcnt_lo/hi).
+// Pool: the index space is cut into numHeads contiguous ranges, one head (counter) each.  A returning atomic on ONE
+// address is served at about 88 per us (MI355X_MICROARCH price list, "dequeue"); with 6 144 waves asking at once --
+// at launch, and again whenever equally long rays (AO) end together -- eight heads made a dequeue wait 8-12 us
+// (profiles/r02b_persistent_vs_perray_timelines.jsonl: 32 % of a wave's life on AO; r02k: 13 % with 64-256 heads, AO batch
+// 208 -> 134 us; 512 heads and more lose again to end-of-pool probing).  So: (1) a wave's FIRST chunk is
+// assigned statically, no atomic; (2) 128 heads, a block works on head blockIdx % numHeads (blocks are dealt round-robin
+// to the XCDs, so head h stays on XCD h % 8 and an XCD's heads cover one contiguous screen region); (3) a wave whose
+// head ran dry reads all heads with one 64-lane load and moves to the next one that still has rays, instead of
+// paying an atomic round trip per dry head.
 // ---------------------------------------------------------------------------------
 // TL: the diagnostic stamps of NTR_TRACE_TIMELINE are compiled into their own instantiation -- they cost 18 VGPRs,
 // i.e. two waves of occupancy per SIMD, which the production kernel must not pay.
@@ -489,9 +497,13 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     bool nice = true;                 // this lane's current ray qualifies for the FAST path
     int chunkNext = 0, chunkEnd = 0;  // wave-uniform
     bool poolEmpty = false;           // wave-uniform
-    // HW_REG_XCC_ID (id 20), bits [3:0]: which of the 8 XCDs this wave runs on (speed only)
-    int shard = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7;
-    int shardTries = 0;
+    const int numHeads = p.numHeads;
+    int shard = (int)(blockIdx.x % (unsigned)numHeads);  // wave-uniform
+    bool firstChunk = true;
+    // range of head h: the heads of one XCD (h % 8) are neighbours in the index space
+    auto range_beg = [&](int h) { return ((h & 7) * (numHeads >> 3) + (h >> 3)) * p.shardRays; };
+    // chunks of head h handed out statically: one per wave of every block with blockIdx % numHeads == h
+    auto static_rays = [&](int h) { return ((p.numBlocks - h + numHeads - 1) / numHeads) * WAVES * p.chunk; };
     LaneStats ls = {0u, 0u, 0u};
 
     // diagnostic stamps (NTR_TRACE_TIMELINE): wave start, end, cycles spent refilling, refill count
@@ -512,20 +524,45 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
                 // "dequeue").  A wave starts on the range of its own XCD -- so an XCD's L2 sees
                 // one screen region -- and moves on to the next range when that one runs dry.
                 bool got = false;
-                while (shardTries < 8) {
-                    const int rangeBeg = shard * p.shardRays;
+                if (firstChunk) {  // static: the (blockIdx / numHeads * WAVES + wave)-th chunk of the block's head
+                    firstChunk = false;
+                    const int rangeBeg = range_beg(shard);
+                    const int rangeEnd = min(rangeBeg + p.shardRays, p.numRays);
+                    const int base = rangeBeg + ((int)(blockIdx.x / (unsigned)numHeads) * WAVES + __builtin_amdgcn_readfirstlane(wave)) * p.chunk;
+                    if (base < rangeEnd) {
+                        chunkNext = base;
+                        chunkEnd = min(base + p.chunk, rangeEnd);
+                        got = true;
+                    }
+                }
+                while (!got) {
+                    const int rangeBeg = range_beg(shard);
                     const int rangeEnd = min(rangeBeg + p.shardRays, p.numRays);
                     int base = 0;
                     if (lane == 0) base = atomicAdd(p.counter + shard * 16, p.chunk);
-                    base = __builtin_amdgcn_readfirstlane(base) + rangeBeg;
+                    base = __builtin_amdgcn_readfirstlane(base) + static_rays(shard) + rangeBeg;
                     if (base < rangeEnd) {
                         chunkNext = base;
                         chunkEnd = min(base + p.chunk, rangeEnd);
                         got = true;
                         break;
                     }
-                    shard = (shard + 1) & 7;
-                    shardTries++;
+                    // dry: lane l looks at head (shard + 1 + l) % numHeads; counters only grow, so a head seen dry stays dry
+                    unsigned long long live = 0ull;
+                    int ofs = 1;
+                    for (; ofs < numHeads && live == 0ull; ofs += 64) {
+                        bool has = false;
+                        if (ofs + lane < numHeads) {
+                            const int h = (shard + ofs + lane) % numHeads;
+                            const int hb = range_beg(h);
+                            const int he = min(hb + p.shardRays, p.numRays);
+                            const int taken = __hip_atomic_load(p.counter + h * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            has = hb + static_rays(h) + taken < he;
+                        }
+                        live = __ballot(has);
+                    }
+                    if (live == 0ull) break;
+                    shard = (shard + ofs - 64 + (int)__builtin_ctzll(live)) % numHeads;
                 }
                 if (!got) { poolEmpty = true; break; }
             }

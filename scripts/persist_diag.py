@@ -88,5 +88,8 @@ def run(kernel, m, any_hit, r, o, tunables=None, label=""):
 for (name, m, ah, r, o) in (("primary", n, False, d_rays, d_res), ("ao", cnt * ns, True, b_rays, b_res)):
     run("fermi_speculative_while_while", m, ah, r, o, label=name)
     run("tesla_persistent_while_while", m, ah, r, o, label=name)
-    for tun in ({"NTR_TRACE_BLOCKS_PER_CU": 5}, {"NTR_TRACE_CHUNK": 128}, {"NTR_TRACE_CHUNK": 256}, {"NTR_TRACE_CHUNK": 64, "NTR_TRACE_FETCH_THRESHOLD": 32}):
+    for tun in ({"NTR_TRACE_POOL_HEADS": 8}, {"NTR_TRACE_POOL_HEADS": 128}, {"NTR_TRACE_POOL_HEADS": 256}, {"NTR_TRACE_POOL_HEADS": 512}, {"NTR_TRACE_POOL_HEADS": 1024},
+                {"NTR_TRACE_POOL_HEADS": 256, "NTR_TRACE_BLOCKS_PER_CU": 7}, {"NTR_TRACE_POOL_HEADS": 256, "NTR_TRACE_BLOCKS_PER_CU": 5},
+                {"NTR_TRACE_POOL_HEADS": 256, "NTR_TRACE_CHUNK": 128}, {"NTR_TRACE_POOL_HEADS": 256, "NTR_TRACE_FETCH_THRESHOLD": 32},
+                {"NTR_TRACE_POOL_HEADS": 64}):
         run("tesla_persistent_while_while", m, ah, r, o, tun, label=name)
