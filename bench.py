@@ -572,8 +572,8 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         lb = nt_ * (56 + 4 * 20 + 96 + 112 + 48) + ni_ * (28 + 48) + nl_ * 20 + max(ni_ - 1, 0) * 96
         info = {"triangles": nt_, "build_ms": best.seconds * 1e3, "mtris_per_s": nt_ / best.seconds / 1e6,
                 "phases_ms": {"morton+digit_histograms": best.mortonMs, "sort_4_onesweep_passes": best.sortMs,
-                              "bottom_up_emit+boxes(agglomerate,runs)": best.emitMs,
-                              "rank+finalize(nodes,woop_rows)": best.refitMs},
+                              "leaf_marks+scan": best.emitMs,
+                              "bottom_up_emit(nodes,boxes,woop_rows: agglomerate,runs)": best.refitMs},
                 "nodes": ni_, "leaves": nl_, "algorithmic_bytes": lb,
                 "roofline": {"bound": "hbm", "achieved": lb / best.seconds / 1e9, "peak": hbm_peak, "unit": "GB/s",
                              "frac": lb / best.seconds / 1e9 / hbm_peak}}

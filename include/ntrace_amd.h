@@ -243,10 +243,13 @@ NTR_API int ntr_count_hits(const NtrRayResult* d_results, int32_t numRays, int32
  * HLBVHBuilder.cpp:382-386) and per-phase GPU times (HLBVHBuilder::getGPUTime, :571-573). */
 typedef struct NtrLbvhResult {
     int32_t numNodes, numLeaves, numLevels, pad;
+    /* extents of what was written.  nodesBytes >= 64 * numNodes and triWoopBytes >= 16 * (3 * numTris + numLeaves): equality except
+     * where the depth rule (level bit 0, emitTreeKernel.cu:289-292) made a leaf of more than leafSize equal Morton codes -- the node
+     * indices and terminator slots set aside inside such a leaf stay unused and are zero-filled. */
     int64_t nodesBytes, triWoopBytes, triIndexBytes;
     float   seconds;                                   /* whole build, GPU time          */
     /* phase times.  Default (bottom-up) path: Morton codes + digit histograms; the four sort passes; woopMs ~ 0; emitMs =
-     * bottom-up emit with boxes (agglomerate kernels + equal-key runs); refitMs = ranking + finalize (node words, Woop rows).
+     * leaf marks + their prefix counts; refitMs = bottom-up emit writing nodes, boxes, Woop rows (agglomerate kernels + equal-key runs).
      * Legacy paths: per-triangle box terms (per-level path: Woop rows) in woopMs; emitMs = top pass (per-level: all levels);
      * refitMs = subtree emit + refit + top refit + Woop placement (per-level: refit). */
     float   mortonMs, sortMs, woopMs, emitMs, refitMs;

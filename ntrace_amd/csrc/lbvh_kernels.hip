@@ -55,6 +55,8 @@ struct LbvhState {
     unsigned int topLevels;      // levels the top pass processed
     unsigned int topLvlOfs[34];  // per-level offsets into the top pass's node list
     unsigned int topTrieLevels;  // cell-table top: deepest trie level holding a top node, plus one
+    unsigned int rootSplit;      // bottom-up path: split position of the root (its node gets index 0)
+    unsigned int holes;          // bottom-up path: node indices (= leaf terminators) set aside inside leaves the depth rule made larger
 };
 
 // ---- Morton codes ------------------------------------------------------------------------------
@@ -960,17 +962,18 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_cells_refit_kernel(const
 //     stops, the second reads it, forms the parent and goes on (one returning atomic per meeting, no spin anywhere, so no
 //     ordering between workgroups is assumed).  Child boxes are complete when a node is formed: the refit comes for free, and
 //     fminf / fmaxf unions are bit-identical in any order.
-//   * A node is IDENTIFIED by its split position B (the root by 0), a leaf by its first sorted position: nothing is allocated
-//     while the tree is formed.  Prefix counts over the node / leaf bit masks then give every node its index (rank of its
-//     position, root = 0) and every leaf its storage (3 * start + leaves before), with no atomic counter on the critical path and
-//     a deterministic numbering.
+//   * A node is NAMED by its split position B (the root by 0), a leaf by its first sorted position, and the leaf starts are known
+//     from the keys alone before the tree is formed (lbvh_leafmark_kernel).  A node's index is the rank of its split position among
+//     the leaf starts (root = 0), a leaf's storage is 3 * start + leaves before: nothing is allocated, no atomic counter is on the
+//     critical path, the numbering is deterministic -- and every node word, Woop row and triangle index is written ONCE, straight to
+//     its final place, by the thread that produces it (no intermediate records, no final pass).
 //   * Meetings whose parent range lies inside the workgroup's 512-key tile -- nearly all of them -- use LDS slots and LDS
 //     atomics; only clusters that outgrow their tile meet through memory (agent-scope stores of the 32-byte slot, drained, then
 //     the atomic; agent-scope loads after it).
 //   * RUNS of more than leafSize equal keys are the reference's median-split subtrees (:282), whose leaf rule depends on the
 //     depth (level bit 0, :289-292).  The bottom-up pass treats such a run as one opaque cluster; lbvh_runs_kernel then walks
-//     the parent positions for its depth and records its median nodes and leaves under the same position scheme.
-// Kernels: lbvh_agglomerate_kernel -> lbvh_runs_kernel -> lbvh_count_kernel -> lbvh_tilescan_kernel -> lbvh_finalize_kernel.
+//     the parent positions for its depth and writes its median nodes under the same naming scheme.
+// Kernels: lbvh_leafmark_kernel (marks + their prefix counts) -> lbvh_agglomerate_kernel (-> lbvh_agglomerate_top_kernel) -> lbvh_runs_kernel.
 // =====================================================================================================================
 constexpr int AGG_TILE = 512;
 constexpr int AGG_HALO = 32;                // neighbour keys kept on either side of the tile (leafSize <= AGG_HALO)
@@ -979,13 +982,13 @@ constexpr int AGG_REF_RUN = 0x7FFFFFFF;     // child reference of a run of equal
 struct AggSlot {             // what the first sibling leaves at the meeting point
     float b[6];              // lo.x hi.x lo.y hi.y lo.z hi.z
     unsigned int farKind;    // far end of its range | kind << 28
-    unsigned int refH;       // node position (kind 1) | height << 27
+    unsigned int refH;       // node index (kind 1) | height << 27
 };
 static_assert(sizeof(AggSlot) == 32, "AggSlot must be 32 bytes");
 
-struct AggSlotG {            // meeting slot of the second stage: the cluster also carries the key difference at its far end
-    float b[6];
-    unsigned int farKind, refH, dFar, pad[3];
+struct AggSlotG {            // meeting slot in memory: the cluster also carries the key difference at its far end (second stage) and
+    float b[6];              // the number of leaves that start before its far end
+    unsigned int farKind, refH, dFar, lbFar, pad[2];
 };
 static_assert(sizeof(AggSlotG) == 48, "AggSlotG must be 48 bytes");
 
@@ -993,49 +996,105 @@ struct AggExport {           // a cluster that has outgrown its tile, handed to 
     float b[6];
     int l;
     unsigned int rKind;      // r | kind << 28
-    unsigned int refH;
+    unsigned int refH;       // node index (kind 1) | height << 27
     unsigned int dl, dr;     // key[l-1] ^ key[l], key[r-1] ^ key[r] (0xFFFFFFFF at the ends of the array)
     unsigned int pad;
 };
 static_assert(sizeof(AggExport) == 48, "AggExport must be 48 bytes");
 constexpr int AGG_EXPORT_CAP = 64;   // a tile's clusters with a parent outside it are children of the <= 2 x 30 nodes that cross its two borders
 
+constexpr int RANK_SHIFT = 10;
+constexpr int RANK_BLOCK = 1 << RANK_SHIFT;    // positions per prefix-count entry (16 mask words)
+
 struct AggCtx {
     const unsigned int* keys;
     const int* triSorted;        // sorted position -> triangle
     const TriVerts* triVerts;    // per triangle (mesh order): the three vertex positions, 36 B -- ONE random access per triangle
-    TriVerts* vertsSorted;       // the same per sorted position: written here, read in order by lbvh_finalize_kernel
     float eps;
     int n, leafSize;
-    int* rec;                    // [n + 1][16] node records by split position (0 = root)
-    unsigned char* nodeFlag;     // [n + 1]
-    unsigned char* leafFlag;     // [n + 1] a leaf starts here
+    // leaf-start marks of lbvh_leafmark_kernel and their prefix counts: every index and storage offset is a rank
+    const unsigned long long* sBits;   // bit p: a leaf starts at sorted position p
+    const unsigned long long* rBits;   // bit p: position p lies in a run of more than leafSize equal keys
+    int numBitWords;
+    const unsigned int* blockBase;     // leaf starts before each RANK_BLOCK positions
+    const unsigned int* subBase;       // ... inside the block before each 256 positions
+    int* nodes;                  // output: BVHLayout_Compact nodes
+    float4* outWoop;             // output: Woop rows + terminators
+    int* outIdx;                 // output: triangle indices, parallel to outWoop
     unsigned int* arrive;        // [n + 1] meeting counters (memory protocol), zeroed
-    AggSlot* slot;               // [n + 1][2]
-    int* parentPos;              // [n + 1] record position of a node's parent
-    int4* runs;                  // (parent position or -1, side, start, end) of the runs of more than leafSize equal keys
+    int* parentPos;              // [nodes] index of a node's parent (the root is node 0)
+    int4* runs;                  // (parent node or -1, side, start, end) of the runs of more than leafSize equal keys
     unsigned int* runCount;
     LbvhState* st;
     int useLds;
     AggExport* exports;          // [tiles][AGG_EXPORT_CAP] (two-stage mode)
     unsigned int* exportCount;   // [tiles], zeroed
-    AggSlotG* slotG;             // [n + 1][2] (two-stage mode)
+    AggSlotG* slotG;             // [n + 1][2] meeting slots in memory
 };
 
-__device__ __forceinline__ void agg_store_slot(AggSlot* dst, const AggSlot& v)
+// exclusive rank of position p (set bits before p) = count before its 1024-block + count inside the block before its 256-tile
+// (both passed in as `base`) + set bits of the tile's words before p
+__device__ __forceinline__ unsigned int agg_rank(const unsigned long long* __restrict__ bits, unsigned int base, int p)
+{
+    const int w = p >> 6;
+    unsigned int acc = base;
+    for (int k = (p >> 8) << 2; k < w; k++) acc += (unsigned int)__popcll(bits[k]);
+    return acc + (unsigned int)__popcll(bits[w] & ((1ull << (p & 63)) - 1ull));
+}
+// leaves that start before sorted position p (0 <= p <= n)
+__device__ __forceinline__ unsigned int agg_leaves_before(const AggCtx& c, int p)
+{
+    return agg_rank(c.sBits, c.blockBase[p >> RANK_SHIFT] + c.subBase[p >> 8], p);
+}
+// A node is identified by its split position, which is where the first leaf of its right child starts: with the leaf starts
+// p_0 = 0 < p_1 < ... the node splitting at p_j gets index j, except that the root takes index 0 and the nodes after it move up.
+__device__ __forceinline__ int agg_node_index(const AggCtx& c, int pos, int rootSplit)
+{
+    if (pos == 0 || pos == rootSplit) return 0;
+    return (int)agg_leaves_before(c, pos) - (pos > rootSplit ? 1 : 0);
+}
+// storage of the leaf that starts at sorted position p: 3 float4 per triangle before it + one terminator per leaf before it
+// (createLeaf, emitTreeKernel.cu:176-181, with the leaves numbered in sorted order)
+__device__ __forceinline__ int agg_leaf_storage(const AggCtx& c, int p) { return (int)(3u * (unsigned int)p + agg_leaves_before(c, p)); }
+
+// The leaf of sorted position i among distinct-enough keys: the largest prefix group around i with at most leafSize members.  With
+// d(x) = highest bit in which key[x-1] and key[x] differ (-1: equal; 64 at the two ends of the array), the highest differing bit
+// between key[i] and a neighbour is the maximum of the d's in between (the keys are sorted), so the neighbours' values are two
+// non-decreasing sequences, left and right; T = the leafSize-th smallest of both, and the leaf is i plus every neighbour below T.
+// T == -1: at least leafSize neighbours carry the same key, i lies inside a run of more than leafSize equal keys (isRun; ls / le
+// are not set).
+template <class DFn>
+__device__ __forceinline__ void agg_leaf_of(int i, int leafSize, DFn d, bool& isRun, int& ls, int& le)
+{
+    int a = 1, b = 1, T = 64;
+    int hl = d(i), hr = d(i + 1);                  // values of the next neighbour to take on either side
+    for (int step = 0; step < leafSize; step++) {
+        if (hl <= hr) { T = hl; a++; hl = max(hl, d(i - a + 1)); } else { T = hr; b++; hr = max(hr, d(i + b)); }
+    }
+    isRun = T == -1;
+    if (isRun) return;
+    ls = i; le = i + 1;
+    int m = d(i);
+    while (i - ls < leafSize && m < T) { ls--; m = max(m, d(ls)); }
+    m = d(i + 1);
+    while (le - i <= leafSize && m < T) { le++; m = max(m, d(le)); }
+}
+
+__device__ __forceinline__ void agg_store_slot(AggSlotG* dst, const AggSlotG& v)
 {
     const unsigned long long* s = reinterpret_cast<const unsigned long long*>(&v);
     unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
 #pragma unroll
-    for (int k = 0; k < 4; k++) __hip_atomic_store(d + k, s[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < 5; k++) __hip_atomic_store(d + k, s[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ AggSlot agg_load_slot(const AggSlot* src)
+__device__ __forceinline__ AggSlotG agg_load_slot(const AggSlotG* src)
 {
-    AggSlot v;
+    AggSlotG v;
     unsigned long long* d = reinterpret_cast<unsigned long long*>(&v);
     const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
 #pragma unroll
-    for (int k = 0; k < 4; k++) d[k] = __hip_atomic_load(s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < 5; k++) d[k] = __hip_atomic_load(s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.pad[0] = v.pad[1] = 0;
     return v;
 }
 
@@ -1077,11 +1136,14 @@ __device__ __forceinline__ void agg_write_record(int* rec, int id, const float* 
     reinterpret_cast<int4*>(nd)[3] = make_int4(link0, link1, splitBit, 0);
 }
 
-// The second sibling to arrive forms the parent of the clusters [l, r) (its own) and the sibling's: children become leaves / keep
-// their node / are recorded as runs, the node record goes to its split position, and the caller's cluster becomes the parent.
+// The second sibling to arrive forms the parent of the clusters [l, r) (its own) and the sibling's, and writes the node -- boxes and
+// child references -- to its final place.  No look-up is needed for that: a cluster carries the number of leaves that start before
+// its two ends (lbL, lbR), which is all its parent's index (rank of the split position, agg_node_index) and a leaf child's storage
+// (agg_leaf_storage) are made of; an inner child carries its index.  The caller's cluster becomes the parent.
 // Returns true when the parent is the root.
-__device__ __forceinline__ bool agg_form_parent(const AggCtx& c, bool sibRight, int B, int hb, int& l, int& r, int& kind, int& ref, int& h,
-                                                float (&box)[6], int sFar, int sKind, int sRef, int sH, const float* sibBox)
+__device__ __forceinline__ bool agg_form_parent(const AggCtx& c, int rootSplit, bool sibRight, int B, int hb, int& l, int& r, int& kind, int& ref,
+                                                int& h, unsigned int& lbL, unsigned int& lbR, float (&box)[6], int sFar, int sKind, int sRef,
+                                                int sH, unsigned int sLbFar, const float* sibBox)
 {
     const int n = c.n;
     const int L = sibRight ? l : sFar, R = sibRight ? sFar : r;
@@ -1091,35 +1153,37 @@ __device__ __forceinline__ bool agg_form_parent(const AggCtx& c, bool sibRight, 
     const int ck[2] = {sibRight ? kind : sKind, sibRight ? sKind : kind};
     const int cr[2] = {sibRight ? ref : sRef, sibRight ? sRef : ref};
     const int hmax = max(h, sH);
-    const int id = (L == 0 && R == n) ? 0 : B;    // record position of the new node
+    const unsigned int lbB = sibRight ? lbR : lbL;          // leaves before the split position, before L and before R
+    const unsigned int lbLo = sibRight ? lbL : sLbFar, lbHi = sibRight ? sLbFar : lbR;
+    const bool root = L == 0 && R == n;
+    const int idx = (root || B == rootSplit) ? 0 : (int)lbB - (B > rootSplit ? 1 : 0);
     const int cs[2] = {L, B}, ce[2] = {B, R};
+    const unsigned int clb[2] = {lbLo, lbB};
     int link[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         if (ck[k] == 0) {                          // createLeaf: the child is a leaf starting at cs[k]
-            c.leafFlag[cs[k]] = 1;
-            link[k] = ~cs[k];
+            link[k] = ~(int)(3u * (unsigned int)cs[k] + clb[k]);
         } else if (ck[k] == 1) {
-            link[k] = cr[k];
-            c.parentPos[cr[k]] = id;
+            link[k] = cr[k] * 64;
+            c.parentPos[cr[k]] = idx;
         } else {
             link[k] = AGG_REF_RUN;
             const unsigned int g = atomicAdd(c.runCount, 1u);
-            c.runs[g] = make_int4(id, k, cs[k], ce[k]);
+            c.runs[g] = make_int4(idx, k, cs[k], ce[k]);
         }
     }
-    agg_write_record(c.rec, id, b0, b1, link[0], link[1], hb % 3);
-    c.nodeFlag[id] = 1;
+    agg_write_record(c.nodes, idx, b0, b1, link[0], link[1], hb % 3);
     float ub[6];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         ub[2 * k] = fminf(b0[2 * k], b1[2 * k]);
         ub[2 * k + 1] = fmaxf(b0[2 * k + 1], b1[2 * k + 1]);
     }
-    l = L; r = R; kind = 1; ref = id; h = 1 + hmax;
+    l = L; r = R; kind = 1; ref = idx; h = 1 + hmax; lbL = lbLo; lbR = lbHi;
 #pragma unroll
     for (int k = 0; k < 6; k++) box[k] = ub[k];
-    if (id == 0) {                                 // the root: deepest level that holds an inner node, plus one
+    if (root) {                                    // the root: deepest level that holds an inner node, plus one
         atomicMax(&c.st->maxLevel, (unsigned int)min(h, 30));
         return true;
     }
@@ -1132,6 +1196,7 @@ __device__ __forceinline__ bool agg_form_parent(const AggCtx& c, bool sibRight, 
 template <bool EXPORT>
 __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
 {
+    constexpr int BIT_WORDS = AGG_TILE / 64 + 2;               // the tile's mark words and two beyond it (leafSize <= AGG_HALO look-ahead)
     __shared__ unsigned int sKeys[AGG_TILE + 2 * AGG_HALO];   // sKeys[AGG_HALO + k] = key of position tileBeg + k
     __shared__ unsigned int sMeet[AGG_TILE + 1];               // per boundary: 0, or 1 + the compacted index of the cluster waiting there
     __shared__ AggSlot sOwn[AGG_TILE];                        // per cluster (compacted index): what it shows to its sibling
@@ -1139,17 +1204,27 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
     __shared__ int sWalkerEnd[AGG_TILE];
     __shared__ unsigned int sWaveCount[AGG_TILE / 64], sNumWalkers, sExports;
     __shared__ float sBox[AGG_TILE][6];                       // box terms of the tile's positions, gathered by all threads at once
+    __shared__ unsigned long long sS[BIT_WORDS], sR[BIT_WORDS];   // leaf-start / in-run marks of positions tileBeg ...
+    __shared__ unsigned int sPre[BIT_WORDS];                  // leaves that start before the first position of each mark word
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = c.n, leafSize = c.leafSize;
+    const int n = c.n;
     const int tileBeg = blockIdx.x * AGG_TILE;
     const int tileEnd = min(tileBeg + AGG_TILE, n);
     for (int k = tid; k < AGG_TILE + 2 * AGG_HALO; k += AGG_TILE) {
         const int x = tileBeg - AGG_HALO + k;
         sKeys[k] = (x >= 0 && x < n) ? c.keys[x] : 0u;
     }
+    if (tid < BIT_WORDS) {
+        const int w = (tileBeg >> 6) + tid;
+        sS[tid] = w < c.numBitWords ? c.sBits[w] : 0ull;
+        sR[tid] = w < c.numBitWords ? c.rBits[w] : 0ull;
+    }
+    const int rootSplit = (int)c.st->rootSplit;
+    int triOfMine = 0;
+    TriVerts tv;
     if (tileBeg + tid < n) {   // one index -> vertex gather (36 contiguous bytes) per position, all in flight together
-        const TriVerts tv = c.triVerts[c.triSorted[tileBeg + tid]];
-        c.vertsSorted[tileBeg + tid] = tv;                            // in sorted order for the final pass
+        triOfMine = c.triSorted[tileBeg + tid];
+        tv = c.triVerts[triOfMine];
         float term[6];
         agg_tri_terms(tv, c.eps, term);
 #pragma unroll
@@ -1158,30 +1233,53 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
     sMeet[tid] = 0;
     if (tid == 0) { sMeet[AGG_TILE] = 0; sExports = 0; }
     __syncthreads();
+    if (tid == 0) {            // AGG_TILE is a multiple of 256: the count before the tile is a block base plus a sub base
+        unsigned int acc = c.blockBase[tileBeg >> RANK_SHIFT] + c.subBase[tileBeg >> 8];
+        for (int w = 0; w < BIT_WORDS; w++) { sPre[w] = acc; acc += (unsigned int)__popcll(sS[w]); }
+    }
+    __syncthreads();
 
     auto key = [&](int x) -> unsigned int {   // sorted key at position x (0 <= x < n)
         const int rel = x - tileBeg + AGG_HALO;
         return (rel >= 0 && rel < AGG_TILE + 2 * AGG_HALO) ? sKeys[rel] : c.keys[x];
     };
-    auto hbit = [](unsigned int x) -> int { return x ? 31 - __clz((int)x) : -1; };   // highest set bit, -1 for equal keys
+    auto leafStartsAt = [&](int x) -> bool {  // tileBeg <= x < tileBeg + 64 * BIT_WORDS
+        const int rel = x - tileBeg;
+        return (sS[rel >> 6] >> (rel & 63)) & 1ull;
+    };
+    auto leavesBefore = [&](int x) -> unsigned int {   // leaves that start before position x: LDS near the tile, memory elsewhere
+        const int rel = x - tileBeg;
+        if (rel >= 0 && rel < 64 * BIT_WORDS) return sPre[rel >> 6] + (unsigned int)__popcll(sS[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
+        return agg_leaves_before(c, x);
+    };
 
-    // ---- the cluster every position starts in ---------------------------------------------------------------------------------
-    // leaf of position i = the largest prefix group around i with at most leafSize members: with the neighbours' highest differing
-    // bits sorted, T = the leafSize-th smallest, the leaf is i plus every neighbour below T.  T == -1: at least leafSize neighbours
-    // carry the same key -- position i is inside a run of more than leafSize equal keys.
     const int i = tileBeg + tid;
+    if (i < n) {
+        // the triangle's Woop rows and index go straight to their final place (calcWoopKernel, emitTreeKernel.cu:574-645): 3 float4
+        // per triangle before it + one terminator per leaf that ended before it
+        const int o = (int)(3u * (unsigned int)i + leavesBefore(i + 1)) - 1;
+        float4 r0, r1, r2;
+        woop_rows_verts(tv.v[0].x, tv.v[0].y, tv.v[0].z, tv.v[1].x, tv.v[1].y, tv.v[1].z, tv.v[2].x, tv.v[2].y, tv.v[2].z, r0, r1, r2);
+        c.outWoop[o + 0] = r0;
+        c.outWoop[o + 1] = r1;
+        c.outWoop[o + 2] = r2;
+        c.outIdx[o + 0] = triOfMine;
+        c.outIdx[o + 1] = 0;
+        c.outIdx[o + 2] = 0;
+        if (i + 1 == n || leafStartsAt(i + 1)) {      // last triangle of its leaf: the terminator
+            const float nz = __uint_as_float(0x80000000u);
+            c.outWoop[o + 3] = make_float4(nz, nz, nz, nz);
+            c.outIdx[o + 3] = 0;
+        }
+    }
+
+    // ---- the cluster every position starts in: its leaf (the marks of lbvh_leafmark_kernel), or the whole run of equal keys --------
     bool starts = false, isRun = false;
     int cEnd = 0;
     if (i < n) {
         const unsigned int myKey = sKeys[AGG_HALO + tid];
-        int a = 1, b = 1, T = 64;
-        for (int step = 0; step < leafSize; step++) {
-            const int hl = (i - a >= 0) ? hbit(key(i - a) ^ myKey) : 64;
-            const int hr = (i + b < n) ? hbit(key(i + b) ^ myKey) : 64;
-            if (hl <= hr) { T = hl; a++; } else { T = hr; b++; }
-        }
-        if (T == -1) {
-            isRun = true;
+        isRun = (sR[tid >> 6] >> (tid & 63)) & 1ull;
+        if (isRun) {
             starts = i == 0 || key(i - 1) != myKey;
             if (starts) {
                 int r = i + 1;
@@ -1189,11 +1287,12 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
                 cEnd = r;
             }
         } else {
-            int ls = i, le = i + 1;
-            while (ls - 1 >= 0 && (i - (ls - 1)) <= leafSize && hbit(key(ls - 1) ^ myKey) < T) ls--;
-            while (le < n && (le - i) <= leafSize && hbit(key(le) ^ myKey) < T) le++;
-            starts = ls == i;
-            cEnd = le;
+            starts = leafStartsAt(i);
+            if (starts) {                              // a leaf holds at most leafSize <= AGG_HALO positions
+                int r = i + 1;
+                while (r < n && !leafStartsAt(r)) r++;
+                cEnd = r;
+            }
         }
     }
     // compact the starting clusters so that they occupy the first lanes of the workgroup
@@ -1216,8 +1315,9 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
 
     int l = sWalker[tid] & 0x7FFFFFFF, r = sWalkerEnd[tid];
     int kind = (sWalker[tid] < 0) ? 2 : 0;            // 0 leaf, 1 inner node, 2 run of equal keys
-    int ref = 0;                                      // kind 1: the node's record position
+    int ref = 0;                                      // kind 1: the node's index
     int h = kind == 2 ? 1 : 0;                        // levels of inner nodes below and including this cluster
+    unsigned int lbL = leavesBefore(l), lbR = leavesBefore(r);
     float box[6];
     {   // the cluster's box, folded from FLT_MAX like calcLeaf (:383-408): tile positions from LDS, the few beyond it from memory
         box[0] = box[2] = box[4] = FLT_MAX;
@@ -1260,32 +1360,39 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
             const bool rightOut = tileEnd >= n || (sKeys[AGG_HALO + AGG_TILE] >> (hb + 1)) != pfx;
             inTile = leftOut && rightOut;
         }
-        AggSlot mine;
-#pragma unroll
-        for (int k = 0; k < 6; k++) mine.b[k] = box[k];
-        mine.farKind = (unsigned int)(sibRight ? l : r) | ((unsigned int)kind << 28);
-        mine.refH = (unsigned int)ref | ((unsigned int)h << 27);
+        const unsigned int farKind = (unsigned int)(sibRight ? l : r) | ((unsigned int)kind << 28);
+        const unsigned int refH = (unsigned int)ref | ((unsigned int)h << 27);
         const int side = sibRight ? 0 : 1;
-        AggSlot sib;
+        float sibBox[6];
+        unsigned int sFarKind, sRefH, sLbFar;
         if (inTile) {
             const int bl = B - tileBeg;
             // Every cluster keeps its record in its own LDS slot and the two siblings exchange slot numbers at the boundary: the
             // first finds 0 and stops (its record stays put), the second finds the first's number.  LDS executes a wave's operations
             // in order and the exchange serialises the two, so only LDS counters are waited for -- the global stores of the node just
             // formed stay in flight.
+            AggSlot mine;
+#pragma unroll
+            for (int k = 0; k < 6; k++) mine.b[k] = box[k];
+            mine.farKind = farKind;
+            mine.refH = refH;
             sOwn[tid] = mine;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const unsigned int old = atomicExch(&sMeet[bl], (unsigned int)tid + 1u);
             if (old == 0) break;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            sib = sOwn[old - 1u];
+            const AggSlot sib = sOwn[old - 1u];
+#pragma unroll
+            for (int k = 0; k < 6; k++) sibBox[k] = sib.b[k];
+            sFarKind = sib.farKind; sRefH = sib.refH;
+            sLbFar = leavesBefore((int)(sib.farKind & 0x0FFFFFFFu));   // the far end lies inside the tile
         } else if (EXPORT) {
             const unsigned int k = atomicAdd(&sExports, 1u);
             if (k < (unsigned int)AGG_EXPORT_CAP) {
                 AggExport e;
 #pragma unroll
                 for (int q = 0; q < 6; q++) e.b[q] = box[q];
-                e.l = l; e.rKind = (unsigned int)r | ((unsigned int)kind << 28); e.refH = mine.refH; e.dl = dl; e.dr = dr; e.pad = 0;
+                e.l = l; e.rKind = (unsigned int)r | ((unsigned int)kind << 28); e.refH = refH; e.dl = dl; e.dr = dr; e.pad = 0;
                 c.exports[(size_t)blockIdx.x * AGG_EXPORT_CAP + k] = e;
                 atomicAdd(&c.exportCount[blockIdx.x], 1u);
             } else {
@@ -1297,17 +1404,25 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
             // announced after their slot had reached memory), and then this cluster is the second for certain -- it neither
             // publishes its own slot nor touches the counter, it just reads the sibling's: two round trips instead of four.
             if (__hip_atomic_load(&c.arrive[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                agg_store_slot(&c.slot[2 * (size_t)B + side], mine);
+                AggSlotG mine;
+#pragma unroll
+                for (int k = 0; k < 6; k++) mine.b[k] = box[k];
+                mine.farKind = farKind; mine.refH = refH; mine.dFar = 0; mine.lbFar = sibRight ? lbL : lbR;
+                mine.pad[0] = mine.pad[1] = 0;
+                agg_store_slot(&c.slotG[2 * (size_t)B + side], mine);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slot has reached memory before the arrival is announced
                 const unsigned int old = __hip_atomic_fetch_add(&c.arrive[B], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (old == 0) break;
             }
             asm volatile("" ::: "memory");
-            sib = agg_load_slot(&c.slot[2 * (size_t)B + (side ^ 1)]);
+            const AggSlotG sib = agg_load_slot(&c.slotG[2 * (size_t)B + (side ^ 1)]);
+#pragma unroll
+            for (int k = 0; k < 6; k++) sibBox[k] = sib.b[k];
+            sFarKind = sib.farKind; sRefH = sib.refH; sLbFar = sib.lbFar;
         }
         // ---- second to arrive: form the parent ------------------------------------------------------------------------------
-        if (agg_form_parent(c, sibRight, B, hb, l, r, kind, ref, h, box, (int)(sib.farKind & 0x0FFFFFFFu), (int)(sib.farKind >> 28),
-                            (int)(sib.refH & 0x07FFFFFFu), (int)(sib.refH >> 27), sib.b))
+        if (agg_form_parent(c, rootSplit, sibRight, B, hb, l, r, kind, ref, h, lbL, lbR, box, (int)(sFarKind & 0x0FFFFFFFu), (int)(sFarKind >> 28),
+                            (int)(sRefH & 0x07FFFFFFu), (int)(sRefH >> 27), sLbFar, sibBox))
             break;
     }
 }
@@ -1320,8 +1435,10 @@ __global__ __launch_bounds__(256) void lbvh_agglomerate_top_kernel(AggCtx c, int
     const int tile = g / AGG_EXPORT_CAP, k = g % AGG_EXPORT_CAP;
     if (tile >= numTiles || (unsigned int)k >= min(c.exportCount[tile], (unsigned int)AGG_EXPORT_CAP)) return;
     const AggExport e = c.exports[(size_t)tile * AGG_EXPORT_CAP + k];
+    const int rootSplit = (int)c.st->rootSplit;
     int l = e.l, r = (int)(e.rKind & 0x0FFFFFFFu), kind = (int)(e.rKind >> 28), ref = (int)(e.refH & 0x07FFFFFFu), h = (int)(e.refH >> 27);
     unsigned int dl = e.dl, dr = e.dr;
+    unsigned int lbL = agg_leaves_before(c, l), lbR = agg_leaves_before(c, r);
     float box[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) box[q] = e.b[q];
@@ -1330,7 +1447,6 @@ __global__ __launch_bounds__(256) void lbvh_agglomerate_top_kernel(AggCtx c, int
         const int B = sibRight ? r : l;
         const int hb = 31 - __clz((int)(sibRight ? dr : dl));
         const int side = sibRight ? 0 : 1;
-        AggSlotG sib;
         if (__hip_atomic_load(&c.arrive[B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
             AggSlotG mine;
 #pragma unroll
@@ -1338,36 +1454,30 @@ __global__ __launch_bounds__(256) void lbvh_agglomerate_top_kernel(AggCtx c, int
             mine.farKind = (unsigned int)(sibRight ? l : r) | ((unsigned int)kind << 28);
             mine.refH = (unsigned int)ref | ((unsigned int)h << 27);
             mine.dFar = sibRight ? dl : dr;
-            mine.pad[0] = mine.pad[1] = mine.pad[2] = 0;
-            {
-                const unsigned long long* sp = reinterpret_cast<const unsigned long long*>(&mine);
-                unsigned long long* dp = reinterpret_cast<unsigned long long*>(&c.slotG[2 * (size_t)B + side]);
-#pragma unroll
-                for (int q = 0; q < 5; q++) __hip_atomic_store(dp + q, sp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            mine.lbFar = sibRight ? lbL : lbR;
+            mine.pad[0] = mine.pad[1] = 0;
+            agg_store_slot(&c.slotG[2 * (size_t)B + side], mine);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slot has reached memory before the arrival is announced
             const unsigned int old = __hip_atomic_fetch_add(&c.arrive[B], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == 0) return;
         }
         asm volatile("" ::: "memory");
-        {
-            unsigned long long* dp = reinterpret_cast<unsigned long long*>(&sib);
-            const unsigned long long* sp = reinterpret_cast<const unsigned long long*>(&c.slotG[2 * (size_t)B + (side ^ 1)]);
-#pragma unroll
-            for (int q = 0; q < 5; q++) dp[q] = __hip_atomic_load(sp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const AggSlotG sib = agg_load_slot(&c.slotG[2 * (size_t)B + (side ^ 1)]);
         if (sibRight) dr = sib.dFar; else dl = sib.dFar;
-        if (agg_form_parent(c, sibRight, B, hb, l, r, kind, ref, h, box, (int)(sib.farKind & 0x0FFFFFFFu), (int)(sib.farKind >> 28),
-                            (int)(sib.refH & 0x07FFFFFFu), (int)(sib.refH >> 27), sib.b))
+        if (agg_form_parent(c, rootSplit, sibRight, B, hb, l, r, kind, ref, h, lbL, lbR, box, (int)(sib.farKind & 0x0FFFFFFFu), (int)(sib.farKind >> 28),
+                            (int)(sib.refH & 0x07FFFFFFu), (int)(sib.refH >> 27), sib.lbFar, sib.b))
             return;
     }
 }
 
 // Runs of more than leafSize equal keys: the reference splits them at the median (emitTreeKernel.cu:282) until a part holds at
 // most leafSize triangles or the level bit reaches 0 (:289-292), so the subtree depends on the run's depth -- the number of its
-// ancestors, found by walking the parent positions.  One thread per run records the median nodes (identified by their split
-// position, which lies strictly inside the run) and flags the leaves, exactly like the bottom-up pass does for the rest of the tree,
-// and patches the reference its parent holds.  Boxes are folded per child range.
+// ancestors, found by walking the parent positions.  One wave per run writes the median nodes (named by their split position, which
+// lies strictly inside the run; lbvh_leafmark_kernel has marked the leaf starts of the run's subtree as it is WITHOUT the depth rule,
+// so indices and storage are ranks like everywhere else) and patches the reference its parent holds.  Boxes are folded per child range.
+// Where the depth rule cuts the subtree short (a node at depth 29 only has leaf children; a run at depth 30 is a leaf whatever its
+// size) the leaf is larger than the marks assume: its triangles are written again, contiguously, at the leaf's storage, and the
+// storage and node indices the marks had set aside inside it stay unused (zero-filled).
 // box of the sorted positions [a, b) by a whole wave: lanes stride over the range, min / max across the lanes by shuffles
 __device__ __forceinline__ void agg_fold_box_wave(const AggCtx& c, int a, int b, float (&box)[6])
 {
@@ -1393,9 +1503,40 @@ __device__ __forceinline__ void agg_fold_box_wave(const AggCtx& c, int a, int b,
     }
 }
 
+// a leaf [a, b) of more than leafSize equal keys (depth rule): rows, indices, terminator; zeroes what the marks had set aside
+__device__ __forceinline__ void agg_rewrite_big_leaf(const AggCtx& c, int rootSplit, int a, int b)
+{
+    const int lane = threadIdx.x & 63;
+    const int base = agg_leaf_storage(c, a);
+    for (int j = a + lane; j < b; j += 64) {
+        const int t = c.triSorted[j];
+        const TriVerts tv = c.triVerts[t];
+        float4 r0, r1, r2;
+        woop_rows_verts(tv.v[0].x, tv.v[0].y, tv.v[0].z, tv.v[1].x, tv.v[1].y, tv.v[1].z, tv.v[2].x, tv.v[2].y, tv.v[2].z, r0, r1, r2);
+        const int o = base + 3 * (j - a);
+        c.outWoop[o + 0] = r0; c.outWoop[o + 1] = r1; c.outWoop[o + 2] = r2;
+        c.outIdx[o + 0] = t; c.outIdx[o + 1] = 0; c.outIdx[o + 2] = 0;
+        const bool reserved = j > a && ((c.sBits[j >> 6] >> (j & 63)) & 1ull);   // a node index the marks set aside inside the leaf
+        if (reserved) {
+            const int idx = agg_node_index(c, j, rootSplit);
+            int4* nd = reinterpret_cast<int4*>(c.nodes + (size_t)idx * 16);
+            nd[0] = nd[1] = nd[2] = nd[3] = make_int4(0, 0, 0, 0);
+        }
+        const unsigned long long rm = __ballot(reserved);
+        if (lane == 0 && rm) atomicAdd(&c.st->holes, (unsigned int)__popcll(rm));
+    }
+    const int term = base + 3 * (b - a), endAll = agg_leaf_storage(c, b);   // b is a marked leaf start (or n)
+    const float nz = __uint_as_float(0x80000000u);
+    for (int o = term + lane; o < endAll; o += 64) {
+        c.outWoop[o] = o == term ? make_float4(nz, nz, nz, nz) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        c.outIdx[o] = 0;
+    }
+}
+
 __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
 {
     const unsigned int numRuns = *c.runCount;
+    const int rootSplit = (int)c.st->rootSplit;
     const int lane = threadIdx.x;
     for (unsigned int g = blockIdx.x; g < numRuns; g += gridDim.x) {   // one wave per run; control flow is wave-uniform
         const int4 q = c.runs[g];
@@ -1404,19 +1545,17 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
             depth = 1;
             for (int p = q.x; p != 0; p = c.parentPos[p]) depth++;
         }
-        int* parentLink = q.x >= 0 ? c.rec + (size_t)q.x * 16 + 12 + q.y : nullptr;
+        int* parentLink = q.x >= 0 ? c.nodes + (size_t)q.x * 16 + 12 + q.y : nullptr;
         if (depth >= 30) {                              // the parent's level bit is 0: a leaf whatever its size
-            if (lane == 0) {
-                c.leafFlag[q.z] = 1;
-                *parentLink = ~q.z;
-            }
+            if (lane == 0) *parentLink = ~agg_leaf_storage(c, q.z);
+            agg_rewrite_big_leaf(c, rootSplit, q.z, q.w);
             continue;
         }
-        // explicit stack of (start, end, depth, record position); a node at depth 29 only has leaf children
+        // explicit stack of (start, end, depth, split position); a node at depth 29 only has leaf children
         int stS[32], stE[32], stD[32], stP[32];
         int sp = 0;
-        const int top = q.x >= 0 ? ((q.z + q.w) >> 1) : 0;
-        if (parentLink && lane == 0) *parentLink = top;
+        const int top = (q.z + q.w) >> 1;               // (the root of an all-equal scene: rootSplit, i.e. index 0)
+        if (parentLink && lane == 0) *parentLink = agg_node_index(c, top, rootSplit) * 64;
         stS[0] = q.z; stE[0] = q.w; stD[0] = depth; stP[0] = top;
         sp = 1;
         unsigned int deepest = 0;
@@ -1433,166 +1572,171 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 if ((ce[k] - cs[k]) <= c.leafSize || d == 29) {
-                    if (lane == 0) c.leafFlag[cs[k]] = 1;
-                    link[k] = ~cs[k];
+                    link[k] = ~agg_leaf_storage(c, cs[k]);
+                    if ((ce[k] - cs[k]) > c.leafSize) agg_rewrite_big_leaf(c, rootSplit, cs[k], ce[k]);
                 } else {
                     const int cm = (cs[k] + ce[k]) >> 1;
-                    link[k] = cm;
+                    link[k] = agg_node_index(c, cm, rootSplit) * 64;
                     stS[sp] = cs[k]; stE[sp] = ce[k]; stD[sp] = d + 1; stP[sp] = cm;
                     sp++;
                 }
             }
             if (lane == 0) {
                 // split word of a median split: level = -1 in the reference (no differing bit), and -1 % 3 == -1
-                agg_write_record(c.rec, id, b0, b1, link[0], link[1], -1);
-                c.nodeFlag[id] = 1;
+                agg_write_record(c.nodes, agg_node_index(c, id, rootSplit), b0, b1, link[0], link[1], -1);
             }
         }
         if (lane == 0) atomicMax(&c.st->maxLevel, min(deepest, 30u));
     }
 }
 
-// Node / leaf-start flags -> bit masks (one 64-bit word per 64 positions) and counts per RANK_BLOCK positions.
-constexpr int CNT_TILE = 256;                  // threads of the count / finalize workgroups
-constexpr int RANK_SHIFT = 10;
-constexpr int RANK_BLOCK = 1 << RANK_SHIFT;    // positions per prefix-count entry (16 mask words)
-
-__global__ __launch_bounds__(CNT_TILE) void lbvh_count_kernel(int n, const unsigned char* __restrict__ nodeFlag, const unsigned char* __restrict__ leafFlag,
-                                                              unsigned long long* __restrict__ nodeBits, unsigned long long* __restrict__ leafBits,
-                                                              uint2* __restrict__ blockCount /* per RANK_BLOCK positions */,
-                                                              uint2* __restrict__ subBase /* per 256 positions: count inside its block before it */)
+// Leaf starts of every sorted position, from the keys alone -- BEFORE the tree is formed, so that the bottom-up pass can write nodes,
+// Woop rows and indices straight to their final places (indices and storage are ranks of these marks).  Distinct-enough keys: the
+// start of agg_leaf_of's leaf.  Inside a run of more than leafSize equal keys: the leaves of the reference's median splits
+// (emitTreeKernel.cu:282) taken until a part holds at most leafSize triangles.  Also finds the root's split position, the one boundary
+// where the highest bit in which the first and the last key differ flips.  One workgroup per RANK_BLOCK positions: bit masks, the
+// block's count and the counts before each 256 positions inside it.
+constexpr int MARK_THREADS = 256;              // one workgroup marks one prefix-count block, four positions per thread
+constexpr int MARK_SUBS = RANK_BLOCK / MARK_THREADS;
+// Exclusive scan of the block counts by one workgroup, four per thread and round with the next round's loads already in flight; the
+// total gives the builder state's nodeCount (one inner node per leaf but the first) and leafPtr.  (Folding this into the mark kernel --
+// the last block to report in scans -- was measured slower than the extra launch: 103 against 67 us at 10 M triangles.)
+__global__ __launch_bounds__(MARK_THREADS) void lbvh_markscan_kernel(int n, int numBlocks, const unsigned int* __restrict__ blockCount,
+                                                                     unsigned int* __restrict__ blockBase, LbvhState* st)
 {
-    constexpr int ROUNDS = RANK_BLOCK / CNT_TILE;
-    __shared__ unsigned int s_n[ROUNDS][CNT_TILE / 64], s_l[ROUNDS][CNT_TILE / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ unsigned int s_scan[MARK_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = 4, ROUND = MARK_THREADS * PER;
+    unsigned int carry = 0;
+    unsigned int nextv[PER];
 #pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        const int p = blockIdx.x * RANK_BLOCK + r * CNT_TILE + threadIdx.x;
-        const bool ok = p <= n;
-        const unsigned long long nb = __ballot(ok && nodeFlag[ok ? p : 0] != 0), lb = __ballot(ok && leafFlag[ok ? p : 0] != 0);
+    for (int q = 0; q < PER; q++) {
+        const int k = tid * PER + q;
+        nextv[q] = k < numBlocks ? blockCount[k] : 0u;
+    }
+    for (int base = 0; base < numBlocks; base += ROUND) {
+        unsigned int v[PER], mine = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            v[q] = nextv[q];
+            mine += v[q];
+            const int k = base + ROUND + tid * PER + q;
+            nextv[q] = k < numBlocks ? blockCount[k] : 0u;
+        }
+        unsigned int ia = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int ua = (unsigned int)__shfl_up((int)ia, off);
+            if (lane >= off) ia += ua;
+        }
+        __syncthreads();
+        if (lane == 63) s_scan[wave] = ia;
+        __syncthreads();
+        unsigned int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < MARK_THREADS / 64; w++) {
+            if (w < wave) before += s_scan[w];
+            all += s_scan[w];
+        }
+        unsigned int run = carry + before + ia - mine;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int k = base + tid * PER + q;
+            if (k < numBlocks) blockBase[k] = run;
+            run += v[q];
+        }
+        carry += all;
+    }
+    if (tid == 0) {
+        st->nodeCount = carry - 1u;
+        st->leafPtr = ((unsigned long long)n << 32) | (unsigned long long)carry;
+    }
+}
+
+__global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int leafSize, const unsigned int* __restrict__ keys,
+                                                                     unsigned long long* __restrict__ sBits, unsigned long long* __restrict__ rBits,
+                                                                     unsigned int* __restrict__ blockCount, unsigned int* __restrict__ subBase,
+                                                                     LbvhState* st)
+{
+    constexpr int SPAN = RANK_BLOCK + 2 * AGG_HALO;
+    __shared__ unsigned int sKeys[SPAN];
+    __shared__ int sD[SPAN + 2];                              // sD[k] = d(beg - AGG_HALO + k), valid for 1 <= k < SPAN
+    __shared__ unsigned int s_c[MARK_SUBS][MARK_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int beg = blockIdx.x * RANK_BLOCK;
+    for (int k = tid; k < SPAN; k += MARK_THREADS) {
+        const int x = beg - AGG_HALO + k;
+        sKeys[k] = (x >= 0 && x < n) ? keys[x] : 0u;
+    }
+    __syncthreads();
+    auto hbit = [](unsigned int x) -> int { return x ? 31 - __clz((int)x) : -1; };
+    for (int k = tid; k < SPAN + 2; k += MARK_THREADS) {
+        const int x = beg - AGG_HALO + k;
+        sD[k] = (k >= 1 && k < SPAN && x > 0 && x < n) ? hbit(sKeys[k - 1] ^ sKeys[k]) : 64;
+    }
+    __syncthreads();
+    // highest differing bit across the boundary before position x; every x agg_leaf_of asks for lies within AGG_HALO of the block
+    auto dAt = [&](int x) -> int { return sD[x - beg + AGG_HALO]; };
+    const int topBit = hbit(keys[0] ^ keys[n - 1]);
+    if (blockIdx.x == 0 && tid == 0 && topBit < 0) st->rootSplit = (unsigned int)(n >> 1);   // all keys equal: the first median
+    for (int r = 0; r < MARK_SUBS; r++) {
+        const int i = beg + r * MARK_THREADS + tid;
+        bool mark = false, isRun = false;
+        if (i < n) {
+            const unsigned int myKey = sKeys[AGG_HALO + r * MARK_THREADS + tid];
+            int ls = 0, le = 0;
+            agg_leaf_of(i, leafSize, dAt, isRun, ls, le);
+            if (!isRun) {
+                mark = ls == i;
+            } else {
+                // the run [s, e) of myKey: the boundary bits held in LDS first; when the run reaches beyond them, gallop over the
+                // sorted keys in memory (doubling steps, then a binary search inside the last step)
+                const int loEdge = max(beg - AGG_HALO + 1, 0), hiEdge = min(beg + RANK_BLOCK + AGG_HALO, n);   // d valid on [loEdge, hiEdge)
+                int s0 = i, e0 = i + 1;
+                while (s0 > loEdge && dAt(s0) == -1) s0--;
+                if (s0 > 0 && s0 == loEdge && dAt(s0) == -1) {
+                    int hi = s0, stepw = 64, lo = max(hi - stepw, 0);        // key[hi] == myKey; find the first position holding myKey
+                    while (lo > 0 && keys[lo] == myKey) { hi = lo; stepw *= 2; lo = max(hi - stepw, 0); }
+                    if (keys[lo] == myKey) { s0 = lo; }
+                    else {
+                        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (keys[m] == myKey) hi = m; else lo = m; }
+                        s0 = hi;
+                    }
+                }
+                while (e0 < hiEdge && dAt(e0) == -1) e0++;
+                if (e0 < n && e0 == hiEdge) {                                 // d(hiEdge) is not held: compare the keys
+                    if (keys[e0] == myKey) {
+                        int lo = e0, stepw = 64, hi = min(lo + stepw, n);    // key[lo] == myKey; find the first position past the run
+                        while (hi < n && keys[hi] == myKey) { lo = hi; stepw *= 2; hi = min(lo + stepw, n); }
+                        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (keys[m] == myKey) lo = m; else hi = m; }
+                        e0 = hi;
+                    }
+                }
+                int a = s0, b = e0;
+                while (b - a > leafSize) {
+                    const int m = (a + b) >> 1;
+                    if (i < m) b = m; else a = m;
+                }
+                mark = i == a;
+            }
+            if (i > 0 && topBit >= 0 && dAt(i) == topBit) st->rootSplit = (unsigned int)i;
+        }
+        const unsigned long long mb = __ballot(mark), rb = __ballot(isRun);
         if (lane == 0) {
-            nodeBits[(size_t)(p >> 6)] = nb;
-            leafBits[(size_t)(p >> 6)] = lb;
-            s_n[r][wave] = (unsigned int)__popcll(nb);
-            s_l[r][wave] = (unsigned int)__popcll(lb);
+            sBits[(size_t)((beg + r * MARK_THREADS + wave * 64) >> 6)] = mb;
+            rBits[(size_t)((beg + r * MARK_THREADS + wave * 64) >> 6)] = rb;
+            s_c[r][wave] = (unsigned int)__popcll(mb);
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int a = 0, b = 0;
-        for (int r = 0; r < ROUNDS; r++) {
-            subBase[(size_t)blockIdx.x * ROUNDS + r] = make_uint2(a, b);
-            for (int w = 0; w < CNT_TILE / 64; w++) { a += s_n[r][w]; b += s_l[r][w]; }
-        }
-        blockCount[blockIdx.x] = make_uint2(a, b);
-    }
-}
-
-// Exclusive scan of the per-tile counts (one workgroup, 1024 tiles per round with the next round's loads already in flight);
-// the totals become the builder state's nodeCount and leafPtr.
-__global__ __launch_bounds__(1024) void lbvh_tilescan_kernel(int numTiles, int n, const uint2* __restrict__ tileCount, uint2* __restrict__ tileBase,
-                                                             LbvhState* st)
-{
-    __shared__ unsigned int s_wa[16], s_wb[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned int carryA = 0, carryB = 0;
-    uint2 next = tid < numTiles ? tileCount[tid] : make_uint2(0u, 0u);
-    for (int base = 0; base < numTiles; base += 1024) {
-        const uint2 v = next;
-        const int nk = base + 1024 + tid;
-        next = nk < numTiles ? tileCount[nk] : make_uint2(0u, 0u);
-        unsigned int ia = v.x, ib = v.y;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int ua = (unsigned int)__shfl_up((int)ia, off), ub = (unsigned int)__shfl_up((int)ib, off);
-            if (lane >= off) { ia += ua; ib += ub; }
-        }
-        if (lane == 63) { s_wa[wave] = ia; s_wb[wave] = ib; }
-        __syncthreads();
-        unsigned int beforeA = 0, beforeB = 0, allA = 0, allB = 0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) {
-            if (w < wave) { beforeA += s_wa[w]; beforeB += s_wb[w]; }
-            allA += s_wa[w]; allB += s_wb[w];
-        }
-        if (base + tid < numTiles) tileBase[base + tid] = make_uint2(carryA + beforeA + ia - v.x, carryB + beforeB + ib - v.y);
-        carryA += allA; carryB += allB;
-        __syncthreads();
-    }
     if (tid == 0) {
-        st->nodeCount = carryA;
-        st->leafPtr = ((unsigned long long)n << 32) | (unsigned long long)carryB;
-    }
-}
-
-// exclusive rank of position p (set bits before p) = count before its 1024-block + count inside the block before its 256-tile
-// (both passed in as `base`) + set bits of the tile's words before p
-__device__ __forceinline__ unsigned int agg_rank(const unsigned long long* __restrict__ bits, unsigned int base, int p)
-{
-    const int w = p >> 6;
-    unsigned int acc = base;
-    for (int k = (p >> 8) << 2; k < w; k++) acc += (unsigned int)__popcll(bits[k]);
-    return acc + (unsigned int)__popcll(bits[w] & ((1ull << (p & 63)) - 1ull));
-}
-
-// Final pass, one thread per sorted position j: the node recorded at j (if any) goes to its ranked index with its child references
-// translated, triangle j's Woop rows and index go to its leaf's storage (calcWoopKernel, emitTreeKernel.cu:574-645; leaf storage
-// = 3 * first position + leaves before, createLeaf :176-181 with the leaves numbered in sorted order), and the leaf that ends
-// before j gets its terminator.
-__global__ __launch_bounds__(CNT_TILE) void lbvh_finalize_kernel(int n, const TriVerts* __restrict__ vertsSorted,
-                                                                 const int* __restrict__ triSorted, const int* __restrict__ rec,
-                                                                 const unsigned long long* __restrict__ nodeBits,
-                                                                 const unsigned long long* __restrict__ leafBits, const uint2* __restrict__ tileBase,
-                                                                 const uint2* __restrict__ subBase,
-                                                                 int* __restrict__ nodes, unsigned int nodeCap, float4* __restrict__ outWoop,
-                                                                 int* __restrict__ outIdx, LbvhState* st)
-{
-    const int j = blockIdx.x * CNT_TILE + threadIdx.x;
-    if (j > n) return;
-    const uint2 tb = tileBase[j >> RANK_SHIFT], sb = subBase[j >> 8];
-    const unsigned int rkN = agg_rank(nodeBits, tb.x + sb.x, j), rkL = agg_rank(leafBits, tb.y + sb.y, j);
-    const bool isNode = (nodeBits[j >> 6] >> (j & 63)) & 1ull, isLeafStart = (leafBits[j >> 6] >> (j & 63)) & 1ull;
-    if (isNode) {
-        if (rkN >= nodeCap) atomicOr(&st->overflow, 1u);
-        else {
-            const int4* src = reinterpret_cast<const int4*>(rec + (size_t)j * 16);
-            int4* dst = reinterpret_cast<int4*>(nodes + (size_t)rkN * 16);
-            const int4 a = src[0], b = src[1], cc = src[2];
-            int4 d = src[3];
-            int* lk = &d.x;
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int ref = k ? d.y : d.x;
-                int out;
-                if (ref < 0) {                                   // leaf starting at s = ~ref: float4 index 3 * s + leaves before s
-                    const int sPos = ~ref;
-                    out = ~(int)(3u * (unsigned int)sPos + agg_rank(leafBits, tileBase[sPos >> RANK_SHIFT].y + subBase[sPos >> 8].y, sPos));
-                } else {                                         // inner child recorded at position ref
-                    out = (int)(agg_rank(nodeBits, tileBase[ref >> RANK_SHIFT].x + subBase[ref >> 8].x, ref) * 64u);
-                }
-                lk[k] = out;
-            }
-            dst[0] = a; dst[1] = b; dst[2] = cc; dst[3] = d;
+        unsigned int acc = 0;
+        for (int q = 0; q < MARK_SUBS; q++) {
+            subBase[(size_t)blockIdx.x * MARK_SUBS + q] = acc;
+            for (int w = 0; w < MARK_THREADS / 64; w++) acc += s_c[q][w];
         }
+        blockCount[blockIdx.x] = acc;
     }
-    const float nz = __uint_as_float(0x80000000u);
-    if ((isLeafStart || j == n) && rkL > 0) {                     // a leaf starts here (or the array ends): close the one before it
-        const unsigned int tp = 3u * (unsigned int)j + rkL - 1u;
-        outWoop[tp] = make_float4(nz, nz, nz, nz);
-        outIdx[tp] = 0;
-    }
-    if (j == n) return;
-    const int o = (int)(3u * (unsigned int)j + rkL + (isLeafStart ? 1u : 0u)) - 1;   // 3 j + leaves up to and including this one - 1
-    const int t = triSorted[j];
-    const TriVerts tv = vertsSorted[j];
-    float4 r0, r1, r2;
-    woop_rows_verts(tv.v[0].x, tv.v[0].y, tv.v[0].z, tv.v[1].x, tv.v[1].y, tv.v[1].z, tv.v[2].x, tv.v[2].y, tv.v[2].z, r0, r1, r2);
-    outWoop[o + 0] = r0;
-    outWoop[o + 1] = r1;
-    outWoop[o + 2] = r2;
-    outIdx[o + 0] = t;
-    outIdx[o + 1] = 0;
-    outIdx[o + 2] = 0;
 }
 
 }  // namespace ntr
@@ -1700,29 +1844,28 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oOsHist = cv.take(4 * 256 * 4);
     const size_t oOsMisc = cv.take(64);            // [0..3] tickets, [4] error flag
     const size_t oClearEnd = cv.off;
+    // bottom-up emit: its zeroed region (meeting counters, export counts, run count, report-in counter) follows, so that ONE memset
+    // clears both
+    const int aggTiles = (n + AGG_TILE - 1) / AGG_TILE;
+    const size_t oArrive = cv.take(((size_t)n + 1) * 4);
+    const size_t oExportCount = cv.take((size_t)aggTiles * 4);
+    const size_t oAggMisc = cv.take(64);           // [0] number of runs of more than leafSize equal keys
+    const int cntTiles = (n + 1 + RANK_BLOCK - 1) / RANK_BLOCK;    // prefix-count blocks
+    const size_t oAggZeroEnd = cv.off;
     const size_t oOsState = cv.take((size_t)osTiles * 256 * 4);
     const size_t oSubList = cv.take(((size_t)n / 2 + 2) * 16);
     const size_t oTopLst = cv.take(((size_t)n + 2) * 4);
     const size_t oTriBox = cv.take((size_t)n * 24), oTriOut = cv.take((size_t)n * 4);
     const size_t oCell = cv.take(((size_t)TOP_CELLS + 1) * 4), oTopIdx = cv.take((size_t)TOP_HEAP * 4);
     // bottom-up emit: zeroed region (flags, meeting counters, scan state) first, then records, slots, ranks
-    const int cntTiles = (n + 1 + RANK_BLOCK - 1) / RANK_BLOCK;    // prefix-count entries
-    const int finTiles = (n + 1 + CNT_TILE - 1) / CNT_TILE;       // workgroups of the final pass
-    const size_t oAggZero = cv.off;
-    const size_t oNodeFlag = cv.take((size_t)n + 1), oLeafFlag = cv.take((size_t)n + 1);
-    const size_t oArrive = cv.take(((size_t)n + 1) * 4);
-    const int aggTiles = (n + AGG_TILE - 1) / AGG_TILE;
-    const size_t oExportCount = cv.take((size_t)aggTiles * 4);
-    const size_t oAggMisc = cv.take(64);           // [0] number of runs of more than leafSize equal keys
-    const size_t oAggZeroEnd = cv.off;
-    const size_t oRec = cv.take(((size_t)n + 1) * 64), oSlot = cv.take(((size_t)n + 1) * 96);
+    const size_t oSlot = cv.take(((size_t)n + 1) * 96);
     const size_t oExports = cv.take((size_t)aggTiles * AGG_EXPORT_CAP * sizeof(AggExport));
-    const size_t oTriVerts = cv.take((size_t)n * 36), oVertsSorted = cv.take((size_t)n * 36);
+    const size_t oTriVerts = cv.take((size_t)n * 36);
     const size_t oParentPos = cv.take(((size_t)n + 1) * 4);
     const size_t oRuns = cv.take(((size_t)n / 2 + 2) * 16);
-    const size_t oNodeBits = cv.take((size_t)cntTiles * (RANK_BLOCK / 8)), oLeafBits = cv.take((size_t)cntTiles * (RANK_BLOCK / 8));
-    const size_t oTileCount = cv.take((size_t)cntTiles * 8), oTileBase = cv.take((size_t)cntTiles * 8);
-    const size_t oSubBase = cv.take((size_t)cntTiles * (RANK_BLOCK / CNT_TILE) * 8);
+    const size_t oLeafBits = cv.take((size_t)cntTiles * (RANK_BLOCK / 8)), oRunBits = cv.take((size_t)cntTiles * (RANK_BLOCK / 8));
+    const size_t oTileCount = cv.take((size_t)cntTiles * 4), oTileBase = cv.take((size_t)cntTiles * 4);
+    const size_t oSubBase = cv.take((size_t)cntTiles * MARK_SUBS * 4);
     void* wsBase = nullptr;
     {
         const int rc = workspace_reserve(cv.off, &wsBase);
@@ -1735,7 +1878,6 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
 
     PhaseEvents pe(s);
     pe.mark(0);
-    NTR_HIP(hipMemsetAsync(ws + oState, 0, oClearEnd - oState, s));
 
     int spillSize = tun.lbvhSplit;
     if (spillSize < 2) spillSize = 2;
@@ -1743,8 +1885,10 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     // 0: the whole tree is one hand-over root; 1: cell-table top + subtree workgroups; 2: level-by-level top with key probes;
     // 3: bottom-up emit with ranked indices (default; it gathers the box terms itself)
     // (a scene of at most leafSize triangles is a root over two leaves: the table / bottom-up paths expect more than one leaf's worth)
-    const int topMode = n <= spillSize ? 0 : ((tun.lbvhLegacyTop || n <= leafSize) ? 2 : (tun.lbvhEmit == 1 ? 1 : 3));
+    // (leaves of more than AGG_HALO triangles: the bottom-up path keeps that many neighbours of a tile in LDS, larger ones take the top-down path)
+    const int topMode = n <= spillSize ? 0 : ((tun.lbvhLegacyTop || n <= leafSize || leafSize > AGG_HALO) ? 2 : (tun.lbvhEmit == 1 ? 1 : 3));
     const bool bottomUp = !levelSync && topMode == 3;
+    NTR_HIP(hipMemsetAsync(ws + oState, 0, (bottomUp ? oAggZeroEnd : oClearEnd) - oState, s));
 
     // L1: Morton codes (step = (max - min) / 1024 on the host, HLBVHBuilder.cpp:76-81)
     F3 lo = {sceneMin[0], sceneMin[1], sceneMin[2]};
@@ -1862,14 +2006,21 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         };
         if (topMode == 3) {
             AggCtx a;
-            a.keys = keys; a.triSorted = triSorted; a.triVerts = (const TriVerts*)(ws + oTriVerts); a.vertsSorted = (TriVerts*)(ws + oVertsSorted);
+            a.keys = keys; a.triSorted = triSorted; a.triVerts = (const TriVerts*)(ws + oTriVerts);
             a.eps = epsilon; a.n = n; a.leafSize = leafSize;
-            a.rec = (int*)(ws + oRec);
-            a.nodeFlag = (unsigned char*)(ws + oNodeFlag); a.leafFlag = (unsigned char*)(ws + oLeafFlag);
-            a.arrive = (unsigned int*)(ws + oArrive); a.slot = (AggSlot*)(ws + oSlot); a.parentPos = (int*)(ws + oParentPos);
+            a.sBits = (const unsigned long long*)(ws + oLeafBits); a.rBits = (const unsigned long long*)(ws + oRunBits);
+            a.numBitWords = cntTiles * (RANK_BLOCK / 64); a.blockBase = (const unsigned int*)(ws + oTileBase);
+            a.subBase = (const unsigned int*)(ws + oSubBase);
+            a.nodes = (int*)d_nodes; a.outWoop = (float4*)d_triWoop; a.outIdx = d_triIndex;
+            a.arrive = (unsigned int*)(ws + oArrive); a.parentPos = (int*)(ws + oParentPos);
             a.runs = (int4*)(ws + oRuns); a.runCount = aggMisc; a.st = state; a.useLds = tun.lbvhAggLds;
             a.exports = (AggExport*)(ws + oExports); a.exportCount = (unsigned int*)(ws + oExportCount); a.slotG = (AggSlotG*)(ws + oSlot);
-            NTR_HIP(hipMemsetAsync(ws + oAggZero, 0, oAggZeroEnd - oAggZero, s));
+            // leaf starts and their prefix counts first: everything after it writes to final places
+            hipLaunchKernelGGL(lbvh_leafmark_kernel, dim3(cntTiles), dim3(MARK_THREADS), 0, s, n, leafSize, keys, (unsigned long long*)(ws + oLeafBits),
+                               (unsigned long long*)(ws + oRunBits), (unsigned int*)(ws + oTileCount), (unsigned int*)(ws + oSubBase), state);
+            hipLaunchKernelGGL(lbvh_markscan_kernel, dim3(1), dim3(MARK_THREADS), 0, s, n, cntTiles, (const unsigned int*)(ws + oTileCount),
+                               (unsigned int*)(ws + oTileBase), state);
+            pe.mark(4);
             // two stages for large inputs (a workgroup leaves as soon as its tile is done, the chains along the tile borders run as plain
             // threads of a second launch); one launch for small ones, where the extra launch costs more than it saves
             const bool staged = tun.lbvhAggStaged < 0 ? n >= (1 << 20) : tun.lbvhAggStaged != 0;
@@ -1879,16 +2030,8 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             } else {
                 hipLaunchKernelGGL(lbvh_agglomerate_kernel<false>, dim3(aggTiles), dim3(AGG_TILE), 0, s, a);
             }
-            hipLaunchKernelGGL(lbvh_runs_kernel, dim3(2048), dim3(64), 0, s, a);
-            pe.mark(4);
-            hipLaunchKernelGGL(lbvh_count_kernel, dim3(cntTiles), dim3(CNT_TILE), 0, s, n, (const unsigned char*)a.nodeFlag, (const unsigned char*)a.leafFlag,
-                               (unsigned long long*)(ws + oNodeBits), (unsigned long long*)(ws + oLeafBits), (uint2*)(ws + oTileCount), (uint2*)(ws + oSubBase));
-            hipLaunchKernelGGL(lbvh_tilescan_kernel, dim3(1), dim3(1024), 0, s, cntTiles, n, (const uint2*)(ws + oTileCount), (uint2*)(ws + oTileBase), state);
             pe.mark(5);
-            hipLaunchKernelGGL(lbvh_finalize_kernel, dim3(finTiles), dim3(CNT_TILE), 0, s, n, (const TriVerts*)a.vertsSorted, triSorted, (const int*)a.rec,
-                               (const unsigned long long*)(ws + oNodeBits), (const unsigned long long*)(ws + oLeafBits), (const uint2*)(ws + oTileBase),
-                               (const uint2*)(ws + oSubBase),
-                               (int*)d_nodes, nodeCap, (float4*)d_triWoop, d_triIndex, state);
+            hipLaunchKernelGGL(lbvh_runs_kernel, dim3(2048), dim3(64), 0, s, a);
             pe.mark(6);
         } else {
         if (topMode == 0) {
@@ -1950,9 +2093,11 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         numLevels = (int)h.maxLevel;
     }
 
+    // Bottom-up path: where the depth rule (level bit 0) made a leaf of more than leafSize equal keys, the node indices and terminator
+    // slots the leaf marks had set aside inside it stay unused (zero-filled): the buffers' extents include them, the counts do not.
     const unsigned int leafs = (unsigned int)(h.leafPtr & 0xFFFFFFFFull);
-    result->numNodes = (int32_t)numNodes;
-    result->numLeaves = (int32_t)leafs;
+    result->numNodes = (int32_t)(numNodes - h.holes);
+    result->numLeaves = (int32_t)(leafs - h.holes);
     result->numLevels = numLevels;
     result->nodesBytes = (int64_t)numNodes * 64;                // HLBVHBuilder.cpp:382-386
     result->triWoopBytes = ((int64_t)n * 3 + leafs) * 16;

@@ -34,7 +34,7 @@ for W in $WHAT; do
   lbvh)
     for S in atrium hairball courtyard; do
       prof_trace lbvh_$S lbvh $S 8
-      for C in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+      for C in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
         prof_pmc lbvh_$S "$C" lbvh $S 4
       done
       $SUM pmc $OUT/lbvh_$S/pmc_* > $OUT/lbvh_$S.pmc.txt 2>&1
