@@ -1053,6 +1053,13 @@ __device__ __forceinline__ int agg_node_index(const AggCtx& c, int pos, int root
     if (pos == 0 || pos == rootSplit) return 0;
     return (int)agg_leaves_before(c, pos) - (pos > rootSplit ? 1 : 0);
 }
+// levels of median nodes in the subtree of a run of m > leafSize equal keys (the larger half holds ceil(m / 2)), the depth rule aside
+__device__ __forceinline__ int agg_run_height(int m, int leafSize)
+{
+    int levels = 0;
+    while (m > leafSize && levels < 31) { m = (m + 1) >> 1; levels++; }
+    return levels;
+}
 // storage of the leaf that starts at sorted position p: 3 float4 per triangle before it + one terminator per leaf before it
 // (createLeaf, emitTreeKernel.cu:176-181, with the leaves numbered in sorted order)
 __device__ __forceinline__ int agg_leaf_storage(const AggCtx& c, int p) { return (int)(3u * (unsigned int)p + agg_leaves_before(c, p)); }
@@ -1170,7 +1177,7 @@ __device__ __forceinline__ bool agg_form_parent(const AggCtx& c, int rootSplit, 
         } else {
             link[k] = AGG_REF_RUN;
             const unsigned int g = atomicAdd(c.runCount, 1u);
-            c.runs[g] = make_int4(idx, k, cs[k], ce[k]);
+            c.runs[g] = make_int4(idx, k | (hb << 1), cs[k], ce[k]);
         }
     }
     agg_write_record(c.nodes, idx, b0, b1, link[0], link[1], hb % 3);
@@ -1180,7 +1187,7 @@ __device__ __forceinline__ bool agg_form_parent(const AggCtx& c, int rootSplit, 
         ub[2 * k] = fminf(b0[2 * k], b1[2 * k]);
         ub[2 * k + 1] = fmaxf(b0[2 * k + 1], b1[2 * k + 1]);
     }
-    l = L; r = R; kind = 1; ref = idx; h = 1 + hmax; lbL = lbLo; lbR = lbHi;
+    l = L; r = R; kind = 1; ref = idx; h = min(1 + hmax, 31); lbL = lbLo; lbR = lbHi;   // 5 bits travel; only min(h, 30) is used
 #pragma unroll
     for (int k = 0; k < 6; k++) box[k] = ub[k];
     if (root) {                                    // the root: deepest level that holds an inner node, plus one
@@ -1316,7 +1323,7 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
     int l = sWalker[tid] & 0x7FFFFFFF, r = sWalkerEnd[tid];
     int kind = (sWalker[tid] < 0) ? 2 : 0;            // 0 leaf, 1 inner node, 2 run of equal keys
     int ref = 0;                                      // kind 1: the node's index
-    int h = kind == 2 ? 1 : 0;                        // levels of inner nodes below and including this cluster
+    int h = kind == 2 ? agg_run_height(r - l, c.leafSize) : 0;   // levels of inner nodes below and including this cluster
     unsigned int lbL = leavesBefore(l), lbR = leavesBefore(r);
     float box[6];
     {   // the cluster's box, folded from FLT_MAX like calcLeaf (:383-408): tile positions from LDS, the few beyond it from memory
@@ -1539,9 +1546,15 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
     const int rootSplit = (int)c.st->rootSplit;
     const int lane = threadIdx.x;
     for (unsigned int g = blockIdx.x; g < numRuns; g += gridDim.x) {   // one wave per run; control flow is wave-uniform
-        const int4 q = c.runs[g];
+        int4 q = c.runs[g];
+        const int parentBit = q.y >> 1;                 // split bit of the run's parent: the parent has at most 29 - parentBit ancestors
+        q.y &= 1;
+        // The depth rule can only bite when the run's subtree could reach level 30: its root lies at depth <= 30 - parentBit, so with
+        // no more median levels than parentBit it cannot, and the walk up the parent indices (a chain of dependent loads) is skipped;
+        // the tree's level count does not need it either -- a run cluster carries its height to the root.
+        const bool walk = q.x >= 0 && agg_run_height(q.w - q.z, c.leafSize) > parentBit;
         int depth = 0;
-        if (q.x >= 0) {
+        if (walk) {
             depth = 1;
             for (int p = q.x; p != 0; p = c.parentPos[p]) depth++;
         }
@@ -1551,6 +1564,28 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
             agg_rewrite_big_leaf(c, rootSplit, q.z, q.w);
             continue;
         }
+        // a run of at most 64 triangles (the common case) is gathered ONCE, one triangle per lane; the child boxes of its median nodes
+        // are then folded across lanes instead of being gathered again per node
+        const bool inRegs = (q.w - q.z) <= 64;
+        float myTerm[6] = {FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX, FLT_MAX, -FLT_MAX};
+        if (inRegs && q.z + lane < q.w) agg_tri_terms(c.triVerts[c.triSorted[q.z + lane]], c.eps, myTerm);
+        auto fold = [&](int a, int b, float (&box)[6]) {
+            if (!inRegs) { agg_fold_box_wave(c, a, b, box); return; }
+            const bool in = lane >= a - q.z && lane < b - q.z;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                box[2 * k] = in ? myTerm[2 * k] : FLT_MAX;
+                box[2 * k + 1] = in ? myTerm[2 * k + 1] : -FLT_MAX;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    box[2 * k] = fminf(box[2 * k], __shfl_xor(box[2 * k], off));
+                    box[2 * k + 1] = fmaxf(box[2 * k + 1], __shfl_xor(box[2 * k + 1], off));
+                }
+            }
+        };
         // explicit stack of (start, end, depth, split position); a node at depth 29 only has leaf children
         int stS[32], stE[32], stD[32], stP[32];
         int sp = 0;
@@ -1565,8 +1600,8 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
             const int mid = (a + b) >> 1;
             deepest = max(deepest, (unsigned int)d + 1u);
             float b0[6], b1[6];
-            agg_fold_box_wave(c, a, mid, b0);
-            agg_fold_box_wave(c, mid, b, b1);
+            fold(a, mid, b0);
+            fold(mid, b, b1);
             const int cs[2] = {a, mid}, ce[2] = {mid, b};
             int link[2];
 #pragma unroll
@@ -1586,7 +1621,7 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
                 agg_write_record(c.nodes, agg_node_index(c, id, rootSplit), b0, b1, link[0], link[1], -1);
             }
         }
-        if (lane == 0) atomicMax(&c.st->maxLevel, min(deepest, 30u));
+        if (lane == 0 && (walk || q.x < 0)) atomicMax(&c.st->maxLevel, min(deepest, 30u));
     }
 }
 
