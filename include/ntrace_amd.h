@@ -200,10 +200,13 @@ NTR_API int ntr_trace_bvh_stats(const char* kernelName, int32_t numRays, int32_t
  *                    is the range in which the kernels' refactored divide is the hardware
  *                    divide (see trace_kernels.hip).
  *   NTR_BVH_NOTINY   every box coordinate is 0 or |x| >= 2^-93 (lets rays with an exactly-zero
- *                    origin component use the same path). */
+ *                    origin component use the same path).
+ *   NTR_BVH_ORDERED  every child box has lo <= hi on each axis: for a wave whose rays share the signs of their direction
+ *                    components the kernels then know which of a slab's two quotients is the smaller one without comparing. */
 #define NTR_BVH_FINITE 1u
 #define NTR_BVH_FASTDIV 2u
 #define NTR_BVH_NOTINY 4u
+#define NTR_BVH_ORDERED 8u
 NTR_API int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_t* flags, void* stream);
 
 /* Device self test: counts quotients x[i]/d[j] for which the FAST divide differs from the

@@ -14,11 +14,12 @@ __global__ __launch_bounds__(256) void bvh_validate_kernel(const float4* __restr
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    bool notFinite = false, notFast = false, tiny = false;
+    bool notFinite = false, notFast = false, tiny = false, unordered = false;
     for (; i < numFloat4; i += stride) {
         if ((i & 3) == 3) continue;  // child / split words
         const float4 v = nodes[i];
         const float c[4] = {v.x, v.y, v.z, v.w};
+        unordered = unordered || !(v.x <= v.y) || !(v.z <= v.w);   // every box float4 is two (lo, hi) pairs
         for (int k = 0; k < 4; k++) {
             const float a = fabsf(c[k]);
             notFinite = notFinite || !(a < 0x1p100f);  // also true for NaN
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void bvh_validate_kernel(const float4* __restr
         }
     }
     const unsigned int bits = (__ballot(notFinite) != 0ull ? 1u : 0u) | (__ballot(notFast) != 0ull ? 2u : 0u) |
-                              (__ballot(tiny) != 0ull ? 4u : 0u);
+                              (__ballot(tiny) != 0ull ? 4u : 0u) | (__ballot(unordered) != 0ull ? 8u : 0u);
     if (bits && (threadIdx.x & 63) == 0) atomicOr(bad, bits);
 }
 
@@ -57,6 +58,7 @@ extern "C" int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_
     if (!(bad & 1u)) *flags |= NTR_BVH_FINITE;
     if (!(bad & 2u)) *flags |= NTR_BVH_FASTDIV;
     if (!(bad & 4u)) *flags |= NTR_BVH_NOTINY;
+    if (!(bad & 8u)) *flags |= NTR_BVH_ORDERED;
     // hosts validate after every (re)build: refresh the top-of-tree table the dispatch-order prediction uses
     return ntr_top_table_refresh(d_nodes, nodesBytes, stream);
 }

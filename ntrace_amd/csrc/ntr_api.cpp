@@ -141,7 +141,7 @@ static void tunables_load_locked()
     t.coop = env_int("NTR_TRACE_COOP", 0);
     t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", 24);     // sweep: flat optimum 16..64 (scripts/trace_sweep.py)
     t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 6);
-    t.uniformFetch = env_int("NTR_TRACE_UNIFORM", 1);
+    t.octant = env_int("NTR_TRACE_OCTANT", 1);
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/persist_diag.py)
     t.predict = env_int("NTR_TRACE_PREDICT", 1);
     t.predictDepth = env_int("NTR_TRACE_PREDICT_DEPTH", 9);
@@ -459,7 +459,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.bvhFlags = bvhFlags;
     p.coop = tun.coop;
     p.leafSwitchBelow = tun.leafSwitchBelow;
-    p.uniformFetch = tun.uniformFetch;
+    p.octant = tun.octant;
     p.stats = ds->stats;
     p.timeline = nullptr;
     p.order = nullptr;

@@ -41,7 +41,7 @@ struct TraceParams {
     int32_t fetchThreshold;  // persistent: refill when fewer lanes are live
     uint32_t bvhFlags;
     int32_t leafSwitchBelow; // serve waiting leaves when fewer lanes than this still hold an inner node
-    int32_t uniformFetch;    // fetch a node through the scalar cache when every lane that holds an inner node holds the same one
+    int32_t octant;          // per-ray kernel: specialise the slab test for waves whose rays share their direction signs
     int32_t coop;            // quad-cooperative LDS-DMA node fetch instead of per-lane loads
     unsigned long long* timeline;  // diagnostic: per-wave realtime stamps (scripts/timeline*.py), or null
     const unsigned int* order;     // per-ray kernel: workgroup i traces ray block order[i] (null = identity)

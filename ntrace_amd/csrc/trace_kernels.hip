@@ -138,7 +138,10 @@ __device__ __forceinline__ float fast_div(float x, float d, float r)
 // the twelve quotients stage by stage (all q0, then all e1, ...) so that consecutive
 // instructions are independent: a lone wave cannot issue a VALU op that depends on the
 // previous one back to back.
-template <bool FAST>
+// OCT < 8 (FAST only): every live ray of the wave has direction signs OCT (bit 0: dx < 0, bit 1: dy < 0, bit 2: dz < 0) and every box
+// has lo <= hi (NTR_BVH_ORDERED).  Rounding is monotone, so (lo - o) / d <= (hi - o) / d for d > 0 and >= for d < 0: the smaller
+// quotient of a slab is known without comparing -- the same value min / max would pick, six instructions per child less.
+template <bool FAST, int OCT = 8>
 __device__ __forceinline__ void ray_box2(const RayRegs& r, const float4& n0, const float4& n1, const float4& nz,
                                          float& mn0, float& mx0, float& mn1, float& mx1)
 {
@@ -159,10 +162,18 @@ __device__ __forceinline__ void ray_box2(const RayRegs& r, const float4& n0, con
         for (int k = 0; k < 12; k++) e[k] = __builtin_fmaf(-d[(k % 6) >> 1], q[k], x[k]);
 #pragma unroll
         for (int k = 0; k < 12; k++) q[k] = __builtin_fmaf(e[k], rc[(k % 6) >> 1], q[k]);
-        mn0 = fmaxf(fmaxf(fminf(q[0], q[1]), fminf(q[2], q[3])), fminf(q[4], q[5]));
-        mx0 = fminf(fminf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])), fmaxf(q[4], q[5]));
-        mn1 = fmaxf(fmaxf(fminf(q[6], q[7]), fminf(q[8], q[9])), fminf(q[10], q[11]));
-        mx1 = fminf(fminf(fmaxf(q[6], q[7]), fmaxf(q[8], q[9])), fmaxf(q[10], q[11]));
+        if (OCT < 8) {
+            constexpr int sx = OCT & 1, sy = (OCT >> 1) & 1, sz = (OCT >> 2) & 1;   // 1: the hi plane is the near one
+            mn0 = fmaxf(fmaxf(q[0 + sx], q[2 + sy]), q[4 + sz]);
+            mx0 = fminf(fminf(q[1 - sx], q[3 - sy]), q[5 - sz]);
+            mn1 = fmaxf(fmaxf(q[6 + sx], q[8 + sy]), q[10 + sz]);
+            mx1 = fminf(fminf(q[7 - sx], q[9 - sy]), q[11 - sz]);
+        } else {
+            mn0 = fmaxf(fmaxf(fminf(q[0], q[1]), fminf(q[2], q[3])), fminf(q[4], q[5]));
+            mx0 = fminf(fminf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])), fmaxf(q[4], q[5]));
+            mn1 = fmaxf(fmaxf(fminf(q[6], q[7]), fminf(q[8], q[9])), fminf(q[10], q[11]));
+            mx1 = fminf(fminf(fmaxf(q[6], q[7]), fmaxf(q[8], q[9])), fmaxf(q[10], q[11]));
+        }
     } else {
         float t0x = (n0.x - r.ox) / r.dx, t1x = (n0.y - r.ox) / r.dx;
         float t0y = (n0.z - r.oy) / r.dy, t1y = (n0.w - r.oy) / r.dy;
@@ -273,50 +284,26 @@ static constexpr int kNoNode = (int)0xFFFFFF00u;  // buffer offset beyond any ex
 // One inner-node step of trace<BVHLayout_Compact> (CudaBVH.cpp:721-775).  Executed by the whole
 // wave (cooperative fetch); only lanes whose current node is an inner node (`inner`) update
 // their state.
-// One 64-byte node through the scalar data cache into SGPRs (the address is wave-uniform): no TA cycles, and the slab arithmetic
-// reads the planes as scalar operands.
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void ld_node_scalar(const char* nodeAddr, float4& n0, float4& n1, float4& nz, float4& nc)
+template <bool FAST, bool COOP, int OCT = 8>
+__device__ __forceinline__ void inner_step(Rsrc nodes, lds_char* stage, int lane, bool inner, const RayRegs& r,
+                                           int& node, LaneStack& st, int (&spill)[SPILL_DEPTH], unsigned int* status)
 {
-    f32x8 a, b;
-    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(nodeAddr) : "memory");
-    n0 = make_float4(a[0], a[1], a[2], a[3]);
-    n1 = make_float4(a[4], a[5], a[6], a[7]);
-    nz = make_float4(b[0], b[1], b[2], b[3]);
-    nc = make_float4(b[4], b[5], b[6], b[7]);
-}
-
-template <bool FAST, bool COOP>
-__device__ __forceinline__ void inner_step(Rsrc nodes, const char* nodesBase, bool uniformFetch, unsigned long long innerMask, lds_char* stage, int lane,
-                                           bool inner, const RayRegs& r, int& node, LaneStack& st, int (&spill)[SPILL_DEPTH], unsigned int* status)
-{
-    float mn0, mx0, mn1, mx1;
-    int c0, c1;
-    // Coherent rays (a primary wave is an 8 x 8 pixel tile) sit on the SAME node in about half of all wave-iterations
-    // (scripts/uniform_node_study.py): that node is then fetched once, through the scalar cache.
-    const int firstNode = __builtin_amdgcn_readlane(node, (int)__builtin_ctzll(innerMask));
-    const bool sameNode = !COOP && uniformFetch && __ballot(inner && node != firstNode) == 0ull;
-    if (sameNode) {
-        float4 n0, n1, nz, nc;
-        ld_node_scalar(nodesBase + firstNode, n0, n1, nz, nc);
-        ray_box2<FAST>(r, n0, n1, nz, mn0, mx0, mn1, mx1);
-        c0 = __float_as_int(nc.x); c1 = __float_as_int(nc.y);
-    } else {
-        float4 n0, n1, nz, nc;
-        if (COOP) {
-            fetch_node_coop(nodes, stage, lane, inner ? node : kNoNode, n0, n1, nz, nc);
-        } else {  // every lane fetches its own node (4 x 16 B)
-            const int ofs = inner ? node : kNoNode;
-            n0 = ld4(nodes, ofs); n1 = ld4(nodes, ofs + 16); nz = ld4(nodes, ofs + 32); nc = ld4(nodes, ofs + 48);
-            keep(nc);
-        }
-        ray_box2<FAST>(r, n0, n1, nz, mn0, mx0, mn1, mx1);
-        c0 = __float_as_int(nc.x); c1 = __float_as_int(nc.y);
+    float4 n0, n1, nz, nc;
+    if (COOP) {
+        fetch_node_coop(nodes, stage, lane, inner ? node : kNoNode, n0, n1, nz, nc);
+    } else {  // every lane fetches its own node (4 x 16 B)
+        const int ofs = inner ? node : kNoNode;
+        n0 = ld4(nodes, ofs); n1 = ld4(nodes, ofs + 16); nz = ld4(nodes, ofs + 32); nc = ld4(nodes, ofs + 48);
+        keep(nc);
     }
+
+    float mn0, mx0, mn1, mx1;
+    ray_box2<FAST, OCT>(r, n0, n1, nz, mn0, mx0, mn1, mx1);
 
     const bool i0 = (mn0 <= mx0) && (mx0 >= r.tmin) && (mn0 <= r.tmax);
     const bool i1 = (mn1 <= mx1) && (mx1 >= r.tmin) && (mn1 <= r.tmax);
 
+    const int c0 = __float_as_int(nc.x), c1 = __float_as_int(nc.y);
     const bool swp = i1 && (!i0 || mn0 > mn1);  // visit c1 first (ties -> c0, CudaBVH.cpp:761)
     const int nearC = swp ? c1 : c0;
     const int farC = swp ? c0 : c1;
@@ -397,8 +384,8 @@ __device__ __forceinline__ void load_ray(const NtrRay* __restrict__ rays, int ra
 // persistent kernel, until too few lanes are live).  Both loops are wave-uniform (ballots), so
 // all 64 lanes stay enabled for the cooperative node fetch; per-ray visiting order is exactly
 // the CPU tracer's depth-first order, whatever the other lanes do.
-template <bool FAST, bool STATS, bool DYNAMIC_FETCH, bool COOP>
-__device__ __forceinline__ void traverse(Rsrc nodes, const char* nodesBase, bool uniformFetch, Rsrc woop, lds_char* stage, int lane, RayRegs& r, int& node,
+template <bool FAST, bool STATS, bool DYNAMIC_FETCH, bool COOP, int OCT = 8>
+__device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, lds_char* stage, int lane, RayRegs& r, int& node,
                                          LaneStack& st, int (&spill)[SPILL_DEPTH], bool anyHit,
                                          int& hitAddr, float& hitU, float& hitV, LaneStats& ls, unsigned int* status,
                                          bool poolEmpty, int fetchThreshold, int leafSwitchBelow)
@@ -413,7 +400,7 @@ __device__ __forceinline__ void traverse(Rsrc nodes, const char* nodesBase, bool
             // lanes still hold an inner node while others already wait at a leaf, serve the leaves first
             // instead of letting a handful of stragglers stall the wave.
             if (__popcll(innerMask) < leafSwitchBelow && __ballot(node < 0) != 0ull) break;
-            inner_step<FAST, COOP>(nodes, nodesBase, uniformFetch, innerMask, stage, lane, inner, r, node, st, spill, status);
+            inner_step<FAST, COOP, OCT>(nodes, stage, lane, inner, r, node, st, spill, status);
             if (STATS && inner) ls.inner++;
         }
         if (node < 0) {
@@ -460,8 +447,31 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     LaneStats ls = {0u, 0u, 0u};
 
     const bool fastWave = (p.bvhFlags & NTR_BVH_FASTDIV) && __ballot(node != kSentinel && !ray_is_nice(r, p.bvhFlags)) == 0ull;
-    if (fastWave) traverse<true, STATS, false, COOP>(nodes, (const char*)p.nodes, p.uniformFetch != 0, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
-    else traverse<false, STATS, false, COOP>(nodes, (const char*)p.nodes, p.uniformFetch != 0, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
+    // direction signs shared by every live ray of the wave (a primary wave is an 8 x 8 pixel tile): the octant's own slab test
+    int oct = 8;
+    if (!STATS && !COOP && fastWave && p.octant && (p.bvhFlags & NTR_BVH_ORDERED)) {
+        const unsigned long long liveMask = __ballot(node != kSentinel);
+        const unsigned long long sx = __ballot(node != kSentinel && r.dx < 0.0f), sy = __ballot(node != kSentinel && r.dy < 0.0f),
+                                 sz = __ballot(node != kSentinel && r.dz < 0.0f);
+        if ((sx == 0ull || sx == liveMask) && (sy == 0ull || sy == liveMask) && (sz == 0ull || sz == liveMask))
+            oct = (sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0);
+    }
+#define NTR_TRAVERSE_OCT(O) traverse<true, STATS, false, COOP, O>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow)
+    if (!STATS && !COOP && oct < 8) {
+        switch (oct) {
+            case 0: NTR_TRAVERSE_OCT(0); break;
+            case 1: NTR_TRAVERSE_OCT(1); break;
+            case 2: NTR_TRAVERSE_OCT(2); break;
+            case 3: NTR_TRAVERSE_OCT(3); break;
+            case 4: NTR_TRAVERSE_OCT(4); break;
+            case 5: NTR_TRAVERSE_OCT(5); break;
+            case 6: NTR_TRAVERSE_OCT(6); break;
+            default: NTR_TRAVERSE_OCT(7); break;
+        }
+    }
+#undef NTR_TRAVERSE_OCT
+    else if (fastWave) traverse<true, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
+    else traverse<false, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
 
     if (p.timeline && lane == 0) {
         const unsigned int w = block * WAVES + wave;
@@ -612,8 +622,8 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
         if (timeline) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tlRefill += __builtin_amdgcn_s_memtime() - tlA; }
         // ---- while-while traversal ------------------------------------------------
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
-        if (fastWave) traverse<true, false, true, COOP>(nodes, (const char*)p.nodes, p.uniformFetch != 0, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
-        else traverse<false, false, true, COOP>(nodes, (const char*)p.nodes, p.uniformFetch != 0, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
+        if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
+        else traverse<false, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
 
         // ---- retire finished rays ---------------------------------------------------
         if (rayIdx >= 0 && node == kSentinel) {

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the scalar wave-uniform node fetch (NTR_TRACE_UNIFORM) on the bench workload: 1080p primary batch and one 2^20-ray AO batch
+"""REJECTED (kept for the record; the kernel no longer has the switch -- commit c766c93..): A/B of the scalar wave-uniform node
+fetch (NTR_TRACE_UNIFORM) on the bench workload: 1080p primary batch and one 2^20-ray AO batch
 on atrium-262k (SAH), interleaved rounds, median kernel time by HIP events; hit records must be identical."""
 import json
 import os
@@ -37,7 +38,7 @@ b_res = torch.zeros(cnt * ns * 16, dtype=torch.uint8, device=dev)
 b_a = torch.zeros(cnt * ns, dtype=torch.int32, device=dev)
 nt.raygen_ao(b_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(), d_res.data_ptr(), d_nrm.data_ptr(), 0, cnt, ns, 5.0, 0xFFF2D5E4)
 
-cfgs = [dict(NTR_TRACE_UNIFORM=0), dict(NTR_TRACE_UNIFORM=1)]
+cfgs = [dict(NTR_TRACE_UNIFORM=0, NTR_TRACE_OCTANT=0), dict(NTR_TRACE_UNIFORM=1, NTR_TRACE_OCTANT=0), dict(NTR_TRACE_UNIFORM=1, NTR_TRACE_OCTANT=1), dict(NTR_TRACE_UNIFORM=0, NTR_TRACE_OCTANT=1)]
 kernels = sys.argv[1:] or ["fermi_speculative_while_while", "tesla_persistent_while_while"]
 for kernel in kernels:
     times = {i: dict(primary=[], ao=[]) for i in range(len(cfgs))}
@@ -57,4 +58,4 @@ for kernel in kernels:
         print(json.dumps(dict(kernel=kernel, cfg=cfg, primary_us=float(np.median(times[i]["primary"][1:])) * 1e6,
                               ao_us=float(np.median(times[i]["ao"][1:])) * 1e6, same_primary_records=ref[i][0] == ref[0][0],
                               same_ao_hits=ref[i][1] == ref[0][1])), flush=True)
-nt.set_tunables(NTR_TRACE_UNIFORM=None)
+nt.set_tunables(NTR_TRACE_UNIFORM=None, NTR_TRACE_OCTANT=None)

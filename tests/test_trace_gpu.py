@@ -209,6 +209,47 @@ def test_dispatch_order_prediction_changes_order_only(soup, n, monkeypatch):
     assert_parity(got, ref, "prediction off n=%d" % n)
 
 
+@pytest.mark.parametrize("octant", [0, 1])
+def test_octant_slabs_change_no_record(soup, monkeypatch, octant):
+    """The octant-specialised slab test (waves whose rays share their direction signs, NTR_BVH_ORDERED) is an instruction-count
+    change only: coherent primary rays (the specialised path for most waves), the edge-case ray set and random rays (mixed
+    octants inside a wave: the general path) give the oracle's records."""
+    from gpu_util import assert_parity, gpu_trace
+    dbvh, cam = soup
+    assert dbvh.flags & nt.BVH_ORDERED
+    monkeypatch.setenv("NTR_TRACE_OCTANT", str(octant))
+    nt.set_tunables()
+    rays = np.concatenate([scenes.primary_rays(cam, 320, 200)[0], edge_rays(), scenes.random_rays(20000, seed=11)])
+    for any_hit in (False, True):
+        ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit, threads=8)
+        for kernel in ("fermi_speculative_while_while", "tesla_persistent_while_while"):
+            got, _ = gpu_trace(kernel, dbvh, rays, any_hit)
+            if any_hit:
+                assert np.array_equal(got["id"] >= 0, ref["id"] >= 0)
+            else:
+                assert_parity(got, ref, "octant=%d %s" % (octant, kernel))
+
+
+def test_validate_flags_an_inverted_box_as_unordered():
+    """NTR_BVH_ORDERED is withheld when any child box has lo > hi on an axis (the octant-specialised slab test relies on lo <= hi);
+    such a tree is still traced like the CPU tracer traces it."""
+    from gpu_util import DeviceBvh, assert_parity, gpu_trace
+    tri, pos, cam = scenes.random_soup(400, seed=5)
+    bvh = nt.sah_build(tri, pos)
+    nodes = bvh.nodes.copy()
+    f = nodes.view(np.float32).reshape(-1, 16)
+    lo, hi = f[0, 0], f[0, 1]
+    f[0, 0], f[0, 1] = hi, lo                                  # root, child 0: lo.x <-> hi.x
+    dbvh = DeviceBvh(nt.HostBvh(nodes, bvh.woop, bvh.tri_index))
+    assert not (dbvh.flags & nt.BVH_ORDERED)
+    good = DeviceBvh(bvh)
+    assert good.flags & nt.BVH_ORDERED
+    rays = scenes.primary_rays(cam, 160, 100)[0]
+    ref, _ = oracle.trace(nodes, bvh.woop, bvh.tri_index, rays, any_hit=False, threads=8)
+    got, _ = gpu_trace("fermi_speculative_while_while", dbvh, rays, False)
+    assert_parity(got, ref, "inverted box")
+
+
 @pytest.mark.parametrize("kernel", ["fermi_speculative_while_while", "kepler_dynamic_fetch"])
 def test_trace_launch_can_be_captured_in_a_hip_graph_and_replayed(soup, monkeypatch, kernel):
     """An asynchronous ntr_trace_bvh (dispatch-order prediction forced on; the persistent kernel's ray-pool counters)
