@@ -97,9 +97,11 @@ def test_lbvh_matches_oracle_random_soups(n, seed):
     check_against_oracle(tri, pos)
 
 
-@pytest.mark.parametrize("leaf_size", [1, 2, 8, 16])
+@pytest.mark.parametrize("leaf_size", [1, 2, 8, 16, 32, 33, 64])   # more than 32 triangles per leaf: the top-down path
 def test_lbvh_leaf_sizes(leaf_size):
     tri, pos, _ = scenes.random_soup(3000, seed=21)
+    check_against_oracle(tri, pos, leaf_size=leaf_size)
+    tri, pos, _ = scenes.random_soup(9000, seed=22, walls=True)   # more triangles than one subtree workgroup takes
     check_against_oracle(tri, pos, leaf_size=leaf_size)
 
 
@@ -115,6 +117,17 @@ def test_lbvh_duplicate_morton_codes_median_split_and_depth_limit():
     tri = np.concatenate([np.arange(n * 3).reshape(-1, 3), np.array([[n * 3, n * 3 + 1, n * 3 + 2], [n * 3 + 3, n * 3 + 4, n * 3 + 5]])]).astype(np.int32)
     nodes, woop, idx, res, ref, _ = check_against_oracle(tri, pos, leaf_size=2, allow_holes=True)
     assert res.numLevels >= 12  # ~log2(6000 / 2) median levels below the split that isolates the cluster
+
+
+@pytest.mark.parametrize("n", [9, 700, 5000])
+def test_lbvh_all_codes_equal(n):
+    """Every triangle in the same Morton cell (n copies of one triangle): the whole tree is the reference's median subtree, rooted at
+    node 0 (emitTreeKernel.cu:282; the bottom-up path's root run)."""
+    one = np.array([[0.25, 0.5, 0.75], [0.5, 0.5, 0.75], [0.25, 0.75, 0.8]], dtype=np.float32)
+    pos = np.tile(one, (n, 1))
+    tri = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+    nodes, woop, idx, res, ref, _ = check_against_oracle(tri, pos, leaf_size=4)
+    assert res.numLeaves >= n // 4
 
 
 def test_lbvh_depth_limit_forces_oversized_leaves():
