@@ -998,9 +998,10 @@ struct AggExport {           // a cluster that has outgrown its tile, handed to 
     unsigned int rKind;      // r | kind << 28
     unsigned int refH;       // node index (kind 1) | height << 27
     unsigned int dl, dr;     // key[l-1] ^ key[l], key[r-1] ^ key[r] (0xFFFFFFFF at the ends of the array)
-    unsigned int pad;
+    unsigned int lbL, lbR;   // leaves that start before l / before r
+    unsigned int pad[3];
 };
-static_assert(sizeof(AggExport) == 48, "AggExport must be 48 bytes");
+static_assert(sizeof(AggExport) == 64, "AggExport must be 64 bytes");
 constexpr int AGG_EXPORT_CAP = 64;   // a tile's clusters with a parent outside it are children of the <= 2 x 30 nodes that cross its two borders
 
 constexpr int RANK_SHIFT = 10;
@@ -1399,7 +1400,8 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
                 AggExport e;
 #pragma unroll
                 for (int q = 0; q < 6; q++) e.b[q] = box[q];
-                e.l = l; e.rKind = (unsigned int)r | ((unsigned int)kind << 28); e.refH = refH; e.dl = dl; e.dr = dr; e.pad = 0;
+                e.l = l; e.rKind = (unsigned int)r | ((unsigned int)kind << 28); e.refH = refH; e.dl = dl; e.dr = dr;
+                e.lbL = lbL; e.lbR = lbR; e.pad[0] = e.pad[1] = e.pad[2] = 0;
                 c.exports[(size_t)blockIdx.x * AGG_EXPORT_CAP + k] = e;
                 atomicAdd(&c.exportCount[blockIdx.x], 1u);
             } else {
@@ -1445,7 +1447,7 @@ __global__ __launch_bounds__(256) void lbvh_agglomerate_top_kernel(AggCtx c, int
     const int rootSplit = (int)c.st->rootSplit;
     int l = e.l, r = (int)(e.rKind & 0x0FFFFFFFu), kind = (int)(e.rKind >> 28), ref = (int)(e.refH & 0x07FFFFFFu), h = (int)(e.refH >> 27);
     unsigned int dl = e.dl, dr = e.dr;
-    unsigned int lbL = agg_leaves_before(c, l), lbR = agg_leaves_before(c, r);
+    unsigned int lbL = e.lbL, lbR = e.lbR;
     float box[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) box[q] = e.b[q];
@@ -2058,6 +2060,10 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             pe.mark(4);
             // two stages for large inputs (a workgroup leaves as soon as its tile is done, the chains along the tile borders run as plain
             // threads of a second launch); one launch for small ones, where the extra launch costs more than it saves
+            // (a third variant -- the exported roots of 16 tiles meeting through LDS in one workgroup, stage after stage until one workgroup
+            // holds the root -- was built and measured slower at every size: a lone thread's chain of meetings costs about 0.7 us per level
+            // in instruction issue alone, little less than the two agent-scope round trips it replaces, and every stage adds a launch and
+            // 8-10 us of set-up; 262 k triangles 0.205 against 0.170 ms, 10 M 1.276 against 1.264 ms)
             const bool staged = tun.lbvhAggStaged < 0 ? n >= (1 << 20) : tun.lbvhAggStaged != 0;
             if (staged && a.useLds) {
                 hipLaunchKernelGGL(lbvh_agglomerate_kernel<true>, dim3(aggTiles), dim3(AGG_TILE), 0, s, a);

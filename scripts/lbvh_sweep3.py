@@ -30,7 +30,7 @@ for name in which:
     dw = torch.zeros(capw, dtype=torch.uint8, device=dev)
     di = torch.zeros(capi, dtype=torch.uint8, device=dev)
     mn, mx = pos.min(0), pos.max(0)
-    configs = [dict(), dict(NTR_LBVH_MARK_FUSED=0), dict(NTR_LBVH_AGG_STAGED=0), dict(NTR_LBVH_AGG_STAGED=1), dict(NTR_LBVH_AGG_LDS=0), dict(NTR_LBVH_LEGACY_SORT=1), dict(NTR_LBVH_EMIT=1), dict(NTR_LBVH_LEGACY_TOP=1, NTR_LBVH_LEGACY_SORT=1)]
+    configs = [dict(), dict(NTR_LBVH_AGG_STAGED=0), dict(NTR_LBVH_AGG_STAGED=1), dict(NTR_LBVH_AGG_LDS=0), dict(NTR_LBVH_LEGACY_SORT=1), dict(NTR_LBVH_EMIT=1), dict(NTR_LBVH_LEGACY_TOP=1, NTR_LBVH_LEGACY_SORT=1)]
     for cfg in configs:
         nt.set_tunables(**cfg)
         best = None

@@ -13,7 +13,7 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "split16-64t", "split40-256t", "bottom-up-no-lds", "bottom-up-no-lds-split16", "bottom-up-staged", "bottom-up-staged-split16", "cells-top", "cells-top-split16",
+@pytest.fixture(autouse=True, params=["default", "split16-64t", "split40-256t", "bottom-up-no-lds", "bottom-up-no-lds-split16", "bottom-up-staged", "bottom-up-staged-split16", "bottom-up-one-launch", "bottom-up-one-launch-split16", "cells-top", "cells-top-split16",
                                        "legacy-top-and-sort", "legacy-top-split16", "levelsync"])
 def build_path(request, monkeypatch):
     """Every test runs on the default path (one-sweep sort, bottom-up emit with scanned indices; scenes of at most `split`
@@ -29,7 +29,12 @@ def build_path(request, monkeypatch):
     elif request.param == "bottom-up-no-lds-split16":
         monkeypatch.setenv("NTR_LBVH_AGG_LDS", "0")
         monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
-    elif request.param == "bottom-up-staged":  # clusters that outgrow their tile go to a second launch (default only from 2^20 triangles)
+    elif request.param == "bottom-up-one-launch":  # border meetings through memory inside the tile kernel (default below 2^20 triangles)
+        monkeypatch.setenv("NTR_LBVH_AGG_STAGED", "0")
+    elif request.param == "bottom-up-one-launch-split16":
+        monkeypatch.setenv("NTR_LBVH_AGG_STAGED", "0")
+        monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
+    elif request.param == "bottom-up-staged":  # clusters that outgrow their tile go to ONE second launch, chains through memory
         monkeypatch.setenv("NTR_LBVH_AGG_STAGED", "1")
     elif request.param == "bottom-up-staged-split16":
         monkeypatch.setenv("NTR_LBVH_AGG_STAGED", "1")
