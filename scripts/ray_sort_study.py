@@ -2,7 +2,8 @@
 """Does the secondary-ray Morton sort (ntr_ray_morton_sort) pay?  Sort time and trace time of the unsorted / sorted batch for
   * one 2^20-ray AO batch on atrium-262k (SAH BVH, any hit, radius 5),
   * 2^20 diffuse rays on hairball-2.8M (device LBVH, closest hit, extent = camera far: BASELINE configuration 4),
-  * 2^20 diffuse rays on courtyard-10M (device LBVH).
+  * 2^20 diffuse rays on courtyard-10M (device LBVH),
+  * bench.py's fully incoherent 2^21-ray batch on courtyard-10M.
 One JSON line per case."""
 import json
 import os
@@ -24,7 +25,7 @@ def up(a):
     return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
 
 
-def case(name, tri, pos, cam, builder, any_hit, radius):
+def case(name, tri, pos, cam, builder, any_hit, radius, box_rays=0):
     n = tri.shape[0]
     keep = []
     if builder == "sah":
@@ -56,6 +57,10 @@ def case(name, tri, pos, cam, builder, any_hit, radius):
     b_res = torch.zeros(m * 16, dtype=torch.uint8, device=dev)
     b_a = torch.zeros(m, dtype=torch.int32, device=dev)
     nt.raygen_ao(b_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(), d_res.data_ptr(), d_nrm.data_ptr(), first, cnt, ns, radius, 0xFFF2D5E4)
+    if box_rays:   # fully incoherent batch: origins uniform in the bounding box, directions uniform on the sphere (bench.py's HBM point)
+        m = box_rays
+        b_rays = up(scenes.box_rays(pos, m, 7))
+        b_res = torch.zeros(m * 16, dtype=torch.uint8, device=dev)
     so = torch.zeros_like(b_rays)
     sa = torch.zeros(m, dtype=torch.int32, device=dev)
     sb = torch.zeros(m, dtype=torch.int32, device=dev)
@@ -78,3 +83,4 @@ tri, pos, cam = scenes.hairball()
 case("hairball-2.8M LBVH, diffuse (closest hit, extent = far)", tri, pos, cam, "lbvh", False, cam["far"])
 tri, pos, cam = scenes.courtyard()
 case("courtyard-10M LBVH, diffuse (closest hit, extent = far)", tri, pos, cam, "lbvh", False, cam["far"])
+case("courtyard-10M LBVH, 2^21 incoherent rays (origins uniform in the box, directions on the sphere)", tri, pos, cam, "lbvh", False, cam["far"], box_rays=1 << 21)
