@@ -20,6 +20,9 @@
 #include "SAHBVHBuilder.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 
 namespace FW {
@@ -31,6 +34,9 @@ SAHBVHBuilder::SAHBVHBuilder(BVH& bvh, const BVH::BuildParams& params)
 
 BVHNode* SAHBVHBuilder::run(void)
 {
+    const bool timing = std::getenv("NTR_SAH_TIMING") != NULL;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     const Scene* scene = m_bvh.getScene();
     const Vec3i* tris = (const Vec3i*)m_bvh.getScene()->getTriVtxIndexBuffer().getPtr();
     const Vec3f* verts = (const Vec3f*)m_bvh.getScene()->getVtxPosBuffer().getPtr();
@@ -44,16 +50,38 @@ BVHNode* SAHBVHBuilder::run(void)
     root.order = 2;
     m_box.resize(numTris);
     for (int d = 0; d < 3; d++) m_key[d].resize(numTris);
+    unsigned hwThreads = std::thread::hardware_concurrency();
+    if (hwThreads == 0) hwThreads = 1;
+    if (hwThreads > 64) hwThreads = 64;
+    const int prepThreads = numTris > 200000 ? (int)hwThreads : 1;
     std::vector<S32> live;
-    live.reserve(numTris);
-    for (S32 t = 0; t < numTris; t++) {
-        AABB b;
-        for (int j = 0; j < 3; j++) b.grow(verts[tris[t][j]]);
-        m_box[t] = b;
-        root.bounds.grow(b);
-        for (int d = 0; d < 3; d++) m_key[d][t] = b.min()[d] + b.max()[d];
-        const Vec3f size = b.max() - b.min();
-        if (!(size.min() < 0.0f || size.sum() == size.max())) live.push_back(t);
+    {   // slices of the triangle range, one per thread; the live list keeps ascending triangle order, unions are exact
+        std::vector<std::vector<S32> > liveOf(prepThreads);
+        std::vector<AABB> boundsOf(prepThreads);
+        auto prep = [&](int p) {
+            const S32 t0 = (S32)((S64)numTris * p / prepThreads), t1 = (S32)((S64)numTris * (p + 1) / prepThreads);
+            liveOf[p].reserve(t1 - t0);
+            for (S32 t = t0; t < t1; t++) {
+                AABB b;
+                for (int j = 0; j < 3; j++) b.grow(verts[tris[t][j]]);
+                m_box[t] = b;
+                boundsOf[p].grow(b);
+                for (int d = 0; d < 3; d++) m_key[d][t] = b.min()[d] + b.max()[d];
+                const Vec3f size = b.max() - b.min();
+                if (!(size.min() < 0.0f || size.sum() == size.max())) liveOf[p].push_back(t);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int p = 1; p < prepThreads; p++) pool.emplace_back(prep, p);
+        prep(0);
+        for (size_t i = 0; i < pool.size(); i++) pool[i].join();
+        size_t total = 0;
+        for (int p = 0; p < prepThreads; p++) total += liveOf[p].size();
+        live.reserve(total);
+        for (int p = 0; p < prepThreads; p++) {
+            live.insert(live.end(), liveOf[p].begin(), liveOf[p].end());
+            if (numTris > 0) root.bounds.grow(boundsOf[p]);
+        }
     }
     const S32 n = (S32)live.size();
     root.begin = 0;
@@ -61,10 +89,31 @@ BVHNode* SAHBVHBuilder::run(void)
     m_side.assign(numTris, 0);
     m_bvh.getTriIndices().assign(n, 0);
 
+    const double t1 = now();
+    // The order is a strict total order, so the sorted sequence is unique however it is produced: chunks sorted by separate threads,
+    // then merged pairwise (the merges of one round run in parallel).
+    const int chunksPerAxis = n > 200000 ? (int)std::max(1u, std::min(hwThreads / 3u, 16u)) : 1;
     auto sortAxis = [&](int d) {
         m_order[d] = live;
         const F32* key = m_key[d].data();
-        std::sort(m_order[d].begin(), m_order[d].end(), [key](S32 a, S32 b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
+        auto less = [key](S32 a, S32 b) { return key[a] < key[b] || (key[a] == key[b] && a < b); };
+        S32* base = m_order[d].data();
+        std::vector<S32> bounds(chunksPerAxis + 1);
+        for (int c = 0; c <= chunksPerAxis; c++) bounds[c] = (S32)((S64)n * c / chunksPerAxis);
+        {
+            std::vector<std::thread> pool;
+            for (int c = 1; c < chunksPerAxis; c++) pool.emplace_back([=]() { std::sort(base + bounds[c], base + bounds[c + 1], less); });
+            std::sort(base + bounds[0], base + bounds[1], less);
+            for (size_t i = 0; i < pool.size(); i++) pool[i].join();
+        }
+        for (int width = 1; width < chunksPerAxis; width *= 2) {
+            std::vector<std::thread> pool;
+            for (int c = 0; c + width < chunksPerAxis; c += 2 * width) {
+                const S32 lo = bounds[c], mid = bounds[c + width], hi = bounds[std::min(c + 2 * width, chunksPerAxis)];
+                pool.emplace_back([=]() { std::inplace_merge(base + lo, base + mid, base + hi, less); });
+            }
+            for (size_t i = 0; i < pool.size(); i++) pool[i].join();
+        }
     };
     if (n > 100000) {
         std::thread t0(sortAxis, 0), t1(sortAxis, 1);
@@ -75,6 +124,7 @@ BVHNode* SAHBVHBuilder::run(void)
         for (int d = 0; d < 3; d++) sortAxis(d);
     }
 
+    const double t2 = now();
     // how many levels of the tree may hand their right child to a new thread
     int spawnDepth = 0;
     if (n > 200000) {
@@ -86,6 +136,7 @@ BVHNode* SAHBVHBuilder::run(void)
     }
     Scratch scratch;
     BVHNode* node = build(root, scratch, spawnDepth);
+    if (timing) std::fprintf(stderr, "SAHBVHBuilder: boxes %.2f s, presort %.2f s, build %.2f s (%d triangles, spawn depth %d)\n", t1 - t0, t2 - t1, now() - t2, (int)n, spawnDepth);
     for (int d = 0; d < 3; d++) { std::vector<S32>().swap(m_order[d]); std::vector<F32>().swap(m_key[d]); }
     std::vector<AABB>().swap(m_box);
     return node;
@@ -100,33 +151,60 @@ BVHNode* SAHBVHBuilder::leaf(const Job& job, int order)
     return new LeafNode(job.bounds, job.triBase, job.triBase + (job.end - job.begin));
 }
 
-// The sweep of findObjectSplit (:206-243) over the three presorted sequences of the node.
-SAHBVHBuilder::Split SAHBVHBuilder::bestSplit(const Job& job, F32 nodeSAH, Scratch& scratch) const
+// The sweep of findObjectSplit (:206-243) over ONE presorted sequence of the node: its best split under the reference's rule
+// "smaller sah, then smaller i^2 + (n-i)^2, then smaller i" (the first minimum met wins).
+static void sweepAxis(const S32* seq, S32 m, const AABB* boxes, const Platform& platform, F32 nodeSAH, F32* rightArea, F32& bestSah,
+                      F32& bestBalance, S32& bestLeft)
+{
+    AABB acc;
+    for (S32 i = m - 1; i > 0; i--) {
+        acc.grow(boxes[seq[i]]);
+        rightArea[i - 1] = acc.area();
+    }
+    AABB left;
+    for (S32 i = 1; i < m; i++) {
+        left.grow(boxes[seq[i - 1]]);
+        const F32 sah = nodeSAH + left.area() * platform.getTriangleCost(i) + rightArea[i - 1] * platform.getTriangleCost(m - i);
+        const F32 fl = (F32)i, fr = (F32)(m - i);
+        const F32 balance = fl * fl + fr * fr;
+        if (sah < bestSah || (sah == bestSah && balance < bestBalance)) {
+            bestSah = sah;
+            bestLeft = i;
+            bestBalance = balance;
+        }
+    }
+}
+
+// The three sweeps; axes are compared in order with the same rule, so an earlier axis wins ties (:221-232).  The sweeps of a large
+// node near the root -- where the tree offers no other parallelism yet -- run on three threads.
+SAHBVHBuilder::Split SAHBVHBuilder::bestSplit(const Job& job, F32 nodeSAH, Scratch& scratch, bool threaded) const
 {
     const S32 m = job.end - job.begin;
+    F32 sah[3] = {FW_F32_MAX, FW_F32_MAX, FW_F32_MAX}, balance[3] = {FW_F32_MAX, FW_F32_MAX, FW_F32_MAX};
+    S32 numLeft[3] = {0, 0, 0};
+    if (threaded) {
+        std::vector<F32> area[3];
+        auto one = [&](int d) {
+            area[d].resize(m);
+            sweepAxis(m_order[d].data() + job.begin, m, m_box.data(), m_platform, nodeSAH, area[d].data(), sah[d], balance[d], numLeft[d]);
+        };
+        std::thread t0(one, 0), t1(one, 1);
+        one(2);
+        t0.join();
+        t1.join();
+    } else {
+        if ((S32)scratch.rightArea.size() < m) scratch.rightArea.resize(m);
+        for (int d = 0; d < 3; d++)
+            sweepAxis(m_order[d].data() + job.begin, m, m_box.data(), m_platform, nodeSAH, scratch.rightArea.data(), sah[d], balance[d], numLeft[d]);
+    }
     Split best;
     F32 bestBalance = FW_F32_MAX;
-    if ((S32)scratch.rightArea.size() < m) scratch.rightArea.resize(m);
-    F32* rightArea = scratch.rightArea.data();
     for (int d = 0; d < 3; d++) {
-        const S32* seq = m_order[d].data() + job.begin;
-        AABB acc;
-        for (S32 i = m - 1; i > 0; i--) {
-            acc.grow(m_box[seq[i]]);
-            rightArea[i - 1] = acc.area();
-        }
-        AABB left;
-        for (S32 i = 1; i < m; i++) {
-            left.grow(m_box[seq[i - 1]]);
-            const F32 sah = nodeSAH + left.area() * m_platform.getTriangleCost(i) + rightArea[i - 1] * m_platform.getTriangleCost(m - i);
-            const F32 fl = (F32)i, fr = (F32)(m - i);
-            const F32 balance = fl * fl + fr * fr;
-            if (sah < best.sah || (sah == best.sah && balance < bestBalance)) {
-                best.sah = sah;
-                best.dim = d;
-                best.numLeft = i;
-                bestBalance = balance;
-            }
+        if (sah[d] < best.sah || (sah[d] == best.sah && balance[d] < bestBalance)) {
+            best.sah = sah[d];
+            best.dim = d;
+            best.numLeft = numLeft[d];
+            bestBalance = balance[d];
         }
     }
     return best;
@@ -141,7 +219,8 @@ BVHNode* SAHBVHBuilder::build(const Job& job, Scratch& scratch, int spawnDepth)
     const F32 area = job.bounds.area();
     const F32 leafSAH = area * m_platform.getTriangleCost(m);
     const F32 nodeSAH = area * m_platform.getNodeCost(2);
-    const Split split = bestSplit(job, nodeSAH, scratch);
+    const bool threaded = spawnDepth > 0 && m > 400000;   // near the root: the node itself is the only work there is
+    const Split split = bestSplit(job, nodeSAH, scratch, threaded);
     const F32 minSAH = FW::min(leafSAH, split.sah);
     // the search has run: the reference's range is now sorted by the last axis (:163-165)
     if (job.level != 0 && minSAH == leafSAH && m <= m_platform.getMaxLeafSize()) return leaf(job, 2);
@@ -151,11 +230,8 @@ BVHNode* SAHBVHBuilder::build(const Job& job, Scratch& scratch, int spawnDepth)
     const S32* chosen = m_order[split.dim].data() + job.begin;
     for (S32 i = 0; i < split.numLeft; i++) { left.bounds.grow(m_box[chosen[i]]); m_side[chosen[i]] = 1; }
     for (S32 i = split.numLeft; i < m; i++) { right.bounds.grow(m_box[chosen[i]]); m_side[chosen[i]] = 0; }
-    if ((S32)scratch.tmp.size() < m) scratch.tmp.resize(m);
-    for (int d = 0; d < 3; d++) {
-        if (d == split.dim) continue;
+    auto partition = [&](int d, S32* tmp) {
         S32* seq = m_order[d].data() + job.begin;
-        S32* tmp = scratch.tmp.data();
         S32 nl = 0, nr = 0;
         for (S32 i = 0; i < m; i++) {
             const S32 t = seq[i];
@@ -163,6 +239,17 @@ BVHNode* SAHBVHBuilder::build(const Job& job, Scratch& scratch, int spawnDepth)
             else tmp[nr++] = t;
         }
         std::copy(tmp, tmp + nr, seq + nl);
+    };
+    const int da = (split.dim + 1) % 3, db = (split.dim + 2) % 3;
+    if ((S32)scratch.tmp.size() < m) scratch.tmp.resize(m);
+    if (threaded) {
+        std::vector<S32> tmp2(m);
+        std::thread other(partition, da, tmp2.data());
+        partition(db, scratch.tmp.data());
+        other.join();
+    } else {
+        partition(da, scratch.tmp.data());
+        partition(db, scratch.tmp.data());
     }
     left.begin = job.begin;
     left.end = job.begin + split.numLeft;

@@ -36,7 +36,7 @@ private:
 
     BVHNode* build(const Job& job, Scratch& scratch, int spawnDepth);
     BVHNode* leaf(const Job& job, int order);
-    Split    bestSplit(const Job& job, F32 nodeSAH, Scratch& scratch) const;
+    Split    bestSplit(const Job& job, F32 nodeSAH, Scratch& scratch, bool threaded) const;
 
     BVH&              m_bvh;
     const Platform&   m_platform;

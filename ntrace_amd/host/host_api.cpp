@@ -3,6 +3,9 @@
 #include <new>
 #include <vector>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "CameraControls.hpp"
 #include "CudaBVH.hpp"
 #include "MeshWavefrontIO.hpp"
@@ -30,16 +33,24 @@ int ntr_sah_build(int32_t numTris, const int32_t* triVtxIndex, int32_t numVerts,
         if (triVtxIndex[i] < 0 || triVtxIndex[i] >= numVerts)
             return ntr::set_error(NTR_ERR_INVALID, "ntr_sah_build: vertex index out of range at triangle %lld", (long long)(i / 3));
     try {
+        const bool timing = std::getenv("NTR_SAH_TIMING") != NULL;
+        auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
         NtrHostBvh* h = new NtrHostBvh();
         h->scene = new Scene(numTris, (const Vec3i*)triVtxIndex, numVerts, (const Vec3f*)vtxPos);
         Platform platform("GPU");  // Renderer.cpp:88-89
         platform.setLeafPreferences(minLeafSize, maxLeafSize);
         BVH::BuildParams params;
         params.stats = &h->stats;
+        const double t1 = now();
+        double t2, t3;
         {
         BVH bvh(h->scene, platform, params);
+        t2 = now();
         h->cbvh = new CudaBVH(bvh, BVHLayout_Compact);
+        t3 = now();
         }
+        if (timing) std::fprintf(stderr, "ntr_sah_build: scene %.2f s, BVH (builder + stats) %.2f s, Compact conversion %.2f s, tree teardown %.2f s\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
         *out = h;
         return NTR_OK;
     } catch (const FatalError& e) {
