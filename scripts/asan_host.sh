@@ -1,14 +1,15 @@
 #!/bin/bash
 # CPU-side AddressSanitizer + UBSan run of the host code (the C-ABI library's host half, the C++ mirror, the threaded SAH builder, the
 # host tracer): the library is rebuilt with -fsanitize=address,undefined for the HOST compilation only (-fno-gpu-sanitize; GPU ASAN is
-# not available on this pool), then tests/host/host_test.cpp (cpu mode) and tests/host/sanitize_driver.cpp run against it.  No GPU needed.
+# not available on this pool; `asan_host.sh <dir> thread` builds with ThreadSanitizer instead), then tests/host/host_test.cpp (cpu mode) and tests/host/sanitize_driver.cpp run against it.  No GPU needed.
 set -eu
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=${1:-/tmp/ntr_asan}
+KIND=${2:-address}                     # "address" (ASan + UBSan, leak check) or "thread" (TSan: the builder's and the converter's threads)
+OUT=${1:-/tmp/ntr_san_$KIND}
 mkdir -p "$OUT"
 R=$ROOT/ntrace_amd
 INC="-I$ROOT/include -I$R/csrc -I$R/host"
-SAN="-fsanitize=address,undefined -fno-omit-frame-pointer"
+if [ "$KIND" = thread ]; then SAN="-fsanitize=thread -fno-omit-frame-pointer"; else SAN="-fsanitize=address,undefined -fno-omit-frame-pointer"; fi
 OBJS=""
 for f in $R/csrc/*.hip $R/csrc/*.cpp $R/host/*.cpp $R/host/bvh/*.cpp; do
   o=$OUT/$(echo "$f" | tr '/' '_').o
@@ -23,4 +24,4 @@ export ASAN_OPTIONS=detect_leaks=1
 "$OUT/host_test_asan" cpu
 "$OUT/sanitize_driver" 300000
 "$OUT/sanitize_driver" 700000      # large enough for the threaded sweeps of the nodes near the root
-echo "asan_host: clean"
+echo "asan_host ($KIND): clean"
