@@ -2134,6 +2134,10 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         numLevels = (int)h.maxLevel;
     }
 
+    // Compact child references are S32 byte offsets below the sentinel 0x76543210 (CudaBVH.hpp:42-46): a tree with more nodes than that
+    // cannot be expressed (the buffers were sized for it, so nothing was written out of bounds; the references are what overflowed)
+    if ((unsigned long long)numNodes * 64ull > 0x76543200ull)
+        return set_error(NTR_ERR_OVERFLOW, "ntr_lbvh_build: %u nodes exceed what BVHLayout_Compact's 32-bit child offsets address", numNodes);
     // Bottom-up path: where the depth rule (level bit 0) made a leaf of more than leafSize equal keys, the node indices and terminator
     // slots the leaf marks had set aside inside it stay unused (zero-filled): the buffers' extents include them, the counts do not.
     const unsigned int leafs = (unsigned int)(h.leafPtr & 0xFFFFFFFFull);
