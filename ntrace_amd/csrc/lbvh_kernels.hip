@@ -1862,8 +1862,9 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const int n = numTris;
     if (n >= (1 << 28)) return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: at most 2^28 - 1 triangles");
     const int nb = (n + SORT_TILE - 1) / SORT_TILE;
-    // one-sweep tiles: 2048 keys while the launch is latency-bound, 4096 (longer runs per digit in the scatter) for large inputs
-    const int osItems = n >= (1 << 21) ? 16 : 8;
+    // one-sweep tiles: 2048 keys while the launch is latency-bound; 6144 / 8192 for large inputs (fewer tiles to look back over, longer
+    // runs per digit in the scatter: 10 M keys 80 -> 71 us per pass, scripts/jobs/gpu_job_r02sort.sh)
+    const int osItems = n >= (1 << 23) ? 32 : (n >= (1 << 21) ? 24 : 8);
     const int osTiles = (n + OS_THREADS * osItems - 1) / (OS_THREADS * osItems);
     const Tunables tun = tunables();
     const bool levelSync = tun.lbvhLevelSync != 0;
@@ -1953,7 +1954,13 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, kOut, vOut, 1,
                                shift, (const unsigned int*)hist, (const unsigned int*)hist + (size_t)nb * 256, nb);
         } else {
-            if (osItems == 16)
+            if (osItems == 32)
+                hipLaunchKernelGGL((onesweep_pass_kernel<32, 0>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
+                                   1, shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
+            else if (osItems == 24)
+                hipLaunchKernelGGL((onesweep_pass_kernel<24, 0>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
+                                   1, shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
+            else if (osItems == 16)
                 hipLaunchKernelGGL((onesweep_pass_kernel<16, 0>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
                                    1, shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
             else
