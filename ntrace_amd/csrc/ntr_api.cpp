@@ -139,7 +139,7 @@ static void tunables_load_locked()
     t.chunk = env_int("NTR_TRACE_CHUNK", 64);
     t.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", -1);  // -1: 24 for kepler_dynamic_fetch, 0 otherwise
     t.coop = env_int("NTR_TRACE_COOP", 0);
-    t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", 24);     // sweep: flat optimum 16..64 (scripts/trace_sweep.py)
+    t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", -1);     // -1: 32 for closest-hit, 24 for any-hit launches (bench-protocol sweep, scripts/jobs/gpu_job_r02ls.sh)
     t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 6);
     t.octant = env_int("NTR_TRACE_OCTANT", 1);
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/persist_diag.py)
@@ -458,7 +458,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.fetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (strcmp(k->name, "kepler_dynamic_fetch") == 0 ? 24 : 0);
     p.bvhFlags = bvhFlags;
     p.coop = tun.coop;
-    p.leafSwitchBelow = tun.leafSwitchBelow;
+    p.leafSwitchBelow = tun.leafSwitchBelow >= 0 ? tun.leafSwitchBelow : (anyHit ? 24 : 32);
     p.octant = tun.octant;
     p.stats = ds->stats;
     p.timeline = nullptr;
