@@ -968,11 +968,12 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_cells_refit_kernel(const
 //     critical path, the numbering is deterministic -- and every node word, Woop row and triangle index is written ONCE, straight to
 //     its final place, by the thread that produces it (no intermediate records, no final pass).
 //   * Meetings whose parent range lies inside the workgroup's 512-key tile -- nearly all of them -- use LDS slots and LDS
-//     atomics; only clusters that outgrow their tile meet through memory (agent-scope stores of the 32-byte slot, drained, then
+//     atomics; only clusters that outgrow their tile meet through memory (agent-scope stores of the 40-byte slot, drained, then
 //     the atomic; agent-scope loads after it).
 //   * RUNS of more than leafSize equal keys are the reference's median-split subtrees (:282), whose leaf rule depends on the
-//     depth (level bit 0, :289-292).  The bottom-up pass treats such a run as one opaque cluster; lbvh_runs_kernel then walks
-//     the parent positions for its depth and writes its median nodes under the same naming scheme.
+//     depth (level bit 0, :289-292).  The bottom-up pass treats such a run as one opaque cluster that carries its height;
+//     lbvh_runs_kernel writes its median nodes under the same naming scheme, and walks up the parent indices for the run's depth
+//     only where the depth rule could bite.
 // Kernels: lbvh_leafmark_kernel (marks + their prefix counts) -> lbvh_agglomerate_kernel (-> lbvh_agglomerate_top_kernel) -> lbvh_runs_kernel.
 // =====================================================================================================================
 constexpr int AGG_TILE = 512;
