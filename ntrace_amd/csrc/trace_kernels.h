@@ -16,6 +16,8 @@
 #define NTR_VARIANT_PERRAY 0      // one ray per lane, while-while
 #define NTR_VARIANT_PERSISTENT 1  // persistent waves, ballot/mbcnt dynamic fetch
 #define NTR_VARIANT_PERRAY_STATS 2 // per-ray kernel + traversal counters
+#define NTR_VARIANT_PERRAY_W2 3    // per-ray kernel in 128-thread workgroups (any-hit launches)
+#define NTR_VARIANT_PERRAY_W1 4    // per-ray kernel in 64-thread workgroups
 
 // bits of the device status word
 #define NTR_STATUS_STACK_OVERFLOW 1u

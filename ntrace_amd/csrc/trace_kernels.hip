@@ -740,6 +740,12 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
         if (p->coop) hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, false, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         else hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, false, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
+    case NTR_VARIANT_PERRAY_W2:   // smaller workgroups for short any-hit rays (numBlocks counts 128-ray blocks)
+        hipLaunchKernelGGL((ntr::trace_bvh_perray<2, false, false>), dim3(numBlocks), dim3(128), 0, stream, *p);
+        break;
+    case NTR_VARIANT_PERRAY_W1:
+        hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
+        break;
     case NTR_VARIANT_PERRAY_STATS:
         hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
