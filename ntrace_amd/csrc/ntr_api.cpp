@@ -142,6 +142,7 @@ static void tunables_load_locked()
     t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", -1);     // -1: 32 for closest-hit, 24 for any-hit launches (bench-protocol sweep, scripts/jobs/gpu_job_r02ls.sh)
     t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 6);
     t.octant = env_int("NTR_TRACE_OCTANT", 1);
+    t.closestWaves = env_int("NTR_TRACE_CLOSEST_WAVES", 1);      // likewise for closest-hit launches: primary +2.1 % with 1
     t.anyHitWaves = env_int("NTR_TRACE_ANYHIT_WAVES", 1);        // waves per workgroup of plain any-hit launches of the per-ray kernel (1, 2, 4): AO +1.7 % with 1
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/persist_diag.py)
     t.predict = env_int("NTR_TRACE_PREDICT", 1);
@@ -566,11 +567,14 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
                                                  predScratch->classList, predScratch->order, s);
         if (pe != hipSuccess) return hip_fail(pe, "predict launch");
     }
+    // Workgroup size of the per-ray kernel: smaller workgroups retire (and are replaced) sooner.  The dispatch order and the cost
+    // feedback stay in units of 256 rays: numBlocks counts those, the launch has 4 / waves workgroups per unit.
     int launchVariant = variant, launchBlocks = numBlocks;
-    if (variant == NTR_VARIANT_PERRAY && anyHit && !hint && !p.order && !p.coop && !p.timeline && !p.cost && tun.anyHitWaves < NTR_TRACE_WAVES_PER_BLOCK) {
-        const int waves = tun.anyHitWaves <= 1 ? 1 : 2;   // short rays: smaller workgroups retire (and are replaced) sooner
+    const int wantWaves = anyHit ? tun.anyHitWaves : tun.closestWaves;
+    if (variant == NTR_VARIANT_PERRAY && !p.coop && wantWaves < NTR_TRACE_WAVES_PER_BLOCK) {
+        const int waves = wantWaves <= 1 ? 1 : 2;
         launchVariant = waves == 1 ? NTR_VARIANT_PERRAY_W1 : NTR_VARIANT_PERRAY_W2;
-        launchBlocks = (numRays + waves * 64 - 1) / (waves * 64);
+        launchBlocks = numBlocks * (4 / waves);
     }
     hipError_t le = ntr_launch_trace(launchVariant, &p, launchBlocks, s);
     if (le != hipSuccess) return hip_fail(le, "trace_bvh launch");

@@ -423,8 +423,12 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     __shared__ __attribute__((aligned(16))) char s_stage[WAVES][COOP ? STAGE_BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned int block = p.order ? p.order[blockIdx.x] : blockIdx.x;
-    const int rayIdx = block * (WAVES * 64) + threadIdx.x;
+    // A "block" is 256 consecutive rays (the unit of the dispatch order and of the cost feedback) whatever the workgroup size: a
+    // workgroup of WAVES waves traces one of its 4 / WAVES parts.
+    constexpr int PARTS = 4 / WAVES;
+    const unsigned int g = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
+    const unsigned int block = p.order ? p.order[g] : g;
+    const int rayIdx = block * 256 + part * (WAVES * 64) + threadIdx.x;
     const bool valid = rayIdx < p.numRays;
     const Rsrc nodes = make_rsrc(p.nodes, p.nodesBytes), woop = make_rsrc(p.woop, p.woopBytes);
     lds_char* stage = (lds_char*)&s_stage[__builtin_amdgcn_readfirstlane(wave)][0];
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     else traverse<false, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
 
     if (p.timeline && lane == 0) {
-        const unsigned int w = block * WAVES + wave;
+        const unsigned int w = block * 4 + part * WAVES + wave;
         p.timeline[3 * w + 0] = tl0;
         p.timeline[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
         p.timeline[3 * w + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
