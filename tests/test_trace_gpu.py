@@ -230,6 +230,29 @@ def test_octant_slabs_change_no_record(soup, monkeypatch, octant):
                 assert_parity(got, ref, "octant=%d %s" % (octant, kernel))
 
 
+@pytest.mark.parametrize("waves", [1, 2, 4])
+def test_workgroup_size_changes_no_record(soup, monkeypatch, waves):
+    """The per-ray kernel runs in workgroups of 1, 2 or 4 waves (NTR_TRACE_CLOSEST_WAVES / NTR_TRACE_ANYHIT_WAVES); the dispatch
+    order (prediction forced on) and the scheduling hint keep their 256-ray units.  Ragged ray counts, both ray kinds."""
+    from gpu_util import assert_parity, gpu_trace
+    dbvh, cam = soup
+    monkeypatch.setenv("NTR_TRACE_CLOSEST_WAVES", str(waves))
+    monkeypatch.setenv("NTR_TRACE_ANYHIT_WAVES", str(waves))
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
+    nt.set_tunables()
+    allrays = np.concatenate([scenes.primary_rays(cam, 300, 240)[0], edge_rays(), scenes.random_rays(5000, seed=4)])
+    for n in (1, 63, 65, 257, 70001):
+        rays = allrays[:n]
+        for any_hit in (False, True):
+            ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit, threads=8)
+            got, _ = gpu_trace("fermi_speculative_while_while", dbvh, rays, any_hit)
+            if any_hit:
+                assert np.array_equal(got["id"] >= 0, ref["id"] >= 0)
+            else:
+                assert_parity(got, ref, "waves=%d n=%d" % (waves, n))
+
+
 def test_validate_flags_an_inverted_box_as_unordered():
     """NTR_BVH_ORDERED is withheld when any child box has lo > hi on an axis (the octant-specialised slab test relies on lo <= hi);
     such a tree is still traced like the CPU tracer traces it."""
