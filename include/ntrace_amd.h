@@ -202,11 +202,15 @@ NTR_API int ntr_trace_bvh_stats(const char* kernelName, int32_t numRays, int32_t
  *   NTR_BVH_NOTINY   every box coordinate is 0 or |x| >= 2^-93 (lets rays with an exactly-zero
  *                    origin component use the same path).
  *   NTR_BVH_ORDERED  every child box has lo <= hi on each axis: for a wave whose rays share the signs of their direction
- *                    components the kernels then know which of a slab's two quotients is the smaller one without comparing. */
+ *                    components the kernels then know which of a slab's two quotients is the smaller one without comparing.
+ *   NTR_BVH_WIDE_LEAVES  leaves hold two or more triangles on average (the device LBVH with leafSize 8; a host SAH tree built with
+ *                    leaf preferences (1,1) has one): the per-ray kernel then advances every lane by one node OR one triangle
+ *                    per iteration instead of alternating between a node phase and a leaf phase (trace_kernels.hip). */
 #define NTR_BVH_FINITE 1u
 #define NTR_BVH_FASTDIV 2u
 #define NTR_BVH_NOTINY 4u
 #define NTR_BVH_ORDERED 8u
+#define NTR_BVH_WIDE_LEAVES 16u
 NTR_API int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_t* flags, void* stream);
 
 /* Device self test: counts quotients x[i]/d[j] for which the FAST divide differs from the

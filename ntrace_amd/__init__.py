@@ -14,7 +14,7 @@ from ._capi import (BvhView, RAY_DTYPE, RESULT_DTYPE, HostBvh, KernelConfig, Ntr
                     camera_nscreen_to_world, obj_load, SchedHint, trace_status, set_tunables, experiment_hooks, host_bvh_wrap)
 
 BVHLayout_Compact = 4
-BVH_FINITE, BVH_FASTDIV, BVH_NOTINY, BVH_ORDERED = 1, 2, 4, 8
+BVH_FINITE, BVH_FASTDIV, BVH_NOTINY, BVH_ORDERED, BVH_WIDE_LEAVES = 1, 2, 4, 8, 16
 KERNELS = ("fermi_speculative_while_while", "tesla_persistent_while_while",
            "tesla_persistent_speculative_while_while", "kepler_dynamic_fetch")
 

@@ -15,9 +15,15 @@ __global__ __launch_bounds__(256) void bvh_validate_kernel(const float4* __restr
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool notFinite = false, notFast = false, tiny = false, unordered = false;
+    unsigned int leaves = 0, maxLeafOfs = 0;
     for (; i < numFloat4; i += stride) {
-        if ((i & 3) == 3) continue;  // child / split words
         const float4 v = nodes[i];
+        if ((i & 3) == 3) {  // child words: a negative child is ~(float4 index of the leaf's first Woop row)
+            const int c0 = __float_as_int(v.x), c1 = __float_as_int(v.y);
+            if (c0 < 0) { leaves++; maxLeafOfs = max(maxLeafOfs, (unsigned int)~c0); }
+            if (c1 < 0) { leaves++; maxLeafOfs = max(maxLeafOfs, (unsigned int)~c1); }
+            continue;
+        }
         const float c[4] = {v.x, v.y, v.z, v.w};
         unordered = unordered || !(v.x <= v.y) || !(v.z <= v.w);   // every box float4 is two (lo, hi) pairs
         for (int k = 0; k < 4; k++) {
@@ -30,6 +36,16 @@ __global__ __launch_bounds__(256) void bvh_validate_kernel(const float4* __restr
     const unsigned int bits = (__ballot(notFinite) != 0ull ? 1u : 0u) | (__ballot(notFast) != 0ull ? 2u : 0u) |
                               (__ballot(tiny) != 0ull ? 4u : 0u) | (__ballot(unordered) != 0ull ? 8u : 0u);
     if (bits && (threadIdx.x & 63) == 0) atomicOr(bad, bits);
+    // leaf statistics (NTR_BVH_WIDE_LEAVES): number of leaves and the last leaf's offset ~ the triWoop extent
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        leaves += (unsigned int)__shfl_xor((int)leaves, off);
+        maxLeafOfs = max(maxLeafOfs, (unsigned int)__shfl_xor((int)maxLeafOfs, off));
+    }
+    if ((threadIdx.x & 63) == 0 && leaves) {
+        atomicAdd(bad + 1, leaves);
+        atomicMax(bad + 2, maxLeafOfs);
+    }
 }
 
 }  // namespace ntr
@@ -44,17 +60,20 @@ extern "C" int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_
         return set_error(NTR_ERR_INVALID, "ntr_bvh_validate: node buffer size must be a multiple of 64 in [64, 0x76543200]");
     hipStream_t s = (hipStream_t)stream;
     unsigned int* d_bad = nullptr;
-    NTR_HIP(hipMalloc((void**)&d_bad, sizeof(unsigned int)));
-    NTR_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), s));
+    NTR_HIP(hipMalloc((void**)&d_bad, 4 * sizeof(unsigned int)));
+    NTR_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(unsigned int), s));
     const int64_t n4 = nodesBytes / 16;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(bvh_validate_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)d_nodes, n4, d_bad);
     NTR_HIP(hipGetLastError());
-    unsigned int bad = 0;
-    NTR_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s));
+    unsigned int h[4] = {0, 0, 0, 0};
+    NTR_HIP(hipMemcpyAsync(h, d_bad, sizeof(h), hipMemcpyDeviceToHost, s));
     NTR_HIP(hipStreamSynchronize(s));
     NTR_HIP(hipFree(d_bad));
+    const unsigned int bad = h[0];
+    // the last leaf starts at float4 index h[2]: with L leaves the triWoop buffer holds about h[2] / L float4 per leaf (3 per triangle + 1)
+    if (h[1] > 0 && (double)h[2] / (double)h[1] >= 7.0) *flags |= NTR_BVH_WIDE_LEAVES;
     if (!(bad & 1u)) *flags |= NTR_BVH_FINITE;
     if (!(bad & 2u)) *flags |= NTR_BVH_FASTDIV;
     if (!(bad & 4u)) *flags |= NTR_BVH_NOTINY;

@@ -144,6 +144,8 @@ static void tunables_load_locked()
     t.octant = env_int("NTR_TRACE_OCTANT", 1);
     t.closestWaves = env_int("NTR_TRACE_CLOSEST_WAVES", 1);      // likewise for closest-hit launches: primary +2.1 % with 1
     t.anyHitWaves = env_int("NTR_TRACE_ANYHIT_WAVES", 1);        // waves per workgroup of plain any-hit launches of the per-ray kernel (1, 2, 4): AO +1.7 % with 1
+    t.unified = env_int("NTR_TRACE_UNIFIED", 1);                  // kepler_dynamic_fetch: unified-step loop (0 = while-while loop + dynamic fetch)
+    t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", -1);    // per-ray kernel with the unified-step loop: -1 = for trees flagged NTR_BVH_WIDE_LEAVES, 0 / 1 = never / always
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/persist_diag.py)
     t.predict = env_int("NTR_TRACE_PREDICT", 1);
     t.predictDepth = env_int("NTR_TRACE_PREDICT_DEPTH", 9);
@@ -457,7 +459,9 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     // named after it (it costs about 10 % here: refilled lanes de-cohere a wave's node fetches)
     const Tunables tun = tunables();
     p.chunk = tun.chunk;
-    p.fetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (strcmp(k->name, "kepler_dynamic_fetch") == 0 ? 24 : 0);
+    const bool dynamicFetch = strcmp(k->name, "kepler_dynamic_fetch") == 0;
+    const bool unified = dynamicFetch && tun.unified != 0 && !tun.coop;
+    p.fetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (dynamicFetch ? (unified ? 48 : 24) : 0);
     p.bvhFlags = bvhFlags;
     p.coop = tun.coop;
     p.leafSwitchBelow = tun.leafSwitchBelow >= 0 ? tun.leafSwitchBelow : (anyHit ? 24 : 32);
@@ -570,11 +574,16 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     // Workgroup size of the per-ray kernel: smaller workgroups retire (and are replaced) sooner.  The dispatch order and the cost
     // feedback stay in units of 256 rays: numBlocks counts those, the launch has 4 / waves workgroups per unit.
     int launchVariant = variant, launchBlocks = numBlocks;
+    if (variant == NTR_VARIANT_PERSISTENT && unified) launchVariant = NTR_VARIANT_PERSISTENT_UNIFIED;
     const int wantWaves = anyHit ? tun.anyHitWaves : tun.closestWaves;
     if (variant == NTR_VARIANT_PERRAY && !p.coop && wantWaves < NTR_TRACE_WAVES_PER_BLOCK) {
         const int waves = wantWaves <= 1 ? 1 : 2;
         launchVariant = waves == 1 ? NTR_VARIANT_PERRAY_W1 : NTR_VARIANT_PERRAY_W2;
         launchBlocks = numBlocks * (4 / waves);
+        if (tun.perrayUnified > 0 || (tun.perrayUnified < 0 && (bvhFlags & NTR_BVH_WIDE_LEAVES))) {
+            launchVariant = NTR_VARIANT_PERRAY_UNIFIED_W1;   // multi-triangle leaves: one node OR one triangle per lane and iteration
+            launchBlocks = numBlocks * 4;
+        }
     }
     hipError_t le = ntr_launch_trace(launchVariant, &p, launchBlocks, s);
     if (le != hipSuccess) return hip_fail(le, "trace_bvh launch");

@@ -18,6 +18,8 @@
 #define NTR_VARIANT_PERRAY_STATS 2 // per-ray kernel + traversal counters
 #define NTR_VARIANT_PERRAY_W2 3    // per-ray kernel in 128-thread workgroups (any-hit launches)
 #define NTR_VARIANT_PERRAY_W1 4    // per-ray kernel in 64-thread workgroups
+#define NTR_VARIANT_PERSISTENT_UNIFIED 5  // persistent waves, unified-step loop (every live lane advances each iteration)
+#define NTR_VARIANT_PERRAY_UNIFIED_W1 6   // per-ray kernel, 64-thread workgroups, unified-step loop
 
 // bits of the device status word
 #define NTR_STATUS_STACK_OVERFLOW 1u

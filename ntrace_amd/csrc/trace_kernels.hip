@@ -414,10 +414,121 @@ __device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, lds_char* stage,
     }
 }
 
+// Unified-step traversal (the dynamic-fetch kernel's loop).  The while-while loop above lets a wave alternate between an
+// inner-node phase and a leaf phase, and a leaf of k triangles costs k dependent round trips during which the lanes that hold
+// inner nodes idle: on divergent batches (diffuse / incoherent rays in LBVH trees with 6-triangle leaves) only 9-20 % of the
+// lane slots of a wave iteration do work (profiles/r03_divergence_*).  Here EVERY live lane advances by one step per iteration,
+// whatever it holds: an inner node (64 B from `nodes`) or the next triangle of its leaf (48 B + the following word from
+// `woop`: also 64 contiguous bytes).  Both fetches are issued before the wave waits, so an iteration is ONE memory round trip.
+// A lane's own visiting order -- and with it every hit record -- is exactly that of traverse(): only the interleaving of the
+// lanes changes.  `node` < 0 doubles as the triangle cursor: the lane's next triangle is at float4 index ~node (a leaf
+// reference IS the index of its first triangle; advancing one triangle subtracts 3).
+// Buffer resource descriptor as four scalar words (what make_rsrc builds): base, base_hi (stride 0), extent in bytes, flags.
+__device__ __forceinline__ u32x4 rsrc_words(const void* p, unsigned int bytes)
+{
+    const unsigned long long a = (unsigned long long)p;
+    u32x4 w;
+    w.x = __builtin_amdgcn_readfirstlane((unsigned int)a);
+    w.y = __builtin_amdgcn_readfirstlane((unsigned int)(a >> 32) & 0xFFFFu);
+    w.z = __builtin_amdgcn_readfirstlane(bytes);
+    w.w = 0x00020000u;
+    return w;
+}
+
+// Lanes of maskA fetch 64 B at byte offset `ofs` of buffer A, lanes of maskB at `ofs` of buffer B (range-checked: beyond the extent
+// a load returns 0 and touches no memory); the other lanes fetch nothing and their a..d are undefined.
+__device__ __forceinline__ void fetch64_two_buffers(u32x4 rsrcA, u32x4 rsrcB, int ofs, unsigned long long maskA,
+                                                    unsigned long long maskB, float4& a, float4& b, float4& c, float4& d)
+{
+    u32x4 va, vb, vc, vd;
+    unsigned long long sav;
+    asm volatile(
+        "s_mov_b64 %[sav], exec\n\t"
+        "s_and_b64 exec, %[sav], %[ma]\n\t"
+        "buffer_load_dwordx4 %[a], %[ofs], %[ra], 0 offen\n\t"
+        "buffer_load_dwordx4 %[b], %[ofs], %[ra], 0 offen offset:16\n\t"
+        "buffer_load_dwordx4 %[c], %[ofs], %[ra], 0 offen offset:32\n\t"
+        "buffer_load_dwordx4 %[d], %[ofs], %[ra], 0 offen offset:48\n\t"
+        "s_and_b64 exec, %[sav], %[mb]\n\t"
+        "buffer_load_dwordx4 %[a], %[ofs], %[rb], 0 offen\n\t"
+        "buffer_load_dwordx4 %[b], %[ofs], %[rb], 0 offen offset:16\n\t"
+        "buffer_load_dwordx4 %[c], %[ofs], %[rb], 0 offen offset:32\n\t"
+        "buffer_load_dwordx4 %[d], %[ofs], %[rb], 0 offen offset:48\n\t"
+        "s_mov_b64 exec, %[sav]\n\t"
+        "s_waitcnt vmcnt(0)"
+        : [a] "=&v"(va), [b] "=&v"(vb), [c] "=&v"(vc), [d] "=&v"(vd), [sav] "=&s"(sav)
+        : [ofs] "v"(ofs), [ra] "s"(rsrcA), [rb] "s"(rsrcB), [ma] "s"(maskA), [mb] "s"(maskB)
+        : "memory");
+    a = make_float4(__uint_as_float(va.x), __uint_as_float(va.y), __uint_as_float(va.z), __uint_as_float(va.w));
+    b = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
+    c = make_float4(__uint_as_float(vc.x), __uint_as_float(vc.y), __uint_as_float(vc.z), __uint_as_float(vc.w));
+    d = make_float4(__uint_as_float(vd.x), __uint_as_float(vd.y), __uint_as_float(vd.z), __uint_as_float(vd.w));
+}
+
+template <bool FAST>
+__device__ __forceinline__ void traverse_unified(u32x4 p_nodes, u32x4 p_woop, RayRegs& r, int& node, LaneStack& st,
+                                                 int (&spill)[SPILL_DEPTH], bool anyHit, int& hitAddr, float& hitU, float& hitV,
+                                                 unsigned int* status, bool poolEmpty, int fetchThreshold)
+{
+    for (;;) {
+        const unsigned long long live = __ballot(node != kSentinel);
+        if (live == 0ull) break;
+        // dynamic fetch (kepler_dynamic_fetch.cu:310): too few live lanes while rays remain in the pool -> refill
+        if (!poolEmpty && __popcll(live) < fetchThreshold) break;
+        const bool inner = (unsigned)node < (unsigned)kSentinel;
+        const bool atTri = node < 0;
+        // one 64-byte fetch per lane from its own buffer: four loads under the inner lanes' mask and four under the triangle lanes'
+        // mask into the SAME registers, one wait.  (Written as `inner ? ld4(nodes, ..) : ld4(woop, ..)` hipcc selects the
+        // descriptor per lane and wraps every load in a waterfall loop.)
+        const int ofs = inner ? node : (~node) * 16;
+        float4 a, b, c, d;
+        fetch64_two_buffers(p_nodes, p_woop, ofs, __ballot(inner), __ballot(atTri), a, b, c, d);
+        if (inner) {   // trace<BVHLayout_Compact>, one inner node (CudaBVH.cpp:721-775)
+            float mn0, mx0, mn1, mx1;
+            ray_box2<FAST>(r, a, b, c, mn0, mx0, mn1, mx1);
+            const bool i0 = (mn0 <= mx0) && (mx0 >= r.tmin) && (mn0 <= r.tmax);
+            const bool i1 = (mn1 <= mx1) && (mx1 >= r.tmin) && (mn1 <= r.tmax);
+            const int c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
+            const bool swp = i1 && (!i0 || mn0 > mn1);
+            const int nearC = swp ? c1 : c0, farC = swp ? c0 : c1;
+            if (i0 && i1) stack_push(st, spill, farC, status);
+            node = (i0 || i1) ? nearC : stack_pop(st, spill);
+        } else if (atTri) {   // intersectTriangles + updateHit, one triangle (CudaBVH.cpp:1084-1126, 1183-1225)
+            bool leafDone = __float_as_uint(a.x) == 0x80000000u;   // terminator: an empty leaf
+            if (!leafDone) {
+                const float Oz = a.w - r.ox * a.x - r.oy * a.y - r.oz * a.z;
+                const float ooDz = 1.0f / dot4(a, r.dx, r.dy, r.dz, 0.0f);
+                const float t = Oz * ooDz;
+                float tt = FLT_MAX, uu = 0.0f, vv = 0.0f;
+                if (t > r.tmin && t < r.tmax) {
+                    const float u = dot4(b, r.ox, r.oy, r.oz, 1.0f) + t * dot4(b, r.dx, r.dy, r.dz, 0.0f);
+                    if (u >= 0.0f) {
+                        const float v = dot4(c, r.ox, r.oy, r.oz, 1.0f) + t * dot4(c, r.dx, r.dy, r.dz, 0.0f);
+                        if (v >= 0.0f && (u + v) <= 1.0f) { tt = t; uu = u; vv = v; }
+                    }
+                }
+                bool terminated = false;
+                if (tt > r.tmin && tt < r.tmax) {
+                    r.tmax = tt;
+                    hitAddr = ~node;
+                    hitU = uu;
+                    hitV = vv;
+                    terminated = anyHit;
+                }
+                if (terminated) node = kSentinel;
+                else if (__float_as_uint(d.x) == 0x80000000u) leafDone = true;   // the terminator came with this triangle
+                else node -= 3;
+            }
+            if (leafDone) node = stack_pop(st, spill);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Variant 1: one ray per lane, while-while ("fermi_speculative_while_while" slot).
 // ---------------------------------------------------------------------------------
-template <int WAVES, bool STATS, bool COOP>
+// UNIFIED: the unified-step loop (traverse_unified) -- for trees whose leaves hold several triangles (the device LBVH).
+template <int WAVES, bool STATS, bool COOP, bool UNIFIED = false>
 __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_perray(TraceParams p)
 {
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
@@ -453,13 +564,17 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     const bool fastWave = (p.bvhFlags & NTR_BVH_FASTDIV) && __ballot(node != kSentinel && !ray_is_nice(r, p.bvhFlags)) == 0ull;
     // direction signs shared by every live ray of the wave (a primary wave is an 8 x 8 pixel tile): the octant's own slab test
     int oct = 8;
-    if (!STATS && !COOP && fastWave && p.octant && (p.bvhFlags & NTR_BVH_ORDERED)) {
+    if (!UNIFIED && !STATS && !COOP && fastWave && p.octant && (p.bvhFlags & NTR_BVH_ORDERED)) {
         const unsigned long long liveMask = __ballot(node != kSentinel);
         const unsigned long long sx = __ballot(node != kSentinel && r.dx < 0.0f), sy = __ballot(node != kSentinel && r.dy < 0.0f),
                                  sz = __ballot(node != kSentinel && r.dz < 0.0f);
         if ((sx == 0ull || sx == liveMask) && (sy == 0ull || sy == liveMask) && (sz == 0ull || sz == liveMask))
             oct = (sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0);
     }
+    if (UNIFIED) {
+        if (fastWave) traverse_unified<true>(rsrc_words(p.nodes, p.nodesBytes), rsrc_words(p.woop, p.woopBytes), r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
+        else traverse_unified<false>(rsrc_words(p.nodes, p.nodesBytes), rsrc_words(p.woop, p.woopBytes), r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
+    } else
 #define NTR_TRAVERSE_OCT(O) traverse<true, STATS, false, COOP, O>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow)
     if (!STATS && !COOP && oct < 8) {
         switch (oct) {
@@ -511,7 +626,8 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
 // ---------------------------------------------------------------------------------
 // TL: the diagnostic stamps of NTR_TRACE_TIMELINE are compiled into their own instantiation -- they cost 18 VGPRs,
 // i.e. two waves of occupancy per SIMD, which the production kernel must not pay.
-template <int WAVES, bool COOP, bool TL>
+// UNIFIED: the unified-step loop (traverse_unified) instead of the while-while loop -- what kepler_dynamic_fetch launches.
+template <int WAVES, bool COOP, bool TL, bool UNIFIED = false>
 __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_persistent(TraceParams p)
 {
     unsigned long long* const timeline = TL ? p.timeline : nullptr;
@@ -626,7 +742,10 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
         if (timeline) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tlRefill += __builtin_amdgcn_s_memtime() - tlA; }
         // ---- while-while traversal ------------------------------------------------
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
-        if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
+        if (UNIFIED) {
+            if (fastWave) traverse_unified<true>(rsrc_words(p.nodes, p.nodesBytes), rsrc_words(p.woop, p.woopBytes), r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
+            else traverse_unified<false>(rsrc_words(p.nodes, p.nodesBytes), rsrc_words(p.woop, p.woopBytes), r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
+        } else if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
         else traverse<false, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
 
         // ---- retire finished rays ---------------------------------------------------
@@ -750,8 +869,15 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
     case NTR_VARIANT_PERRAY_W1:
         hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
+    case NTR_VARIANT_PERRAY_UNIFIED_W1:
+        hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false, true>), dim3(numBlocks), dim3(64), 0, stream, *p);
+        break;
     case NTR_VARIANT_PERRAY_STATS:
         hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        break;
+    case NTR_VARIANT_PERSISTENT_UNIFIED:
+        if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, false, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERSISTENT:
         if (p->coop) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);

@@ -46,7 +46,7 @@ for W in $WHAT; do
       $SUM pmc $OUT/trace_atrium_$K/pmc_* > $OUT/trace_atrium_$K.pmc.txt 2>&1
     done ;;
   hbm)
-    K=fermi_speculative_while_while
+    K=${PROF_KERNEL:-fermi_speculative_while_while}
     prof_trace trace_courtyard_$K trace courtyard $K 6
     for C in "${TRACE_SETS[@]}"; do prof_pmc trace_courtyard_$K "$C" trace courtyard $K 4; done
     $SUM pmc $OUT/trace_courtyard_$K/pmc_* > $OUT/trace_courtyard_$K.pmc.txt 2>&1 ;;

@@ -76,6 +76,16 @@ def main():
         bvh_bytes = best.nodesBytes + best.triWoopBytes + best.triIndexBytes
     view.validate()
     w, h = 1920, 1080
+    only = os.environ.get("WL_ONLY", "")   # "incoherent": only that batch (the persistent kernels' grid is the same for every batch,
+    if only == "incoherent":                # so per-batch PMC means need a run of their own)
+        nr = 1 << 21
+        d_rr = up(scenes.box_rays(pos, nr, seed=21))
+        d_ro = torch.zeros(nr * 16, dtype=torch.uint8, device=dev)
+        view.trace(kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr())
+        tr = [view.trace(kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr()) for _ in range(reps)]
+        print(json.dumps(dict(workload="trace", scene=scene, kernel=kernel, only=only, incoherent=dict(rays=nr, ms_mean=float(np.mean(tr)) * 1e3,
+                                                                                                     ms_min=float(np.min(tr)) * 1e3))))
+        return
     rays, _ = scenes.primary_rays(cam, w, h)
     npr = rays.shape[0]
     d_rays = up(rays)

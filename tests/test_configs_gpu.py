@@ -83,7 +83,7 @@ def test_config3_conference_primary_plus_ao():
 def test_config4_hairball_gpu_lbvh_refit_then_diffuse():
     """Hairball-class (2.8 M tris): on-device LBVH build + refit, then diffuse secondary rays (closest hit)."""
     import torch
-    from gpu_util import up
+    from gpu_util import assert_parity, up
     tri, pos, cam = scenes.hairball()
     view, res, keep = device_lbvh(tri, pos)
     ref = oracle.lbvh_build(tri, pos, 8, 0.001)
@@ -94,19 +94,30 @@ def test_config4_hairball_gpu_lbvh_refit_then_diffuse():
     rays, _ = scenes.primary_rays(cam, 1920, 1080)
     got, d_rays, d_res = trace(view, rays, False)
     check_sample(view, res, keep, rays, got, False)
-    # diffuse = AO generator with maxDist = camera far, closest hit (Renderer.cpp:533-537)
-    ns, cnt = 8, 131072
+    # diffuse = AO generator with maxDist = camera far, closest hit (Renderer.cpp:533-537): EVERY batch of the frame, as
+    # RayGen::ao cuts them (at most 2^20 output rays per batch, Renderer.cpp:45, RayGen.cpp:582-602), both kernel families
+    ns, per = 8, (1 << 20) // 8
+    n = rays.shape[0]
     d_nrm = up(scenes.tri_normals(tri, pos))
-    d_df = torch.zeros(cnt * ns * 32, dtype=torch.uint8, device="cuda:0")
-    d_a = torch.zeros(cnt * ns, dtype=torch.int32, device="cuda:0")
-    nt.raygen_ao(d_df.data_ptr(), d_a.data_ptr(), d_a.data_ptr(), d_rays.data_ptr(), d_res.data_ptr(), d_nrm.data_ptr(),
-                 900000, cnt, ns, cam["far"], 0xFFF2D5E4)
-    torch.cuda.synchronize()
-    df = d_df.cpu().numpy().view(nt.RAY_DTYPE)
-    d_dres = torch.zeros(cnt * ns * 16, dtype=torch.uint8, device="cuda:0")
-    view.trace(K, cnt * ns, False, d_df.data_ptr(), d_dres.data_ptr())
-    gd = d_dres.cpu().numpy().view(nt.RESULT_DTYPE)
-    check_sample(view, res, keep, df, gd, False)
+    d_df = torch.zeros(per * ns * 32, dtype=torch.uint8, device="cuda:0")
+    d_a = torch.zeros(per * ns, dtype=torch.int32, device="cuda:0")
+    d_dres = torch.zeros(per * ns * 16, dtype=torch.uint8, device="cuda:0")
+    batches = live = 0
+    for bi, first in enumerate(range(0, n, per)):
+        cnt = min(per, n - first)
+        nt.raygen_ao(d_df.data_ptr(), d_a.data_ptr(), d_a.data_ptr(), d_rays.data_ptr(), d_res.data_ptr(), d_nrm.data_ptr(),
+                     first, cnt, ns, cam["far"], 0xFFF2D5E4)
+        torch.cuda.synchronize()
+        df = d_df.cpu().numpy().view(nt.RAY_DTYPE)[:cnt * ns].copy()
+        exp, _ = oracle.trace(nodes, woop, idx, df, any_hit=False, threads=THREADS)
+        for kernel in ((K, "kepler_dynamic_fetch") if bi % 4 == 0 else (K,)):
+            d_dres.fill_(0xCD)
+            view.trace(kernel, cnt * ns, False, d_df.data_ptr(), d_dres.data_ptr())
+            gd = d_dres.cpu().numpy().view(nt.RESULT_DTYPE)[:cnt * ns]
+            assert_parity(gd, exp, "hairball diffuse batch %d (%s), every record" % (bi, kernel))
+        batches += 1
+        live += int((df["tmax"] > df["tmin"]).sum())
+    assert batches == (n + per - 1) // per and live > 1000000
 
 
 def test_config5_san_miguel_class_10m_triangles():
@@ -129,3 +140,41 @@ def test_config5_san_miguel_class_10m_triangles():
     whole = np.concatenate(parts)
     assert np.array_equal(whole["id"], got["id"]) and np.array_equal(whole["t"].view(np.uint32), got["t"].view(np.uint32))
     check_sample(view, res, keep, rays, got, False)
+
+
+def test_config5_san_miguel_class_ao_leg():
+    """The 8 x AO leg of configuration 5 on the 10 M-triangle device LBVH: AO batches of 2^20 rays generated on the device from
+    the primary hits (rayGenAOKernel semantics, radius scaled to the scene), traced any-hit by both kernel families, every
+    record compared with the oracle on the downloaded buffers (Renderer.cpp:501-564, CudaBVH.cpp:1183-1225)."""
+    import torch
+    from gpu_util import assert_parity, up
+    tri, pos, cam = scenes.courtyard()
+    view, res, keep = device_lbvh(tri, pos)
+    nodes = keep[0].cpu().numpy()[:res.nodesBytes]
+    woop = keep[1].cpu().numpy()[:res.triWoopBytes]
+    idx = keep[2].cpu().numpy()[:res.triIndexBytes].view(np.int32)
+    rays, _ = scenes.primary_rays(cam, 1920, 1080)
+    got, d_rays, d_res = trace(view, rays, False)
+    ns, cnt = 8, (1 << 20) // 8
+    diag = float(np.linalg.norm(pos.max(0).astype(np.float64) - pos.min(0)))
+    radius = 5.0 * diag / 4300.0           # config.conf's aoRadius 5 is in Sponza units
+    d_nrm = up(scenes.tri_normals(tri, pos))
+    d_ao = torch.zeros(cnt * ns * 32, dtype=torch.uint8, device="cuda:0")
+    d_a = torch.zeros(cnt * ns, dtype=torch.int32, device="cuda:0")
+    d_aores = torch.zeros(cnt * ns * 16, dtype=torch.uint8, device="cuda:0")
+    hits = 0
+    for first in (0, 917504, rays.shape[0] - cnt):   # the first, a middle and the last batch of the frame
+        nt.raygen_ao(d_ao.data_ptr(), d_a.data_ptr(), d_a.data_ptr(), d_rays.data_ptr(), d_res.data_ptr(), d_nrm.data_ptr(),
+                     first, cnt, ns, radius, 0xFFF2D5E4)
+        torch.cuda.synchronize()
+        ao = d_ao.cpu().numpy().view(nt.RAY_DTYPE).copy()
+        exp, _ = oracle.trace(nodes, woop, idx, ao, any_hit=True, threads=THREADS)
+        for kernel in (K, "kepler_dynamic_fetch", "tesla_persistent_while_while"):
+            d_aores.fill_(0xCD)
+            view.trace(kernel, cnt * ns, True, d_ao.data_ptr(), d_aores.data_ptr())
+            gao = d_aores.cpu().numpy().view(nt.RESULT_DTYPE)
+            assert_parity(gao, exp, "courtyard-10M AO batch at %d (%s), every record" % (first, kernel))
+        degenerate = ao["tmax"] < ao["tmin"]
+        assert (exp["id"][degenerate] == -1).all()
+        hits += int((exp["id"] >= 0).sum())
+    assert hits > 10000   # the radius is large enough for occlusion to occur

@@ -224,10 +224,7 @@ def test_octant_slabs_change_no_record(soup, monkeypatch, octant):
         ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit, threads=8)
         for kernel in ("fermi_speculative_while_while", "tesla_persistent_while_while"):
             got, _ = gpu_trace(kernel, dbvh, rays, any_hit)
-            if any_hit:
-                assert np.array_equal(got["id"] >= 0, ref["id"] >= 0)
-            else:
-                assert_parity(got, ref, "octant=%d %s" % (octant, kernel))
+            assert_parity(got, ref, "octant=%d %s anyHit=%d" % (octant, kernel, any_hit))
 
 
 @pytest.mark.parametrize("waves", [1, 2, 4])
@@ -247,10 +244,7 @@ def test_workgroup_size_changes_no_record(soup, monkeypatch, waves):
         for any_hit in (False, True):
             ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit, threads=8)
             got, _ = gpu_trace("fermi_speculative_while_while", dbvh, rays, any_hit)
-            if any_hit:
-                assert np.array_equal(got["id"] >= 0, ref["id"] >= 0)
-            else:
-                assert_parity(got, ref, "waves=%d n=%d" % (waves, n))
+            assert_parity(got, ref, "waves=%d n=%d anyHit=%d" % (waves, n, any_hit))
 
 
 def test_validate_flags_an_inverted_box_as_unordered():
@@ -303,3 +297,51 @@ def test_trace_launch_can_be_captured_in_a_hip_graph_and_replayed(soup, monkeypa
         g.replay()
         torch.cuda.synchronize()
         assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), ref, "%s graph replay %d" % (kernel, rep))
+
+
+@pytest.mark.parametrize("tree", ["sah leaves of 1", "sah leaves of up to 6", "device lbvh"])
+def test_unified_step_loop_changes_no_record(soup, monkeypatch, tree):
+    """The unified-step loop (every live lane advances by one inner node OR one triangle per iteration; kepler_dynamic_fetch always, the
+    per-ray kernel on trees flagged NTR_BVH_WIDE_LEAVES) interleaves the lanes differently from the while-while loop and nothing
+    else: forced on and off for both kernels, on one-triangle leaves, multi-triangle leaves and a device-built LBVH; coherent, edge-case
+    and random rays; ragged counts; closest hit and any hit; dynamic-fetch thresholds from 'never refill' to 'refill at once'."""
+    import torch
+    from gpu_util import DeviceBvh, assert_parity, gpu_trace, up
+    tri, pos, cam = scenes.random_soup(6000, seed=23)
+    if tree == "sah leaves of 1":
+        dbvh = DeviceBvh(nt.sah_build(tri, pos, 1, 1))
+        assert not (dbvh.flags & nt.BVH_WIDE_LEAVES)
+    elif tree == "sah leaves of up to 6":
+        dbvh = DeviceBvh(nt.sah_build(tri, pos, 3, 6))
+        assert dbvh.flags & nt.BVH_WIDE_LEAVES
+    else:
+        n = tri.shape[0]
+        capn, capw, capi = nt.lbvh_capacity(n)
+        d_tri, d_pos = up(tri), up(pos)
+        bufs = [torch.zeros(c, dtype=torch.uint8, device="cuda:0") for c in (capn, capw, capi)]
+        mn, mx = oracle.scene_bbox(pos)
+        res = nt.lbvh_build(n, d_tri.data_ptr(), pos.shape[0], d_pos.data_ptr(), mn, mx, 8, 0.001, bufs[0].data_ptr(), capn, bufs[1].data_ptr(), capw,
+                            bufs[2].data_ptr(), capi)
+        torch.cuda.synchronize()
+        host = nt.HostBvh(bufs[0].cpu().numpy()[:res.nodesBytes].copy(), bufs[1].cpu().numpy()[:res.triWoopBytes].copy(),
+                          bufs[2].cpu().numpy()[:res.triIndexBytes].view(np.int32).copy())
+        dbvh = DeviceBvh(host)
+        assert dbvh.flags & nt.BVH_WIDE_LEAVES
+    allrays = np.concatenate([scenes.primary_rays(cam, 200, 160)[0], edge_rays(), scenes.random_rays(20000, seed=5)])
+    for any_hit in (False, True):
+        ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, allrays, any_hit=any_hit, threads=8)
+        for env in ({"NTR_TRACE_PERRAY_UNIFIED": "1"}, {"NTR_TRACE_PERRAY_UNIFIED": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            nt.set_tunables()
+            for n in (allrays.shape[0], 1, 65, 4097):
+                got, _ = gpu_trace("fermi_speculative_while_while", dbvh, allrays[:n], any_hit)
+                assert_parity(got, ref[:n], "%s per-ray %s n=%d anyHit=%d" % (tree, env, n, any_hit))
+        for env in ({"NTR_TRACE_UNIFIED": "1", "NTR_TRACE_FETCH_THRESHOLD": "48"}, {"NTR_TRACE_UNIFIED": "1", "NTR_TRACE_FETCH_THRESHOLD": "64"},
+                    {"NTR_TRACE_UNIFIED": "1", "NTR_TRACE_FETCH_THRESHOLD": "1"}, {"NTR_TRACE_UNIFIED": "0", "NTR_TRACE_FETCH_THRESHOLD": "24"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            nt.set_tunables()
+            for n in (allrays.shape[0], 63, 4097):
+                got, _ = gpu_trace("kepler_dynamic_fetch", dbvh, allrays[:n], any_hit)
+                assert_parity(got, ref[:n], "%s dynamic fetch %s n=%d anyHit=%d" % (tree, env, n, any_hit))
