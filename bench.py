@@ -43,12 +43,28 @@ NUM_TAS = 256              # one texture-address unit per CU
 PEAK_CLOCK_GHZ = 2.4
 
 
-def load_pmc(n_rays, kernel_substr):
-    """Per-dispatch counter means of the launch with `n_rays` work-items from the newest committed rocprofv3 PMC summary
-    (profiles/*_pmc_summary.json, written by scripts/summarize_rocprof.py from separate --pmc passes).  Returns
-    (dict counter -> mean, file name) or ({}, None)."""
+# kernel symbol a selector launches by default (ntr_api.cpp: 64-thread workgroups of the per-ray kernel; template arguments
+# <WAVES, STATS, COOP, UNIFIED> / <WAVES, COOP, TL, UNIFIED>), and the grid it is launched with for n rays
+def launched_symbol(kernel, wide_leaves=False):
+    if kernel.startswith("fermi"):
+        return "trace_bvh_perray<1, false, false, %s>" % ("true" if wide_leaves else "false")
+    return "trace_bvh_persistent<4, false, false, %s>" % ("true" if kernel == "kepler_dynamic_fetch" else "false")
+
+
+def launched_grid(kernel, n_rays, cus=256):
+    if kernel.startswith("fermi"):
+        return ((n_rays + 255) // 256) * 256
+    return min(cus * 6, (n_rays + 255) // 256) * 256
+
+
+def load_pmc(symbol, grid, tag=None):
+    """Per-dispatch counter means of the launches of exactly `symbol` with `grid` work-items from the newest committed rocprofv3
+    PMC summary (profiles/*_pmc_summary.json, written by scripts/summarize_rocprof.py from separate --pmc passes; `tag` restricts
+    the search to files whose name contains it).  Returns (dict counter -> mean, file name) or ({}, None)."""
     best, src = {}, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        if tag and tag not in os.path.basename(f):
+            continue
         try:
             d = json.load(open(f))
         except Exception:
@@ -56,12 +72,41 @@ def load_pmc(n_rays, kernel_substr):
         got = {}
         for k, v in d.items():
             parts = k.split("|")
-            # production instantiations only: the STATS / COOP / timeline variants carry a `true` template argument
-            if len(parts) == 3 and kernel_substr in parts[0] and parts[1] == str(n_rays) and "true" not in parts[0]:
+            if len(parts) == 3 and parts[0].strip() == symbol and parts[1] == str(grid):
                 got[parts[2]] = v
         if got:
             best, src = got, os.path.basename(f)
     return best, src
+
+
+def binding_roofs(pmc, pmc_src, sec, visits=None):
+    """Busy fractions of the units that can bind a trace launch, from per-dispatch PMC means of the same kernel symbol and launch
+    shape and THIS run's launch duration: VALU issue (a wave64 instruction occupies its SIMD-32 for two cycles), the texture-address
+    unit (one per CU), and -- where the bytes are not cache-served -- HBM traffic."""
+    if not pmc:
+        return None
+    clk = pmc.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / sec / 1e9 if pmc.get("GRBM_GUI_ACTIVE") else None
+    use_clk = min(clk, PEAK_CLOCK_GHZ) if clk else PEAK_CLOCK_GHZ
+    b = {"source": "profiles/" + pmc_src, "effective_clock_ghz": clk}
+    if "SQ_INSTS_VALU" in pmc:
+        b["valu_issue_frac"] = pmc["SQ_INSTS_VALU"] / sec / (NUM_SIMDS * use_clk * 1e9 / 2.0)
+    if "TA_BUFFER_TOTAL_CYCLES_sum" in pmc:
+        b["ta_frac"] = pmc["TA_BUFFER_TOTAL_CYCLES_sum"] / NUM_TAS / (sec * use_clk * 1e9)
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:  # KiB; gfx950: FETCH_SIZE counts 64 B per 128-B request
+        b["hbm_traffic_bytes"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        b["hbm_traffic_frac"] = b["hbm_traffic_bytes"] / sec / 1e9 / HBM_PEAK_GBS
+    if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc and (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]) > 0:
+        b["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
+    if visits and "SQ_INSTS_VMEM_RD" in pmc:  # 4 buffer loads per wave-iteration (node: 4 x 16 B; triangle: 3 x 16 B + 4 B)
+        b["lane_util"] = visits / (pmc["SQ_INSTS_VMEM_RD"] / 4.0 * 64.0)
+    if "SQ_WAIT_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"] > 0:
+        b["wave_wait_share"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
+    fr = {k: v for k, v in b.items() if k in ("valu_issue_frac", "ta_frac", "hbm_traffic_frac")}
+    if fr:
+        top = max(fr, key=fr.get)
+        b["bound"] = {"valu_issue_frac": "valu", "ta_frac": "ta", "hbm_traffic_frac": "hbm"}[top]
+        b["frac"] = fr[top]
+    return b
 
 
 def parse(argv=None):
@@ -71,6 +116,12 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong (default): ONE frame sharded by screen tile over the ranks; weak: a full frame per rank")
+    ap.add_argument("--balance", choices=("predicted", "count"), default="count",
+                    help="strong scaling: ranges of equal ray count (default), or of equal predicted cost (ntr_predict_block_costs; "
+                         "measured no better on the simulated ranks: profiles/r03_shard_balance_study.jsonl)")
+    ap.add_argument("--flat-share", type=float, default=4.0,
+                    help="balanced cuts: cost of a block that does not depend on where its rays go (ray load / store, its AO rays), "
+                         "as a multiple of the mean predicted cost (scripts/shard_balance_study.py)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--ao-samples", type=int, default=8)
@@ -132,10 +183,10 @@ class Frame:
     """The ray batches one rank traces of one frame (ntrace_amd.dist.FramePlan), resident in HBM: its slice of the primary
     batch and the AO batches generated on the device from its own primary hits."""
 
-    def __init__(self, nt, torch, view, plan, cam, w, h, tri_normals, args, dev, stream, scenes):
+    def __init__(self, nt, torch, view, make_plan, cam, w, h, tri_normals, args, dev, stream, scenes):
         i32 = torch.int32
         n = w * h
-        self.plan, self.n_primary = plan, n
+        self.n_primary = n
         d_tab = torch.zeros(n, dtype=i32, device=dev)
         nt.pixel_table(w, h, d_tab.data_ptr(), 0, stream)
         self.d_rays = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
@@ -146,6 +197,7 @@ class Frame:
         # a rank traces only [lo, hi) of them
         nt.raygen_primary(self.d_rays.data_ptr(), self.d_i2s.data_ptr(), self.d_s2i.data_ptr(), d_tab.data_ptr(), cam["eye"],
                           scenes.nscreen_to_world(cam, w, h), w, h, cam["far"], 0, stream)
+        plan = self.plan = make_plan(self.d_rays)   # the cut may depend on the rays (ranges of equal predicted cost)
         lo, hi = plan.lo, plan.hi
         self.batches = [dict(name="primary", n=hi - lo, any_hit=False, rays=self.d_rays.data_ptr() + lo * 32,
                              res=self.d_res.data_ptr() + lo * 16, live=hi - lo)]
@@ -198,6 +250,12 @@ def main():
     # NTR_BENCH_FORCE_DIST=1 runs the RCCL code path (init, barrier, all-reduce, broadcast, gather) at world size 1 too
     use_dist = world > 1 or os.environ.get("NTR_BENCH_FORCE_DIST") == "1"
     if use_dist:
+        if world == 1 and "RANK" not in os.environ:   # NTR_BENCH_FORCE_DIST=1 without a launcher: a one-rank RCCL group of our own
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(sk.getsockname()[1]), "RANK": "0", "WORLD_SIZE": "1",
+                               "LOCAL_RANK": "0"})
+            sk.close()
         dist.init_process_group("nccl", device_id=dev)
     nt.lib()
     stream = torch.cuda.current_stream().cuda_stream
@@ -228,16 +286,35 @@ def main():
     w, h = args.width, args.height
     n_primary = w * h
     ns = args.ao_samples
+    cut_info = {"mode": "single range"}
     if args.scaling == "weak" and world > 1:
         # round-1 mode: rank r renders its own frame of a slow camera move (2 units per rank in a 3 600-unit hall keeps the
         # frames distinct but equally costly)
         eye = np.array(cam["eye"], dtype=np.float64)
         eye[2] += 2.0 * rank
         cam["eye"] = tuple(eye)
-        plan = ntd.FramePlan(n_primary, 0, 1, ns, args.ao_batch_rays)
+
+        def make_plan(d_rays):
+            return ntd.FramePlan(n_primary, 0, 1, ns, args.ao_batch_rays)
     else:
-        plan = ntd.FramePlan(n_primary, rank, world, ns, args.ao_batch_rays)
-    frame = Frame(nt, torch, view, plan, cam, w, h, d_nrm, args, dev, stream, scenes)
+        def make_plan(d_rays):
+            # strong scaling: N contiguous PixelTable ranges of equal PREDICTED cost (ntr_predict_block_costs on rank 0, one small
+            # launch outside the timed region; cut points broadcast), instead of equal ray counts
+            cuts = None
+            if world > 1 or use_dist:
+                if args.balance == "predicted":
+                    if rank == 0:
+                        d_cost = torch.zeros((n_primary + 255) // 256, dtype=torch.int32, device=dev)
+                        nt.predict_block_costs(n_primary, d_rays.data_ptr(), d_nodes.data_ptr(), d_nodes.numel(), d_cost.data_ptr(), stream)
+                        torch.cuda.synchronize()
+                        cuts = ntd.balanced_cuts(d_cost.cpu().numpy(), n_primary, world, args.flat_share)
+                    cuts = ntd.broadcast_cuts(cuts, world, dev)
+                    cut_info.update({"mode": "equal predicted cost (ntr_predict_block_costs, flat share %g)" % args.flat_share, "cuts": cuts})
+                else:
+                    cut_info.update({"mode": "equal ray counts"})
+            return ntd.FramePlan(n_primary, rank, world, ns, args.ao_batch_rays, cuts=cuts)
+    frame = Frame(nt, torch, view, make_plan, cam, w, h, d_nrm, args, dev, stream, scenes)
+    plan = frame.plan
     batches = frame.batches
 
     def run_batch(b, timed=False, s=stream):
@@ -276,7 +353,7 @@ def main():
         barrier()
         g0 = time.perf_counter()
         if sharded:
-            full = ntd.gather_hit_records(frame.own_primary_records(), n_primary)
+            full = ntd.gather_hit_records(frame.own_primary_records(), n_primary, cuts=plan.cuts)
         else:
             outs = [torch.empty_like(frame.d_res) for _ in range(world)] if rank == 0 else None
             dist.gather(frame.d_res, outs, dst=0)
@@ -294,7 +371,7 @@ def main():
                 prim_equal = bool(torch.equal(ref_res, full))
                 ref_ao = 0
                 for r in range(world):
-                    pl = ntd.FramePlan(n_primary, r, world, ns, args.ao_batch_rays)
+                    pl = ntd.FramePlan(n_primary, r, world, ns, args.ao_batch_rays, cuts=plan.cuts)
                     for (first, cnt) in pl.ao_batches:
                         t_rays = torch.zeros(cnt * ns * 32, dtype=torch.uint8, device=dev)
                         t_res = torch.zeros(cnt * ns * 16, dtype=torch.uint8, device=dev)
@@ -305,7 +382,7 @@ def main():
                         ref_ao += ntd.records_checksum(t_res)
                 ao_equal = ntd.wrap_i64(ref_ao) == ntd.wrap_i64(ao_sum)
                 frame_check = {"primary_records_equal_single_gpu_frame": prim_equal, "ao_checksum_equal_single_gpu_frame": ao_equal,
-                               "records_compared": n_primary, "ao_records_checksummed": int(sum(ntd.FramePlan(n_primary, r, world, ns, args.ao_batch_rays).num_own_primary for r in range(world)) * ns)}
+                               "records_compared": n_primary, "ao_records_checksummed": int(n_primary * ns)}
                 if not (prim_equal and ao_equal):
                     raise SystemExit("bench.py: the assembled sharded frame differs from the single-GPU frame: %s" % frame_check)
 
@@ -321,6 +398,15 @@ def main():
         ao_alg += view.trace_stats(args.kernel, b["n"], True, b["rays"], b["res"], stream).algorithmic_bytes()
     ao_live = sum(b["live"] for b in batches[1:])
 
+    overlapped = None
+    if world > 1 and not args.no_extras:
+        # every rank's frame share on three streams (no graph: one capture per rank is not worth its set-up here), between barriers;
+        # the job's overlapped rate = rays of all ranks / MAX over ranks of the wall time per frame
+        barrier()
+        ov_s, how, _ = overlapped_frame(args, nt, torch, view, frame, dev, stream, try_graph=False)
+        barrier()
+        tot, ov_max = ntd.job_throughput(rays_per_step, ov_s, dev)
+        overlapped = {"how": how + ", per rank, MAX over ranks", "ms_per_frame": ov_max * 1e3, "mrays_wall": tot / ov_max / 1e6}
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
         try:
@@ -334,29 +420,14 @@ def main():
         return
 
     value = total_rays_per_step * args.steps / kernel_seconds_max / 1e6
-    # binding roofs of the primary launch from the committed PMC passes of the same launch shape (the counters are fixed by
-    # the binary and the rays; the duration is this run's)
-    pmc, pmc_src = load_pmc(b0["n"], "trace_bvh_perray" if args.kernel.startswith("fermi") else "trace_bvh_persistent")
-    binding = None
-    traffic = None
-    if pmc:
-        sec = prim_ms * 1e-3
-        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:  # KiB; gfx950: FETCH_SIZE counts 64 B per 128-B request
-            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-        clk = pmc.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / sec / 1e9 if pmc.get("GRBM_GUI_ACTIVE") else None
-        use_clk = min(clk, PEAK_CLOCK_GHZ) if clk else PEAK_CLOCK_GHZ
-        binding = {"source": "profiles/" + pmc_src, "effective_clock_ghz": clk}
-        if "SQ_INSTS_VALU" in pmc:  # a wave64 VALU instruction occupies its SIMD-32 for two cycles
-            binding["valu_issue_frac"] = pmc["SQ_INSTS_VALU"] / sec / (NUM_SIMDS * use_clk * 1e9 / 2.0)
-        if "TA_BUFFER_TOTAL_CYCLES_sum" in pmc:
-            binding["ta_frac"] = pmc["TA_BUFFER_TOTAL_CYCLES_sum"] / NUM_TAS / (sec * use_clk * 1e9)
-        if "SQ_INSTS_VMEM_RD" in pmc:  # 4 buffer loads per wave-iteration (node: 4 x 16 B; leaf: 3 x 16 B + 4 B)
-            visits = st.numInnerVisits + st.numTriTests + st.numLeafVisits
-            binding["lane_util"] = visits / (pmc["SQ_INSTS_VMEM_RD"] / 4.0 * 64.0)
-        fr = {k: v for k, v in binding.items() if k in ("valu_issue_frac", "ta_frac")}
-        if fr:
-            binding["bound"] = max(fr, key=fr.get).replace("_frac", "").replace("_issue", "")
-            binding["frac"] = max(fr.values())
+    # binding roofs of the primary launch from the committed PMC passes of the SAME kernel symbol and launch shape (the counters
+    # are fixed by the binary and the rays; the duration is this run's)
+    wide = bool(view.flags & nt.BVH_WIDE_LEAVES)
+    symbol = launched_symbol(args.kernel, wide)
+    pmc, pmc_src = load_pmc(symbol, launched_grid(args.kernel, b0["n"]))
+    visits = st.numInnerVisits + st.numTriTests + (st.numLeafVisits if not (wide or args.kernel == "kepler_dynamic_fetch") else 0)
+    binding = binding_roofs(pmc, pmc_src, prim_ms * 1e-3, visits)
+    traffic = binding.get("hbm_traffic_bytes") if binding else None
     par = ("one frame sharded by screen tile over %d ranks (PixelTable ranges), BVH built on rank 0 and broadcast, RCCL gather of hit records" % world
            if not (args.scaling == "weak" and world > 1) else "weak scaling: one full frame per rank (camera shifted per rank), BVH replicated")
     out = {
@@ -379,7 +450,7 @@ def main():
                    "kernel": args.kernel, "bvh_flags": view.flags, "triangles": int(tri.shape[0]),
                    "rays_per_step": int(total_rays_per_step), "rays_per_step_rank0": rays_per_step,
                    "primary_rays_rank0": b0["n"], "primary_hits_rank0": frame.own_hits, "ao_rays_nondegenerate_rank0": ao_live,
-                   "ao_batches_rank0": len(batches) - 1, "parallelism": par},
+                   "ao_batches_rank0": len(batches) - 1, "parallelism": par, "frame_cut": cut_info},
         "primary_mrays": prim_live_total * args.steps / prim_kernel_max / 1e6,
         "ao_mrays": (ao_live_total * args.steps / ao_kernel_max / 1e6) if ao_kernel_max > 0 else None,
         "kernel_ms": {"primary": prim_ms, "ao_total": ao_ms, "per_step_rank0": float(kern_ms.sum(axis=1).mean())},
@@ -387,25 +458,41 @@ def main():
         "sharded_frame_check": frame_check,
         "host_sah_build_s": sah_seconds,
         "trace_stats": st.as_dict(),
+        "overlapped_multi_gpu": overlapped,
         "extras": extras,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "trace_bvh (%s), primary batch of rank 0" % args.kernel,
-                     "launch_ms": prim_ms,
-                     "launch_includes": "predict_kernel + flatten_kernel (dispatch-order prediction, about 30 us) + trace_bvh_perray; "
-                                        "rocprofv3's per-kernel average for trace_bvh_perray alone is in profiles/",
-                     "note": "SURVEY 8(d) accounting: algorithmic bytes / HIP-event time over 8 TB/s.  frac > 1 means the bytes are served "
-                             "by L1/L2/Infinity Cache (the 34 MB BVH is cache-resident; HBM-side bytes per launch are in `traffic`), so "
-                             "HBM is not what binds this launch: `binding` holds the fractions of the roofs that do (VALU issue, "
-                             "texture-address unit), and extras.hbm_resident_point the same kernel on a 0.75 GB BVH with coherent and with incoherent rays",
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "binding": binding,
-                     "cache_ceilings": {"l2_gather_peak": L2_GATHER_PEAK_GBS, "frac_of_l2_gather": achieved / L2_GATHER_PEAK_GBS,
-                                        "infinity_cache_gather_peak": MALL_GATHER_PEAK_GBS,
-                                        "source": "MI355X_MICROARCH.md gather table"},
-                     "ao": {"achieved": (ao_alg / (ao_ms * 1e-3) / 1e9) if ao_ms > 0 else None,
-                            "algorithmic_bytes_all_batches": ao_alg}},
+        "roofline": None,
     }
+    # roofline of the dominant kernel (the primary launch).  The 34 MB BVH of the headline workload is cache-resident, so the SURVEY
+    # 8(d) HBM figure (algorithmic bytes / time / 8 TB/s) exceeds 1 and is not an efficiency: it is kept as `hbm_algorithmic`
+    # ("cache-served"), and the top-level bound / frac name the unit that actually binds the launch, from the PMC passes of the same
+    # kernel symbol.  The launch whose bytes HBM really delivers is `roofline_hbm_resident` (10 M-triangle BVH, incoherent rays).
+    hbm_alg = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "cache_served": True, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic,
+               "note": "SURVEY 8(d) accounting; frac > 1 because L1 / L2 / Infinity Cache serve the bytes (HBM-side bytes per launch in `traffic`)"}
+    roof = {"kernel": "%s (%s), primary batch of rank 0" % (symbol, args.kernel), "launch_ms": prim_ms,
+            "launch_includes": "predict_kernel + flatten_kernel (dispatch-order prediction, about 20 us) + the trace kernel; rocprofv3's "
+                               "per-kernel average for the trace kernel alone is in profiles/",
+            "traffic": traffic, "hbm_algorithmic": hbm_alg, "binding": binding,
+            "cache_ceilings": {"l2_gather_peak": L2_GATHER_PEAK_GBS, "frac_of_l2_gather": achieved / L2_GATHER_PEAK_GBS,
+                               "infinity_cache_gather_peak": MALL_GATHER_PEAK_GBS, "source": "MI355X_MICROARCH.md gather table"},
+            "ao": {"hbm_algorithmic_achieved": (ao_alg / (ao_ms * 1e-3) / 1e9) if ao_ms > 0 else None, "algorithmic_bytes_all_batches": ao_alg}}
+    if binding and binding.get("bound") in ("ta", "valu"):
+        clk = min(binding.get("effective_clock_ghz") or PEAK_CLOCK_GHZ, PEAK_CLOCK_GHZ)
+        if binding["bound"] == "ta":
+            roof.update({"bound": "ta", "unit": "Gcycles/s", "peak": NUM_TAS * clk,
+                         "achieved": pmc["TA_BUFFER_TOTAL_CYCLES_sum"] / (prim_ms * 1e-3) / 1e9, "frac": binding["ta_frac"],
+                         "note": "texture-address unit busy cycles (TA_BUFFER_TOTAL_CYCLES, one TA per CU) over the launch; VALU issue is in binding"})
+        else:
+            roof.update({"bound": "valu", "unit": "Ginstr/s", "peak": NUM_SIMDS * clk / 2.0,
+                         "achieved": pmc["SQ_INSTS_VALU"] / (prim_ms * 1e-3) / 1e9, "frac": binding["valu_issue_frac"],
+                         "note": "wave64 VALU instructions (two cycles each on a SIMD-32) over the launch; the TA fraction is in binding"})
+    else:  # no PMC summary of this symbol committed: only the 8(d) figure is available
+        roof.update({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                     "note": "cache-served (see hbm_algorithmic); no PMC summary of %s under profiles/" % symbol})
+    out["roofline"] = roof
+    hp = extras.get("hbm_resident_point") if isinstance(extras, dict) else None
+    if hp and hp.get("incoherent"):
+        out["roofline_hbm_resident"] = hp["incoherent"]["roofline"]
 
     # ---- CPU baseline: the oracle (restated reference CPU tracer) on a bounded sample, rank 0 at N=1 only -----------------
     if world == 1 and not args.no_cpu_baseline:
@@ -448,20 +535,12 @@ def main():
     sys.stdout.flush()
 
 
-def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, hbm_peak):
-    """Measured outside the timed region, one GPU only: the frame overlapped on streams and replayed as a HIP graph, the
-    opt-in scheduling hints, the device-to-device copy ceiling, the on-device LBVH build of the bench scene, the ray sort
-    and the HBM-resident roofline point (10 M-triangle BVH)."""
-    extras = {}
+def overlapped_frame(args, nt, torch, view, frame, dev, stream, try_graph=True):
+    """The frame's independent AO batches round-robin on a few HIP streams behind the primary batch, the whole frame captured once
+    into a HIP graph and replayed (every kernel runs on every replay): what an application that is not bound to the reference's
+    synchronous launches gets.  Not the protocol, so not `value`.  Returns (seconds per frame, how)."""
     batches = frame.batches
-    n_primary = batches[0]["n"]
-    rays_per_step = frame.rays_per_step
-    i32 = torch.int32
     E = torch.cuda.Event
-
-    # (1) the frame's independent AO batches round-robin on a few HIP streams, the whole frame captured once into a HIP graph
-    # and replayed (every kernel runs on every replay): what an application that is not bound to the reference's synchronous
-    # launches gets.  Not the protocol, so not `value`.
     main_stream = torch.cuda.Stream(device=dev)
     ao_streams = [torch.cuda.Stream(device=dev) for _ in range(args.ao_streams)] if (args.ao_streams > 1 and len(batches) > 2) else []
 
@@ -488,20 +567,21 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
     steps = max(5, min(args.steps, 20))
     note = "launch by launch on %d streams" % max(1, len(ao_streams))
     graph = None
-    try:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
-            run_step(torch.cuda.current_stream())
-        graph.replay()
-        torch.cuda.synchronize()
-        note = "HIP graph replay, AO batches on %d streams" % max(1, len(ao_streams))
-    except Exception as e:
-        graph = None
-        note += " (graph capture failed: %s)" % type(e).__name__
+    if try_graph:
         try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
+                run_step(torch.cuda.current_stream())
+            graph.replay()
             torch.cuda.synchronize()
-        except Exception:
-            pass
+            note = "HIP graph replay, AO batches on %d streams" % max(1, len(ao_streams))
+        except Exception as e:
+            graph = None
+            note += " (graph capture failed: %s)" % type(e).__name__
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
     t0 = time.perf_counter()
     for _ in range(steps):
         if graph is not None:
@@ -511,7 +591,24 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
     torch.cuda.synchronize()
     ov = time.perf_counter() - t0
     nt.trace_status(stream)
-    extras["overlapped_frame"] = {"how": note, "ms_per_frame": ov / steps * 1e3, "mrays_wall": rays_per_step * steps / ov / 1e6, "steps": steps}
+    del graph
+    return ov / steps, note, steps
+
+
+def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, hbm_peak):
+    """Measured outside the timed region, one GPU only: the frame overlapped on streams and replayed as a HIP graph, the
+    opt-in scheduling hints, the device-to-device copy ceiling, the on-device LBVH build of the bench scene, the ray sort
+    and the HBM-resident roofline point (10 M-triangle BVH)."""
+    extras = {}
+    batches = frame.batches
+    n_primary = batches[0]["n"]
+    rays_per_step = frame.rays_per_step
+    i32 = torch.int32
+    E = torch.cuda.Event
+
+    # (1) the frame overlapped on streams and replayed as a HIP graph
+    ov_s, note, steps = overlapped_frame(args, nt, torch, view, frame, dev, stream)
+    extras["overlapped_frame"] = {"how": note, "ms_per_frame": ov_s * 1e3, "mrays_wall": rays_per_step / ov_s / 1e6, "steps": steps}
 
     # (2) opt-in scheduling hints (ntr_trace_bvh_hinted): block order learned from the previous trace of the same batch
     hints = [nt.SchedHint() for _ in batches]
@@ -618,20 +715,35 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         nr = 1 << 21
         d_rr = up(scenes.box_rays(pos10, nr, seed=21))
         d_ro = torch.zeros(nr * 16, dtype=torch.uint8, device=dev)
-        lview.trace(args.kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream)
-        tr = [lview.trace(args.kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream) for _ in range(5)]
+        wide10 = bool(lview.flags & nt.BVH_WIDE_LEAVES)
+        per_kernel = {}
+        for kn in (args.kernel, "kepler_dynamic_fetch"):   # the selector of the frame, and the one made for divergent batches
+            lview.trace(kn, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream)
+            tr = [lview.trace(kn, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream) for _ in range(5)]
+            per_kernel[kn] = float(np.mean(tr))
         sr = lview.trace_stats(args.kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream)
-        secr = float(np.mean(tr))
+        best_kn = min(per_kernel, key=per_kernel.get)
+        secr = per_kernel[best_kn]
 
         def roof(st_, s_):
             return {"bound": "hbm", "achieved": st_.algorithmic_bytes() / s_ / 1e9, "peak": hbm_peak, "unit": "GB/s",
                     "frac": st_.algorithmic_bytes() / s_ / 1e9 / hbm_peak, "algorithmic_bytes_per_launch": st_.algorithmic_bytes()}
+        r_inc = roof(sr, secr)
+        sym = launched_symbol(best_kn, wide10)
+        pmc_i, src_i = load_pmc(sym, launched_grid(best_kn, nr), tag="courtyard")
+        bind_i = binding_roofs(pmc_i, src_i, secr, sr.numInnerVisits + sr.numTriTests) if pmc_i else None
+        r_inc.update({"kernel": "%s (%s)" % (sym, best_kn), "launch_ms": secr * 1e3,
+                      "traffic": bind_i.get("hbm_traffic_bytes") if bind_i else None, "binding": bind_i,
+                      "workload": "courtyard-10M device LBVH (0.75 GB), 2^21 incoherent closest-hit rays",
+                      "note": "the launch whose bytes HBM really delivers: SURVEY 8(d) algorithmic bytes / time / 8 TB/s; `traffic` = PMC bytes of "
+                              "the same kernel symbol (FETCH_SIZE x 2 + WRITE_SIZE) from profiles/"})
         extras["hbm_resident_point"] = {
             "scene": "courtyard-10M stand-in for San Miguel, device LBVH (leafSize 8)", "triangles": int(tri10.shape[0]),
             "bvh_bytes": int(best.nodesBytes + best.triWoopBytes + best.triIndexBytes),
             "primary": {"rays": w * h, "ms": sec * 1e3, "mrays": w * h / sec / 1e6, "trace_stats": s10.as_dict(), "roofline": roof(s10, sec)},
             "incoherent": {"rays": nr, "what": "2^21 closest-hit rays, origins uniform in the bounding box, directions uniform on the sphere",
-                           "ms": secr * 1e3, "mrays": nr / secr / 1e6, "trace_stats": sr.as_dict(), "roofline": roof(sr, secr)},
+                           "ms_by_kernel": {k: v * 1e3 for k, v in per_kernel.items()}, "kernel": best_kn,
+                           "ms": secr * 1e3, "mrays": nr / secr / 1e6, "trace_stats": sr.as_dict(), "roofline": r_inc},
             "note": "HBM-side bytes (FETCH_SIZE / WRITE_SIZE / L2 hit rate) of these launches: profiles/*_trace_courtyard_* summaries",
             "lbvh_build": info10}
         del keep, lview, d_r10, d_o10, d_rr, d_ro

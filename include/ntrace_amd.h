@@ -144,6 +144,20 @@ NTR_API int ntr_trace_bvh(const char* kernelName, int32_t numRays, int32_t anyHi
  * (seconds != NULL) perform the same check themselves.  The word is shared by all streams of the device. */
 NTR_API int ntr_trace_status(void* stream, uint32_t* statusBits);
 
+/* HIP graphs.  An asynchronous ntr_trace_bvh (seconds == NULL) may be captured into a HIP graph.  Nothing can be allocated
+ * during a capture, and the scratch of a captured launch must outlive the graph, so the library hands such a launch scratch
+ * of its OWN from per-device stores that are filled outside captures and never recycled while pinned:
+ *   - pool counters of the persistent kernels: 192 captured launches per device;
+ *   - dispatch-order prediction scratch (closest-hit per-ray launches of >= 2^20 rays): private to each captured launch
+ *     (a replay on any stream never shares it with a live launch); every live launch of a size keeps 4 spares of that size
+ *     ready, ntr_trace_graph_reserve(launches, numRays) provisions more (48 entries per process in all);
+ *   - the top-of-tree table of a BVH (16 BVHs): trace the BVH once, or call ntr_bvh_validate, before capturing.
+ * When a store is exhausted the capture-time call fails with NTR_ERR_NOMEM / NTR_ERR_INVALID and says so.  A host that
+ * re-captures graphs (e.g. every frame) calls ntr_trace_graph_release_all() once the graphs holding earlier captures are
+ * destroyed: it waits for the device and returns every pinned resource of the current device to its store. */
+NTR_API int ntr_trace_graph_reserve(int32_t launches, int32_t numRays);
+NTR_API int ntr_trace_graph_release_all(void);
+
 /* Re-reads the NTR_* environment tunables.  They are read once, at first use; sweep scripts
  * that change a variable inside one process call this afterwards.  Not needed by applications. */
 NTR_API int ntr_tunables_reload(void);
@@ -173,6 +187,14 @@ NTR_API int ntr_trace_bvh_hinted(const char* kernelName, int32_t numRays, int32_
                                  const void* d_triWoop, int64_t triWoopBytes, const int32_t* d_triIndex,
                                  int32_t layout, uint32_t bvhFlags, void* stream, float* seconds,
                                  NtrSchedHint* hint);
+
+/* Cost estimate of every 256-ray block of a batch, without tracing it: d_blockCost[b] = number of boxes of the BVH's top-of-tree
+ * table (the child boxes of the nodes of depth <= 9) that the block's sample ray (its 100th) intersects -- the predictor behind
+ * the dispatch order of large closest-hit launches (Spearman 0.86-0.89 against the true block cost on primary batches).  No
+ * counterpart in the reference; a multi-GPU host uses it to cut a frame into ranges of equal predicted cost instead of equal
+ * ray count (ntrace_amd/dist.py FramePlan).  d_blockCost: (numRays + 255) / 256 words.  Asynchronous on `stream`. */
+NTR_API int ntr_predict_block_costs(int32_t numRays, const NtrRay* d_rays, const void* d_nodes, int64_t nodesBytes,
+                                    uint32_t* d_blockCost, void* stream);
 
 /* Traversal counters: the reference's RayStats (src/rt/bvh/BVH.hpp:44-60), filled by its
  * CPU tracer at src/rt/cuda/CudaBVH.cpp:746-757 and 1107-1111.  numInnerVisits =
@@ -276,6 +298,11 @@ NTR_API int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_
                            const float sceneMin[3], const float sceneMax[3], int32_t leafSize, float epsilon,
                            void* d_nodes, int64_t nodesCapacity, void* d_triWoop, int64_t triWoopCapacity,
                            int32_t* d_triIndex, int64_t triIndexCapacity, NtrLbvhResult* result, void* stream);
+
+/* The builder keeps one grow-only scratch workspace per device between builds (a rebuild per frame must not pay allocations):
+ * about 175 B per triangle on the default path (1.75 GB after a 10 M-triangle build).  A host that builds once and then only
+ * traces returns it with this call (it waits for the device first); the next build allocates again. */
+NTR_API int ntr_lbvh_release_workspace(void);
 
 /* reconstructKernel (src/rt/cuda/RendererKernels.cu:59-172; ReconstructInput, RendererKernels.hpp:46-70;
  * Renderer::updateResult, Renderer.cpp:583-659): hit records of one batch -> ABGR8 pixels.

@@ -59,6 +59,7 @@ def lib_path():
 
 
 _lib = None
+_libs = {}   # path -> loaded CDLL (use_library switches between the product library and the experiment build inside one process)
 
 # every symbol include/ntrace_amd.h declares: (name, restype, argtypes)
 _vp, _i32, _i64, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
@@ -81,6 +82,10 @@ SYMBOLS = [
                                        C.POINTER(C.c_float), _vp]),
     ("ntr_trace_status", C.c_int, [_vp, C.POINTER(_u32)]),
     ("ntr_tunables_reload", C.c_int, []),
+    ("ntr_predict_block_costs", C.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
+    ("ntr_trace_graph_reserve", C.c_int, [_i32, _i32]),
+    ("ntr_trace_graph_release_all", C.c_int, []),
+    ("ntr_lbvh_release_workspace", C.c_int, []),
     ("ntr_sched_hint_create", C.c_int, [C.POINTER(_vp)]),
     ("ntr_sched_hint_destroy", C.c_int, [_vp]),
     ("ntr_sched_hint_reset", C.c_int, [_vp]),
@@ -113,11 +118,8 @@ SYMBOLS = [
 ]
 
 
-def lib():
-    """Load libntrace_amd.so; raises if it was not built (no fallback)."""
-    global _lib
-    if _lib is None:
-        path = lib_path()
+def _load(path):
+    if path not in _libs:
         if not os.path.exists(path):
             raise ImportError("ntrace_amd: %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(the HIP extension is mandatory; there is no CPU fallback)" % path)
@@ -133,7 +135,28 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = L
+        _libs[path] = L
+    return _libs[path]
+
+
+def lib():
+    """Load libntrace_amd.so; raises if it was not built (no fallback)."""
+    global _lib
+    if _lib is None:
+        _lib = _load(lib_path())
+    return _lib
+
+
+def exp_lib_path():
+    return os.path.join(_HERE, "libntrace_amd_exp.so")
+
+
+def use_library(path=None):
+    """Tests / scripts only: make `path` (default: the product library, or NTR_LIB_OVERRIDE) the library every wrapper of this
+    module calls.  The experiment build (exp_lib_path(): diagnostic hooks + the superseded LBVH build paths kept for A/B runs) and
+    the product library can both be loaded in one process; each has its own tunables and workspaces."""
+    global _lib
+    _lib = _load(path or lib_path())
     return _lib
 
 
@@ -191,6 +214,25 @@ def trace_status(stream=0):
     bits = _u32(0)
     _check(lib().ntr_trace_status(_vp(stream), C.byref(bits)))
     return int(bits.value)
+
+
+def predict_block_costs(num_rays, d_rays, d_nodes, nodes_bytes, d_block_cost, stream=0):
+    """ntr_predict_block_costs: predicted cost (top-of-tree boxes hit by the sample ray) of every 256-ray block, into d_block_cost."""
+    _check(lib().ntr_predict_block_costs(int(num_rays), _vp(d_rays), _vp(d_nodes), int(nodes_bytes), _vp(d_block_cost), _vp(stream)))
+
+
+def trace_graph_reserve(launches, num_rays):
+    """ntr_trace_graph_reserve: provision scratch for `launches` captured launches of num_rays rays."""
+    _check(lib().ntr_trace_graph_reserve(int(launches), int(num_rays)))
+
+
+def trace_graph_release_all():
+    """ntr_trace_graph_release_all: return every resource pinned by captured launches (call when their graphs are destroyed)."""
+    _check(lib().ntr_trace_graph_release_all())
+
+
+def lbvh_release_workspace():
+    _check(lib().ntr_lbvh_release_workspace())
 
 
 def set_tunables(**kv):

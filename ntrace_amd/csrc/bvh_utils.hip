@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "ntr_internal.h"
 
 namespace ntr {
@@ -42,9 +44,13 @@ __global__ __launch_bounds__(256) void bvh_validate_kernel(const float4* __restr
         leaves += (unsigned int)__shfl_xor((int)leaves, off);
         maxLeafOfs = max(maxLeafOfs, (unsigned int)__shfl_xor((int)maxLeafOfs, off));
     }
-    if ((threadIdx.x & 63) == 0 && leaves) {
-        atomicAdd(bad + 1, leaves);
-        atomicMax(bad + 2, maxLeafOfs);
+    // per-workgroup partials, summed on the host (thousands of waves adding to ONE word cost more than the whole pass)
+    __shared__ unsigned int s_leaves[4], s_max[4];
+    if ((threadIdx.x & 63) == 0) { s_leaves[threadIdx.x >> 6] = leaves; s_max[threadIdx.x >> 6] = maxLeafOfs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bad[4 + 2 * blockIdx.x] = s_leaves[0] + s_leaves[1] + s_leaves[2] + s_leaves[3];
+        bad[5 + 2 * blockIdx.x] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
     }
 }
 
@@ -59,19 +65,22 @@ extern "C" int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_
     if (!d_nodes || nodesBytes < 64 || (nodesBytes % 64) != 0 || nodesBytes > 0x76543200ll)
         return set_error(NTR_ERR_INVALID, "ntr_bvh_validate: node buffer size must be a multiple of 64 in [64, 0x76543200]");
     hipStream_t s = (hipStream_t)stream;
-    unsigned int* d_bad = nullptr;
-    NTR_HIP(hipMalloc((void**)&d_bad, 4 * sizeof(unsigned int)));
-    NTR_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(unsigned int), s));
     const int64_t n4 = nodesBytes / 16;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
+    unsigned int* d_bad = nullptr;   // [0] flag bits, [4 + 2 b], [5 + 2 b]: leaf count / last leaf offset seen by workgroup b
+    const size_t words = 4 + 2 * (size_t)blocks;
+    NTR_HIP(hipMalloc((void**)&d_bad, words * sizeof(unsigned int)));
+    NTR_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(unsigned int), s));
     hipLaunchKernelGGL(bvh_validate_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)d_nodes, n4, d_bad);
     NTR_HIP(hipGetLastError());
-    unsigned int h[4] = {0, 0, 0, 0};
-    NTR_HIP(hipMemcpyAsync(h, d_bad, sizeof(h), hipMemcpyDeviceToHost, s));
+    std::vector<unsigned int> hv(words, 0u);
+    NTR_HIP(hipMemcpyAsync(hv.data(), d_bad, words * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     NTR_HIP(hipStreamSynchronize(s));
     NTR_HIP(hipFree(d_bad));
-    const unsigned int bad = h[0];
+    const unsigned int bad = hv[0];
+    unsigned int h[4] = {bad, 0, 0, 0};
+    for (int b = 0; b < blocks; b++) { h[1] += hv[4 + 2 * b]; h[2] = hv[5 + 2 * b] > h[2] ? hv[5 + 2 * b] : h[2]; }
     // the last leaf starts at float4 index h[2]: with L leaves the triWoop buffer holds about h[2] / L float4 per leaf (3 per triangle + 1)
     if (h[1] > 0 && (double)h[2] / (double)h[1] >= 7.0) *flags |= NTR_BVH_WIDE_LEAVES;
     if (!(bad & 1u)) *flags |= NTR_BVH_FINITE;

@@ -1,33 +1,30 @@
 // lbvh_kernels.hip -- on-device LBVH builder for gfx950.
 //
-// Rebuilds the pipeline of HLBVHBuilder::buildLBVH (src/rt/bvh/HLBVH/HLBVHBuilder.cpp:451-593):
-//   calcMorton      emitTreeKernel.cu:655-691   -> lbvh_morton_kernel
-//   radixSortCuda   radixSort.cu:22-50 (Thrust) -> hand-written LSD radix sort, 4 x 8 bits:
-//                                                  per-tile LDS histograms, one scan, and a stable
-//                                                  scatter ranked with wave64 ballots (match-any)
-//   calcWoopKernel  emitTreeKernel.cu:574-645   -> woop_rows(): computed once per triangle by
-//                                                  lbvh_place_kernel, straight into the slot its leaf
-//                                                  reserved (no intermediate array, no copy)
-//   emitTreeKernel  emitTreeKernel.cu:233-381   -> three launches instead of one per level (the
-//   + createLeaf    :170-231                       reference also reads g_outQueuePtr back to the host
-//   calcAABB        emitTreeKernel.cu:417-562      every level, HLBVHBuilder.cpp:347): lbvh_top_kernel
-//   + calcLeaf      :383-408                       (one workgroup) splits ranges larger than S = 3072
-//                                                  triangles level by level; lbvh_subtree_kernel gives
-//                                                  every smaller range to one workgroup: topology of the
-//                                                  whole subtree in an LDS entry list, one pair of global
-//                                                  atomics, all nodes / leaf boxes / slots written in
-//                                                  parallel, bottom-up refit; lbvh_top_refit_kernel closes
-//                                                  the boxes of the top levels.  Leaf boxes are folded from
-//                                                  per-triangle terms (lbvh_tribox_kernel).
-//                                                  NTR_LBVH_LEVELSYNC=1 selects the older one-launch-per-
-//                                                  level kernels (lbvh_emit_kernel / lbvh_refit_kernel /
-//                                                  lbvh_woop_kernel).
+// Rebuilds the pipeline of HLBVHBuilder::buildLBVH (src/rt/bvh/HLBVH/HLBVHBuilder.cpp:451-593).  Default path, ten launches and no
+// host read-back before the end:
+//   calcMorton      emitTreeKernel.cu:655-691   -> lbvh_morton_hist_kernel: codes, the digit histograms of all four sort passes and a
+//                                                  packed 36-B vertex record per triangle in ONE read of the mesh
+//   radixSortCuda   radixSort.cu:22-50 (Thrust) -> onesweep_pass_kernel x 4 (radix_sort.h): one launch per 8-bit digit, chained scan
+//                                                  with decoupled look-back, match-any ballot ranking
+//   emitTreeKernel  emitTreeKernel.cu:233-381   -> BOTTOM-UP: lbvh_leafmark_kernel + lbvh_markscan_kernel find every leaf start from the
+//   + createLeaf    :170-231                       sorted keys alone and rank them (node index = rank of the split position, leaf storage =
+//   calcWoopKernel  :574-645                       3 * start + leaves before); lbvh_agglomerate_kernel (+ lbvh_agglomerate_top_kernel from
+//   calcAABB        :417-562                       2^20 triangles) grows the radix tree from the leaves -- two siblings meet at their split
+//   + calcLeaf      :383-408                       position, the second to arrive forms the parent WITH its boxes -- and writes every node
+//                                                  word, Woop row, index and terminator once, to its final place; lbvh_runs_kernel adds the
+//                                                  reference's median subtrees for runs of equal codes.  (Section "Bottom-up emit" below.)
+// Fallback, top-down (scenes of at most NTR_LBVH_SPLIT = 3072 triangles, n <= leafSize, leaves of more than 32 triangles):
+//   lbvh_gather_box_kernel (box terms in sorted order), lbvh_top_kernel (one workgroup splits ranges larger than the split size level
+//   by level), lbvh_subtree_kernel (one workgroup per smaller range: topology in an LDS entry list, one pair of global atomics, bottom-up
+//   refit), lbvh_top_refit_kernel, lbvh_place_kernel (Woop rows straight into the slots the leaves reserved).
+// The round-1 / round-2 A/B paths (one launch per level, three-kernel sort passes, cell-table top pass) are compiled only with
+// -DNTR_EXPERIMENTS into libntrace_amd_exp.so (`make exp`); tests/test_lbvh_gpu.py runs them against that library.
 //
 // The tree is the reference's tree: same split rule (highest differing Morton bit at or below the
 // level's bit, median when none), same leaf rule (count <= leafSize, or the level's bit is 0), same
 // Woop rows and boxes (strict IEEE evaluation of the reference expressions; the reference builds
 // these kernels with -use_fast_math so its own bits are toolchain dependent).  Node numbering and
-// leaf placement depend on atomic order, as in the reference (emitTreeKernel.cu:176,303); parity is
+// leaf placement depend on atomic order in the reference (emitTreeKernel.cu:176,303) and are position ranks here; parity is
 // checked on the canonical (numbering-independent) form.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -75,6 +72,7 @@ struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
 struct __attribute__((packed, aligned(4))) TriVerts { V3 v[3]; };
 static_assert(sizeof(TriVerts) == 36, "TriVerts must be 36 bytes");
 
+#ifdef NTR_EXPERIMENTS // round-1 per-level path (A/B scaffolding: libntrace_amd_exp.so only)
 __global__ __launch_bounds__(256) void lbvh_morton_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
                                                           F3 lo, F3 step, unsigned int* __restrict__ keys,
                                                           int* __restrict__ idx)
@@ -96,6 +94,7 @@ __global__ __launch_bounds__(256) void lbvh_morton_kernel(int n, const int* __re
     idx[t] = t;
 }
 
+#endif  // NTR_EXPERIMENTS
 // Morton codes as lbvh_morton_kernel, fused with everything else that one pass over the mesh can produce:
 //   * the digit histograms of all four radix passes (LDS, then one global add per non-empty bin and workgroup), so
 //     that the sort is four one-sweep launches and nothing else;
@@ -106,8 +105,10 @@ __global__ __launch_bounds__(256) void lbvh_morton_kernel(int n, const int* __re
 // Grid-stride over a bounded number of workgroups, so that the histogram flush stays at <= 2048 x 1024 atomics.
 constexpr int MORTON_THREADS = 256;
 constexpr int MORTON_MAX_BLOCKS = 2048;
-constexpr int TOP_CELL_BITS = 14;                      // the top of the tree is derived from the keys' upper 14 bits
+#ifdef NTR_EXPERIMENTS
+constexpr int TOP_CELL_BITS = 14;                      // cell-table top pass: the top of the tree is derived from the keys' upper 14 bits
 constexpr int TOP_CELLS = 1 << TOP_CELL_BITS;
+#endif
 
 __global__ __launch_bounds__(MORTON_THREADS) void lbvh_morton_hist_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
                                                                           F3 lo, F3 step, float eps, unsigned int* __restrict__ keys,
@@ -164,11 +165,15 @@ __global__ __launch_bounds__(256) void lbvh_gather_box_kernel(int n, const unsig
     const int t = triSorted[j];
     const float2 a = boxMesh[3 * (size_t)t], b = boxMesh[3 * (size_t)t + 1], c = boxMesh[3 * (size_t)t + 2];
     triBox[3 * (size_t)j] = a; triBox[3 * (size_t)j + 1] = b; triBox[3 * (size_t)j + 2] = c;
-    const int c1 = (int)(keys[j] >> (30 - TOP_CELL_BITS));
-    const int c0 = j ? (int)(keys[j - 1] >> (30 - TOP_CELL_BITS)) : -1;
-    for (int cc = c0 + 1; cc <= c1; cc++) cellStart[cc] = (unsigned int)j;
-    if (j == n - 1)
-        for (int cc = c1 + 1; cc <= TOP_CELLS; cc++) cellStart[cc] = (unsigned int)n;
+#ifdef NTR_EXPERIMENTS
+    if (cellStart) {
+        const int c1 = (int)(keys[j] >> (30 - TOP_CELL_BITS));
+        const int c0 = j ? (int)(keys[j - 1] >> (30 - TOP_CELL_BITS)) : -1;
+        for (int cc = c0 + 1; cc <= c1; cc++) cellStart[cc] = (unsigned int)j;
+        if (j == n - 1)
+            for (int cc = c1 + 1; cc <= TOP_CELLS; cc++) cellStart[cc] = (unsigned int)n;
+    }
+#endif
 }
 
 // ---- Woop rows (emitTreeKernel.cu:574-635) ---------------------------------------------------------
@@ -202,6 +207,7 @@ __device__ __forceinline__ void woop_rows(const int* __restrict__ tri, const flo
                     pos[3 * i2 + 1], pos[3 * i2 + 2], r0, r1, r2);
 }
 
+#ifdef NTR_EXPERIMENTS // round-1 per-level path
 __global__ __launch_bounds__(256) void lbvh_woop_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
                                                         float4* __restrict__ out)
 {
@@ -214,22 +220,7 @@ __global__ __launch_bounds__(256) void lbvh_woop_kernel(int n, const int* __rest
     out[3 * t + 2] = r2;
 }
 
-// Subtree path, before the emit: the term every triangle contributes to its leaf's box
-// (calcLeaf, emitTreeKernel.cu:383-408: min/max over the three vertices, -/+ epsilon), in sorted order,
-// stored as (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z).
-__global__ __launch_bounds__(256) void lbvh_tribox_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
-                                                          const int* __restrict__ triSorted, float eps, float2* __restrict__ triBox)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int t = triSorted[j];
-    const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float a = pos[3 * i0 + k], b = pos[3 * i1 + k], c = pos[3 * i2 + k];
-        triBox[3 * j + k] = make_float2(fminf(a, fminf(b, c)) - eps, fmaxf(a, fmaxf(b, c)) + eps);
-    }
-}
+#endif  // NTR_EXPERIMENTS
 
 // Subtree path, after the emit: Woop rows and original index of every triangle, written straight to the
 // slot its leaf reserved (triOut[j] = float4 index of sorted triangle j).
@@ -250,6 +241,7 @@ __global__ __launch_bounds__(256) void lbvh_place_kernel(int n, const int* __res
     outIdx[o + 2] = 0;
 }
 
+#ifdef NTR_EXPERIMENTS // round-1 per-level emit / refit kernels
 // ---- tree emission, one level per launch (emitTreeKernel.cu:233-381) ------------------------------
 __device__ __forceinline__ int create_leaf(LbvhState* st, const float4* __restrict__ inWoop, const int* __restrict__ triSorted,
                                            float4* __restrict__ outWoop, int* __restrict__ outIdx, int start, int end)
@@ -396,6 +388,7 @@ __global__ __launch_bounds__(256) void lbvh_refit_kernel(int lvl, float eps, con
 }
 
 
+#endif  // NTR_EXPERIMENTS
 // ---- subtree path: emit + refit with workgroup barriers only ------------------------------------------
 // Position where bit `level` of the sorted keys flips inside [nStart, nEnd) (emitTreeKernel.cu:263-280).
 // keys[nStart] and keys[nEnd-1] differ in that bit and agree above it, so the flip is unique; K-1
@@ -604,6 +597,7 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_kernel(EmitCtx c, int n,
     }
 }
 
+#ifdef NTR_EXPERIMENTS // cell-table top pass (measured slower than the bottom-up emit; A/B only)
 // ---- top of the tree from the cell table ---------------------------------------------------------------------------------------
 // Above the cells (the keys' upper TOP_CELL_BITS bits) the tree is a function of the cell table alone: a tree node whose keys
 // first differ in bit 29 - L is the trie node (L, prefix) whose two halves are both non-empty, its range is the trie node's range
@@ -757,6 +751,8 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_cells_kernel(EmitCtx c, 
         c.st->topTrieLevels = s_trieLevels;
     }
 }
+
+#endif  // NTR_EXPERIMENTS
 
 // Split position as find_split, for ranges of fewer than 2^16 keys held in LDS: 32-bit probe arithmetic.
 template <int LOGK>
@@ -928,6 +924,7 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_refit_kernel(const LbvhS
     refit_levels<TOP_THREADS>(ofs, lv, topLst, nodes);
 }
 
+#ifdef NTR_EXPERIMENTS // cell-table top pass
 // Refit of the cell-table top: the oversize cells' levels first (deepest first), then the trie levels bottom-up, each
 // level's top nodes found through the heap-indexed map.
 __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_cells_refit_kernel(const LbvhState* __restrict__ st, const int* __restrict__ topLst,
@@ -946,6 +943,8 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_cells_refit_kernel(const
         __syncthreads();  // the level above reads these boxes (same workgroup, same CU)
     }
 }
+
+#endif  // NTR_EXPERIMENTS
 
 
 // =====================================================================================================================
@@ -1032,6 +1031,8 @@ struct AggCtx {
     AggExport* exports;          // [tiles][AGG_EXPORT_CAP] (two-stage mode)
     unsigned int* exportCount;   // [tiles], zeroed
     AggSlotG* slotG;             // [n + 1][2] meeting slots in memory
+    const unsigned int* abortFlag;     // non-zero: the sort gave up (a look-back timed out) -- the keys are not sorted, and the meeting
+                                       // protocol (exactly two arrivals per boundary) only terminates on sorted keys: emit nothing
 };
 
 // exclusive rank of position p (set bits before p) = count before its 1024-block + count inside the block before its 256-tile
@@ -1205,6 +1206,7 @@ __device__ __forceinline__ bool agg_form_parent(const AggCtx& c, int rootSplit, 
 template <bool EXPORT>
 __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
 {
+    if (*c.abortFlag) return;   // workgroup-uniform
     constexpr int BIT_WORDS = AGG_TILE / 64 + 2;               // the tile's mark words and two beyond it (leafSize <= AGG_HALO look-ahead)
     __shared__ unsigned int sKeys[AGG_TILE + 2 * AGG_HALO];   // sKeys[AGG_HALO + k] = key of position tileBeg + k
     __shared__ unsigned int sMeet[AGG_TILE + 1];               // per boundary: 0, or 1 + the compacted index of the cluster waiting there
@@ -1441,6 +1443,7 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
 // key differences at the cluster's two ends carried along (no key is read any more).
 __global__ __launch_bounds__(256) void lbvh_agglomerate_top_kernel(AggCtx c, int numTiles)
 {
+    if (*c.abortFlag) return;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int tile = g / AGG_EXPORT_CAP, k = g % AGG_EXPORT_CAP;
     if (tile >= numTiles || (unsigned int)k >= min(c.exportCount[tile], (unsigned int)AGG_EXPORT_CAP)) return;
@@ -1545,6 +1548,7 @@ __device__ __forceinline__ void agg_rewrite_big_leaf(const AggCtx& c, int rootSp
 
 __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
 {
+    if (*c.abortFlag) return;
     const unsigned int numRuns = *c.runCount;
     const int rootSplit = (int)c.st->rootSplit;
     const int lane = threadIdx.x;
@@ -1826,6 +1830,21 @@ int workspace_reserve(size_t bytes, void** out)
     return NTR_OK;
 }
 
+int workspace_release()
+{
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return set_error(NTR_ERR_INVALID, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_wsMu);
+    Workspace& w = g_ws[dev];
+    if (w.p) {
+        NTR_HIP(hipDeviceSynchronize());
+        NTR_HIP(hipFree(w.p));
+        w.p = nullptr; w.bytes = 0;
+    }
+    return NTR_OK;
+}
+
 struct Carver {  // 256-byte aligned slices of the workspace
     size_t off = 0;
     size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
@@ -1834,6 +1853,8 @@ struct Carver {  // 256-byte aligned slices of the workspace
 }  // namespace
 
 extern "C" {
+
+int ntr_lbvh_release_workspace(void) { return workspace_release(); }
 
 int ntr_lbvh_capacity(int32_t numTris, int64_t* nodesBytes, int64_t* triWoopBytes, int64_t* triIndexBytes)
 {
@@ -1862,22 +1883,45 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     hipStream_t s = (hipStream_t)stream;
     const int n = numTris;
     if (n >= (1 << 28)) return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: at most 2^28 - 1 triangles");
+#ifdef NTR_EXPERIMENTS
     const int nb = (n + SORT_TILE - 1) / SORT_TILE;
+#endif
     // one-sweep tiles: 2048 keys while the launch is latency-bound; 6144 / 8192 for large inputs (fewer tiles to look back over, longer
     // runs per digit in the scatter: 10 M keys 80 -> 71 us per pass, scripts/jobs/gpu_job_r02sort.sh)
     const int osItems = n >= (1 << 23) ? 32 : (n >= (1 << 21) ? 24 : 8);
     const int osTiles = (n + OS_THREADS * osItems - 1) / (OS_THREADS * osItems);
     const Tunables tun = tunables();
+#ifdef NTR_EXPERIMENTS   // A/B scaffolding of rounds 1-2, compiled into libntrace_amd_exp.so only (tests/test_lbvh_gpu.py runs them against it)
     const bool levelSync = tun.lbvhLevelSync != 0;
     const bool legacySort = levelSync || tun.lbvhLegacySort != 0;
+    const bool cellsTop = tun.lbvhEmit == 1;
+    const bool legacyTop = tun.lbvhLegacyTop != 0;
+#else
+    constexpr bool levelSync = false, legacySort = false, cellsTop = false, legacyTop = false;
+#endif
     if (n >= (1 << 27)) return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: at most 2^27 - 1 triangles");
 
+    int spillSize = tun.lbvhSplit;
+    if (spillSize < 2) spillSize = 2;
+    if (spillSize > 7168) spillSize = 7168;  // 20 bytes of LDS per triangle of a subtree (140 KB), 16-bit positions
+    // 0: the whole tree is one hand-over root (scenes of at most `spill` triangles: one subtree workgroup);
+    // 2: level-by-level top pass with key probes + subtree workgroups (n <= leafSize: a root over two leaves; leaves of more than
+    //    AGG_HALO triangles: the bottom-up path keeps that many neighbours of a tile in LDS);
+    // 3: bottom-up emit with ranked indices -- the default; [experiments: 1 = cell-table top + subtree workgroups]
+    const int topMode = n <= spillSize ? 0 : ((legacyTop || n <= leafSize || leafSize > AGG_HALO) ? 2 : (cellsTop ? 1 : 3));
+    const bool bottomUp = !levelSync && topMode == 3;
+    const bool topDown = !levelSync && topMode != 3;
+
+    // workspace: only the slices of the path that runs are reserved (bottom-up: about 175 B per triangle, top-down: about 100 B)
     Carver cv;
+    auto takeIf = [&](bool cond, size_t bytes) { return cv.take(cond ? bytes : 0); };
     const size_t oKeysA = cv.take((size_t)n * 4), oKeysB = cv.take((size_t)n * 4);
     const size_t oIdxA = cv.take((size_t)n * 4), oIdxB = cv.take((size_t)n * 4);
-    const size_t oWoop = cv.take((size_t)n * 48);  // per-level path: Woop rows in mesh order; subtree path: box terms in mesh order (24 B)
-    const size_t oQ0 = cv.take(((size_t)n + 2) * 16), oQ1 = cv.take(((size_t)n + 2) * 16);
-    const size_t oHist = cv.take(((size_t)nb * 256 + 256) * 4);
+    const size_t oWoop = takeIf(levelSync || topDown, (size_t)n * (levelSync ? 48 : 24));  // per-level path: Woop rows in mesh order; top-down path: box terms in mesh order
+    const size_t oQ0 = takeIf(levelSync || topDown, ((size_t)n + 2) * 16), oQ1 = takeIf(levelSync || topDown, ((size_t)n + 2) * 16);
+#ifdef NTR_EXPERIMENTS
+    const size_t oHist = takeIf(legacySort, ((size_t)nb * 256 + 256) * 4);
+#endif
     // cleared by ONE memset per build: builder state, one-sweep digit histograms, error flag and tickets
     const size_t oState = cv.take(sizeof(LbvhState));
     const size_t oOsHist = cv.take(4 * 256 * 4);
@@ -1886,25 +1930,27 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     // bottom-up emit: its zeroed region (meeting counters, export counts, run count, report-in counter) follows, so that ONE memset
     // clears both
     const int aggTiles = (n + AGG_TILE - 1) / AGG_TILE;
-    const size_t oArrive = cv.take(((size_t)n + 1) * 4);
-    const size_t oExportCount = cv.take((size_t)aggTiles * 4);
-    const size_t oAggMisc = cv.take(64);           // [0] number of runs of more than leafSize equal keys
+    const size_t oArrive = takeIf(bottomUp, ((size_t)n + 1) * 4);
+    const size_t oExportCount = takeIf(bottomUp, (size_t)aggTiles * 4);
+    const size_t oAggMisc = takeIf(bottomUp, 64);           // [0] number of runs of more than leafSize equal keys
     const int cntTiles = (n + 1 + RANK_BLOCK - 1) / RANK_BLOCK;    // prefix-count blocks
     const size_t oAggZeroEnd = cv.off;
     const size_t oOsState = cv.take((size_t)osTiles * 256 * 4);
-    const size_t oSubList = cv.take(((size_t)n / 2 + 2) * 16);
-    const size_t oTopLst = cv.take(((size_t)n + 2) * 4);
-    const size_t oTriBox = cv.take((size_t)n * 24), oTriOut = cv.take((size_t)n * 4);
-    const size_t oCell = cv.take(((size_t)TOP_CELLS + 1) * 4), oTopIdx = cv.take((size_t)TOP_HEAP * 4);
-    // bottom-up emit: zeroed region (flags, meeting counters, scan state) first, then records, slots, ranks
-    const size_t oSlot = cv.take(((size_t)n + 1) * 96);
-    const size_t oExports = cv.take((size_t)aggTiles * AGG_EXPORT_CAP * sizeof(AggExport));
-    const size_t oTriVerts = cv.take((size_t)n * 36);
-    const size_t oParentPos = cv.take(((size_t)n + 1) * 4);
-    const size_t oRuns = cv.take(((size_t)n / 2 + 2) * 16);
-    const size_t oLeafBits = cv.take((size_t)cntTiles * (RANK_BLOCK / 8)), oRunBits = cv.take((size_t)cntTiles * (RANK_BLOCK / 8));
-    const size_t oTileCount = cv.take((size_t)cntTiles * 4), oTileBase = cv.take((size_t)cntTiles * 4);
-    const size_t oSubBase = cv.take((size_t)cntTiles * MARK_SUBS * 4);
+    const size_t oSubList = takeIf(topDown, ((size_t)n / 2 + 2) * 16);
+    const size_t oTopLst = takeIf(topDown, ((size_t)n + 2) * 4);
+    const size_t oTriBox = takeIf(topDown, (size_t)n * 24), oTriOut = takeIf(topDown, (size_t)n * 4);
+#ifdef NTR_EXPERIMENTS
+    const size_t oCell = takeIf(topMode == 1, ((size_t)TOP_CELLS + 1) * 4), oTopIdx = takeIf(topMode == 1, (size_t)TOP_HEAP * 4);
+#endif
+    // bottom-up emit: slots of the border meetings, exported roots, vertex records, parent indices, runs, leaf / run marks and their counts
+    const size_t oSlot = takeIf(bottomUp, ((size_t)n + 1) * 96);
+    const size_t oExports = takeIf(bottomUp, (size_t)aggTiles * AGG_EXPORT_CAP * sizeof(AggExport));
+    const size_t oTriVerts = takeIf(bottomUp, (size_t)n * 36);
+    const size_t oParentPos = takeIf(bottomUp, ((size_t)n + 1) * 4);
+    const size_t oRuns = takeIf(bottomUp, ((size_t)n / 2 + 2) * 16);
+    const size_t oLeafBits = takeIf(bottomUp, (size_t)cntTiles * (RANK_BLOCK / 8)), oRunBits = takeIf(bottomUp, (size_t)cntTiles * (RANK_BLOCK / 8));
+    const size_t oTileCount = takeIf(bottomUp, (size_t)cntTiles * 4), oTileBase = takeIf(bottomUp, (size_t)cntTiles * 4);
+    const size_t oSubBase = takeIf(bottomUp, (size_t)cntTiles * MARK_SUBS * 4);
     void* wsBase = nullptr;
     {
         const int rc = workspace_reserve(cv.off, &wsBase);
@@ -1918,15 +1964,6 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     PhaseEvents pe(s);
     pe.mark(0);
 
-    int spillSize = tun.lbvhSplit;
-    if (spillSize < 2) spillSize = 2;
-    if (spillSize > 7168) spillSize = 7168;  // 20 bytes of LDS per triangle of a subtree (140 KB), 16-bit positions
-    // 0: the whole tree is one hand-over root; 1: cell-table top + subtree workgroups; 2: level-by-level top with key probes;
-    // 3: bottom-up emit with ranked indices (default; it gathers the box terms itself)
-    // (a scene of at most leafSize triangles is a root over two leaves: the table / bottom-up paths expect more than one leaf's worth)
-    // (leaves of more than AGG_HALO triangles: the bottom-up path keeps that many neighbours of a tile in LDS, larger ones take the top-down path)
-    const int topMode = n <= spillSize ? 0 : ((tun.lbvhLegacyTop || n <= leafSize || leafSize > AGG_HALO) ? 2 : (tun.lbvhEmit == 1 ? 1 : 3));
-    const bool bottomUp = !levelSync && topMode == 3;
     NTR_HIP(hipMemsetAsync(ws + oState, 0, (bottomUp ? oAggZeroEnd : oClearEnd) - oState, s));
 
     // L1: Morton codes (step = (max - min) / 1024 on the host, HLBVHBuilder.cpp:76-81)
@@ -1934,9 +1971,12 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     F3 step = {(sceneMax[0] - sceneMin[0]) / 1024.0f, (sceneMax[1] - sceneMin[1]) / 1024.0f, (sceneMax[2] - sceneMin[2]) / 1024.0f};
     unsigned int *kIn = (unsigned int*)(ws + oKeysA), *kOut = (unsigned int*)(ws + oKeysB);
     int *vIn = (int*)(ws + oIdxA), *vOut = (int*)(ws + oIdxB);
+#ifdef NTR_EXPERIMENTS
     if (levelSync) {
         hipLaunchKernelGGL(lbvh_morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, lo, step, kIn, vIn);
-    } else {
+    } else
+#endif
+    {
         int mb = (n + MORTON_THREADS * 4 - 1) / (MORTON_THREADS * 4);
         if (mb > MORTON_MAX_BLOCKS) mb = MORTON_MAX_BLOCKS;
         hipLaunchKernelGGL(lbvh_morton_hist_kernel, dim3(mb), dim3(MORTON_THREADS), 0, s, n, d_triVtxIndex, d_vtxPos, lo, step, epsilon, kIn, vIn,
@@ -1946,15 +1986,18 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     pe.mark(1);
 
     // L2: stable radix sort by key, 4 passes of 8 bits (the 30-bit code fits)
-    unsigned int* hist = (unsigned int*)(ws + oHist);
     for (int pass = 0; pass < 4; pass++) {
         const int shift = pass * 8;
+#ifdef NTR_EXPERIMENTS
         if (legacySort) {
+            unsigned int* hist = (unsigned int*)(ws + oHist);
             hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, 1, shift, hist, nb);
             hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(256), dim3(256), 0, s, hist, nb, hist + (size_t)nb * 256);
             hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, kOut, vOut, 1,
                                shift, (const unsigned int*)hist, (const unsigned int*)hist + (size_t)nb * 256, nb);
-        } else {
+        } else
+#endif
+        {
             if (osItems == 32)
                 hipLaunchKernelGGL((onesweep_pass_kernel<32, 0>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
                                    1, shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
@@ -1977,16 +2020,23 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
 
     // L4: Woop rows in original triangle order (per-level path), or the per-triangle box terms in sorted order plus the
     // cell table of the top pass (subtree path; its Woop rows are produced by lbvh_place_kernel once the leaves have their slots)
+#ifdef NTR_EXPERIMENTS
     if (levelSync)
         hipLaunchKernelGGL(lbvh_woop_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, (float4*)(ws + oWoop));
     else if (topMode != 3)
         hipLaunchKernelGGL(lbvh_gather_box_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, keys, triSorted, (const float2*)(ws + oWoop),
-                           (float2*)(ws + oTriBox), (unsigned int*)(ws + oCell));
+                           (float2*)(ws + oTriBox), topMode == 1 ? (unsigned int*)(ws + oCell) : (unsigned int*)nullptr);
+#else
+    if (topMode != 3)
+        hipLaunchKernelGGL(lbvh_gather_box_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, keys, triSorted, (const float2*)(ws + oWoop),
+                           (float2*)(ws + oTriBox), (unsigned int*)nullptr);
+#endif
     pe.mark(3);
 
     // L3 + L5: emit and refit
     const unsigned int nodeCap = (unsigned int)(nodesCapacity / 64);
     LbvhState h;
+#ifdef NTR_EXPERIMENTS
     if (levelSync) {
         LbvhState init;
         memset(&init, 0, sizeof(init));
@@ -2021,7 +2071,9 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         }
         pe.mark(5);
         pe.mark(6);
-    } else {
+    } else
+#endif
+    {
         EmitCtx c;
         c.st = state; c.keys = keys; c.triBox = (const float2*)(ws + oTriBox); c.triOut = (int*)(ws + oTriOut);
         c.nodes = (int*)d_nodes; c.nodeCap = nodeCap; c.outWoop = (float4*)d_triWoop; c.outIdx = d_triIndex;
@@ -2060,6 +2112,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             a.arrive = (unsigned int*)(ws + oArrive); a.parentPos = (int*)(ws + oParentPos);
             a.runs = (int4*)(ws + oRuns); a.runCount = aggMisc; a.st = state; a.useLds = tun.lbvhAggLds;
             a.exports = (AggExport*)(ws + oExports); a.exportCount = (unsigned int*)(ws + oExportCount); a.slotG = (AggSlotG*)(ws + oSlot);
+            a.abortFlag = osMisc + 4;
             // leaf starts and their prefix counts first: everything after it writes to final places
             hipLaunchKernelGGL(lbvh_leafmark_kernel, dim3(cntTiles), dim3(MARK_THREADS), 0, s, n, leafSize, keys, (unsigned long long*)(ws + oLeafBits),
                                (unsigned long long*)(ws + oRunBits), (unsigned int*)(ws + oTileCount), (unsigned int*)(ws + oSubBase), state);
@@ -2092,10 +2145,12 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             NTR_HIP(hipMemcpyAsync(state, &init, sizeof(init), hipMemcpyHostToDevice, s));
             const int root[4] = {0, 0, n, 0};
             NTR_HIP(hipMemcpyAsync(c.subList, root, 16, hipMemcpyHostToDevice, s));
+#ifdef NTR_EXPERIMENTS
         } else if (topMode == 1) {
             NTR_HIP(hipFuncSetAttribute((const void*)lbvh_top_cells_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopLds)));
             hipLaunchKernelGGL(lbvh_top_cells_kernel, dim3(1), dim3(TOP_THREADS), sizeof(TopLds), s, c, n, (const unsigned int*)(ws + oCell),
                                (int*)(ws + oTopIdx), q0, q1, (int*)(ws + oTopLst));
+#endif
         } else {
             hipLaunchKernelGGL(lbvh_top_kernel, dim3(1), dim3(TOP_THREADS), 0, s, c, n, q0, q1, (int*)(ws + oTopLst));
         }
@@ -2109,10 +2164,13 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             if (rc != NTR_OK) return rc;
         }
         pe.mark(5);
+#ifdef NTR_EXPERIMENTS
         if (topMode == 1)
             hipLaunchKernelGGL(lbvh_top_cells_refit_kernel, dim3(1), dim3(TOP_THREADS), 0, s, (const LbvhState*)state, (const int*)(ws + oTopLst),
                                (const int*)(ws + oTopIdx), (int*)d_nodes);
-        else if (topMode == 2)
+        else
+#endif
+        if (topMode == 2)
             hipLaunchKernelGGL(lbvh_top_refit_kernel, dim3(1), dim3(TOP_THREADS), 0, s, (const LbvhState*)state, (const int*)(ws + oTopLst),
                                (int*)d_nodes);
         hipLaunchKernelGGL(lbvh_place_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, triSorted,
@@ -2141,6 +2199,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         numNodes = h.nodeCount;
         numLevels = (int)h.maxLevel;
     }
+    (void)legacySort; (void)cellsTop;
 
     // Compact child references are S32 byte offsets below the sentinel 0x76543210 (CudaBVH.hpp:42-46): a tree with more nodes than that
     // cannot be expressed (the buffers were sized for it, so nothing was written out of bounds; the references are what overflowed)

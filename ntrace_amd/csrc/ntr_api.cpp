@@ -58,6 +58,7 @@ static constexpr int kMaxDevices = 64;
 static constexpr int64_t kMaxNodesBytes = 0x76543200ll;  // largest multiple of 64 below the sentinel 0x76543210
 static DeviceState g_dev[kMaxDevices];
 static std::mutex g_mu;
+static std::mutex g_statusMu;
 
 bool stream_is_capturing(hipStream_t s)
 {
@@ -294,19 +295,25 @@ static TopTable g_top[kTopTables];
 static unsigned long long g_topClock = 0;
 static constexpr size_t kTopTableBytes = (((size_t)2 << NTR_TOP_DEPTH_MAX) + 16) * 32;  // + padding read by predict_kernel's batches
 
-// Class counters / lists / block order of one prediction, per stream (launches on one stream are ordered;
-// two streams must not share them).
+// Class counters / lists / block order of one prediction.  A live (not captured) launch uses the entry owned by its stream
+// (launches on one stream are ordered; two streams must not share an entry).  A launch that is being captured into a HIP graph
+// gets an entry of its OWN, taken from spares that live launches provision (nothing may be allocated during a capture): a graph
+// replayed on whatever stream then never shares order[] with a live launch or with another captured launch.  Pinned entries are
+// returned to the spares by ntr_trace_graph_release_all().
 struct PredictScratch {
-    void* stream = nullptr;
+    enum State { FREE = 0, LIVE, SPARE, PINNED };
+    State state = FREE;
+    void* stream = nullptr;              // LIVE: the owning stream (the null stream is a stream like any other)
     int device = -1;
     unsigned int* classCount = nullptr;  // NTR_SCHED_PRED_CLASSES counters, zero whenever no prediction is in flight
     unsigned int* classList = nullptr;
     unsigned int* order = nullptr;
     int capBlocks = 0;
     unsigned long long lastUse = 0;
-    bool pinned = false;                 // referenced by a captured HIP graph: never evicted, never regrown
 };
-static constexpr int kScratch = 32;
+static constexpr int kScratch = 48;
+static constexpr int kScratchSpares = 4;   // spares a live launch keeps ready (per device, sized for the largest launch seen) for captured launches
+static constexpr int kScratchLive = 16;    // streams with an entry of their own before the least recently used one is recycled
 static PredictScratch g_scratch[kScratch];
 
 static int top_table_get(const void* d_nodes, int64_t nodesBytes, hipStream_t s, bool rebuild, TopTable** out)
@@ -350,44 +357,112 @@ extern "C" int ntr_top_table_refresh(const void* d_nodes, int64_t nodesBytes, vo
     return top_table_get(d_nodes, nodesBytes, (hipStream_t)stream, true, &t);
 }
 
+static int scratch_alloc(PredictScratch* p, int dev, int numBlocks)
+{
+    if (!p->classCount) {
+        NTR_HIP(hipMalloc((void**)&p->classCount, NTR_SCHED_PRED_CLASSES * sizeof(unsigned int)));
+        NTR_HIP(hipMemset(p->classCount, 0, NTR_SCHED_PRED_CLASSES * sizeof(unsigned int)));
+    }
+    if (p->capBlocks < numBlocks) {
+        if (p->classList) { (void)hipFree(p->classList); (void)hipFree(p->order); p->classList = p->order = nullptr; p->capBlocks = 0; }
+        NTR_HIP(hipMalloc((void**)&p->classList, (size_t)NTR_SCHED_PRED_CLASSES * numBlocks * sizeof(unsigned int)));
+        NTR_HIP(hipMalloc((void**)&p->order, (size_t)numBlocks * sizeof(unsigned int)));
+        p->capBlocks = numBlocks;
+    }
+    p->device = dev;
+    return NTR_OK;
+}
+
+static void scratch_free(PredictScratch* p)
+{
+    if (p->classCount) (void)hipFree(p->classCount);
+    if (p->classList) (void)hipFree(p->classList);
+    if (p->order) (void)hipFree(p->order);
+    *p = PredictScratch();
+}
+
+// spares of at least numBlocks on `dev` (g_mu held)
+static int scratch_count_spares(int dev, int numBlocks)
+{
+    int n = 0;
+    for (auto& e : g_scratch)
+        if (e.state == PredictScratch::SPARE && e.device == dev && e.capBlocks >= numBlocks) n++;
+    return n;
+}
+
+// makes sure `want` spares of at least numBlocks exist on `dev` (g_mu held, not capturing): smaller spares are regrown first (nothing
+// references a spare), then free slots are taken; running out of slots is not an error here
+static int scratch_provision_spares(int dev, int numBlocks, int want)
+{
+    int have = scratch_count_spares(dev, numBlocks);
+    for (auto& e : g_scratch) {
+        if (have >= want) break;
+        if (e.state == PredictScratch::SPARE && e.device == dev && e.capBlocks < numBlocks) {
+            const int rc = scratch_alloc(&e, dev, numBlocks);
+            if (rc != NTR_OK) return rc;
+            have++;
+        }
+    }
+    for (auto& e : g_scratch) {
+        if (have >= want) break;
+        if (e.state != PredictScratch::FREE) continue;
+        const int rc = scratch_alloc(&e, dev, numBlocks);
+        if (rc != NTR_OK) return rc;
+        e.state = PredictScratch::SPARE;
+        have++;
+    }
+    return NTR_OK;
+}
+
 static int predict_scratch_get(hipStream_t s, int numBlocks, PredictScratch** out)
 {
     int dev = 0;
     NTR_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
     const bool capturing = stream_is_capturing(s);
+    if (capturing) {   // a private entry from the spares: the smallest that fits
+        PredictScratch* best = nullptr;
+        for (auto& e : g_scratch)
+            if (e.state == PredictScratch::SPARE && e.device == dev && e.capBlocks >= numBlocks && (!best || e.capBlocks < best->capBlocks)) best = &e;
+        if (!best)
+            return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: no prediction scratch is ready for a captured launch of this size: trace a batch "
+                                              "of this size once outside the capture (it keeps %d spares ready), call ntr_trace_graph_reserve, or "
+                                              "release the captures of destroyed graphs (ntr_trace_graph_release_all)", kScratchSpares);
+        best->state = PredictScratch::PINNED;
+        best->lastUse = ++g_topClock;
+        *out = best;
+        return NTR_OK;
+    }
     PredictScratch* p = nullptr;
     PredictScratch* lru = nullptr;
+    PredictScratch* empty = nullptr;
+    int live = 0;
     for (auto& e : g_scratch) {
-        // a pinned entry (held by a graph) serves later launches of its stream only while it is large enough
-        if (e.classCount && e.stream == (void*)s && e.device == dev && (!e.pinned || e.capBlocks >= numBlocks)) { p = &e; break; }
-        if (!e.pinned && (!lru || e.lastUse < lru->lastUse)) lru = &e;
+        if (e.state == PredictScratch::LIVE) {
+            live++;
+            if (e.stream == (void*)s && e.device == dev) { p = &e; break; }
+            if (!lru || e.lastUse < lru->lastUse) lru = &e;
+        } else if (e.state == PredictScratch::FREE && !empty) {
+            empty = &e;
+        }
     }
-    if (capturing && (!p || p->capBlocks < numBlocks))
-        return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: a launch of this size must run once on the stream before it can be captured");
     if (!p) {
-        if (!lru) return set_error(NTR_ERR_NOMEM, "ntr_trace_bvh: every prediction scratch is held by a captured HIP graph");
-        p = lru;
-        if (p->classCount) {
-            NTR_HIP(hipDeviceSynchronize());  // an evicted stream's launches may still read it
-            (void)hipFree(p->classCount); (void)hipFree(p->classList); (void)hipFree(p->order);
-            p->classCount = p->classList = p->order = nullptr; p->capBlocks = 0;
+        p = (empty && live < kScratchLive) ? empty : (lru ? lru : empty);
+        if (!p) return set_error(NTR_ERR_NOMEM, "ntr_trace_bvh: every prediction scratch is held by a captured HIP graph (ntr_trace_graph_release_all)");
+        if (p->state == PredictScratch::LIVE) {
+            NTR_HIP(hipDeviceSynchronize());  // the evicted stream's launches may still read it
+            scratch_free(p);
         }
-        NTR_HIP(hipMalloc((void**)&p->classCount, NTR_SCHED_PRED_CLASSES * sizeof(unsigned int)));
-        NTR_HIP(hipMemset(p->classCount, 0, NTR_SCHED_PRED_CLASSES * sizeof(unsigned int)));
-        p->stream = (void*)s; p->device = dev;
+    } else if (p->capBlocks < numBlocks && p->classList) {
+        NTR_HIP(hipStreamSynchronize(s));
     }
-    if (p->capBlocks < numBlocks) {
-        if (p->classList) {
-            NTR_HIP(hipStreamSynchronize(s));
-            (void)hipFree(p->classList); (void)hipFree(p->order);
-        }
-        NTR_HIP(hipMalloc((void**)&p->classList, (size_t)NTR_SCHED_PRED_CLASSES * numBlocks * sizeof(unsigned int)));
-        NTR_HIP(hipMalloc((void**)&p->order, (size_t)numBlocks * sizeof(unsigned int)));
-        p->capBlocks = numBlocks;
-    }
+    int rc = scratch_alloc(p, dev, numBlocks);
+    if (rc != NTR_OK) return rc;
+    p->state = PredictScratch::LIVE;
+    p->stream = (void*)s;
     p->lastUse = ++g_topClock;
-    if (capturing) p->pinned = true;
+    rc = scratch_provision_spares(dev, numBlocks, kScratchSpares);
+    if (rc != NTR_OK) return rc;
     *out = p;
     return NTR_OK;
 }
@@ -600,12 +675,13 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         *seconds = ms * 1e-3f;
         (void)hipEventDestroy(ev0);
         (void)hipEventDestroy(ev1);
-        unsigned int st = 0;
-        NTR_HIP(hipMemcpy(&st, ds->status, sizeof(st), hipMemcpyDeviceToHost));
-        if (st & NTR_STATUS_STACK_OVERFLOW) {
-            (void)hipMemset(ds->status, 0, sizeof(st));
-            return set_error(NTR_ERR_OVERFLOW, "trace_bvh: traversal stack overflow");
-        }
+        unsigned int st = 0;   // fetch-and-clear in one device-side step (the word is shared by all streams of the device)
+        std::lock_guard<std::mutex> slk(g_statusMu);
+        const hipError_t xe = ntr_launch_status_exchange(ds->status, ds->status + 8, s);
+        if (xe != hipSuccess) return hip_fail(xe, "status_exchange launch");
+        NTR_HIP(hipMemcpyAsync(&st, ds->status + 8, sizeof(st), hipMemcpyDeviceToHost, s));
+        NTR_HIP(hipStreamSynchronize(s));
+        if (st & NTR_STATUS_STACK_OVERFLOW) return set_error(NTR_ERR_OVERFLOW, "trace_bvh: traversal stack overflow");
     }
     if (stats) {
         unsigned long long h[4];
@@ -646,15 +722,63 @@ int ntr_trace_status(void* stream, uint32_t* statusBits)
     if (rc != NTR_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     unsigned int st = 0;
-    NTR_HIP(hipMemcpyAsync(&st, ds->status, sizeof(st), hipMemcpyDeviceToHost, s));
+    // fetched and cleared in ONE device-side step: a bit set by a launch on another stream is either in this answer or in the next
+    std::lock_guard<std::mutex> lk(g_statusMu);   // the result word ds->status[8] is shared by the callers of one device
+    const hipError_t xe = ntr_launch_status_exchange(ds->status, ds->status + 8, s);
+    if (xe != hipSuccess) return hip_fail(xe, "status_exchange launch");
+    NTR_HIP(hipMemcpyAsync(&st, ds->status + 8, sizeof(st), hipMemcpyDeviceToHost, s));
     NTR_HIP(hipStreamSynchronize(s));
     if (statusBits) *statusBits = st;
-    if (st != 0) {
-        NTR_HIP(hipMemsetAsync(ds->status, 0, sizeof(st), s));
-        NTR_HIP(hipStreamSynchronize(s));
-    }
     if (st & NTR_STATUS_STACK_OVERFLOW)
         return set_error(NTR_ERR_OVERFLOW, "trace_bvh: traversal stack overflow in a launch since the last status check");
+    return NTR_OK;
+}
+
+int ntr_predict_block_costs(int32_t numRays, const NtrRay* d_rays, const void* d_nodes, int64_t nodesBytes, uint32_t* d_blockCost, void* stream)
+{
+    if (numRays < 0) return set_error(NTR_ERR_INVALID, "ntr_predict_block_costs: numRays < 0");
+    if (numRays == 0) return NTR_OK;
+    if (!d_rays || !d_nodes || !d_blockCost) return set_error(NTR_ERR_INVALID, "ntr_predict_block_costs: null argument");
+    if (nodesBytes < 64 || (nodesBytes % 64) != 0 || nodesBytes > kMaxNodesBytes)
+        return set_error(NTR_ERR_INVALID, "ntr_predict_block_costs: node buffer size must be a multiple of 64 in [64, 0x76543200]");
+    TopTable* t = nullptr;
+    const int rc = top_table_get(d_nodes, nodesBytes, (hipStream_t)stream, false, &t);
+    if (rc != NTR_OK) return rc;
+    const hipError_t e = ntr_launch_predict_costs(d_rays, numRays, (numRays + 255) / 256, t->table, t->count, d_blockCost, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "predict_costs launch");
+    return NTR_OK;
+}
+
+int ntr_trace_graph_reserve(int32_t launches, int32_t numRays)
+{
+    if (launches < 0 || numRays < 0) return set_error(NTR_ERR_INVALID, "ntr_trace_graph_reserve: negative argument");
+    DeviceState* ds = nullptr;
+    int rc = get_device_state(&ds);
+    if (rc != NTR_OK) return rc;
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    const int numBlocks = (numRays + 255) / 256;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (numBlocks > 0 && launches > 0) {
+        rc = scratch_provision_spares(dev, numBlocks, launches);
+        if (rc != NTR_OK) return rc;
+        if (scratch_count_spares(dev, numBlocks) < launches)
+            return set_error(NTR_ERR_NOMEM, "ntr_trace_graph_reserve: at most %d prediction scratches exist (ntr_trace_graph_release_all returns the pinned ones)", kScratch);
+    }
+    return NTR_OK;
+}
+
+int ntr_trace_graph_release_all(void)
+{
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    NTR_HIP(hipDeviceSynchronize());   // replays in flight still read the scratch
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& e : g_scratch)
+        if (e.state == PredictScratch::PINNED && e.device == dev) e.state = PredictScratch::SPARE;   // back to the spares
+    for (auto& t : g_top)
+        if (t.device == dev) t.pinned = false;
+    if (dev >= 0 && dev < kMaxDevices) g_dev[dev].nextPinned = 0;
     return NTR_OK;
 }
 

@@ -17,6 +17,7 @@ static constexpr int SORT_THREADS = 256;
 static constexpr int SORT_ITEMS = 8;
 static constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // keys per workgroup
 
+#ifdef NTR_EXPERIMENTS   // the round-1 three-kernel pass (histogram / scan / scatter): A/B scaffolding, libntrace_amd_exp.so only
 template <bool INDEXED>
 __device__ __forceinline__ unsigned int sort_key(const unsigned int* __restrict__ keys, const int* __restrict__ vals, int stride, int k)
 {
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(int n, const
         }
     }
 }
+
+#endif  // NTR_EXPERIMENTS
 
 }  // namespace ntr
 

@@ -72,7 +72,8 @@ constexpr int PRED_SAMPLE = 100;        // sample ray inside the block (any fixe
 __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* __restrict__ rays, int numRays, int numBlocks,
                                                                   const float4* __restrict__ table,
                                                                   const unsigned int* __restrict__ tableCount,
-                                                                  unsigned int* __restrict__ classCount, unsigned int* __restrict__ classList)
+                                                                  unsigned int* __restrict__ classCount, unsigned int* __restrict__ classList,
+                                                                  unsigned int* __restrict__ blockCost /* or null: counts only, no class lists */)
 {
     constexpr int PER_MAX = ((2 << NTR_TOP_DEPTH_MAX) + PRED_WAVES - 1) / PRED_WAVES;  // boxes per wave, at most
     __shared__ float2 s_tab[PRED_WAVES][PER_MAX * 3];  // per wave: its slice of the table, (lo, hi) per axis
@@ -111,6 +112,10 @@ __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* 
     }
     if (cnt) atomicAdd(&s_cnt[lane], cnt);
     __syncthreads();
+    if (blockCost) {   // cost query (ntr_predict_block_costs): the raw box counts, nothing else
+        if (tid < 64 && block < numBlocks) blockCost[block] = s_cnt[lane];
+        return;
+    }
     unsigned int cls = 0;
     if (tid < 64 && block < numBlocks) {
         cls = min(s_cnt[lane] >> 1, (unsigned int)(NTR_SCHED_PRED_CLASSES - 1));
@@ -167,7 +172,20 @@ __global__ __launch_bounds__(256) void zero_words_kernel(unsigned int* __restric
     for (int i = blockIdx.x * 256 + threadIdx.x; i < words; i += gridDim.x * 256) p[i] = 0;
 }
 
+// Fetches and clears the sticky status word in ONE device-side step (an overflow bit set by a launch on another stream between a
+// copy and a separate clear would be lost): out[0] = atomicExch(status, 0).
+__global__ void status_exchange_kernel(unsigned int* __restrict__ status, unsigned int* __restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = atomicExch(status, 0u);
+}
+
 }  // namespace ntr
+
+extern "C" hipError_t ntr_launch_status_exchange(unsigned int* d_status, unsigned int* d_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ntr::status_exchange_kernel, dim3(1), dim3(64), 0, stream, d_status, d_out);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t ntr_launch_top_table(const void* d_nodes, unsigned int nodesBytes, int depth, void* d_table,
                                            unsigned int* d_tableCount, hipStream_t stream)
@@ -186,9 +204,18 @@ extern "C" hipError_t ntr_launch_predict(const void* d_rays, int numRays, int nu
 {
     const int grid = (numBlocks + 63) / 64;
     hipLaunchKernelGGL(ntr::predict_kernel, dim3(grid), dim3(ntr::PRED_WAVES * 64), 0, stream, (const float4*)d_rays, numRays, numBlocks,
-                       (const float4*)d_table, d_tableCount, d_classCount, d_classList);
+                       (const float4*)d_table, d_tableCount, d_classCount, d_classList, (unsigned int*)nullptr);
     hipLaunchKernelGGL(ntr::flatten_kernel, dim3(1), dim3(ntr::FLATTEN_THREADS), 0, stream, d_classCount, (const unsigned int*)d_classList,
                        numBlocks, d_order);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ntr_launch_predict_costs(const void* d_rays, int numRays, int numBlocks, const void* d_table,
+                                               const unsigned int* d_tableCount, unsigned int* d_blockCost, hipStream_t stream)
+{
+    const int grid = (numBlocks + 63) / 64;
+    hipLaunchKernelGGL(ntr::predict_kernel, dim3(grid), dim3(ntr::PRED_WAVES * 64), 0, stream, (const float4*)d_rays, numRays, numBlocks,
+                       (const float4*)d_table, d_tableCount, (unsigned int*)nullptr, (unsigned int*)nullptr, d_blockCost);
     return hipGetLastError();
 }
 

@@ -64,8 +64,13 @@ extern "C" hipError_t ntr_launch_top_table(const void* d_nodes, unsigned int nod
 extern "C" hipError_t ntr_launch_predict(const void* d_rays, int numRays, int numBlocks, const void* d_table,
                                          const unsigned int* d_tableCount, unsigned int* d_classCount, unsigned int* d_classList,
                                          unsigned int* d_order, hipStream_t stream);
+// cost query: d_blockCost[b] = boxes of the top-of-tree table the sample ray of 256-ray block b intersects
+extern "C" hipError_t ntr_launch_predict_costs(const void* d_rays, int numRays, int numBlocks, const void* d_table,
+                                               const unsigned int* d_tableCount, unsigned int* d_blockCost, hipStream_t stream);
 // clears 32-bit words with a kernel (graph-replay safe, unlike a memset node)
 extern "C" hipError_t ntr_launch_zero_words(void* d_ptr, int words, hipStream_t stream);
+// out[0] = atomicExch(status, 0): fetch-and-clear of the sticky status word in one device-side step
+extern "C" hipError_t ntr_launch_status_exchange(unsigned int* d_status, unsigned int* d_out, hipStream_t stream);
 extern "C" hipError_t ntr_launch_sched_order(const unsigned int* d_cost, int numBlocks, int classes, unsigned int* d_order,
                                              hipStream_t stream);
 extern "C" hipError_t ntr_launch_selftest_division(const float* d_x, const float* d_d, int nx, int nd,

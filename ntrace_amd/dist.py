@@ -23,16 +23,64 @@ def shard_range(num_rays, rank, world, align=64):
     return min(lo_b * align, num_rays), min(hi_b * align, num_rays)
 
 
+def balanced_cuts(block_cost, num_rays, world, flat_share=1.0, block=256):
+    """Cut points c[0] = 0 <= c[1] <= ... <= c[world] = num_rays (multiples of `block` rays, hence of the 64-ray tile alignment)
+    such that every range [c[r], c[r+1]) carries about the same share of the PREDICTED cost of the frame.
+
+    block_cost   predicted cost of every `block`-ray block of the primary batch (ntr_predict_block_costs: top-of-tree boxes the
+                 block's sample ray intersects), any array-like of non-negative numbers
+    flat_share   the part of a block's cost that does not depend on where its rays go -- ray load / result store and the AO
+                 rays of its hits, which are short and cost about the same everywhere -- as a multiple of the MEAN predicted
+                 cost: a block weighs cost[b] + flat_share * mean(cost).  0 balances the predictor alone; a large value tends
+                 to equal ray counts (shard_range).  Fitted on the simulated ranks of scripts/shard_balance_study.py.
+    The ranges stay contiguous in the PixelTable index space, so a rank still owns a compact set of screen tiles."""
+    import numpy as np
+    c = np.asarray(block_cost, dtype=np.float64).reshape(-1)
+    nb = (int(num_rays) + block - 1) // block
+    if c.size < nb:
+        c = np.concatenate([c, np.full(nb - c.size, c.mean() if c.size else 1.0)])
+    c = c[:nb]
+    w = c + flat_share * (c.mean() if nb else 0.0) + 1e-9
+    if nb:   # the last block may be partial: weigh it by its ray count
+        w[-1] *= (int(num_rays) - (nb - 1) * block) / float(block)
+    acc = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for r in range(1, world):
+        target = acc[-1] * r / world
+        b = int(np.searchsorted(acc, target, side="left"))   # first boundary with at least the target before it
+        if b > 0 and abs(acc[b - 1] - target) <= abs(acc[min(b, nb)] - target):
+            b -= 1
+        cuts.append(max(min(b, nb) * block, cuts[-1]))
+    cuts.append(int(num_rays))
+    return [min(int(x), int(num_rays)) for x in cuts]
+
+
+def broadcast_cuts(cuts, world, device, src=0):
+    """The planning rank's cut points to every rank (identity without a process group)."""
+    t = torch.tensor([int(x) for x in cuts] if cuts is not None else [0] * (world + 1), dtype=torch.int64, device=device)
+    if dist.is_initialized():
+        dist.broadcast(t, src)
+    return [int(x) for x in t.tolist()]
+
+
 class FramePlan:
     """What `rank` of `world` traces of one frame of `num_primary` primary rays.
 
-    lo, hi       the rank's slice of the primary index space
+    lo, hi       the rank's slice of the primary index space: the rank-th of `world` equal 64-aligned ranges, or [cuts[rank],
+                 cuts[rank + 1]) when cut points are given (balanced_cuts: ranges of equal predicted cost)
     ao_batches   [(first_input_slot, num_inputs)], global primary slots: batch b generates
                  num_inputs * samples secondary rays from the rank's primary hits (none when samples == 0)"""
 
-    def __init__(self, num_primary, rank, world, samples=8, max_batch_rays=1 << 20, align=64):
+    def __init__(self, num_primary, rank, world, samples=8, max_batch_rays=1 << 20, align=64, cuts=None):
         self.num_primary, self.rank, self.world, self.samples = int(num_primary), int(rank), int(world), int(samples)
-        self.lo, self.hi = shard_range(num_primary, rank, world, align)
+        if cuts is not None:
+            if len(cuts) != world + 1 or cuts[0] != 0 or cuts[-1] != num_primary or any(cuts[i] > cuts[i + 1] for i in range(world)) \
+                    or any(c % align for c in cuts[:-1]):
+                raise ValueError("FramePlan: cut points must be %d non-decreasing multiples of %d from 0 to %d" % (world + 1, align, num_primary))
+            self.lo, self.hi = int(cuts[rank]), int(cuts[rank + 1])
+        else:
+            self.lo, self.hi = shard_range(num_primary, rank, world, align)
+        self.cuts = list(cuts) if cuts is not None else None
         self.ao_batches = []
         if samples > 0:
             per = max(int(max_batch_rays) // samples, 1)
@@ -44,11 +92,15 @@ class FramePlan:
         return self.hi - self.lo
 
 
-def gather_hit_records(local, num_rays, align=64, dst=0):
+def gather_hit_records(local, num_rays, align=64, dst=0, cuts=None):
     """Gather every rank's slice of 16-byte hit records (uint8 tensor of (hi-lo)*16 bytes) into the
-    full frame on `dst`.  Returns the assembled uint8 tensor on dst, None elsewhere."""
+    full frame on `dst` (slices as FramePlan cuts them: equal ranges, or `cuts`).  Returns the assembled uint8 tensor on
+    dst, None elsewhere."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    sizes = [(lambda r: (r[1] - r[0]) * 16)(shard_range(num_rays, k, world, align)) for k in range(world)]
+    if cuts is not None:
+        sizes = [(int(cuts[k + 1]) - int(cuts[k])) * 16 for k in range(world)]
+    else:
+        sizes = [(lambda r: (r[1] - r[0]) * 16)(shard_range(num_rays, k, world, align)) for k in range(world)]
     pad = max(sizes)
     buf = torch.zeros(pad, dtype=torch.uint8, device=local.device)
     buf[: local.numel()] = local

@@ -5,6 +5,8 @@
 #include <istream>
 #include <ostream>
 #include <thread>
+
+#include "Threads.hpp"
 #include <utility>
 #include <vector>
 
@@ -147,13 +149,13 @@ void CudaBVH::createCompact(const BVH& bvh, int nodeOffsetSizeDiv)
         fillInner(0, inner.size());
         fillLeaves(0, leaves.size());
     } else {
-        std::vector<std::thread> pool;
+        ThreadGroup pool;
         for (unsigned t = 0; t < threads; t++)
-            pool.emplace_back([&, t]() {
+            pool.spawn([&, t]() {
                 fillInner(inner.size() * t / threads, inner.size() * (t + 1) / threads);
                 fillLeaves(leaves.size() * t / threads, leaves.size() * (t + 1) / threads);
             });
-        for (std::thread& th : pool) th.join();
+        pool.join();
     }
 
     m_flagsValid = false;

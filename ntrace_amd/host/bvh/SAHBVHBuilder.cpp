@@ -25,6 +25,8 @@
 #include <cstdlib>
 #include <thread>
 
+#include "../Threads.hpp"
+
 namespace FW {
 
 SAHBVHBuilder::SAHBVHBuilder(BVH& bvh, const BVH::BuildParams& params)
@@ -71,10 +73,10 @@ BVHNode* SAHBVHBuilder::run(void)
                 if (!(size.min() < 0.0f || size.sum() == size.max())) liveOf[p].push_back(t);
             }
         };
-        std::vector<std::thread> pool;
-        for (int p = 1; p < prepThreads; p++) pool.emplace_back(prep, p);
-        prep(0);
-        for (size_t i = 0; i < pool.size(); i++) pool[i].join();
+        ThreadGroup pool;
+        for (int p = 1; p < prepThreads; p++) pool.spawn([&prep, p]() { prep(p); });
+        pool.run([&prep]() { prep(0); });
+        pool.join();
         size_t total = 0;
         for (int p = 0; p < prepThreads; p++) total += liveOf[p].size();
         live.reserve(total);
@@ -101,25 +103,26 @@ BVHNode* SAHBVHBuilder::run(void)
         std::vector<S32> bounds(chunksPerAxis + 1);
         for (int c = 0; c <= chunksPerAxis; c++) bounds[c] = (S32)((S64)n * c / chunksPerAxis);
         {
-            std::vector<std::thread> pool;
-            for (int c = 1; c < chunksPerAxis; c++) pool.emplace_back([=]() { std::sort(base + bounds[c], base + bounds[c + 1], less); });
-            std::sort(base + bounds[0], base + bounds[1], less);
-            for (size_t i = 0; i < pool.size(); i++) pool[i].join();
+            ThreadGroup pool;
+            for (int c = 1; c < chunksPerAxis; c++) pool.spawn([=]() { std::sort(base + bounds[c], base + bounds[c + 1], less); });
+            pool.run([=]() { std::sort(base + bounds[0], base + bounds[1], less); });
+            pool.join();
         }
         for (int width = 1; width < chunksPerAxis; width *= 2) {
-            std::vector<std::thread> pool;
+            ThreadGroup pool;
             for (int c = 0; c + width < chunksPerAxis; c += 2 * width) {
                 const S32 lo = bounds[c], mid = bounds[c + width], hi = bounds[std::min(c + 2 * width, chunksPerAxis)];
-                pool.emplace_back([=]() { std::inplace_merge(base + lo, base + mid, base + hi, less); });
+                pool.spawn([=]() { std::inplace_merge(base + lo, base + mid, base + hi, less); });
             }
-            for (size_t i = 0; i < pool.size(); i++) pool[i].join();
+            pool.join();
         }
     };
     if (n > 100000) {
-        std::thread t0(sortAxis, 0), t1(sortAxis, 1);
-        sortAxis(2);
-        t0.join();
-        t1.join();
+        ThreadGroup axes;
+        axes.spawn([&sortAxis]() { sortAxis(0); });
+        axes.spawn([&sortAxis]() { sortAxis(1); });
+        axes.run([&sortAxis]() { sortAxis(2); });
+        axes.join();
     } else {
         for (int d = 0; d < 3; d++) sortAxis(d);
     }
@@ -188,10 +191,11 @@ SAHBVHBuilder::Split SAHBVHBuilder::bestSplit(const Job& job, F32 nodeSAH, Scrat
             area[d].resize(m);
             sweepAxis(m_order[d].data() + job.begin, m, m_box.data(), m_platform, nodeSAH, area[d].data(), sah[d], balance[d], numLeft[d]);
         };
-        std::thread t0(one, 0), t1(one, 1);
-        one(2);
-        t0.join();
-        t1.join();
+        ThreadGroup axes;
+        axes.spawn([&one]() { one(0); });
+        axes.spawn([&one]() { one(1); });
+        axes.run([&one]() { one(2); });
+        axes.join();
     } else {
         if ((S32)scratch.rightArea.size() < m) scratch.rightArea.resize(m);
         for (int d = 0; d < 3; d++)
@@ -244,9 +248,11 @@ BVHNode* SAHBVHBuilder::build(const Job& job, Scratch& scratch, int spawnDepth)
     if ((S32)scratch.tmp.size() < m) scratch.tmp.resize(m);
     if (threaded) {
         std::vector<S32> tmp2(m);
-        std::thread other(partition, da, tmp2.data());
-        partition(db, scratch.tmp.data());
-        other.join();
+        ThreadGroup pair;
+        S32* tmp2p = tmp2.data();
+        pair.spawn([&partition, da, tmp2p]() { partition(da, tmp2p); });
+        pair.run([&]() { partition(db, scratch.tmp.data()); });
+        pair.join();
     } else {
         partition(da, scratch.tmp.data());
         partition(db, scratch.tmp.data());
@@ -264,9 +270,16 @@ BVHNode* SAHBVHBuilder::build(const Job& job, Scratch& scratch, int spawnDepth)
     BVHNode* rightNode = NULL;
     BVHNode* leftNode = NULL;
     if (spawnDepth > 0 && m > 65536) {
-        std::thread other([&]() { Scratch own; rightNode = build(right, own, spawnDepth - 1); });
-        leftNode = build(left, scratch, spawnDepth - 1);
-        other.join();
+        ThreadGroup pair;   // an exception in either half (bad_alloc, FatalError) is rethrown here, after both have ended
+        pair.spawn([&]() { Scratch own; rightNode = build(right, own, spawnDepth - 1); });
+        pair.run([&]() { leftNode = build(left, scratch, spawnDepth - 1); });
+        try {
+            pair.join();
+        } catch (...) {
+            if (rightNode) rightNode->deleteSubtree();
+            if (leftNode) leftNode->deleteSubtree();
+            throw;
+        }
     } else {
         rightNode = build(right, scratch, 0);
         leftNode = build(left, scratch, 0);

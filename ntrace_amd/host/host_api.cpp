@@ -4,6 +4,7 @@
 #include <vector>
 
 #include <chrono>
+#include <exception>
 #include <cstdio>
 #include <cstdlib>
 #include "CameraControls.hpp"
@@ -57,6 +58,10 @@ int ntr_sah_build(int32_t numTris, const int32_t* triVtxIndex, int32_t numVerts,
         return ntr::set_error(NTR_ERR_INVALID, "%s", e.message.c_str());
     } catch (const std::bad_alloc&) {
         return ntr::set_error(NTR_ERR_NOMEM, "ntr_sah_build: out of host memory");
+    } catch (const std::exception& e) {   // e.g. std::system_error from a thread constructor: nothing may escape the extern "C" boundary
+        return ntr::set_error(NTR_ERR_INVALID, "%s: %s", __func__, e.what());
+    } catch (...) {
+        return ntr::set_error(NTR_ERR_INVALID, "%s: unknown exception", __func__);
     }
 }
 
@@ -99,6 +104,10 @@ int ntr_host_bvh_wrap(const void* nodes, int64_t nodesBytes, const void* triWoop
         return ntr::set_error(NTR_ERR_INVALID, "%s", e.message.c_str());
     } catch (const std::bad_alloc&) {
         return ntr::set_error(NTR_ERR_NOMEM, "ntr_host_bvh_wrap: out of host memory");
+    } catch (const std::exception& e) {   // e.g. std::system_error from a thread constructor: nothing may escape the extern "C" boundary
+        return ntr::set_error(NTR_ERR_INVALID, "%s: %s", __func__, e.what());
+    } catch (...) {
+        return ntr::set_error(NTR_ERR_INVALID, "%s: unknown exception", __func__);
     }
 }
 
@@ -126,6 +135,10 @@ int ntr_host_bvh_trace(const NtrHostBvh* bvh, int32_t numRays, int32_t anyHit, c
         return ntr::set_error(NTR_ERR_INVALID, "%s", e.message.c_str());
     } catch (const std::bad_alloc&) {
         return ntr::set_error(NTR_ERR_NOMEM, "ntr_host_bvh_trace: out of host memory");
+    } catch (const std::exception& e) {   // e.g. std::system_error from a thread constructor: nothing may escape the extern "C" boundary
+        return ntr::set_error(NTR_ERR_INVALID, "%s: %s", __func__, e.what());
+    } catch (...) {
+        return ntr::set_error(NTR_ERR_INVALID, "%s: unknown exception", __func__);
     }
 }
 

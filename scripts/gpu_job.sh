@@ -51,9 +51,9 @@ EOF
     python3 scripts/summarize_rocprof.py trace $OUT/prof_bench > $OUT/bench_kernel_summary.txt 2>&1; head -n 12 $OUT/bench_kernel_summary.txt
     find $OUT/prof_bench -name "*.csv" -size +8M -delete ;;
   shard)
-    timeout -k 5 1200 python3 scripts/shard_balance_study.py $ARG > $OUT/shard_balance.jsonl 2> $OUT/shard_balance.err; echo "rc=$?"; cat $OUT/shard_balance.jsonl; tail -n 3 $OUT/shard_balance.err ;;
+    timeout -k 5 1200 python3 scripts/shard_balance_study.py ${ARG//:/ } > $OUT/shard_balance.jsonl 2> $OUT/shard_balance.err; echo "rc=$?"; cat $OUT/shard_balance.jsonl; tail -n 3 $OUT/shard_balance.err ;;
   lbvh)
-    timeout -k 5 900 python3 scripts/lbvh_sweep3.py $ARG > $OUT/lbvh_sweep.jsonl 2> $OUT/lbvh_sweep.err; echo "rc=$?"; cat $OUT/lbvh_sweep.jsonl; tail -n 3 $OUT/lbvh_sweep.err ;;
+    timeout -k 5 900 python3 scripts/lbvh_sweep3.py ${ARG//:/ } > $OUT/lbvh_sweep.jsonl 2> $OUT/lbvh_sweep.err; echo "rc=$?"; cat $OUT/lbvh_sweep.jsonl; tail -n 3 $OUT/lbvh_sweep.err ;;
   fuzz)
     timeout -k 5 $((ARG + 120)) python3 tests/fuzz_parity.py --seconds $ARG --seed ${FUZZ_SEED:-41} > $OUT/fuzz.json 2> $OUT/fuzz.err; echo "rc=$?"; tail -c 1500 $OUT/fuzz.json; tail -n 3 $OUT/fuzz.err ;;
   pyexp)   # py: with the experiment build of the library (diagnostic hooks)

@@ -1,12 +1,16 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun).  rocprofv3 kernel-trace + separate PMC passes for
-#   (1) every LBVH kernel at 262 k / 2.8 M / 10 M triangles,
-#   (2) the trace kernels (per-ray and persistent) on the cache-resident 262 k SAH BVH,
-#   (3) the HBM-resident point: 1080p primary + one AO batch on the 10 M-triangle LBVH (1.3 GB > 256 MB MALL).
+# Runs on the GPU box (via gpurun / scripts/gpu_job.sh profile).  rocprofv3 kernel-trace + separate PMC passes for
+#   lbvh   every LBVH kernel at 262 k / 2.8 M / 10 M triangles,
+#   trace  the trace kernels (per-ray, persistent, dynamic fetch) on the cache-resident 262 k SAH BVH,
+#   hbm    the HBM-resident point on the 10 M-triangle LBVH (0.75 GB > 256 MB Infinity Cache): 1080p primary + one AO batch +
+#          2^21 incoherent rays with the per-ray kernel, and the incoherent batch alone with kepler_dynamic_fetch (a persistent
+#          kernel's grid is the same for every batch, so its per-batch counter means need a run of their own),
+#   hair   the same two for hairball-2.8M.
 # PMC passes never share a run with another trace domain than --kernel-trace.
-# Usage: scripts/profile_round.sh <tag> [lbvh] [trace] [hbm]
+# Writes gpurun_out/prof_<tag>/{*.kernels.txt, *.pmc.txt, pmc_summary.json}; copy what is to be judged into profiles/<tag>_*.
+# Usage: scripts/profile_round.sh <tag> [lbvh] [trace] [hbm] [hair]
 set -u
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 WHAT="${*:-lbvh trace hbm}"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -16,7 +20,7 @@ SUM="python3 scripts/summarize_rocprof.py"
 prof_trace() {  # name, workload args...
   local name=$1; shift
   timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/trace -- python3 scripts/workloads.py "$@" > $OUT/$name.trace.log 2>&1
-  { echo "== rocprofv3 --kernel-trace --stats -- python3 scripts/workloads.py $*"; tail -n 1 $OUT/$name.trace.log; $SUM trace $OUT/$name/trace; } > $OUT/$name.kernels.txt 2>&1
+  { echo "== rocprofv3 --kernel-trace --stats -- python3 scripts/workloads.py $* (WL_ONLY=${WL_ONLY:-})"; tail -n 1 $OUT/$name.trace.log; $SUM trace $OUT/$name/trace; } > $OUT/$name.kernels.txt 2>&1
 }
 prof_pmc() {  # name, "counters", workload args...
   local name=$1; local ctr=$2; shift; shift
@@ -29,6 +33,12 @@ TRACE_SETS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
   "TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum" "TA_BUFFER_WAVEFRONTS_sum" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum")
 
+trace_all() {  # name, scene, kernel
+  prof_trace $1 trace $2 $3 6
+  for C in "${TRACE_SETS[@]}"; do prof_pmc $1 "$C" trace $2 $3 4; done
+  $SUM pmc $OUT/$1/pmc_* > $OUT/$1.pmc.txt 2>&1
+}
+
 for W in $WHAT; do
   case $W in
   lbvh)
@@ -40,18 +50,23 @@ for W in $WHAT; do
       $SUM pmc $OUT/lbvh_$S/pmc_* > $OUT/lbvh_$S.pmc.txt 2>&1
     done ;;
   trace)
-    for K in fermi_speculative_while_while tesla_persistent_while_while kepler_dynamic_fetch; do
-      prof_trace trace_atrium_$K trace atrium $K 6
-      for C in "${TRACE_SETS[@]}"; do prof_pmc trace_atrium_$K "$C" trace atrium $K 4; done
-      $SUM pmc $OUT/trace_atrium_$K/pmc_* > $OUT/trace_atrium_$K.pmc.txt 2>&1
-    done ;;
+    for K in fermi_speculative_while_while tesla_persistent_while_while; do trace_all trace_atrium_$K atrium $K; done ;;
   hbm)
-    K=${PROF_KERNEL:-fermi_speculative_while_while}
-    prof_trace trace_courtyard_$K trace courtyard $K 6
-    for C in "${TRACE_SETS[@]}"; do prof_pmc trace_courtyard_$K "$C" trace courtyard $K 4; done
-    $SUM pmc $OUT/trace_courtyard_$K/pmc_* > $OUT/trace_courtyard_$K.pmc.txt 2>&1 ;;
+    trace_all trace_courtyard_fermi_speculative_while_while courtyard fermi_speculative_while_while
+    WL_ONLY=incoherent; export WL_ONLY
+    trace_all trace_courtyard_incoherent_kepler_dynamic_fetch courtyard kepler_dynamic_fetch
+    unset WL_ONLY ;;
+  hair)
+    trace_all trace_hairball_fermi_speculative_while_while hairball fermi_speculative_while_while
+    WL_ONLY=incoherent; export WL_ONLY
+    trace_all trace_hairball_incoherent_kepler_dynamic_fetch hairball kepler_dynamic_fetch
+    unset WL_ONLY ;;
   esac
 done
+# what bench.py reads for roofline.binding: {"kernel symbol|grid|counter": mean per dispatch}
+ls $OUT/*atrium*.pmc.txt $OUT/lbvh_*.pmc.txt > /dev/null 2>&1 && $SUM json $(ls $OUT/*atrium*.pmc.txt $OUT/lbvh_*.pmc.txt 2>/dev/null) > $OUT/pmc_summary.json
+ls $OUT/*courtyard*.pmc.txt > /dev/null 2>&1 && $SUM json $OUT/*courtyard*.pmc.txt > $OUT/courtyard10m_pmc_summary.json
+ls $OUT/*hairball*.pmc.txt > /dev/null 2>&1 && $SUM json $OUT/trace_hairball*.pmc.txt > $OUT/hairball_pmc_summary.json
 # raw rocprof directories are large: keep the summaries, drop the CSVs of the PMC passes
 du -sh $OUT
 find $OUT -name "*_counter_collection.csv" -size +8M -delete

@@ -143,7 +143,7 @@ def main(argv=None):
                 # build paths drawn at random: bottom-up emit (tile meetings through LDS or all through memory) or the
                 # cell-table top pass, with the default or a small hand-over size
                 nt.set_tunables(NTR_LBVH_SPLIT=int(rng.choice([2, 16, 100, 3000])) if rng.random() < 0.3 else None,
-                                NTR_LBVH_EMIT=int(rng.choice([0, 0, 1])), NTR_LBVH_AGG_LDS=int(rng.choice([1, 1, 0])),
+                                NTR_LBVH_AGG_LDS=int(rng.choice([1, 1, 0])),
                                 NTR_LBVH_AGG_STAGED=int(rng.choice([-1, 0, 1])))
                 if os.environ.get("NTR_FUZZ_VERBOSE"):
                     print("lbvh n=%d leaf=%d eps=%g %s" % (tri.shape[0], leaf, eps, {k: v for k, v in os.environ.items() if k.startswith("NTR_LBVH")}),
@@ -183,6 +183,12 @@ def main(argv=None):
                 nt.set_tunables(NTR_TRACE_PREDICT_MIN_RAYS=1, NTR_TRACE_PREDICT_MIN_NODES=1)
             else:
                 nt.set_tunables(NTR_TRACE_PREDICT_MIN_RAYS=None, NTR_TRACE_PREDICT_MIN_NODES=None)
+            # loop variants only change how the lanes of a wave interleave: while-while or unified-step loop in the per-ray kernel (by the
+            # tree's leaf sizes, or forced either way) and in kepler_dynamic_fetch, any dynamic-fetch threshold
+            loop = dict(NTR_TRACE_PERRAY_UNIFIED=int(rng.choice([-1, 0, 1])), NTR_TRACE_UNIFIED=int(rng.choice([1, 1, 0])),
+                        NTR_TRACE_FETCH_THRESHOLD=int(rng.choice([-1, -1, 1, 16, 33, 64])))
+            nt.set_tunables(**loop)
+            tot["loop_%s" % "_".join(str(v) for v in loop.values())] = tot.get("loop_%s" % "_".join(str(v) for v in loop.values()), 0) + 1
             hint = nt.SchedHint() if sched == 2 else None
             tot["sched_%d_rounds" % sched] = tot.get("sched_%d_rounds" % sched, 0) + 1
             for any_hit in (False, True):

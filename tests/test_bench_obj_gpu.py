@@ -45,3 +45,19 @@ def test_bench_scene_obj_path(tmp_path, camera):
     assert out["cpu_baseline"]["rays_compared"] >= 320 * 200
     if camera == "bounding-box":
         assert out["config"]["primary_hits_rank0"] > 1000   # looking down the long axis from inside the box
+
+
+def test_bench_rccl_path_at_world_size_one():
+    """The multi-GPU code path of bench.py -- RCCL process group, barriers, BVH broadcast, MAX / SUM reductions, the gather of hit
+    records to rank 0 and the assembled-frame check -- exercised on one GPU (NTR_BENCH_FORCE_DIST=1), so that the GPU test tier
+    loads RCCL and runs every collective the 2 / 4 / 8-GPU runs use."""
+    env = dict(os.environ, NTR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", "640", "--height", "360", "--steps", "2", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["gather_ms"] is not None and out["gather_ms"] > 0
+    chk = out["sharded_frame_check"]
+    assert chk and chk["primary_records_equal_single_gpu_frame"] and chk["ao_checksum_equal_single_gpu_frame"]
+    assert chk["records_compared"] == 640 * 360

@@ -146,3 +146,69 @@ def test_bench_refuses_mismatched_world_size():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "--gpus 4 but the launcher started WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def _balanced_frame_worker(rank, world, port, num_primary, samples, max_batch, out_path):
+    """The N>1 flow with ranges of equal PREDICTED cost: rank 0 alone knows the block costs, cuts the frame and broadcasts the cut
+    points; the ranks' unequal slices are gathered; the assembled frame equals the single-rank frame."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cpu = torch.device("cpu")
+    cuts = None
+    if rank == 0:
+        cost = np.ones((num_primary + 255) // 256)
+        cost[: cost.size // 4] = 9.0          # a heavy first quarter of the screen
+        cuts = ntd.balanced_cuts(cost, num_primary, world, flat_share=0.5)
+    cuts = ntd.broadcast_cuts(cuts, world, cpu)
+    plan = ntd.FramePlan(num_primary, rank, world, samples, max_batch, cuts=cuts)
+    ok = plan.lo == cuts[rank] and plan.hi == cuts[rank + 1] and plan.lo % 64 == 0
+    own = _standin_primary(plan.lo, plan.hi)
+    ao_ck = 0
+    for (first, cnt) in plan.ao_batches:
+        ok = ok and plan.lo <= first and first + cnt <= plan.hi
+        ao_ck += ntd.records_checksum(torch.from_numpy(_standin_ao(_standin_primary, first, cnt, samples).view(np.uint8).copy()))
+    full = ntd.gather_hit_records(torch.from_numpy(own.view(np.uint8).copy()), num_primary, cuts=plan.cuts)
+    ao_sum = ntd.all_sum_int64(ao_ck, cpu)
+    if rank == 0:
+        ok = ok and cuts[1] < num_primary // world          # the heavy region makes rank 0's range shorter than an equal share
+        ref = _standin_primary(0, num_primary)
+        ok = ok and torch.equal(full, torch.from_numpy(ref.view(np.uint8).copy()))
+        one = 0
+        for (first, cnt) in ntd.FramePlan(num_primary, 0, 1, samples, max_batch).ao_batches:
+            one += ntd.records_checksum(torch.from_numpy(_standin_ao(_standin_primary, first, cnt, samples).view(np.uint8).copy()))
+        ok = ok and ntd.wrap_i64(one) == ntd.wrap_i64(ao_sum)
+        open(out_path, "w").write("ok" if ok else "bad %s" % cuts)
+    dist.destroy_process_group()
+
+
+def test_two_rank_balanced_frame_gloo(tmp_path):
+    out = str(tmp_path / "balanced.txt")
+    mp.spawn(_balanced_frame_worker, args=(2, _free_port(), 20000, 8, 4096, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_balanced_cuts_properties():
+    rng = np.random.default_rng(3)
+    n = 1920 * 1080
+    cost = rng.integers(0, 60, (n + 255) // 256).astype(np.float64)
+    cost[2000:3000] += 100
+    for world in (1, 2, 3, 8):
+        for flat in (0.0, 1.0, 50.0):
+            cuts = ntd.balanced_cuts(cost, n, world, flat)
+            assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == n
+            assert all(a <= b for a, b in zip(cuts, cuts[1:])) and all(c % 256 == 0 for c in cuts[:-1])
+            w = cost + flat * cost.mean()
+            shares = [w[a // 256:(b + 255) // 256].sum() for a, b in zip(cuts, cuts[1:])]
+            assert max(shares) <= 1.02 * np.mean(shares) + w.max()      # equal shares up to one block
+            for r in range(world):
+                ntd.FramePlan(n, r, world, 8, 1 << 20, cuts=cuts)           # valid plans
+    # a large flat share tends to equal ray counts
+    cuts = ntd.balanced_cuts(cost, n, 8, 1e6)
+    assert all(abs((b - a) - n / 8) <= 512 for a, b in zip(cuts, cuts[1:]))
+    # degenerate inputs
+    assert ntd.balanced_cuts([], 0, 4) == [0, 0, 0, 0, 0]
+    assert ntd.balanced_cuts([5.0], 100, 4)[-1] == 100
+    import pytest
+    with pytest.raises(ValueError):
+        ntd.FramePlan(1000, 0, 2, cuts=[0, 100, 1000])      # not tile-aligned

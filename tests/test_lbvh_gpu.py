@@ -20,6 +20,11 @@ def build_path(request, monkeypatch):
     triangles are one subtree workgroup), on the same path with a tiny `split` (so that small scenes take the bottom-up emit, and
     runs of equal keys its slow path with hand-over roots and the oversize fallback), with every meeting through memory, on the
     cell-table top pass + subtree workgroups, on the round-1 sort / top pass, and on the per-level kernels."""
+    # the round-1 / round-2 paths (per-level kernels, three-kernel sort, cell-table top, forced legacy top) are A/B scaffolding compiled
+    # only into the experiment build of the library: those parameters run against libntrace_amd_exp.so
+    exp_only = request.param in ("cells-top", "cells-top-split16", "legacy-top-and-sort", "legacy-top-split16", "levelsync")
+    nt.use_library(nt.exp_lib_path() if exp_only else None)
+    request.addfinalizer(lambda: (nt.use_library(None), nt.set_tunables()))
     for k in ("NTR_LBVH_LEVELSYNC", "NTR_LBVH_SPLIT", "NTR_LBVH_SUB_THREADS", "NTR_LBVH_LEGACY_TOP", "NTR_LBVH_LEGACY_SORT", "NTR_LBVH_EMIT", "NTR_LBVH_AGG_LDS", "NTR_LBVH_AGG_STAGED"):
         monkeypatch.delenv(k, raising=False)
     if request.param == "levelsync":

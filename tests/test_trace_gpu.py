@@ -345,3 +345,75 @@ def test_unified_step_loop_changes_no_record(soup, monkeypatch, tree):
             for n in (allrays.shape[0], 63, 4097):
                 got, _ = gpu_trace("kepler_dynamic_fetch", dbvh, allrays[:n], any_hit)
                 assert_parity(got, ref[:n], "%s dynamic fetch %s n=%d anyHit=%d" % (tree, env, n, any_hit))
+
+
+def test_captured_launches_own_their_scratch_and_release_returns_it(soup, monkeypatch):
+    """HIP-graph resources: a captured launch gets prediction scratch / pool counters of its own -- two launches captured
+    back to back on one stream, with no live launch in between, and live launches of other ray counts on the same stream while the
+    graphs exist, all give the oracle's records on replay --, the stores are finite (the capture-time call says so instead of
+    corrupting anything), and ntr_trace_graph_release_all() returns everything: a host that re-captures every frame keeps going."""
+    import torch
+    from gpu_util import assert_parity, up
+    dbvh, cam = soup
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
+    nt.set_tunables()
+    nt.trace_graph_release_all()
+    batches = []
+    for (w, h, seed) in ((200, 150, 3), (160, 120, 4)):
+        rays = np.concatenate([scenes.primary_rays(cam, w, h)[0], scenes.random_rays(3000, seed=seed)])
+        ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
+        batches.append((rays.shape[0], up(rays), torch.full((rays.shape[0] * 16,), 0xCD, dtype=torch.uint8, device="cuda:0"), ref))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):   # one live launch of the larger size provisions the spares
+        dbvh.view.trace("fermi_speculative_while_while", batches[0][0], False, batches[0][1].data_ptr(), batches[0][2].data_ptr(), s.cuda_stream, False)
+    torch.cuda.synchronize()
+    graphs = []
+    for (n, d_r, d_o, ref) in batches:   # two captures back to back
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            dbvh.view.trace("fermi_speculative_while_while", n, False, d_r.data_ptr(), d_o.data_ptr(), torch.cuda.current_stream().cuda_stream, False)
+        graphs.append(g)
+    with torch.cuda.stream(s):   # live launches on the capture stream must not disturb the graphs' scratch
+        for k in (1, 257, 5000):
+            tmp = torch.zeros(k * 16, dtype=torch.uint8, device="cuda:0")
+            dbvh.view.trace("fermi_speculative_while_while", k, False, batches[0][1].data_ptr(), tmp.data_ptr(), s.cuda_stream, False)
+    for rep in range(2):
+        for g, (n, d_r, d_o, ref) in zip(graphs, batches):
+            d_o.fill_(0xCD)
+            g.replay()
+        torch.cuda.synchronize()
+        for (n, d_r, d_o, ref) in batches:
+            assert_parity(d_o.cpu().numpy().view(nt.RESULT_DTYPE), ref, "captured launch, replay %d" % rep)
+    # the persistent kernels' pinned pool counters: 192 per device, then a clear error; release_all makes room again
+    n, d_r, d_o, ref = batches[1]
+    del graphs
+    nt.trace_graph_release_all()
+    with torch.cuda.stream(s):
+        dbvh.view.trace("kepler_dynamic_fetch", n, False, d_r.data_ptr(), d_o.data_ptr(), s.cuda_stream, False)
+    torch.cuda.synchronize()
+    held, failed = [], False
+    for i in range(200):
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, stream=s):
+                dbvh.view.trace("kepler_dynamic_fetch", n, False, d_r.data_ptr(), d_o.data_ptr(), torch.cuda.current_stream().cuda_stream, False)
+            held.append(g)
+        except nt.NtrError as e:
+            failed = True
+            assert "captured" in str(e)
+            break
+    assert failed and len(held) == 192
+    torch.cuda.synchronize()
+    del held
+    nt.trace_graph_release_all()
+    for frame in range(3):   # re-capture per frame with a release in between
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            dbvh.view.trace("kepler_dynamic_fetch", n, False, d_r.data_ptr(), d_o.data_ptr(), torch.cuda.current_stream().cuda_stream, False)
+        d_o.fill_(0xCD)
+        g.replay()
+        torch.cuda.synchronize()
+        assert_parity(d_o.cpu().numpy().view(nt.RESULT_DTYPE), ref, "re-captured frame %d" % frame)
+        del g
+        nt.trace_graph_release_all()
