@@ -137,6 +137,7 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (profiling runs)")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the 10 M-triangle HBM-resident roofline point (extras)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold-order", action="store_true", help="skip the extra K steps with the scheduling feedback off")
     ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     return ap.parse_args(argv)
 
@@ -346,6 +347,30 @@ def main():
     prim_live_total, prim_kernel_max = ntd.job_throughput(batches[0]["live"], float(kern_ms[:, 0].sum()) * 1e-3, dev)
     ao_live_total, ao_kernel_max = ntd.job_throughput(sum(b["live"] for b in batches[1:]), float(kern_ms[:, 1:].sum()) * 1e-3, dev)
 
+    # ---- the same K steps with the library's scheduling feedback off (NTR_TRACE_AUTO_HINT=0): every launch dispatched as if its batch
+    # had never been traced before (predicted order for the primary batch, buffer order for the AO batches).  `value` is the reference's
+    # protocol, which re-traces the SAME batches step after step, so its launches run in the order learned from the previous step;
+    # this is the figure for batches that are new every time.  Untimed by the driver contract (reported beside `value`).
+    cold = None
+    if not args.no_cold_order:
+        nt.set_tunables(NTR_TRACE_AUTO_HINT=0)
+        for b in batches:
+            run_batch(b)
+        evc = [[(E(enable_timing=True), E(enable_timing=True)) for _ in batches] for _ in range(args.steps)]
+        barrier()
+        for s_ in range(args.steps):
+            for bi, b in enumerate(batches):
+                evc[s_][bi][0].record()
+                run_batch(b)
+                evc[s_][bi][1].record()
+        barrier()
+        cms = np.array([[e0.elapsed_time(e1) for (e0, e1) in step] for step in evc])
+        _, cold_kernel_max = ntd.job_throughput(0, float(cms.sum()) * 1e-3, dev)
+        cold = {"what": "the same steps with NTR_TRACE_AUTO_HINT=0: no dispatch order learned from earlier launches of a batch",
+                "mrays": total_rays_per_step * args.steps / cold_kernel_max / 1e6,
+                "primary_ms": float(cms[:, 0].mean()), "ao_total_ms": float(cms[:, 1:].sum(axis=1).mean()) if len(batches) > 1 else 0.0}
+        nt.set_tunables(NTR_TRACE_AUTO_HINT=None)
+
     # ---- final framebuffer gather (hit records of the primary batch -> rank 0) over RCCL, timed separately ---------------
     gather_ms, frame_check = None, None
     sharded = use_dist and not (args.scaling == "weak" and world > 1)
@@ -444,7 +469,9 @@ def main():
         "dtype": "f32",
         "data": ("synthetic (%s)" % scene_name) if not args.scene_obj else scene_name,
         "value_definition": "non-degenerate rays of all ranks / (sum of per-batch kernel times by HIP events, MAX over ranks): the "
-                            "reference's protocol (App.cpp:955-969); wall_mrays is the same rays / wall clock of the K steps",
+                            "reference's protocol (App.cpp:955-969), which re-traces the same batches every step -- the library dispatches a "
+                            "re-traced batch in the order its previous launch measured (cold_dispatch_order: the figure without that); "
+                            "wall_mrays is the same rays / wall clock of the K steps",
         "wall_mrays": total_rays_per_step * args.steps / elapsed_max / 1e6,
         "config": {"workload": "Sponza-262k prebuilt SAH BVH, %dx%d primary + %dxAO (radius %g), one frame per step" % (w, h, ns, args.ao_radius),
                    "kernel": args.kernel, "bvh_flags": view.flags, "triangles": int(tri.shape[0]),
@@ -458,6 +485,7 @@ def main():
         "sharded_frame_check": frame_check,
         "host_sah_build_s": sah_seconds,
         "trace_stats": st.as_dict(),
+        "cold_dispatch_order": cold,
         "overlapped_multi_gpu": overlapped,
         "extras": extras,
         "roofline": None,

@@ -148,11 +148,14 @@ static void tunables_load_locked()
     t.unified = env_int("NTR_TRACE_UNIFIED", 1);                  // kepler_dynamic_fetch: unified-step loop (0 = while-while loop + dynamic fetch)
     t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", -1);    // per-ray kernel with the unified-step loop: -1 = for trees flagged NTR_BVH_WIDE_LEAVES, 0 / 1 = never / always
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/persist_diag.py)
+    t.autoHint = env_int("NTR_TRACE_AUTO_HINT", 1);               // dispatch order learned from the previous launch of the same batch (stream, rays, count, BVH)
+    t.autoHintMinRays = env_int("NTR_TRACE_AUTO_HINT_MIN_RAYS", 1 << 17);
     t.predict = env_int("NTR_TRACE_PREDICT", 1);
+    t.predictPersistent = env_int("NTR_TRACE_PREDICT_PERSISTENT", 1);   // persistent kernels: pool in predicted-cost order (closest-hit launches of >= predictMinRays)
     t.predictDepth = env_int("NTR_TRACE_PREDICT_DEPTH", 9);
     t.predictMinRays = env_int("NTR_TRACE_PREDICT_MIN_RAYS", 1 << 20);
     t.predictMinNodes = env_int("NTR_TRACE_PREDICT_MIN_NODES", 4096);
-    t.schedRefreshEvery = env_int("NTR_SCHED_REFRESH_EVERY", 8);
+    t.schedRefreshEvery = env_int("NTR_SCHED_REFRESH_EVERY", 16);
     t.schedClasses = env_int("NTR_SCHED_CLASSES", 32);
     t.lbvhLevelSync = env_int("NTR_LBVH_LEVELSYNC", 0);
     t.lbvhSplit = env_int("NTR_LBVH_SPLIT", 3072);
@@ -485,6 +488,52 @@ static void sched_hint_release(NtrSchedHint* h)
     h->numBlocks = 0; h->uses = 0; h->valid = false;
 }
 
+// Automatic scheduling feedback.  The launch time of the per-ray kernel is set by where its long-lived blocks start;
+// what a launch MEASURED about its blocks is the best order for the next launch of the same batch.  The reference's benchmark traces
+// every batch 1 + warm-up + measure times (App.cpp:955-958), a renderer with a parked or slowly moving camera regenerates nearly the
+// same rays into the same buffers frame after frame -- so the library keeps, per (stream, ray buffer, ray count, ray kind, BVH), the
+// scheduling hint a caller could have kept by hand (NtrSchedHint) and uses it without being asked.  Only the dispatch ORDER changes;
+// a stale entry (new rays at the old address) is merely a worse order and adapts within a launch or two.  Entries are per stream
+// (launches on one stream are ordered, so order[] is never rewritten under a launch that reads it); captured launches do not use them.
+struct AutoHint {
+    const void* rays = nullptr;
+    const void* nodes = nullptr;
+    void* stream = nullptr;
+    int numRays = 0, anyHit = 0, device = -1;
+    bool used = false;
+    unsigned long long lastUse = 0;
+    NtrSchedHint hint;
+};
+static constexpr int kAutoHints = 96;
+static AutoHint g_auto[kAutoHints];
+
+static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, int anyHit, hipStream_t s, NtrSchedHint** out)
+{
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    AutoHint* lru = nullptr;
+    for (auto& e : g_auto) {
+        if (e.used && e.rays == d_rays && e.nodes == d_nodes && e.numRays == numRays && e.anyHit == anyHit && e.stream == (void*)s && e.device == dev) {
+            e.lastUse = ++g_topClock;
+            *out = &e.hint;
+            return NTR_OK;
+        }
+        if (!e.used) { if (!lru || lru->used) lru = &e; }                       // a free entry first
+        else if (!lru || (lru->used && e.lastUse < lru->lastUse)) lru = &e;     // else the least recently used
+    }
+    if (lru->used) {
+        NTR_HIP(hipDeviceSynchronize());   // a launch in flight may still read the evicted order
+        sched_hint_release(&lru->hint);
+    }
+    lru->rays = d_rays; lru->nodes = d_nodes; lru->numRays = numRays; lru->anyHit = anyHit; lru->stream = (void*)s; lru->device = dev;
+    lru->used = true;
+    lru->lastUse = ++g_topClock;
+    lru->hint.uses = 0; lru->hint.valid = false;
+    *out = &lru->hint;
+    return NTR_OK;
+}
+
 static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
                       NtrRayResult* d_results, const void* d_nodes, int64_t nodesBytes, const void* d_triWoop,
                       int64_t triWoopBytes, const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags,
@@ -530,6 +579,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.shardRays = 0;
     p.numHeads = 8;
     p.numBlocks = 0;
+    p.orderBlocks = 0;
     // persistent kernels (scripts/persist_sweep.py): 64-ray chunks, 6 workgroups per CU; dynamic fetch only for the kernel
     // named after it (it costs about 10 % here: refilled lanes de-cohere a wave's node fetches)
     const Tunables tun = tunables();
@@ -593,6 +643,11 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         numBlocks = (numRays + blockThreads - 1) / blockThreads;
     }
 
+    // no hint from the caller: the library's own, keyed by (stream, batch, BVH)
+    if (!hint && !stats && tun.autoHint != 0 && variant == NTR_VARIANT_PERRAY && numRays >= tun.autoHintMinRays && !stream_is_capturing(s)) {
+        rc = auto_hint_get(d_rays, d_nodes, numRays, anyHit ? 1 : 0, s, &hint);
+        if (rc != NTR_OK) return rc;
+    }
     // Scheduling hint: the per-ray kernel dispatches blocks in the hint's order; on refresh launches it
     // also records per-block costs, from which the next order is derived right after the launch.
     bool refresh = false;
@@ -625,13 +680,22 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     TopTable* predTable = nullptr;
     PredictScratch* predScratch = nullptr;
     // (a tree of a few hundred nodes is traced faster than it is predicted: Cornell-box class scenes are left alone)
-    if (!hint && !p.order && variant == NTR_VARIANT_PERRAY && !anyHit && numRays >= tun.predictMinRays &&
+    // The persistent kernels hand their pool out in the same predicted order (the heavy blocks' long rays start first instead of being
+    // the chunks fetched last): there the prediction covers batches of all 256-ray blocks and needs pool chunks that divide 256.
+    const bool persistentOrder = variant == NTR_VARIANT_PERSISTENT && tun.predictPersistent != 0 && (256 % p.chunk) == 0 && !p.coop;
+    const int orderBlocks = (numRays + 255) / 256;
+    // (a launch whose hint holds no measured order yet -- the first one of a batch -- is predicted like an unhinted one)
+    if (!(hint && hint->valid) && !p.order && (variant == NTR_VARIANT_PERRAY || persistentOrder) && !anyHit && numRays >= tun.predictMinRays &&
         nodesBytes >= (int64_t)tun.predictMinNodes * 64 && tun.predict != 0) {
         rc = top_table_get(d_nodes, nodesBytes, s, false, &predTable);
         if (rc != NTR_OK) return rc;
-        rc = predict_scratch_get(s, numBlocks, &predScratch);
+        rc = predict_scratch_get(s, orderBlocks, &predScratch);
         if (rc != NTR_OK) return rc;
         p.order = predScratch->order;
+        if (variant == NTR_VARIANT_PERSISTENT) {   // every head walks its share of the order: ranges of whole 256-ray blocks
+            p.orderBlocks = orderBlocks;
+            p.shardRays = ((orderBlocks + p.numHeads - 1) / p.numHeads) * 256;
+        }
     }
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -642,7 +706,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         NTR_HIP(hipEventRecord(ev0, s));
     }
     if (predScratch) {  // inside the timed bracket: the prediction is part of what the launch costs
-        const hipError_t pe = ntr_launch_predict(d_rays, numRays, numBlocks, predTable->table, predTable->count, predScratch->classCount,
+        const hipError_t pe = ntr_launch_predict(d_rays, numRays, orderBlocks, predTable->table, predTable->count, predScratch->classCount,
                                                  predScratch->classList, predScratch->order, s);
         if (pe != hipSuccess) return hip_fail(pe, "predict launch");
     }

@@ -42,13 +42,15 @@ struct TraceParams {
     int32_t shardRays;       // persistent: rays per pool shard (numHeads shards, a multiple of chunk)
     int32_t numHeads;        // persistent: pool heads, a multiple of 8 (one group per XCD), <= 1024
     int32_t numBlocks;       // persistent: grid size (the statically assigned first chunks are counted from it)
+    int32_t orderBlocks;     // persistent, with `order`: number of 256-ray blocks in order[]
     int32_t fetchThreshold;  // persistent: refill when fewer lanes are live
     uint32_t bvhFlags;
     int32_t leafSwitchBelow; // serve waiting leaves when fewer lanes than this still hold an inner node
     int32_t octant;          // per-ray kernel: specialise the slab test for waves whose rays share their direction signs
     int32_t coop;            // quad-cooperative LDS-DMA node fetch instead of per-lane loads
     unsigned long long* timeline;  // diagnostic: per-wave realtime stamps (scripts/timeline*.py), or null
-    const unsigned int* order;     // per-ray kernel: workgroup i traces ray block order[i] (null = identity)
+    const unsigned int* order;     // per-ray kernel: workgroup i traces ray block order[i] (null = identity); persistent kernels: the pool
+                                   // hands the 256-ray blocks out in this order
     unsigned int* cost;            // per-ray kernel: cost[block] = max wave lifetime in 10 ns ticks (null = off)
     unsigned long long* stats;  // STATS variant: {innerVisits, triTests, leafVisits, hits}
 };

@@ -87,6 +87,7 @@ __device__ __forceinline__ unsigned int ld1(Rsrc r, int byteOfs)
     return __builtin_amdgcn_raw_buffer_load_b32(r, byteOfs, 0, 0);
 }
 
+
 __device__ __forceinline__ float sel_min(float a, float b) { return (a < b) ? a : b; }
 __device__ __forceinline__ float sel_max(float a, float b) { return (a > b) ? a : b; }
 
@@ -293,7 +294,8 @@ __device__ __forceinline__ void inner_step(Rsrc nodes, lds_char* stage, int lane
         fetch_node_coop(nodes, stage, lane, inner ? node : kNoNode, n0, n1, nz, nc);
     } else {  // every lane fetches its own node (4 x 16 B)
         const int ofs = inner ? node : kNoNode;
-        n0 = ld4(nodes, ofs); n1 = ld4(nodes, ofs + 16); nz = ld4(nodes, ofs + 32); nc = ld4(nodes, ofs + 48);
+        n0 = ld4(nodes, ofs); n1 = ld4(nodes, ofs + 16); nz = ld4(nodes, ofs + 32);
+        nc = ld4(nodes, ofs + 48);   // (an 8-byte load of the two child words alone: 0.9 % slower, profiles/r03_ab_child_load_b64.jsonl)
         keep(nc);
     }
 
@@ -654,8 +656,15 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     const int numHeads = p.numHeads;
     int shard = (int)(blockIdx.x % (unsigned)numHeads);  // wave-uniform
     bool firstChunk = true;
-    // range of head h: the heads of one XCD (h % 8) are neighbours in the index space
-    auto range_beg = [&](int h) { return ((h & 7) * (numHeads >> 3) + (h >> 3)) * p.shardRays; };
+    // Pool positions.  Buffer order (p.order == null): position = ray index; range of head h: the heads of one XCD (h % 8) are
+    // neighbours in the index space.  Predicted-cost order (p.order: the 256-ray blocks heaviest class first, sched_kernels.hip): the
+    // positions of head h are the blocks order[h], order[h + numHeads], order[h + 2 numHeads], ... -- every head hands its blocks
+    // out from heavy to light, so the long-lived rays of the batch start first instead of forming the tail of the launch.  The pool
+    // then spans numHeads * shardRays positions (shardRays a multiple of 256) and a position may lie beyond the batch: it is skipped.
+    const unsigned int* const order = p.order;
+    const int poolEnd = order ? numHeads * p.shardRays : p.numRays;
+    auto range_beg = [&](int h) { return order ? h * p.shardRays : ((h & 7) * (numHeads >> 3) + (h >> 3)) * p.shardRays; };
+    int chunkHead = 0;                // wave-uniform: the head the current chunk was taken from
     // chunks of head h handed out statically: one per wave of every block with blockIdx % numHeads == h
     auto static_rays = [&](int h) { return ((p.numBlocks - h + numHeads - 1) / numHeads) * WAVES * p.chunk; };
     LaneStats ls = {0u, 0u, 0u};
@@ -681,23 +690,25 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
                 if (firstChunk) {  // static: the (blockIdx / numHeads * WAVES + wave)-th chunk of the block's head
                     firstChunk = false;
                     const int rangeBeg = range_beg(shard);
-                    const int rangeEnd = min(rangeBeg + p.shardRays, p.numRays);
+                    const int rangeEnd = min(rangeBeg + p.shardRays, poolEnd);
                     const int base = rangeBeg + ((int)(blockIdx.x / (unsigned)numHeads) * WAVES + __builtin_amdgcn_readfirstlane(wave)) * p.chunk;
                     if (base < rangeEnd) {
                         chunkNext = base;
                         chunkEnd = min(base + p.chunk, rangeEnd);
+                        chunkHead = shard;
                         got = true;
                     }
                 }
                 while (!got) {
                     const int rangeBeg = range_beg(shard);
-                    const int rangeEnd = min(rangeBeg + p.shardRays, p.numRays);
+                    const int rangeEnd = min(rangeBeg + p.shardRays, poolEnd);
                     int base = 0;
                     if (lane == 0) base = atomicAdd(p.counter + shard * 16, p.chunk);
                     base = __builtin_amdgcn_readfirstlane(base) + static_rays(shard) + rangeBeg;
                     if (base < rangeEnd) {
                         chunkNext = base;
                         chunkEnd = min(base + p.chunk, rangeEnd);
+                        chunkHead = shard;
                         got = true;
                         break;
                     }
@@ -709,7 +720,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
                         if (ofs + lane < numHeads) {
                             const int h = (shard + ofs + lane) % numHeads;
                             const int hb = range_beg(h);
-                            const int he = min(hb + p.shardRays, p.numRays);
+                            const int he = min(hb + p.shardRays, poolEnd);
                             const int taken = __hip_atomic_load(p.counter + h * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             has = hb + static_rays(h) + taken < he;
                         }
@@ -724,8 +735,18 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
             const int prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(empty >> 32),
                                __builtin_amdgcn_mbcnt_lo((unsigned)empty, 0));
             const int avail = chunkEnd - chunkNext;
-            if (rayIdx < 0 && prefix < avail) {
-                rayIdx = chunkNext + prefix;
+            int pos = chunkNext + prefix;   // pool position -> ray index (-1: beyond the batch)
+            if (order) {
+                const int off = pos - chunkHead * p.shardRays;         // inside the head's range: its block off / 256
+                const int q = (off >> 8) * numHeads + chunkHead;       // that block's place in the predicted order
+                pos = -1;
+                if (q < p.orderBlocks) {
+                    const int a = (int)order[q] * 256 + (off & 255);
+                    pos = a < p.numRays ? a : -1;
+                }
+            }
+            if (rayIdx < 0 && prefix < avail && pos >= 0) {
+                rayIdx = pos;
                 load_ray(p.rays, rayIdx, r);
                 hitAddr = -1;
                 hitU = hitV = 0.0f;
@@ -797,7 +818,7 @@ __global__ __launch_bounds__(256) void selftest_division_kernel(const float* __r
 // measured slower than the coarse one because it gives that locality up (scripts/order_experiment.py).
 // One workgroup; stable counting sort with a per-thread segment of the block range.
 // ---------------------------------------------------------------------------------
-constexpr int SCHED_THREADS = 128;
+constexpr int SCHED_THREADS = 256;   // 64 classes x 256 threads x 4 B = the 64 KB of static LDS
 constexpr int SCHED_MAX_CLASSES = 64;
 
 __global__ __launch_bounds__(SCHED_THREADS) void sched_order_kernel(const unsigned int* __restrict__ cost, int numBlocks, int classes,

@@ -14,6 +14,7 @@
 #   shard            scripts/shard_balance_study.py
 #   lbvh             scripts/lbvh_sweep3.py
 #   fuzz:<seconds>   tests/fuzz_parity.py for that long
+#   ab:<reps>        scripts/ab_bench.sh: bench.py alternately against libntrace_amd.so and libntrace_amd_ab.so
 #   py:<script>[:args...]   python3 scripts/<script>.py args (':' separated); pyexp: the same with libntrace_amd_exp.so
 set -u
 TAG=${1:?tag}; shift
@@ -56,6 +57,8 @@ EOF
     timeout -k 5 900 python3 scripts/lbvh_sweep3.py ${ARG//:/ } > $OUT/lbvh_sweep.jsonl 2> $OUT/lbvh_sweep.err; echo "rc=$?"; cat $OUT/lbvh_sweep.jsonl; tail -n 3 $OUT/lbvh_sweep.err ;;
   fuzz)
     timeout -k 5 $((ARG + 120)) python3 tests/fuzz_parity.py --seconds $ARG --seed ${FUZZ_SEED:-41} > $OUT/fuzz.json 2> $OUT/fuzz.err; echo "rc=$?"; tail -c 1500 $OUT/fuzz.json; tail -n 3 $OUT/fuzz.err ;;
+  ab)      # interleaved A/B of libntrace_amd.so and libntrace_amd_ab.so: ab:<reps>
+    AB_OUT=$OUT bash scripts/ab_bench.sh ${ARG:-3} 2>&1 | tail -n 4 ;;
   pyexp)   # py: with the experiment build of the library (diagnostic hooks)
     SCRIPT=${ARG%%:*}; REST=""; [[ "$ARG" == *:* ]] && REST=${ARG#*:}
     NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_exp.so timeout -k 5 1500 python3 scripts/$SCRIPT.py ${REST//:/ } > $OUT/$SCRIPT.out 2> $OUT/$SCRIPT.err; echo "rc=$?"; tail -n 40 $OUT/$SCRIPT.out | cut -c1-1500; tail -n 5 $OUT/$SCRIPT.err ;;

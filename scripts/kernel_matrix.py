@@ -21,9 +21,9 @@ from workloads import lbvh, scene_of, up  # noqa: E402
 
 dev = torch.device("cuda:0")
 VARIANTS = [("fermi_speculative_while_while", {}),
-            ("fermi_speculative_while_while", {"NTR_TRACE_PERRAY_UNIFIED": "1"}),
+            ("tesla_persistent_while_while", {"NTR_TRACE_PREDICT_PERSISTENT": "0"}),
             ("tesla_persistent_while_while", {}),
-            ("kepler_dynamic_fetch", {"NTR_TRACE_UNIFIED": "0"}),   # while-while loop + dynamic fetch (round 2)
+            ("kepler_dynamic_fetch", {"NTR_TRACE_PREDICT_PERSISTENT": "0"}),
             ("kepler_dynamic_fetch", {})]
 EXTRA = [e for e in os.environ.get("KM_EXTRA_ENV", "").split(";") if e]   # e.g. "NTR_TRACE_CHUNK=128;NTR_TRACE_POOL_HEADS=256"
 

@@ -64,9 +64,9 @@ for W in $WHAT; do
   esac
 done
 # what bench.py reads for roofline.binding: {"kernel symbol|grid|counter": mean per dispatch}
-ls $OUT/*atrium*.pmc.txt $OUT/lbvh_*.pmc.txt > /dev/null 2>&1 && $SUM json $(ls $OUT/*atrium*.pmc.txt $OUT/lbvh_*.pmc.txt 2>/dev/null) > $OUT/pmc_summary.json
-ls $OUT/*courtyard*.pmc.txt > /dev/null 2>&1 && $SUM json $OUT/*courtyard*.pmc.txt > $OUT/courtyard10m_pmc_summary.json
-ls $OUT/*hairball*.pmc.txt > /dev/null 2>&1 && $SUM json $OUT/trace_hairball*.pmc.txt > $OUT/hairball_pmc_summary.json
+F=$(ls $OUT/*atrium*.pmc.txt $OUT/lbvh_*.pmc.txt 2>/dev/null); [ -n "$F" ] && $SUM json $F > $OUT/pmc_summary.json
+F=$(ls $OUT/trace_courtyard*.pmc.txt 2>/dev/null); [ -n "$F" ] && $SUM json $F > $OUT/courtyard10m_pmc_summary.json
+F=$(ls $OUT/trace_hairball*.pmc.txt 2>/dev/null); [ -n "$F" ] && $SUM json $F > $OUT/hairball_pmc_summary.json
 # raw rocprof directories are large: keep the summaries, drop the CSVs of the PMC passes
 du -sh $OUT
 find $OUT -name "*_counter_collection.csv" -size +8M -delete

@@ -191,8 +191,9 @@ def test_sched_hint_changes_order_only(soup, any_hit):
 
 @pytest.mark.parametrize("n", [1, 255, 257, 16385, 70001])
 def test_dispatch_order_prediction_changes_order_only(soup, n, monkeypatch):
-    """Closest-hit launches of the per-ray kernel are dispatched in predicted-cost order (sched_kernels.hip);
-    forced on for small, ragged launches here (block counts that are not multiples of 64, a single block)."""
+    """Closest-hit launches are dispatched in predicted-cost order (sched_kernels.hip): the per-ray kernel maps workgroup i to block
+    order[i], the persistent kernels hand their pool out in that order (every head walks its share of it).  Forced on for small, ragged
+    launches here (block counts that are not multiples of 64 or of the number of pool heads, a single block)."""
     from gpu_util import assert_parity, gpu_trace
     dbvh, cam = soup
     monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
@@ -200,13 +201,22 @@ def test_dispatch_order_prediction_changes_order_only(soup, n, monkeypatch):
     nt.set_tunables()
     rays = np.concatenate([scenes.primary_rays(cam, 300, 240)[0], edge_rays()])[:n]
     ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
-    for rep in range(3):  # the class counters alternate between two sets
-        got, _ = gpu_trace("fermi_speculative_while_while", dbvh, rays, False)
-        assert_parity(got, ref, "prediction n=%d rep=%d" % (n, rep))
+    kernels = ("fermi_speculative_while_while", "tesla_persistent_while_while", "kepler_dynamic_fetch")
+    for kernel in kernels:
+        for rep in range(3):  # the class counters alternate between two sets
+            got, _ = gpu_trace(kernel, dbvh, rays, False)
+            assert_parity(got, ref, "prediction %s n=%d rep=%d" % (kernel, n, rep))
+    monkeypatch.setenv("NTR_TRACE_POOL_HEADS", "8")     # few heads: long per-head shares of the order
+    monkeypatch.setenv("NTR_TRACE_CHUNK", "32")
+    nt.set_tunables()
+    for kernel in kernels[1:]:
+        got, _ = gpu_trace(kernel, dbvh, rays, False)
+        assert_parity(got, ref, "prediction %s n=%d, 8 heads, 32-ray chunks" % (kernel, n))
     monkeypatch.setenv("NTR_TRACE_PREDICT", "0")
     nt.set_tunables()
-    got, _ = gpu_trace("fermi_speculative_while_while", dbvh, rays, False)
-    assert_parity(got, ref, "prediction off n=%d" % n)
+    for kernel in kernels:
+        got, _ = gpu_trace(kernel, dbvh, rays, False)
+        assert_parity(got, ref, "prediction off %s n=%d" % (kernel, n))
 
 
 @pytest.mark.parametrize("octant", [0, 1])
@@ -386,9 +396,12 @@ def test_captured_launches_own_their_scratch_and_release_returns_it(soup, monkey
         for (n, d_r, d_o, ref) in batches:
             assert_parity(d_o.cpu().numpy().view(nt.RESULT_DTYPE), ref, "captured launch, replay %d" % rep)
     # the persistent kernels' pinned pool counters: 192 per device, then a clear error; release_all makes room again
+    # (prediction off: a captured persistent launch with a predicted pool order would run out of its four scratch spares first)
     n, d_r, d_o, ref = batches[1]
     del graphs
     nt.trace_graph_release_all()
+    monkeypatch.setenv("NTR_TRACE_PREDICT", "0")
+    nt.set_tunables()
     with torch.cuda.stream(s):
         dbvh.view.trace("kepler_dynamic_fetch", n, False, d_r.data_ptr(), d_o.data_ptr(), s.cuda_stream, False)
     torch.cuda.synchronize()
@@ -417,3 +430,44 @@ def test_captured_launches_own_their_scratch_and_release_returns_it(soup, monkey
         assert_parity(d_o.cpu().numpy().view(nt.RESULT_DTYPE), ref, "re-captured frame %d" % frame)
         del g
         nt.trace_graph_release_all()
+
+
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_automatic_scheduling_feedback_changes_no_record(soup, monkeypatch, any_hit):
+    """Launches of the per-ray kernel on the same batch (stream, ray buffer, count, kind, BVH) dispatch their blocks in the order the
+    previous launch measured (the library's own NtrSchedHint, NTR_TRACE_AUTO_HINT): every generation of the order -- natural or
+    predicted, first measured, re-measured, new rays written into the same buffer, the feature switched off -- gives the oracle's
+    records."""
+    import torch
+    from gpu_util import assert_parity, up
+    dbvh, cam = soup
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
+    monkeypatch.setenv("NTR_TRACE_AUTO_HINT_MIN_RAYS", "1000")
+    nt.set_tunables()
+    a = np.concatenate([scenes.primary_rays(cam, 400, 300)[0], edge_rays(), scenes.random_rays(30001, seed=12)])
+    b = np.concatenate([scenes.random_rays(30001, seed=13), scenes.primary_rays(cam, 400, 300)[0], edge_rays()])   # same count, other rays
+    n = a.shape[0]
+    ref_a, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, a, any_hit=any_hit, threads=8)
+    ref_b, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, b, any_hit=any_hit, threads=8)
+    d_rays = up(a)
+    d_res = torch.full((n * 16,), 0xCD, dtype=torch.uint8, device="cuda:0")
+    s = torch.cuda.Stream()
+    for stream in (0, s.cuda_stream):
+        for gen in range(10):
+            if gen == 6:   # new rays at the old address: the learned order is stale, never wrong
+                d_rays.copy_(up(b))
+                torch.cuda.synchronize()
+            d_res.fill_(0xCD)
+            torch.cuda.synchronize()
+            dbvh.view.trace("fermi_speculative_while_while", n, any_hit, d_rays.data_ptr(), d_res.data_ptr(), stream, gen % 2 == 0)
+            torch.cuda.synchronize()
+            assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), ref_b if gen >= 6 else ref_a, "feedback generation %d stream %s" % (gen, stream))
+        d_rays.copy_(up(a))
+        torch.cuda.synchronize()
+    monkeypatch.setenv("NTR_TRACE_AUTO_HINT", "0")
+    nt.set_tunables()
+    d_res.fill_(0xCD)
+    dbvh.view.trace("fermi_speculative_while_while", n, any_hit, d_rays.data_ptr(), d_res.data_ptr())
+    torch.cuda.synchronize()
+    assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), ref_a, "feedback off")
