@@ -45,10 +45,12 @@ PEAK_CLOCK_GHZ = 2.4
 
 # kernel symbol a selector launches by default (ntr_api.cpp: 64-thread workgroups of the per-ray kernel; template arguments
 # <WAVES, STATS, COOP, UNIFIED> / <WAVES, COOP, TL, UNIFIED>), and the grid it is launched with for n rays
-def launched_symbol(kernel, wide_leaves=False):
+def launched_symbol(kernel, wide_leaves=False, any_hit=False):
+    """<WAVES, STATS, COOP, UNIFIED, FLATF> / <WAVES, COOP, TL, UNIFIED, FLATF>: closest-hit launches of the per-ray kernel run the
+    unified-step loop on every tree, any-hit launches on trees of multi-triangle leaves (ntr_api.cpp)."""
     if kernel.startswith("fermi"):
-        return "trace_bvh_perray<1, false, false, %s>" % ("true" if wide_leaves else "false")
-    return "trace_bvh_persistent<4, false, false, %s>" % ("true" if kernel == "kepler_dynamic_fetch" else "false")
+        return "trace_bvh_perray<1, false, false, %s, true>" % ("true" if (wide_leaves or not any_hit) else "false")
+    return "trace_bvh_persistent<4, false, false, %s, true>" % ("true" if kernel == "kepler_dynamic_fetch" else "false")
 
 
 def launched_grid(kernel, n_rays, cus=256):
@@ -450,7 +452,7 @@ def main():
     wide = bool(view.flags & nt.BVH_WIDE_LEAVES)
     symbol = launched_symbol(args.kernel, wide)
     pmc, pmc_src = load_pmc(symbol, launched_grid(args.kernel, b0["n"]))
-    visits = st.numInnerVisits + st.numTriTests + (st.numLeafVisits if not (wide or args.kernel == "kepler_dynamic_fetch") else 0)
+    visits = st.numInnerVisits + st.numTriTests   # lane steps of the unified-step loop (a terminator arrives with its triangle)
     binding = binding_roofs(pmc, pmc_src, prim_ms * 1e-3, visits)
     traffic = binding.get("hbm_traffic_bytes") if binding else None
     par = ("one frame sharded by screen tile over %d ranks (PixelTable ranges), BVH built on rank 0 and broadcast, RCCL gather of hit records" % world

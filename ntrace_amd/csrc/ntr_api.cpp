@@ -145,8 +145,9 @@ static void tunables_load_locked()
     t.octant = env_int("NTR_TRACE_OCTANT", 1);
     t.closestWaves = env_int("NTR_TRACE_CLOSEST_WAVES", 1);      // likewise for closest-hit launches: primary +2.1 % with 1
     t.anyHitWaves = env_int("NTR_TRACE_ANYHIT_WAVES", 1);        // waves per workgroup of plain any-hit launches of the per-ray kernel (1, 2, 4): AO +1.7 % with 1
+    t.flatFetch = env_int("NTR_TRACE_FLAT_FETCH", 1);             // unified-step loop: one group of global loads per iteration (0 = two masked groups of range-checked buffer loads)
     t.unified = env_int("NTR_TRACE_UNIFIED", 1);                  // kepler_dynamic_fetch: unified-step loop (0 = while-while loop + dynamic fetch)
-    t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", -1);    // per-ray kernel with the unified-step loop: -1 = for trees flagged NTR_BVH_WIDE_LEAVES, 0 / 1 = never / always
+    t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", -1);    // per-ray kernel with the unified-step loop: -1 = closest-hit launches always, any-hit launches on trees flagged NTR_BVH_WIDE_LEAVES; 0 / 1 = never / always
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/persist_diag.py)
     t.autoHint = env_int("NTR_TRACE_AUTO_HINT", 1);               // dispatch order learned from the previous launch of the same batch (stream, rays, count, BVH)
     t.autoHintMinRays = env_int("NTR_TRACE_AUTO_HINT_MIN_RAYS", 1 << 17);
@@ -589,6 +590,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.fetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (dynamicFetch ? (unified ? 48 : 24) : 0);
     p.bvhFlags = bvhFlags;
     p.coop = tun.coop;
+    p.flatFetch = (tun.flatFetch != 0 && nodesBytes >= 64 && triWoopBytes >= 64) ? 1 : 0;
     p.leafSwitchBelow = tun.leafSwitchBelow >= 0 ? tun.leafSwitchBelow : (anyHit ? 24 : 32);
     p.octant = tun.octant;
     p.stats = ds->stats;
@@ -719,8 +721,11 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         const int waves = wantWaves <= 1 ? 1 : 2;
         launchVariant = waves == 1 ? NTR_VARIANT_PERRAY_W1 : NTR_VARIANT_PERRAY_W2;
         launchBlocks = numBlocks * (4 / waves);
-        if (tun.perrayUnified > 0 || (tun.perrayUnified < 0 && (bvhFlags & NTR_BVH_WIDE_LEAVES))) {
-            launchVariant = NTR_VARIANT_PERRAY_UNIFIED_W1;   // multi-triangle leaves: one node OR one triangle per lane and iteration
+        // unified-step loop (one node OR one triangle per lane and iteration, one group of loads): closest-hit launches on any tree
+        // (atrium primary +5 %, conference +21 %, LBVH trees +50 %), any-hit launches where leaves hold several triangles (short AO rays
+        // in one-triangle-leaf trees rarely reach a leaf: the while-while loop is 2-3 % ahead there)
+        if (tun.perrayUnified > 0 || (tun.perrayUnified < 0 && (!anyHit || (bvhFlags & NTR_BVH_WIDE_LEAVES)))) {
+            launchVariant = NTR_VARIANT_PERRAY_UNIFIED_W1;
             launchBlocks = numBlocks * 4;
         }
     }

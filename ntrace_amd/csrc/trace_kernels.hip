@@ -467,8 +467,61 @@ __device__ __forceinline__ void fetch64_two_buffers(u32x4 rsrcA, u32x4 rsrcB, in
     d = make_float4(__uint_as_float(vd.x), __uint_as_float(vd.y), __uint_as_float(vd.z), __uint_as_float(vd.w));
 }
 
-template <bool FAST>
-__device__ __forceinline__ void traverse_unified(u32x4 p_nodes, u32x4 p_woop, RayRegs& r, int& node, LaneStack& st,
+// The same loads INTO registers that already hold other lanes' data (read-write operands: lanes outside both masks keep theirs).
+__device__ __forceinline__ void fetch64_two_buffers_into(u32x4 rsrcA, u32x4 rsrcB, int ofs, unsigned long long maskA,
+                                                         unsigned long long maskB, float4& a, float4& b, float4& c, float4& d)
+{
+    u32x4 va = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)};
+    u32x4 vb = {__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w)};
+    u32x4 vc = {__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), __float_as_uint(c.w)};
+    u32x4 vd = {__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), __float_as_uint(d.w)};
+    unsigned long long sav;
+    asm volatile(
+        "s_mov_b64 %[sav], exec\n\t"
+        "s_and_b64 exec, %[sav], %[ma]\n\t"
+        "buffer_load_dwordx4 %[a], %[ofs], %[ra], 0 offen\n\t"
+        "buffer_load_dwordx4 %[b], %[ofs], %[ra], 0 offen offset:16\n\t"
+        "buffer_load_dwordx4 %[c], %[ofs], %[ra], 0 offen offset:32\n\t"
+        "buffer_load_dwordx4 %[d], %[ofs], %[ra], 0 offen offset:48\n\t"
+        "s_and_b64 exec, %[sav], %[mb]\n\t"
+        "buffer_load_dwordx4 %[a], %[ofs], %[rb], 0 offen\n\t"
+        "buffer_load_dwordx4 %[b], %[ofs], %[rb], 0 offen offset:16\n\t"
+        "buffer_load_dwordx4 %[c], %[ofs], %[rb], 0 offen offset:32\n\t"
+        "buffer_load_dwordx4 %[d], %[ofs], %[rb], 0 offen offset:48\n\t"
+        "s_mov_b64 exec, %[sav]\n\t"
+        "s_waitcnt vmcnt(0)"
+        : [a] "+v"(va), [b] "+v"(vb), [c] "+v"(vc), [d] "+v"(vd), [sav] "=&s"(sav)
+        : [ofs] "v"(ofs), [ra] "s"(rsrcA), [rb] "s"(rsrcB), [ma] "s"(maskA), [mb] "s"(maskB)
+        : "memory");
+    a = make_float4(__uint_as_float(va.x), __uint_as_float(va.y), __uint_as_float(va.z), __uint_as_float(va.w));
+    b = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
+    c = make_float4(__uint_as_float(vc.x), __uint_as_float(vc.y), __uint_as_float(vc.z), __uint_as_float(vc.w));
+    d = make_float4(__uint_as_float(vd.x), __uint_as_float(vd.y), __uint_as_float(vd.z), __uint_as_float(vd.w));
+}
+
+// The two buffers of a unified fetch, as plain pointers + extents (FLAT = true: one set of four global loads for all live lanes) and as
+// descriptor words (the range-checked two-buffer form: lanes whose 64 bytes would cross the end of their buffer, FLAT = false).
+struct UnifiedBufs {
+    const char* nodes; const char* woop;
+    unsigned int nodesBytes, woopBytes;
+    u32x4 rNodes, rWoop;
+};
+__device__ __forceinline__ UnifiedBufs unified_bufs(const TraceParams& p)
+{
+    UnifiedBufs u;
+    u.nodes = (const char*)p.nodes; u.woop = (const char*)p.woop;
+    u.nodesBytes = p.nodesBytes; u.woopBytes = p.woopBytes;
+    u.rNodes = rsrc_words(p.nodes, p.nodesBytes); u.rWoop = rsrc_words(p.woop, p.woopBytes);
+    return u;
+}
+
+// FLAT: the texture-address unit charges a wave-level load instruction about 16 cycles whatever its exec mask, so the two masked
+// groups of fetch64_two_buffers cost 128 TA cycles per iteration and made the unified loop TA-bound (0.6-0.87 busy, profiles/r03v_*).
+// With FLAT every live lane forms the 64-bit address of its own 64 bytes and ONE group of four global loads serves nodes and triangles
+// alike (64 TA cycles).  Global loads are not range-checked: a lane whose 64 bytes would end beyond its buffer (an empty leaf's
+// terminator in the last 48 bytes of triWoop; a malformed child offset) takes the descriptor path instead, which reads zeros there.
+template <bool FAST, bool FLAT, int OCT = 8>
+__device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs& r, int& node, LaneStack& st,
                                                  int (&spill)[SPILL_DEPTH], bool anyHit, int& hitAddr, float& hitU, float& hitV,
                                                  unsigned int* status, bool poolEmpty, int fetchThreshold)
 {
@@ -484,10 +537,24 @@ __device__ __forceinline__ void traverse_unified(u32x4 p_nodes, u32x4 p_woop, Ra
         // descriptor per lane and wraps every load in a waterfall loop.)
         const int ofs = inner ? node : (~node) * 16;
         float4 a, b, c, d;
-        fetch64_two_buffers(p_nodes, p_woop, ofs, __ballot(inner), __ballot(atTri), a, b, c, d);
+        if (FLAT) {
+            const bool flatOk = (inner || atTri) && (unsigned)ofs <= (inner ? ub.nodesBytes : ub.woopBytes) - 64u;   // (extents are >= 64 here)
+            asm volatile("" : "=v"(a.x), "=v"(a.y), "=v"(a.z), "=v"(a.w), "=v"(b.x), "=v"(b.y), "=v"(b.z), "=v"(b.w));   // defined, whatever the lane
+            asm volatile("" : "=v"(c.x), "=v"(c.y), "=v"(c.z), "=v"(c.w), "=v"(d.x), "=v"(d.y), "=v"(d.z), "=v"(d.w));
+            if (flatOk) {
+                const float4* q = reinterpret_cast<const float4*>((inner ? ub.nodes : ub.woop) + (unsigned)ofs);
+                a = q[0]; b = q[1]; c = q[2]; d = q[3];
+            }
+            keep(a); keep(b); keep(c); keep(d);
+            const unsigned long long odd = __ballot((inner || atTri) && !flatOk);
+            if (odd != 0ull)   // rare: range-checked descriptor loads, into the same registers, for the lanes at the very end of a buffer
+                fetch64_two_buffers_into(ub.rNodes, ub.rWoop, ofs, __ballot(inner && !flatOk), __ballot(atTri && !flatOk), a, b, c, d);
+        } else {
+            fetch64_two_buffers(ub.rNodes, ub.rWoop, ofs, __ballot(inner), __ballot(atTri), a, b, c, d);
+        }
         if (inner) {   // trace<BVHLayout_Compact>, one inner node (CudaBVH.cpp:721-775)
             float mn0, mx0, mn1, mx1;
-            ray_box2<FAST>(r, a, b, c, mn0, mx0, mn1, mx1);
+            ray_box2<FAST, OCT>(r, a, b, c, mn0, mx0, mn1, mx1);
             const bool i0 = (mn0 <= mx0) && (mx0 >= r.tmin) && (mn0 <= r.tmax);
             const bool i1 = (mn1 <= mx1) && (mx1 >= r.tmin) && (mn1 <= r.tmax);
             const int c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
@@ -530,7 +597,7 @@ __device__ __forceinline__ void traverse_unified(u32x4 p_nodes, u32x4 p_woop, Ra
 // Variant 1: one ray per lane, while-while ("fermi_speculative_while_while" slot).
 // ---------------------------------------------------------------------------------
 // UNIFIED: the unified-step loop (traverse_unified) -- for trees whose leaves hold several triangles (the device LBVH).
-template <int WAVES, bool STATS, bool COOP, bool UNIFIED = false>
+template <int WAVES, bool STATS, bool COOP, bool UNIFIED = false, bool FLATF = true>
 __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_perray(TraceParams p)
 {
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
@@ -566,7 +633,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     const bool fastWave = (p.bvhFlags & NTR_BVH_FASTDIV) && __ballot(node != kSentinel && !ray_is_nice(r, p.bvhFlags)) == 0ull;
     // direction signs shared by every live ray of the wave (a primary wave is an 8 x 8 pixel tile): the octant's own slab test
     int oct = 8;
-    if (!UNIFIED && !STATS && !COOP && fastWave && p.octant && (p.bvhFlags & NTR_BVH_ORDERED)) {
+    if (!STATS && !COOP && fastWave && p.octant && (p.bvhFlags & NTR_BVH_ORDERED)) {
         const unsigned long long liveMask = __ballot(node != kSentinel);
         const unsigned long long sx = __ballot(node != kSentinel && r.dx < 0.0f), sy = __ballot(node != kSentinel && r.dy < 0.0f),
                                  sz = __ballot(node != kSentinel && r.dz < 0.0f);
@@ -574,8 +641,23 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
             oct = (sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0);
     }
     if (UNIFIED) {
-        if (fastWave) traverse_unified<true>(rsrc_words(p.nodes, p.nodesBytes), rsrc_words(p.woop, p.woopBytes), r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
-        else traverse_unified<false>(rsrc_words(p.nodes, p.nodesBytes), rsrc_words(p.woop, p.woopBytes), r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
+        const UnifiedBufs ub = unified_bufs(p);
+#define NTR_UNIFIED_OCT(O) traverse_unified<true, FLATF, O>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0)
+        if (oct < 8) {
+            switch (oct) {
+                case 0: NTR_UNIFIED_OCT(0); break;
+                case 1: NTR_UNIFIED_OCT(1); break;
+                case 2: NTR_UNIFIED_OCT(2); break;
+                case 3: NTR_UNIFIED_OCT(3); break;
+                case 4: NTR_UNIFIED_OCT(4); break;
+                case 5: NTR_UNIFIED_OCT(5); break;
+                case 6: NTR_UNIFIED_OCT(6); break;
+                default: NTR_UNIFIED_OCT(7); break;
+            }
+        }
+#undef NTR_UNIFIED_OCT
+        else if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
+        else traverse_unified<false, FLATF>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
     } else
 #define NTR_TRAVERSE_OCT(O) traverse<true, STATS, false, COOP, O>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow)
     if (!STATS && !COOP && oct < 8) {
@@ -629,7 +711,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
 // TL: the diagnostic stamps of NTR_TRACE_TIMELINE are compiled into their own instantiation -- they cost 18 VGPRs,
 // i.e. two waves of occupancy per SIMD, which the production kernel must not pay.
 // UNIFIED: the unified-step loop (traverse_unified) instead of the while-while loop -- what kepler_dynamic_fetch launches.
-template <int WAVES, bool COOP, bool TL, bool UNIFIED = false>
+template <int WAVES, bool COOP, bool TL, bool UNIFIED = false, bool FLATF = true>
 __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_persistent(TraceParams p)
 {
     unsigned long long* const timeline = TL ? p.timeline : nullptr;
@@ -764,8 +846,9 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
         // ---- while-while traversal ------------------------------------------------
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
         if (UNIFIED) {
-            if (fastWave) traverse_unified<true>(rsrc_words(p.nodes, p.nodesBytes), rsrc_words(p.woop, p.woopBytes), r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
-            else traverse_unified<false>(rsrc_words(p.nodes, p.nodesBytes), rsrc_words(p.woop, p.woopBytes), r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
+            const UnifiedBufs ub = unified_bufs(p);
+            if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
+            else traverse_unified<false, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
         } else if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
         else traverse<false, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
 
@@ -890,15 +973,17 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
     case NTR_VARIANT_PERRAY_W1:
         hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
-    case NTR_VARIANT_PERRAY_UNIFIED_W1:
-        hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false, true>), dim3(numBlocks), dim3(64), 0, stream, *p);
+    case NTR_VARIANT_PERRAY_UNIFIED_W1:   // flatFetch 0: the two-group descriptor fetch (A/B; extents below 64 bytes)
+        if (p->flatFetch) hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false, true, true>), dim3(numBlocks), dim3(64), 0, stream, *p);
+        else hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false, true, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_STATS:
         hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERSISTENT_UNIFIED:
-        if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
-        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, false, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        else if (p->flatFetch) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, false, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, false, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERSISTENT:
         if (p->coop) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);

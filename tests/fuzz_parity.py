@@ -186,7 +186,7 @@ def main(argv=None):
             # loop variants only change how the lanes of a wave interleave: while-while or unified-step loop in the per-ray kernel (by the
             # tree's leaf sizes, or forced either way) and in kepler_dynamic_fetch, any dynamic-fetch threshold
             loop = dict(NTR_TRACE_PERRAY_UNIFIED=int(rng.choice([-1, 0, 1])), NTR_TRACE_UNIFIED=int(rng.choice([1, 1, 0])),
-                        NTR_TRACE_FETCH_THRESHOLD=int(rng.choice([-1, -1, 1, 16, 33, 64])))
+                        NTR_TRACE_FETCH_THRESHOLD=int(rng.choice([-1, -1, 1, 16, 33, 64])), NTR_TRACE_FLAT_FETCH=int(rng.choice([1, 1, 0])))
             nt.set_tunables(**loop)
             tot["loop_%s" % "_".join(str(v) for v in loop.values())] = tot.get("loop_%s" % "_".join(str(v) for v in loop.values()), 0) + 1
             hint = nt.SchedHint() if sched == 2 else None

@@ -340,14 +340,16 @@ def test_unified_step_loop_changes_no_record(soup, monkeypatch, tree):
     allrays = np.concatenate([scenes.primary_rays(cam, 200, 160)[0], edge_rays(), scenes.random_rays(20000, seed=5)])
     for any_hit in (False, True):
         ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, allrays, any_hit=any_hit, threads=8)
-        for env in ({"NTR_TRACE_PERRAY_UNIFIED": "1"}, {"NTR_TRACE_PERRAY_UNIFIED": "0"}):
+        for env in ({"NTR_TRACE_PERRAY_UNIFIED": "1", "NTR_TRACE_FLAT_FETCH": "1"}, {"NTR_TRACE_PERRAY_UNIFIED": "1", "NTR_TRACE_FLAT_FETCH": "0"},
+                    {"NTR_TRACE_PERRAY_UNIFIED": "0"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             nt.set_tunables()
             for n in (allrays.shape[0], 1, 65, 4097):
                 got, _ = gpu_trace("fermi_speculative_while_while", dbvh, allrays[:n], any_hit)
                 assert_parity(got, ref[:n], "%s per-ray %s n=%d anyHit=%d" % (tree, env, n, any_hit))
-        for env in ({"NTR_TRACE_UNIFIED": "1", "NTR_TRACE_FETCH_THRESHOLD": "48"}, {"NTR_TRACE_UNIFIED": "1", "NTR_TRACE_FETCH_THRESHOLD": "64"},
+        for env in ({"NTR_TRACE_UNIFIED": "1", "NTR_TRACE_FETCH_THRESHOLD": "48", "NTR_TRACE_FLAT_FETCH": "1"},
+                    {"NTR_TRACE_UNIFIED": "1", "NTR_TRACE_FETCH_THRESHOLD": "48", "NTR_TRACE_FLAT_FETCH": "0"}, {"NTR_TRACE_UNIFIED": "1", "NTR_TRACE_FETCH_THRESHOLD": "64"},
                     {"NTR_TRACE_UNIFIED": "1", "NTR_TRACE_FETCH_THRESHOLD": "1"}, {"NTR_TRACE_UNIFIED": "0", "NTR_TRACE_FETCH_THRESHOLD": "24"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
