@@ -92,8 +92,13 @@ def binding_roofs(pmc, pmc_src, sec, visits=None):
     b = {"source": "profiles/" + pmc_src, "effective_clock_ghz": clk}
     if "SQ_INSTS_VALU" in pmc:
         b["valu_issue_frac"] = pmc["SQ_INSTS_VALU"] / sec / (NUM_SIMDS * use_clk * 1e9 / 2.0)
+    # texture-address unit: busy cycles over the launch.  TA_TA_BUSY counts every kind of vector-memory instruction (the unified-step loop
+    # fetches with global loads, which TA_BUFFER_TOTAL_CYCLES does not see); the buffer-only figure is kept where it is the larger part
+    if "TA_TA_BUSY_sum" in pmc:
+        b["ta_frac"] = pmc["TA_TA_BUSY_sum"] / NUM_TAS / (sec * use_clk * 1e9)
     if "TA_BUFFER_TOTAL_CYCLES_sum" in pmc:
-        b["ta_frac"] = pmc["TA_BUFFER_TOTAL_CYCLES_sum"] / NUM_TAS / (sec * use_clk * 1e9)
+        b["ta_buffer_frac"] = pmc["TA_BUFFER_TOTAL_CYCLES_sum"] / NUM_TAS / (sec * use_clk * 1e9)
+        b.setdefault("ta_frac", b["ta_buffer_frac"])
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:  # KiB; gfx950: FETCH_SIZE counts 64 B per 128-B request
         b["hbm_traffic_bytes"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         b["hbm_traffic_frac"] = b["hbm_traffic_bytes"] / sec / 1e9 / HBM_PEAK_GBS
@@ -510,8 +515,8 @@ def main():
         clk = min(binding.get("effective_clock_ghz") or PEAK_CLOCK_GHZ, PEAK_CLOCK_GHZ)
         if binding["bound"] == "ta":
             roof.update({"bound": "ta", "unit": "Gcycles/s", "peak": NUM_TAS * clk,
-                         "achieved": pmc["TA_BUFFER_TOTAL_CYCLES_sum"] / (prim_ms * 1e-3) / 1e9, "frac": binding["ta_frac"],
-                         "note": "texture-address unit busy cycles (TA_BUFFER_TOTAL_CYCLES, one TA per CU) over the launch; VALU issue is in binding"})
+                         "achieved": pmc.get("TA_TA_BUSY_sum", pmc.get("TA_BUFFER_TOTAL_CYCLES_sum", 0.0)) / (prim_ms * 1e-3) / 1e9, "frac": binding["ta_frac"],
+                         "note": "texture-address unit busy cycles (TA_TA_BUSY, one TA per CU) over the launch; VALU issue is in binding"})
         else:
             roof.update({"bound": "valu", "unit": "Ginstr/s", "peak": NUM_SIMDS * clk / 2.0,
                          "achieved": pmc["SQ_INSTS_VALU"] / (prim_ms * 1e-3) / 1e9, "frac": binding["valu_issue_frac"],

@@ -101,7 +101,7 @@ struct KernelInfo {
 // for every BVH it builds, src/rt/cuda/CudaBVH.cpp:65-82).
 static const KernelInfo kKernels[] = {
     {"fermi_speculative_while_while", NTR_VARIANT_PERRAY,
-     {NTR_BVHLayout_Compact, 64, NTR_TRACE_WAVES_PER_BLOCK, 0}},
+     {NTR_BVHLayout_Compact, 64, 1, 0}},   // the per-ray kernel is launched in 64-thread workgroups (one wave)
     {"tesla_persistent_while_while", NTR_VARIANT_PERSISTENT,
      {NTR_BVHLayout_Compact, 64, NTR_TRACE_WAVES_PER_BLOCK, 1}},
     {"tesla_persistent_speculative_while_while", NTR_VARIANT_PERSISTENT,
