@@ -46,10 +46,12 @@ PEAK_CLOCK_GHZ = 2.4
 # kernel symbol a selector launches by default (ntr_api.cpp: 64-thread workgroups of the per-ray kernel; template arguments
 # <WAVES, STATS, COOP, UNIFIED> / <WAVES, COOP, TL, UNIFIED>), and the grid it is launched with for n rays
 def launched_symbol(kernel, wide_leaves=False, any_hit=False):
-    """<WAVES, STATS, COOP, UNIFIED, FLATF> / <WAVES, COOP, TL, UNIFIED, FLATF>: closest-hit launches of the per-ray kernel run the
-    unified-step loop on every tree, any-hit launches on trees of multi-triangle leaves (ntr_api.cpp)."""
+    """<WAVES, STATS, COOP, UNIFIED, FLATF, MINI> / <WAVES, COOP, TL, UNIFIED, FLATF>: closest-hit launches of the per-ray kernel run the
+    unified-step loop on every tree (in the instantiation that can turn into the wave-private mini-pool), any-hit launches on trees of
+    multi-triangle leaves (ntr_api.cpp)."""
     if kernel.startswith("fermi"):
-        return "trace_bvh_perray<1, false, false, %s, true>" % ("true" if (wide_leaves or not any_hit) else "false")
+        return "trace_bvh_perray<1, false, false, %s, true, %s>" % ("true" if (wide_leaves or not any_hit) else "false",
+                                                                    "false" if any_hit else "true")
     return "trace_bvh_persistent<4, false, false, %s, true>" % ("true" if kernel == "kepler_dynamic_fetch" else "false")
 
 

@@ -12,7 +12,7 @@ from ._capi import (BvhView, RAY_DTYPE, RESULT_DTYPE, HostBvh, KernelConfig, Ntr
                     raygen_primary, raygen_ao, count_hits, selftest_division, lbvh_capacity,
                     lbvh_build, LbvhResult, reconstruct, ray_morton_sort, camera_decode, camera_reencode,
                     camera_nscreen_to_world, obj_load, SchedHint, trace_status, set_tunables, experiment_hooks, host_bvh_wrap, use_library, exp_lib_path, trace_graph_reserve, trace_graph_release_all,
-                    lbvh_release_workspace, predict_block_costs)
+                    lbvh_release_workspace, predict_block_costs, predict_batch_coherence)
 
 BVHLayout_Compact = 4
 BVH_FINITE, BVH_FASTDIV, BVH_NOTINY, BVH_ORDERED, BVH_WIDE_LEAVES = 1, 2, 4, 8, 16

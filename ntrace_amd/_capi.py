@@ -83,6 +83,7 @@ SYMBOLS = [
     ("ntr_trace_status", C.c_int, [_vp, C.POINTER(_u32)]),
     ("ntr_tunables_reload", C.c_int, []),
     ("ntr_predict_block_costs", C.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
+    ("ntr_predict_batch_coherence", C.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
     ("ntr_trace_graph_reserve", C.c_int, [_i32, _i32]),
     ("ntr_trace_graph_release_all", C.c_int, []),
     ("ntr_lbvh_release_workspace", C.c_int, []),
@@ -214,6 +215,11 @@ def trace_status(stream=0):
     bits = _u32(0)
     _check(lib().ntr_trace_status(_vp(stream), C.byref(bits)))
     return int(bits.value)
+
+
+def predict_batch_coherence(num_rays, d_rays, d_nodes, nodes_bytes, d_out, stream=0):
+    """ntr_predict_batch_coherence: d_out[0] = 256-ray blocks whose sample rays start far apart, d_out[1] = the pool K derived from it."""
+    _check(lib().ntr_predict_batch_coherence(int(num_rays), _vp(d_rays), _vp(d_nodes), int(nodes_bytes), _vp(d_out), _vp(stream)))
 
 
 def predict_block_costs(num_rays, d_rays, d_nodes, nodes_bytes, d_block_cost, stream=0):

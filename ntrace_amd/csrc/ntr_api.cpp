@@ -146,6 +146,9 @@ static void tunables_load_locked()
     t.closestWaves = env_int("NTR_TRACE_CLOSEST_WAVES", 1);      // likewise for closest-hit launches: primary +2.1 % with 1
     t.anyHitWaves = env_int("NTR_TRACE_ANYHIT_WAVES", 1);        // waves per workgroup of plain any-hit launches of the per-ray kernel (1, 2, 4): AO +1.7 % with 1
     t.flatFetch = env_int("NTR_TRACE_FLAT_FETCH", 1);             // unified-step loop: one group of global loads per iteration (0 = two masked groups of range-checked buffer loads)
+    t.minipool = env_int("NTR_TRACE_MINIPOOL", -1);              // closest-hit per-ray launches: rays owned by a wave / 64.  -1: decided per batch on the device (1, or minipoolWide when the prediction finds the batch incoherent); 0: the plain per-ray kernel; 1 / 2 / 4: forced
+    t.minipoolWide = env_int("NTR_TRACE_MINIPOOL_WIDE", -1);     // K of an incoherent batch: 2 / 4, or -1 = by tree size (4 from 32 MB of nodes up)
+    t.minipoolThreshold = env_int("NTR_TRACE_MINIPOOL_THRESHOLD", 48);   // refill a wave's finished lanes when fewer than this many are live
     t.unified = env_int("NTR_TRACE_UNIFIED", 1);                  // kepler_dynamic_fetch: unified-step loop (0 = while-while loop + dynamic fetch)
     t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", -1);    // per-ray kernel with the unified-step loop: -1 = closest-hit launches always, any-hit launches on trees flagged NTR_BVH_WIDE_LEAVES; 0 / 1 = never / always
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/persist_diag.py)
@@ -309,7 +312,8 @@ struct PredictScratch {
     State state = FREE;
     void* stream = nullptr;              // LIVE: the owning stream (the null stream is a stream like any other)
     int device = -1;
-    unsigned int* classCount = nullptr;  // NTR_SCHED_PRED_CLASSES counters, zero whenever no prediction is in flight
+    unsigned int* classCount = nullptr;  // NTR_SCHED_PRED_WORDS words: class counters + incoherent-block counter (zero whenever no prediction is
+                                         // in flight) + the mini-pool K of the last prediction
     unsigned int* classList = nullptr;
     unsigned int* order = nullptr;
     int capBlocks = 0;
@@ -364,8 +368,8 @@ extern "C" int ntr_top_table_refresh(const void* d_nodes, int64_t nodesBytes, vo
 static int scratch_alloc(PredictScratch* p, int dev, int numBlocks)
 {
     if (!p->classCount) {
-        NTR_HIP(hipMalloc((void**)&p->classCount, NTR_SCHED_PRED_CLASSES * sizeof(unsigned int)));
-        NTR_HIP(hipMemset(p->classCount, 0, NTR_SCHED_PRED_CLASSES * sizeof(unsigned int)));
+        NTR_HIP(hipMalloc((void**)&p->classCount, NTR_SCHED_PRED_WORDS * sizeof(unsigned int)));
+        NTR_HIP(hipMemset(p->classCount, 0, NTR_SCHED_PRED_WORDS * sizeof(unsigned int)));
     }
     if (p->capBlocks < numBlocks) {
         if (p->classList) { (void)hipFree(p->classList); (void)hipFree(p->order); p->classList = p->order = nullptr; p->capBlocks = 0; }
@@ -535,6 +539,14 @@ static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, i
     return NTR_OK;
 }
 
+// pool K of an incoherent batch: long rays (big trees) amortise a deeper private pool; measured on 2^21 box rays K = 4 / 2 / 1:
+// courtyard-10M 4.71 / 5.38 / 6.35 ms, hairball-2.8M 3.69 / 3.77 / 4.93, atrium-262k 0.592 / 0.562 / 0.614 (profiles/r03_minipool_matrix.txt)
+static int minipool_wide(const Tunables& tun, int64_t nodesBytes)
+{
+    if (tun.minipoolWide == 2 || tun.minipoolWide == 4) return tun.minipoolWide;
+    return nodesBytes >= (int64_t)32 << 20 ? 4 : 2;
+}
+
 static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
                       NtrRayResult* d_results, const void* d_nodes, int64_t nodesBytes, const void* d_triWoop,
                       int64_t triWoopBytes, const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags,
@@ -597,6 +609,8 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.timeline = nullptr;
     p.order = nullptr;
     p.cost = nullptr;
+    p.poolK = nullptr;
+    p.poolKConst = 1;
 #ifdef NTR_EXPERIMENTS
     p.timeline = g_expTimeline;
     p.order = g_expOrder;
@@ -658,13 +672,18 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         NTR_HIP(hipGetDevice(&dev));
         if (hint->numBlocks != numBlocks || hint->device != dev) {
             sched_hint_release(hint);
-            NTR_HIP(hipMalloc((void**)&hint->order, (size_t)numBlocks * sizeof(unsigned int)));
+            // order[numBlocks]: the mini-pool K of the batch (0 = not predicted yet, read as 1), kept from the first, predicted launch on
+            NTR_HIP(hipMalloc((void**)&hint->order, ((size_t)numBlocks + 1) * sizeof(unsigned int)));
             NTR_HIP(hipMalloc((void**)&hint->cost, (size_t)numBlocks * sizeof(unsigned int)));
             hint->numBlocks = numBlocks;
             hint->device = dev;
         }
         // costs measured under the natural order differ from those under the derived order, so the first
         // launches all refresh; afterwards every 8th does (slowly drifting rays keep their schedule)
+        if (hint->uses == 0) {   // a hint that starts over (new, or an automatic one recycled for another batch) forgets its K
+            const hipError_t zk = ntr_launch_zero_words(hint->order + numBlocks, 1, s);
+            if (zk != hipSuccess) return hip_fail(zk, "zero_words launch");
+        }
         const int every = tun.schedRefreshEvery;
         refresh = hint->uses < 3 || every <= 1 || (hint->uses % every) == 0;
         hint->uses++;
@@ -709,7 +728,8 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     }
     if (predScratch) {  // inside the timed bracket: the prediction is part of what the launch costs
         const hipError_t pe = ntr_launch_predict(d_rays, numRays, orderBlocks, predTable->table, predTable->count, predScratch->classCount,
-                                                 predScratch->classList, predScratch->order, s);
+                                                 predScratch->classList, predScratch->order,
+                                                 (hint && variant == NTR_VARIANT_PERRAY) ? hint->order + numBlocks : nullptr, minipool_wide(tun, nodesBytes), s);
         if (pe != hipSuccess) return hip_fail(pe, "predict launch");
     }
     // Workgroup size of the per-ray kernel: smaller workgroups retire (and are replaced) sooner.  The dispatch order and the cost
@@ -727,6 +747,17 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         if (tun.perrayUnified > 0 || (tun.perrayUnified < 0 && (!anyHit || (bvhFlags & NTR_BVH_WIDE_LEAVES)))) {
             launchVariant = NTR_VARIANT_PERRAY_UNIFIED_W1;
             launchBlocks = numBlocks * 4;
+            // wave-private mini-pool: a wave owns K x 64 rays and refills its finished lanes from them.  K is decided on the device: the
+            // prediction of this launch wrote it (incoherent batch: minipoolWide, else 1), or the batch's hint kept it from its first launch.
+            if (p.flatFetch && tun.minipool != 0 && !anyHit) {
+                launchVariant = NTR_VARIANT_PERRAY_UNIFIED_MINI;
+                p.fetchThreshold = tun.minipoolThreshold;
+                p.poolKConst = tun.minipool > 0 ? tun.minipool : 1;
+                if (tun.minipool < 0) {
+                    if (predScratch) p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 1;
+                    else if (hint && hint->numBlocks == numBlocks && hint->order) p.poolK = hint->order + numBlocks;
+                }
+            }
         }
     }
     hipError_t le = ntr_launch_trace(launchVariant, &p, launchBlocks, s);
@@ -815,6 +846,22 @@ int ntr_predict_block_costs(int32_t numRays, const NtrRay* d_rays, const void* d
     if (rc != NTR_OK) return rc;
     const hipError_t e = ntr_launch_predict_costs(d_rays, numRays, (numRays + 255) / 256, t->table, t->count, d_blockCost, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "predict_costs launch");
+    return NTR_OK;
+}
+
+int ntr_predict_batch_coherence(int32_t numRays, const NtrRay* d_rays, const void* d_nodes, int64_t nodesBytes, uint32_t* d_out, void* stream)
+{
+    if (numRays < 0) return set_error(NTR_ERR_INVALID, "ntr_predict_batch_coherence: numRays < 0");
+    if (!d_out) return set_error(NTR_ERR_INVALID, "ntr_predict_batch_coherence: null argument");
+    if (numRays > 0 && (!d_rays || !d_nodes)) return set_error(NTR_ERR_INVALID, "ntr_predict_batch_coherence: null argument");
+    if (nodesBytes < 64 || (nodesBytes % 64) != 0 || nodesBytes > kMaxNodesBytes)
+        return set_error(NTR_ERR_INVALID, "ntr_predict_batch_coherence: node buffer size must be a multiple of 64 in [64, 0x76543200]");
+    TopTable* t = nullptr;
+    const int rc = top_table_get(d_nodes, nodesBytes, (hipStream_t)stream, false, &t);
+    if (rc != NTR_OK) return rc;
+    const hipError_t e = ntr_launch_coherence(d_rays, numRays, (numRays + 255) / 256, t->table, t->count, d_out, minipool_wide(tunables(), nodesBytes),
+                                              (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "coherence launch");
     return NTR_OK;
 }
 

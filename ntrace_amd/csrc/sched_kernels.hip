@@ -68,6 +68,22 @@ __global__ __launch_bounds__(256) void top_table_kernel(const float4* __restrict
 // (one LDS broadcast for all 64 lanes).
 constexpr int PRED_WAVES = 16;
 constexpr int PRED_SAMPLE = 100;        // sample ray inside the block (any fixed lane)
+constexpr int PRED_SAMPLE2 = 227;       // second sample, for the coherence estimate
+
+// Coherence of a 256-ray block: does a second ray of the block (in another wave of it) start far from the sample ray -- further than
+// 1/8 of the scene's extent?  Rays that do share no deep nodes and their step counts are uncorrelated: the mini-pool case
+// (trace_kernels.hip).  o = origin of the block's sample ray; table[0..3] = the root's two child boxes.
+__device__ __forceinline__ bool block_starts_apart(const float4* __restrict__ rays, int numRays, int block, const float4 o,
+                                                   const float4* __restrict__ table)
+{
+    const int r2 = min(block * 256 + PRED_SAMPLE2, numRays - 1);
+    const float4 o2 = rays[2 * r2];
+    const float4 a0 = table[0], a1 = table[1], b0 = table[2], b1 = table[3];
+    const float ext = fmaxf(fmaxf(fmaxf(a0.y, b0.y) - fminf(a0.x, b0.x), fmaxf(a0.w, b0.w) - fminf(a0.z, b0.z)),
+                            fmaxf(a1.y, b1.y) - fminf(a1.x, b1.x));
+    const float dist = fmaxf(fmaxf(fabsf(o2.x - o.x), fabsf(o2.y - o.y)), fabsf(o2.z - o.z));
+    return dist > 0.125f * ext;   // (false for NaN)
+}
 
 __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* __restrict__ rays, int numRays, int numBlocks,
                                                                   const float4* __restrict__ table,
@@ -116,6 +132,11 @@ __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* 
         if (tid < 64 && block < numBlocks) blockCost[block] = s_cnt[lane];
         return;
     }
+    if (wave == 0) {
+        const bool apart = block < numBlocks && nBoxes >= 2 && block_starts_apart(rays, numRays, block, o, table);
+        const unsigned long long m = __ballot(apart);
+        if (lane == 0 && m) atomicAdd(&classCount[NTR_SCHED_PRED_CLASSES], (unsigned int)__popcll(m));
+    }
     unsigned int cls = 0;
     if (tid < 64 && block < numBlocks) {
         cls = min(s_cnt[lane] >> 1, (unsigned int)(NTR_SCHED_PRED_CLASSES - 1));
@@ -139,10 +160,20 @@ __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* 
 // when a captured HIP graph is replayed; kernels do).
 constexpr int FLATTEN_THREADS = 1024;
 __global__ __launch_bounds__(FLATTEN_THREADS) void flatten_kernel(unsigned int* __restrict__ classCount, const unsigned int* __restrict__ classList,
-                                                                  int numBlocks, unsigned int* __restrict__ order)
+                                                                  int numBlocks, unsigned int* __restrict__ order,
+                                                                  unsigned int* __restrict__ poolKCopy, int poolKWide)
 {
     __shared__ unsigned int s_end[NTR_SCHED_PRED_CLASSES];  // s_end[k] = entries in the k+1 heaviest classes
     const int tid = threadIdx.x;
+    if (tid == 64) {
+        // most blocks incoherent -> the mini-pool kernel's waves own poolKWide x 64 rays; else one ray per lane (the word outlives this
+        // prediction: the trace launch behind it reads it, the next prediction on this scratch is ordered after that launch)
+        const unsigned int apart = classCount[NTR_SCHED_PRED_CLASSES];
+        const unsigned int k = (2u * apart >= (unsigned int)numBlocks) ? (unsigned int)poolKWide : 1u;
+        classCount[NTR_SCHED_PRED_CLASSES] = 0;
+        classCount[NTR_SCHED_PRED_CLASSES + 1] = k;
+        if (poolKCopy) *poolKCopy = k;
+    }
     if (tid < 64) {
         static_assert(NTR_SCHED_PRED_CLASSES == 64, "one class per lane");
         unsigned int incl = classCount[NTR_SCHED_PRED_CLASSES - 1 - tid];
@@ -164,6 +195,25 @@ __global__ __launch_bounds__(FLATTEN_THREADS) void flatten_kernel(unsigned int* 
         const int cls = NTR_SCHED_PRED_CLASSES - 1 - k;
         order[e] = classList[(size_t)cls * numBlocks + ((unsigned int)e - begin)];
     }
+}
+
+// Coherence query (ntr_predict_batch_coherence): out[0] += blocks whose sample rays start apart; the finish step turns the count into
+// the pool K exactly as flatten_kernel does.
+__global__ __launch_bounds__(256) void coherence_kernel(const float4* __restrict__ rays, int numRays, int numBlocks, const float4* __restrict__ table,
+                                                        const unsigned int* __restrict__ tableCount, unsigned int* __restrict__ out)
+{
+    const int block = blockIdx.x * 256 + threadIdx.x;
+    bool apart = false;
+    if (block < numBlocks && *tableCount >= 2u) {
+        const int r = min(block * 256 + PRED_SAMPLE, numRays - 1);
+        apart = block_starts_apart(rays, numRays, block, rays[2 * r], table);
+    }
+    const unsigned long long m = __ballot(apart);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&out[0], (unsigned int)__popcll(m));
+}
+__global__ void coherence_finish_kernel(unsigned int* __restrict__ out, int numBlocks, int poolKWide)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[1] = (2u * out[0] >= (unsigned int)numBlocks) ? (unsigned int)poolKWide : 1u;
 }
 
 // Clears `words` 32-bit words (a kernel, not hipMemsetAsync: see flatten_kernel).
@@ -197,16 +247,17 @@ extern "C" hipError_t ntr_launch_top_table(const void* d_nodes, unsigned int nod
     return hipGetLastError();
 }
 
-// d_classCount must be zero on entry (NTR_SCHED_PRED_CLASSES words) and is zero again when the launches have run.
+// d_classCount: NTR_SCHED_PRED_WORDS words; the first NTR_SCHED_PRED_CLASSES + 1 must be zero on entry and are zero again when the
+// launches have run, the last one receives the pool K of the mini-pool kernel (also stored to d_poolKCopy when given).
 extern "C" hipError_t ntr_launch_predict(const void* d_rays, int numRays, int numBlocks, const void* d_table,
                                          const unsigned int* d_tableCount, unsigned int* d_classCount, unsigned int* d_classList,
-                                         unsigned int* d_order, hipStream_t stream)
+                                         unsigned int* d_order, unsigned int* d_poolKCopy, int poolKWide, hipStream_t stream)
 {
     const int grid = (numBlocks + 63) / 64;
     hipLaunchKernelGGL(ntr::predict_kernel, dim3(grid), dim3(ntr::PRED_WAVES * 64), 0, stream, (const float4*)d_rays, numRays, numBlocks,
                        (const float4*)d_table, d_tableCount, d_classCount, d_classList, (unsigned int*)nullptr);
     hipLaunchKernelGGL(ntr::flatten_kernel, dim3(1), dim3(ntr::FLATTEN_THREADS), 0, stream, d_classCount, (const unsigned int*)d_classList,
-                       numBlocks, d_order);
+                       numBlocks, d_order, d_poolKCopy, poolKWide);
     return hipGetLastError();
 }
 
@@ -216,6 +267,17 @@ extern "C" hipError_t ntr_launch_predict_costs(const void* d_rays, int numRays, 
     const int grid = (numBlocks + 63) / 64;
     hipLaunchKernelGGL(ntr::predict_kernel, dim3(grid), dim3(ntr::PRED_WAVES * 64), 0, stream, (const float4*)d_rays, numRays, numBlocks,
                        (const float4*)d_table, d_tableCount, (unsigned int*)nullptr, (unsigned int*)nullptr, d_blockCost);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ntr_launch_coherence(const void* d_rays, int numRays, int numBlocks, const void* d_table, const unsigned int* d_tableCount,
+                                           unsigned int* d_out, int poolKWide, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ntr::zero_words_kernel, dim3(1), dim3(256), 0, stream, d_out, 2);
+    if (numBlocks > 0)
+        hipLaunchKernelGGL(ntr::coherence_kernel, dim3((numBlocks + 255) / 256), dim3(256), 0, stream, (const float4*)d_rays, numRays, numBlocks,
+                           (const float4*)d_table, d_tableCount, d_out);
+    hipLaunchKernelGGL(ntr::coherence_finish_kernel, dim3(1), dim3(64), 0, stream, d_out, numBlocks, poolKWide);
     return hipGetLastError();
 }
 

@@ -20,6 +20,8 @@
 #define NTR_VARIANT_PERRAY_W1 4    // per-ray kernel in 64-thread workgroups
 #define NTR_VARIANT_PERSISTENT_UNIFIED 5  // persistent waves, unified-step loop (every live lane advances each iteration)
 #define NTR_VARIANT_PERRAY_UNIFIED_W1 6   // per-ray kernel, 64-thread workgroups, unified-step loop
+#define NTR_VARIANT_PERRAY_UNIFIED_MINI 7 // the same launch, which runs as the wave-private mini-pool instead when the batch's pool K (TraceParams::poolK,
+                                          // decided on the device) is 2 or 4: a wave owns K x 64 rays and refills its finished lanes from them
 
 // bits of the device status word
 #define NTR_STATUS_STACK_OVERFLOW 1u
@@ -54,6 +56,9 @@ struct TraceParams {
                                    // hands the 256-ray blocks out in this order
     unsigned int* cost;            // per-ray kernel: cost[block] = max wave lifetime in 10 ns ticks (null = off)
     unsigned long long* stats;  // STATS variant: {innerVisits, triTests, leafVisits, hits}
+    const unsigned int* poolK;  // mini-pool kernel: device word holding the rays a wave owns / 64 (1, 2 or 4; anything else reads as 1),
+                                // written by the dispatch-order prediction of this launch or kept in the launch's hint; null = poolKConst
+    int32_t poolKConst;
 };
 
 }  // namespace ntr
@@ -62,14 +67,18 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
 // dispatch-order prediction (sched_kernels.hip)
 #define NTR_TOP_DEPTH_MAX 10          // top-of-tree table: child boxes of the nodes above this depth
 #define NTR_SCHED_PRED_CLASSES 64     // cost classes of the predictor (one per lane in the flatten step)
+#define NTR_SCHED_PRED_WORDS (NTR_SCHED_PRED_CLASSES + 2)   // + [CLASSES]: blocks whose two sample rays start far apart, [CLASSES + 1]: pool K
 extern "C" hipError_t ntr_launch_top_table(const void* d_nodes, unsigned int nodesBytes, int depth, void* d_table,
                                            unsigned int* d_tableCount, hipStream_t stream);
 extern "C" hipError_t ntr_launch_predict(const void* d_rays, int numRays, int numBlocks, const void* d_table,
                                          const unsigned int* d_tableCount, unsigned int* d_classCount, unsigned int* d_classList,
-                                         unsigned int* d_order, hipStream_t stream);
+                                         unsigned int* d_order, unsigned int* d_poolKCopy, int poolKWide, hipStream_t stream);
 // cost query: d_blockCost[b] = boxes of the top-of-tree table the sample ray of 256-ray block b intersects
 extern "C" hipError_t ntr_launch_predict_costs(const void* d_rays, int numRays, int numBlocks, const void* d_table,
                                                const unsigned int* d_tableCount, unsigned int* d_blockCost, hipStream_t stream);
+// coherence query: d_out[0] = 256-ray blocks whose two sample rays start further apart than 1/8 of the scene extent, d_out[1] = pool K
+extern "C" hipError_t ntr_launch_coherence(const void* d_rays, int numRays, int numBlocks, const void* d_table, const unsigned int* d_tableCount,
+                                           unsigned int* d_out, int poolKWide, hipStream_t stream);
 // clears 32-bit words with a kernel (graph-replay safe, unlike a memset node)
 extern "C" hipError_t ntr_launch_zero_words(void* d_ptr, int words, hipStream_t stream);
 // out[0] = atomicExch(status, 0): fetch-and-clear of the sticky status word in one device-side step

@@ -597,10 +597,23 @@ __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs&
 // Variant 1: one ray per lane, while-while ("fermi_speculative_while_while" slot).
 // ---------------------------------------------------------------------------------
 // UNIFIED: the unified-step loop (traverse_unified) -- for trees whose leaves hold several triangles (the device LBVH).
-template <int WAVES, bool STATS, bool COOP, bool UNIFIED = false, bool FLATF = true>
+// MINI: the launch may run as the wave-private mini-pool instead (minipool_body below), decided on the device per batch.
+template <bool FLATF>
+__device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int K, lds_int* stackBase);
+
+template <int WAVES, bool STATS, bool COOP, bool UNIFIED = false, bool FLATF = true, bool MINI = false>
 __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_perray(TraceParams p)
 {
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
+    if constexpr (MINI) {
+        static_assert(WAVES == 1 && UNIFIED && !STATS && !COOP, "the mini-pool shares the one-wave unified-step launch");
+        unsigned int K = (unsigned int)p.poolKConst;
+        if (p.poolK) K = *p.poolK;   // wave-uniform (scalar load)
+        if (K == 2u || K == 4u) {
+            minipool_body<FLATF>(p, K, (lds_int*)&s_stack[0][0][threadIdx.x]);
+            return;
+        }
+    }
     __shared__ __attribute__((aligned(16))) char s_stage[WAVES][COOP ? STAGE_BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // A "block" is 256 consecutive rays (the unit of the dispatch order and of the cost feedback) whatever the workgroup size: a
@@ -871,6 +884,80 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
 }
 
 // ---------------------------------------------------------------------------------
+// Variant 3: per-ray kernel with a wave-private mini-pool (round 3).  A hardware-scheduled 64-thread workgroup owns K x 64 consecutive
+// rays instead of 64: its lanes start on the first 64, and a lane that finishes takes the wave's next unstarted ray (ballot + mbcnt
+// prefix over the wave's OWN range: no atomic, no shared head).  On divergent batches the per-ray kernel's waves live as long as their
+// longest ray while most lanes idle (lane utilisation 0.22-0.48 on the LBVH scenes, scripts/divergence_study.py); list scheduling K x 64
+// rays on 64 lanes lifts that to 0.33-0.63 (K = 2) / 0.49-0.77 (K = 4) by the per-ray step counts, at the price of a longer critical
+// path per wave -- which is why the pool stays small and private: the global pool of the persistent kernels keeps every lane busy
+// until it runs dry, and then 6 144 waves each hold a few long rays (a tail of 60-70 % of their launch, profiles/r03_divergence_timelines.jsonl).
+// Unified-step loop, flat fetch; 256-ray blocks keep their role as the unit of the dispatch order and of the cost feedback.
+// ---------------------------------------------------------------------------------
+template <bool FLATF>
+__device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int K, lds_int* stackBase)
+{
+    // The launch has one wave per 64 rays (the per-ray kernel's grid): four consecutive workgroups per 256-ray block, of which only 4 / K
+    // have rays here.  WHICH of the four must not follow a power-of-two pattern: workgroups are dealt round-robin to XCDs, shader
+    // engines and CUs, and "every 4th workgroup" put all live waves on a quarter of the chip (measured 2.7x slower, with the XCD bits
+    // excluded just the same).  So the parts are rotated per block by a golden-ratio hash of the block's position.
+    const int lane = threadIdx.x;
+    const unsigned int g = blockIdx.x >> 2;
+    const unsigned int part = ((blockIdx.x & 3u) - ((g * 0x9E3779B1u) >> 30)) & 3u;
+    if (part & (K - 1u)) return;
+    const unsigned int block = p.order ? p.order[g] : g;
+    int poolNext = (int)(block * 256 + part * 64);                              // wave-uniform
+    const int poolEnd = min(poolNext + (int)K * 64, p.numRays);
+    if (poolNext >= poolEnd) return;
+    const bool anyHit = p.anyHit != 0;
+    const bool bvhFast = (p.bvhFlags & NTR_BVH_FASTDIV) != 0;
+    const UnifiedBufs ub = unified_bufs(p);
+
+    unsigned long long tl0 = 0;
+    if (p.cost) tl0 = __builtin_amdgcn_s_memrealtime();
+
+    LaneStack st;
+    int spill[SPILL_DEPTH];
+    st.lds = stackBase;
+    NTR_STACK_RESET(st);
+    RayRegs r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int node = kSentinel, rayIdx = -1, hitAddr = -1;
+    float hitU = 0.0f, hitV = 0.0f;
+    bool nice = true;
+
+    for (;;) {
+        // ---- start the wave's next rays on its empty lanes --------------------------------------------------------------------
+        const unsigned long long empty = __ballot(rayIdx < 0);
+        if (empty != 0ull && poolNext < poolEnd) {
+            const int prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(empty >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)empty, 0));
+            const int avail = poolEnd - poolNext;
+            if (rayIdx < 0 && prefix < avail) {
+                rayIdx = poolNext + prefix;
+                load_ray(p.rays, rayIdx, r);
+                hitAddr = -1;
+                hitU = hitV = 0.0f;
+                NTR_STACK_RESET(st);
+                node = (r.tmin < r.tmax) ? 0 : kSentinel;   // degenerate rays (Util.hpp:65) are misses without traversal
+                nice = ray_is_nice(r, p.bvhFlags);
+            }
+            poolNext += min(__popcll(empty), avail);
+        }
+        const bool poolEmpty = poolNext >= poolEnd;
+        // ---- unified-step traversal until every lane is done, or until enough lanes are free to be worth a refill -------------
+        const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
+        if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
+        else traverse_unified<false, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
+        // ---- retire finished rays ---------------------------------------------------------------------------------------------
+        if (rayIdx >= 0 && node == kSentinel) {
+            store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
+            rayIdx = -1;
+        }
+        if (poolEmpty && __ballot(rayIdx >= 0) == 0ull) break;
+    }
+    if (p.cost && lane == 0)  // scheduling feedback: a block's cost is the lifetime of its longest wave
+        atomicMax(&p.cost[block], (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0));
+}
+
+// ---------------------------------------------------------------------------------
 // Self test: FAST division == GENERIC division, bit for bit, on device.
 // mismatches += number of differing quotients among x[i] / d[j] for all i, j.
 // ---------------------------------------------------------------------------------
@@ -976,6 +1063,9 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
     case NTR_VARIANT_PERRAY_UNIFIED_W1:   // flatFetch 0: the two-group descriptor fetch (A/B; extents below 64 bytes)
         if (p->flatFetch) hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false, true, true>), dim3(numBlocks), dim3(64), 0, stream, *p);
         else hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false, true, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
+        break;
+    case NTR_VARIANT_PERRAY_UNIFIED_MINI:   // numBlocks counts waves of 64 rays; needs flatFetch
+        hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false, true, true, true>), dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_STATS:
         hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);

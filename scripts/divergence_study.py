@@ -97,7 +97,25 @@ def main():
             live = steps > 0
             wave_max = steps.reshape(-1, 64).max(axis=1)
             wave_sum = steps.reshape(-1, 64).sum(axis=1)
-            print(json.dumps(dict(scene=scene, batch=bname, rays=n, sample=int(sel.size), ms=times,
+            # what a wave-private mini-pool would buy: a wave owns K x 64 consecutive rays and a lane that finishes takes the wave's next
+            # unstarted ray (greedy list scheduling on 64 lanes); iterations of the wave = its makespan
+            import heapq
+            pool = {}
+            for K in (1, 2, 4, 8):
+                tot_it = 0
+                longest = 0
+                groups = steps[: (steps.size // (64 * K)) * 64 * K].reshape(-1, 64 * K)
+                for g in groups:
+                    lanes = list(g[:64].astype(int))
+                    heapq.heapify(lanes)
+                    for x in g[64:]:
+                        t = heapq.heappop(lanes)
+                        heapq.heappush(lanes, t + int(x))
+                    mk = max(lanes)
+                    tot_it += mk
+                    longest = max(longest, mk)
+                pool[K] = dict(util=float(groups.sum() / max(tot_it * 64.0, 1)), wave_iterations=int(tot_it), longest_wave=int(longest))
+            print(json.dumps(dict(scene=scene, batch=bname, rays=n, sample=int(sel.size), ms=times, wave_private_pool=pool,
                                   steps_per_ray=pct(steps[live]) if live.any() else None,
                                   wave_max_steps=pct(wave_max), lane_util_perray_model=float(wave_sum.sum() / (wave_max.sum() * 64.0)),
                                   top_rays_share=dict(top_1pct=float(np.sort(steps)[-max(sel.size // 100, 1):].sum() / max(steps.sum(), 1)),

@@ -54,11 +54,9 @@ def main():
     for bname in want:
         n, dr = batches[bname]
         d_o = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
-        for kernel, env in (("fermi_speculative_while_while", {}),
-                            ("kepler_dynamic_fetch", {"NTR_TRACE_UNIFIED": "0", "NTR_TRACE_FETCH_THRESHOLD": "48"}),
-                            ("kepler_dynamic_fetch", {"NTR_TRACE_FETCH_THRESHOLD": "48"}),
-                            ("kepler_dynamic_fetch", {"NTR_TRACE_FETCH_THRESHOLD": "56", "NTR_TRACE_CHUNK": "32"}),
-                            ("kepler_dynamic_fetch", {"NTR_TRACE_FETCH_THRESHOLD": "48", "NTR_TRACE_BLOCKS_PER_CU": "8"})):
+        for kernel, env in (("fermi_speculative_while_while", {"NTR_TRACE_PERRAY_UNIFIED": "0"}),
+                            ("fermi_speculative_while_while", {}),
+                            ("kepler_dynamic_fetch", {})):
             nt.set_tunables(**env)
             persistent = not kernel.startswith("fermi")
             per = 6 if persistent else 3

@@ -359,6 +359,88 @@ def test_unified_step_loop_changes_no_record(soup, monkeypatch, tree):
                 assert_parity(got, ref[:n], "%s dynamic fetch %s n=%d anyHit=%d" % (tree, env, n, any_hit))
 
 
+@pytest.mark.parametrize("tree", ["sah leaves of 1", "device lbvh"])
+def test_wave_private_mini_pool_changes_no_record(monkeypatch, tree):
+    """The wave-private mini-pool (a wave owns K x 64 rays of a 256-ray block and refills its finished lanes from them; closest-hit
+    launches of the per-ray kernel, K decided on the device) changes which lane traces which ray and when, nothing else: K forced to
+    1 / 2 / 4 and left to the device, refill thresholds from 'only when the wave is empty' to 'at once', ragged counts around the
+    64 / 128 / 256 boundaries, natural, predicted and measured (hinted) dispatch orders, coherent + edge-case + random rays."""
+    import torch
+    from gpu_util import DeviceBvh, assert_parity, gpu_trace, up
+    tri, pos, cam = scenes.random_soup(6000, seed=29)
+    if tree == "sah leaves of 1":
+        dbvh = DeviceBvh(nt.sah_build(tri, pos, 1, 1))
+    else:
+        n = tri.shape[0]
+        capn, capw, capi = nt.lbvh_capacity(n)
+        d_tri, d_pos = up(tri), up(pos)
+        bufs = [torch.zeros(c, dtype=torch.uint8, device="cuda:0") for c in (capn, capw, capi)]
+        mn, mx = oracle.scene_bbox(pos)
+        res = nt.lbvh_build(n, d_tri.data_ptr(), pos.shape[0], d_pos.data_ptr(), mn, mx, 8, 0.001, bufs[0].data_ptr(), capn, bufs[1].data_ptr(), capw,
+                            bufs[2].data_ptr(), capi)
+        torch.cuda.synchronize()
+        dbvh = DeviceBvh(nt.HostBvh(bufs[0].cpu().numpy()[:res.nodesBytes].copy(), bufs[1].cpu().numpy()[:res.triWoopBytes].copy(),
+                                    bufs[2].cpu().numpy()[:res.triIndexBytes].view(np.int32).copy()))
+    allrays = np.concatenate([scenes.primary_rays(cam, 200, 160)[0], edge_rays(), scenes.random_rays(20000, seed=7)])
+    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, allrays, any_hit=False, threads=8)
+    counts = (allrays.shape[0], 1, 63, 65, 129, 255, 257, 4097)
+    for predict in ("0", "1"):
+        monkeypatch.setenv("NTR_TRACE_PREDICT", predict)
+        monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+        monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
+        for env in ({"NTR_TRACE_MINIPOOL": "1"}, {"NTR_TRACE_MINIPOOL": "2"}, {"NTR_TRACE_MINIPOOL": "4"},
+                    {"NTR_TRACE_MINIPOOL": "4", "NTR_TRACE_MINIPOOL_THRESHOLD": "1"}, {"NTR_TRACE_MINIPOOL": "2", "NTR_TRACE_MINIPOOL_THRESHOLD": "64"},
+                    {"NTR_TRACE_MINIPOOL": "-1", "NTR_TRACE_MINIPOOL_WIDE": "4"}, {"NTR_TRACE_MINIPOOL": "-1", "NTR_TRACE_MINIPOOL_WIDE": "2"},
+                    {"NTR_TRACE_MINIPOOL": "0"}):
+            for k in ("NTR_TRACE_MINIPOOL", "NTR_TRACE_MINIPOOL_THRESHOLD", "NTR_TRACE_MINIPOOL_WIDE"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            nt.set_tunables()
+            for n in counts:
+                got, _ = gpu_trace("fermi_speculative_while_while", dbvh, allrays[:n], False)
+                assert_parity(got, ref[:n], "%s mini-pool %s predict=%s n=%d" % (tree, env, predict, n))
+    # measured order: the same buffers traced repeatedly keep a hint (and their K in it) -- random rays first, so that the device picks K > 1
+    monkeypatch.setenv("NTR_TRACE_AUTO_HINT_MIN_RAYS", "1")
+    monkeypatch.delenv("NTR_TRACE_MINIPOOL", raising=False)
+    monkeypatch.delenv("NTR_TRACE_MINIPOOL_THRESHOLD", raising=False)
+    nt.set_tunables()
+    for rays, want in ((scenes.random_rays(30000, seed=11), None), (allrays, ref)):
+        if want is None:
+            want, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
+        d_rays = up(rays)
+        d_res = torch.zeros(rays.shape[0] * 16, dtype=torch.uint8, device="cuda:0")
+        for rep in range(5):
+            d_res.zero_()
+            dbvh.view.trace("fermi_speculative_while_while", rays.shape[0], False, d_rays.data_ptr(), d_res.data_ptr())
+            torch.cuda.synchronize()
+            assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), want, "%s mini-pool, hinted launch %d" % (tree, rep))
+
+
+def test_batch_coherence_estimate_separates_camera_rays_from_scattered_ones(soup):
+    """ntr_predict_batch_coherence (the two words the dispatch-order prediction derives on the device): rays from one camera start
+    together -- no incoherent block, K = 1; rays that start anywhere in the scene's box are incoherent in nearly every block -- K = the
+    wide pool; an empty batch is coherent."""
+    import torch
+    from gpu_util import up
+    dbvh, cam = soup
+    out = torch.full((2,), 77, dtype=torch.int32, device="cuda:0")
+    prim = scenes.primary_rays(cam, 320, 200)[0]
+    d = up(prim)
+    nt.predict_batch_coherence(prim.shape[0], d.data_ptr(), dbvh.nodes.data_ptr(), dbvh.host.nodes.nbytes, out.data_ptr())
+    torch.cuda.synchronize()
+    assert out.cpu().tolist() == [0, 1]
+    rnd = scenes.random_rays(64000, seed=3)
+    d = up(rnd)
+    nt.predict_batch_coherence(rnd.shape[0], d.data_ptr(), dbvh.nodes.data_ptr(), dbvh.host.nodes.nbytes, out.data_ptr())
+    torch.cuda.synchronize()
+    apart, k = out.cpu().tolist()
+    assert apart >= 0.8 * (rnd.shape[0] // 256) and k == 2, (apart, k)   # (a small tree: the wide pool is 2)
+    nt.predict_batch_coherence(0, 0, dbvh.nodes.data_ptr(), dbvh.host.nodes.nbytes, out.data_ptr())
+    torch.cuda.synchronize()
+    assert out.cpu().tolist() == [0, 1]
+
+
 def test_captured_launches_own_their_scratch_and_release_returns_it(soup, monkeypatch):
     """HIP-graph resources: a captured launch gets prediction scratch / pool counters of its own -- two launches captured
     back to back on one stream, with no live launch in between, and live launches of other ray counts on the same stream while the
