@@ -754,7 +754,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
                 p.fetchThreshold = tun.minipoolThreshold;
                 p.poolKConst = tun.minipool > 0 ? tun.minipool : 1;
                 if (tun.minipool < 0) {
-                    if (predScratch) p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 1;
+                    if (predScratch) p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 2;
                     else if (hint && hint->numBlocks == numBlocks && hint->order) p.poolK = hint->order + numBlocks;
                 }
             }

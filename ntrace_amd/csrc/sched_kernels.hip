@@ -70,19 +70,23 @@ constexpr int PRED_WAVES = 16;
 constexpr int PRED_SAMPLE = 100;        // sample ray inside the block (any fixed lane)
 constexpr int PRED_SAMPLE2 = 227;       // second sample, for the coherence estimate
 
-// Coherence of a 256-ray block: does a second ray of the block (in another wave of it) start far from the sample ray -- further than
-// 1/8 of the scene's extent?  Rays that do share no deep nodes and their step counts are uncorrelated: the mini-pool case
-// (trace_kernels.hip).  o = origin of the block's sample ray; table[0..3] = the root's two child boxes.
-__device__ __forceinline__ bool block_starts_apart(const float4* __restrict__ rays, int numRays, int block, const float4 o,
-                                                   const float4* __restrict__ table)
+// Coherence of a 256-ray block, from its sample ray and a second ray of the block (in another wave of it).  Bit 0: the two start
+// further apart than 1/8 of the scene's extent -- such rays share no deep nodes and their step counts are uncorrelated; bit 1: they start
+// together but their directions are more than 60 degrees apart (bounce rays off neighbouring surface points).  The mini-pool cases
+// (trace_kernels.hip).  o, d = origin and direction of the block's sample ray; table[0..3] = the root's two child boxes.
+__device__ __forceinline__ unsigned int block_incoherence(const float4* __restrict__ rays, int numRays, int block, const float4 o, const float4 d,
+                                                          const float4* __restrict__ table)
 {
     const int r2 = min(block * 256 + PRED_SAMPLE2, numRays - 1);
-    const float4 o2 = rays[2 * r2];
+    const float4 o2 = rays[2 * r2], d2 = rays[2 * r2 + 1];
     const float4 a0 = table[0], a1 = table[1], b0 = table[2], b1 = table[3];
     const float ext = fmaxf(fmaxf(fmaxf(a0.y, b0.y) - fminf(a0.x, b0.x), fmaxf(a0.w, b0.w) - fminf(a0.z, b0.z)),
                             fmaxf(a1.y, b1.y) - fminf(a1.x, b1.x));
     const float dist = fmaxf(fmaxf(fabsf(o2.x - o.x), fabsf(o2.y - o.y)), fabsf(o2.z - o.z));
-    return dist > 0.125f * ext;   // (false for NaN)
+    if (dist > 0.125f * ext) return 1u;   // (comparisons are false for NaN: coherent)
+    const float dot = d.x * d2.x + d.y * d2.y + d.z * d2.z;
+    const float l1 = d.x * d.x + d.y * d.y + d.z * d.z, l2 = d2.x * d2.x + d2.y * d2.y + d2.z * d2.z;
+    return (dot < 0.0f || 4.0f * dot * dot < l1 * l2) ? 2u : 0u;   // cos < 1/2, directions of any length
 }
 
 __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* __restrict__ rays, int numRays, int numBlocks,
@@ -133,9 +137,10 @@ __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* 
         return;
     }
     if (wave == 0) {
-        const bool apart = block < numBlocks && nBoxes >= 2 && block_starts_apart(rays, numRays, block, o, table);
-        const unsigned long long m = __ballot(apart);
-        if (lane == 0 && m) atomicAdd(&classCount[NTR_SCHED_PRED_CLASSES], (unsigned int)__popcll(m));
+        const unsigned int inc = (block < numBlocks && nBoxes >= 2) ? block_incoherence(rays, numRays, block, o, d, table) : 0u;
+        const unsigned long long m1 = __ballot(inc == 1u), m2 = __ballot(inc == 2u);
+        if (lane == 0 && m1) atomicAdd(&classCount[NTR_SCHED_PRED_CLASSES], (unsigned int)__popcll(m1));
+        if (lane == 0 && m2) atomicAdd(&classCount[NTR_SCHED_PRED_CLASSES + 1], (unsigned int)__popcll(m2));
     }
     unsigned int cls = 0;
     if (tid < 64 && block < numBlocks) {
@@ -159,6 +164,19 @@ __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* 
 // prediction is in flight, without a memset in the stream (hipMemsetAsync nodes were observed not to re-execute
 // when a captured HIP graph is replayed; kernels do).
 constexpr int FLATTEN_THREADS = 1024;
+
+// Rays a wave of the mini-pool kernel owns / 64, from the batch's incoherent blocks: scattered origins in at least half of the blocks ->
+// poolKWide (4 on big trees, else 2); otherwise, on big trees, scattered directions (or origins) in at least a quarter of them (two
+// cosine-distributed bounce directions are more than 60 degrees apart about half of the time, two camera rays never) -> 2; else 1.
+// Measured (profiles/r03_minipool_matrix.txt): 2^21 box rays +29-33 % on the 2.8 M / 10 M-triangle LBVHs with K = 4, +9 % on the
+// 262 k SAH tree with K = 2 (K = 4: +4 %); diffuse bounce batches +4 % on the big trees with K = 2, -1 % on the small one;
+// camera rays lose with any K > 1 (-15 % to -50 %).
+__device__ __forceinline__ unsigned int pool_k(unsigned int originApart, unsigned int dirApart, int numBlocks, int poolKWide)
+{
+    if (originApart > 0u && 2u * originApart >= (unsigned int)numBlocks) return (unsigned int)poolKWide;
+    if (poolKWide == 4 && originApart + dirApart > 0u && 4u * (originApart + dirApart) >= (unsigned int)numBlocks) return 2u;
+    return 1u;
+}
 __global__ __launch_bounds__(FLATTEN_THREADS) void flatten_kernel(unsigned int* __restrict__ classCount, const unsigned int* __restrict__ classList,
                                                                   int numBlocks, unsigned int* __restrict__ order,
                                                                   unsigned int* __restrict__ poolKCopy, int poolKWide)
@@ -168,10 +186,10 @@ __global__ __launch_bounds__(FLATTEN_THREADS) void flatten_kernel(unsigned int* 
     if (tid == 64) {
         // most blocks incoherent -> the mini-pool kernel's waves own poolKWide x 64 rays; else one ray per lane (the word outlives this
         // prediction: the trace launch behind it reads it, the next prediction on this scratch is ordered after that launch)
-        const unsigned int apart = classCount[NTR_SCHED_PRED_CLASSES];
-        const unsigned int k = (2u * apart >= (unsigned int)numBlocks) ? (unsigned int)poolKWide : 1u;
+        const unsigned int k = pool_k(classCount[NTR_SCHED_PRED_CLASSES], classCount[NTR_SCHED_PRED_CLASSES + 1], numBlocks, poolKWide);
         classCount[NTR_SCHED_PRED_CLASSES] = 0;
-        classCount[NTR_SCHED_PRED_CLASSES + 1] = k;
+        classCount[NTR_SCHED_PRED_CLASSES + 1] = 0;
+        classCount[NTR_SCHED_PRED_CLASSES + 2] = k;
         if (poolKCopy) *poolKCopy = k;
     }
     if (tid < 64) {
@@ -197,23 +215,24 @@ __global__ __launch_bounds__(FLATTEN_THREADS) void flatten_kernel(unsigned int* 
     }
 }
 
-// Coherence query (ntr_predict_batch_coherence): out[0] += blocks whose sample rays start apart; the finish step turns the count into
-// the pool K exactly as flatten_kernel does.
+// Coherence query (ntr_predict_batch_coherence): out[0] / out[1] += blocks whose sample rays start apart / start together and point apart;
+// the finish step turns the counts into the pool K (out[2]) exactly as flatten_kernel does.
 __global__ __launch_bounds__(256) void coherence_kernel(const float4* __restrict__ rays, int numRays, int numBlocks, const float4* __restrict__ table,
                                                         const unsigned int* __restrict__ tableCount, unsigned int* __restrict__ out)
 {
     const int block = blockIdx.x * 256 + threadIdx.x;
-    bool apart = false;
+    unsigned int inc = 0;
     if (block < numBlocks && *tableCount >= 2u) {
         const int r = min(block * 256 + PRED_SAMPLE, numRays - 1);
-        apart = block_starts_apart(rays, numRays, block, rays[2 * r], table);
+        inc = block_incoherence(rays, numRays, block, rays[2 * r], rays[2 * r + 1], table);
     }
-    const unsigned long long m = __ballot(apart);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&out[0], (unsigned int)__popcll(m));
+    const unsigned long long m1 = __ballot(inc == 1u), m2 = __ballot(inc == 2u);
+    if ((threadIdx.x & 63) == 0 && m1) atomicAdd(&out[0], (unsigned int)__popcll(m1));
+    if ((threadIdx.x & 63) == 0 && m2) atomicAdd(&out[1], (unsigned int)__popcll(m2));
 }
 __global__ void coherence_finish_kernel(unsigned int* __restrict__ out, int numBlocks, int poolKWide)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[1] = (2u * out[0] >= (unsigned int)numBlocks) ? (unsigned int)poolKWide : 1u;
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[2] = pool_k(out[0], out[1], numBlocks, poolKWide);
 }
 
 // Clears `words` 32-bit words (a kernel, not hipMemsetAsync: see flatten_kernel).
@@ -247,7 +266,7 @@ extern "C" hipError_t ntr_launch_top_table(const void* d_nodes, unsigned int nod
     return hipGetLastError();
 }
 
-// d_classCount: NTR_SCHED_PRED_WORDS words; the first NTR_SCHED_PRED_CLASSES + 1 must be zero on entry and are zero again when the
+// d_classCount: NTR_SCHED_PRED_WORDS words; the first NTR_SCHED_PRED_CLASSES + 2 must be zero on entry and are zero again when the
 // launches have run, the last one receives the pool K of the mini-pool kernel (also stored to d_poolKCopy when given).
 extern "C" hipError_t ntr_launch_predict(const void* d_rays, int numRays, int numBlocks, const void* d_table,
                                          const unsigned int* d_tableCount, unsigned int* d_classCount, unsigned int* d_classList,
@@ -273,7 +292,7 @@ extern "C" hipError_t ntr_launch_predict_costs(const void* d_rays, int numRays, 
 extern "C" hipError_t ntr_launch_coherence(const void* d_rays, int numRays, int numBlocks, const void* d_table, const unsigned int* d_tableCount,
                                            unsigned int* d_out, int poolKWide, hipStream_t stream)
 {
-    hipLaunchKernelGGL(ntr::zero_words_kernel, dim3(1), dim3(256), 0, stream, d_out, 2);
+    hipLaunchKernelGGL(ntr::zero_words_kernel, dim3(1), dim3(256), 0, stream, d_out, 3);
     if (numBlocks > 0)
         hipLaunchKernelGGL(ntr::coherence_kernel, dim3((numBlocks + 255) / 256), dim3(256), 0, stream, (const float4*)d_rays, numRays, numBlocks,
                            (const float4*)d_table, d_tableCount, d_out);

@@ -67,7 +67,7 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
 // dispatch-order prediction (sched_kernels.hip)
 #define NTR_TOP_DEPTH_MAX 10          // top-of-tree table: child boxes of the nodes above this depth
 #define NTR_SCHED_PRED_CLASSES 64     // cost classes of the predictor (one per lane in the flatten step)
-#define NTR_SCHED_PRED_WORDS (NTR_SCHED_PRED_CLASSES + 2)   // + [CLASSES]: blocks whose two sample rays start far apart, [CLASSES + 1]: pool K
+#define NTR_SCHED_PRED_WORDS (NTR_SCHED_PRED_CLASSES + 3)   // + blocks whose two sample rays start far apart, blocks whose rays point apart, pool K
 extern "C" hipError_t ntr_launch_top_table(const void* d_nodes, unsigned int nodesBytes, int depth, void* d_table,
                                            unsigned int* d_tableCount, hipStream_t stream);
 extern "C" hipError_t ntr_launch_predict(const void* d_rays, int numRays, int numBlocks, const void* d_table,
@@ -76,7 +76,8 @@ extern "C" hipError_t ntr_launch_predict(const void* d_rays, int numRays, int nu
 // cost query: d_blockCost[b] = boxes of the top-of-tree table the sample ray of 256-ray block b intersects
 extern "C" hipError_t ntr_launch_predict_costs(const void* d_rays, int numRays, int numBlocks, const void* d_table,
                                                const unsigned int* d_tableCount, unsigned int* d_blockCost, hipStream_t stream);
-// coherence query: d_out[0] = 256-ray blocks whose two sample rays start further apart than 1/8 of the scene extent, d_out[1] = pool K
+// coherence query: d_out[0] = 256-ray blocks whose two sample rays start further apart than 1/8 of the scene extent, d_out[1] = blocks
+// whose sample rays start together and point more than 60 degrees apart, d_out[2] = pool K
 extern "C" hipError_t ntr_launch_coherence(const void* d_rays, int numRays, int numBlocks, const void* d_table, const unsigned int* d_tableCount,
                                            unsigned int* d_out, int poolKWide, hipStream_t stream);
 // clears 32-bit words with a kernel (graph-replay safe, unlike a memset node)

@@ -22,9 +22,6 @@ from workloads import lbvh, scene_of, up  # noqa: E402
 dev = torch.device("cuda:0")
 VARIANTS = [("fermi_speculative_while_while", {"NTR_TRACE_MINIPOOL": "0"}),
             ("fermi_speculative_while_while", {}),
-            ("fermi_speculative_while_while", {"NTR_TRACE_MINIPOOL": "1"}),
-            ("fermi_speculative_while_while", {"NTR_TRACE_MINIPOOL": "2"}),
-            ("fermi_speculative_while_while", {"NTR_TRACE_MINIPOOL": "4"}),
             ("kepler_dynamic_fetch", {})]
 EXTRA = [e for e in os.environ.get("KM_EXTRA_ENV", "").split(";") if e]   # e.g. "NTR_TRACE_CHUNK=128;NTR_TRACE_POOL_HEADS=256"
 

@@ -417,28 +417,37 @@ def test_wave_private_mini_pool_changes_no_record(monkeypatch, tree):
             assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), want, "%s mini-pool, hinted launch %d" % (tree, rep))
 
 
-def test_batch_coherence_estimate_separates_camera_rays_from_scattered_ones(soup):
-    """ntr_predict_batch_coherence (the two words the dispatch-order prediction derives on the device): rays from one camera start
-    together -- no incoherent block, K = 1; rays that start anywhere in the scene's box are incoherent in nearly every block -- K = the
-    wide pool; an empty batch is coherent."""
+def test_batch_coherence_estimate_separates_camera_rays_from_scattered_ones(soup, monkeypatch):
+    """ntr_predict_batch_coherence (the words the dispatch-order prediction derives on the device): rays from one camera start together
+    and point alike -- no incoherent block, K = 1; rays that start anywhere in the scene's box are incoherent in nearly every block --
+    K = the wide pool (2 on a small tree, 4 when asked for); rays that start together and point anywhere count as direction-incoherent
+    -- K = 2 where the wide pool is 4, else 1; an empty batch is coherent."""
     import torch
     from gpu_util import up
     dbvh, cam = soup
-    out = torch.full((2,), 77, dtype=torch.int32, device="cuda:0")
+    out = torch.full((3,), 77, dtype=torch.int32, device="cuda:0")
+
+    def query(rays):
+        d = up(rays) if rays.shape[0] else None
+        nt.predict_batch_coherence(rays.shape[0], d.data_ptr() if d is not None else 0, dbvh.nodes.data_ptr(), dbvh.host.nodes.nbytes, out.data_ptr())
+        torch.cuda.synchronize()
+        return out.cpu().tolist()
+
     prim = scenes.primary_rays(cam, 320, 200)[0]
-    d = up(prim)
-    nt.predict_batch_coherence(prim.shape[0], d.data_ptr(), dbvh.nodes.data_ptr(), dbvh.host.nodes.nbytes, out.data_ptr())
-    torch.cuda.synchronize()
-    assert out.cpu().tolist() == [0, 1]
     rnd = scenes.random_rays(64000, seed=3)
-    d = up(rnd)
-    nt.predict_batch_coherence(rnd.shape[0], d.data_ptr(), dbvh.nodes.data_ptr(), dbvh.host.nodes.nbytes, out.data_ptr())
-    torch.cuda.synchronize()
-    apart, k = out.cpu().tolist()
-    assert apart >= 0.8 * (rnd.shape[0] // 256) and k == 2, (apart, k)   # (a small tree: the wide pool is 2)
-    nt.predict_batch_coherence(0, 0, dbvh.nodes.data_ptr(), dbvh.host.nodes.nbytes, out.data_ptr())
-    torch.cuda.synchronize()
-    assert out.cpu().tolist() == [0, 1]
+    fan = rnd.copy()
+    for k in ("ox", "oy", "oz"):
+        fan[k] = prim[k][0]
+    blocks = rnd.shape[0] // 256
+    assert query(prim) == [0, 0, 1]
+    o, d, k = query(rnd)
+    assert o >= 0.8 * blocks and k == 2, (o, d, k)   # (a small tree: the wide pool is 2)
+    o, d, k = query(fan)
+    assert o == 0 and d >= 0.6 * blocks and k == 1, (o, d, k)
+    monkeypatch.setenv("NTR_TRACE_MINIPOOL_WIDE", "4")
+    nt.set_tunables()
+    assert query(rnd)[2] == 4 and query(fan)[2] == 2 and query(prim)[2] == 1
+    assert query(prim[:0]) == [0, 0, 1]
 
 
 def test_captured_launches_own_their_scratch_and_release_returns_it(soup, monkeypatch):
