@@ -539,12 +539,16 @@ static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, i
     return NTR_OK;
 }
 
-// pool K of an incoherent batch: long rays (big trees) amortise a deeper private pool; measured on 2^21 box rays K = 4 / 2 / 1:
-// courtyard-10M 4.71 / 5.38 / 6.35 ms, hairball-2.8M 3.69 / 3.77 / 4.93, atrium-262k 0.592 / 0.562 / 0.614 (profiles/r03_minipool_matrix.txt)
-static int minipool_wide(const Tunables& tun, int64_t nodesBytes)
+// Pool K of an incoherent batch.  Long rays (big trees) amortise a deeper private pool, and the batch must oversubscribe the machine
+// (rays / 64 / K waves against 7 168 wave slots): below that a launch is bound by its longest rays, and fewer, longer-lived waves only
+// lengthen that path.  Box rays, K = 1 / 2 / 4 (scripts/small_batch_minipool.py, profiles/r03_minipool_batch_sizes.jsonl), ms:
+//   courtyard-10M  2^19: 2.81 / 3.12 / 3.52   2^20: 3.74 / 3.33 / 3.55   1.5 M: 5.23 / 4.36 / 3.84   2^21: 6.79 / 5.38 / 4.73   2^22: 12.8 / 9.9 / 7.8
+//   hairball-2.8M  2^19: 1.76 / 1.50 / 1.69   2^20: 2.79 / 2.38 / 2.39   1.5 M: 3.92 / 3.10 / 3.28   2^21: 5.04 / 3.77 / 3.80   2^22: 9.5 / 6.6 / 6.4
+//   atrium-262k    2^19: .230 / .217 / .276   2^20: .374 / .375 / .349   1.5 M: .520 / .483 / .520   2^21: .670 / .598 / .627   2^22: 1.24 / 1.04 / 1.03
+static int minipool_wide(const Tunables& tun, int64_t nodesBytes, int numRays)
 {
     if (tun.minipoolWide == 2 || tun.minipoolWide == 4) return tun.minipoolWide;
-    return nodesBytes >= (int64_t)32 << 20 ? 4 : 2;
+    return (nodesBytes >= (int64_t)32 << 20 && numRays >= (3 << 19)) ? 4 : 2;
 }
 
 static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
@@ -672,8 +676,9 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         NTR_HIP(hipGetDevice(&dev));
         if (hint->numBlocks != numBlocks || hint->device != dev) {
             sched_hint_release(hint);
-            // order[numBlocks]: the mini-pool K of the batch (0 = not predicted yet, read as 1), kept from the first, predicted launch on
-            NTR_HIP(hipMalloc((void**)&hint->order, ((size_t)numBlocks + 1) * sizeof(unsigned int)));
+            // order[numBlocks .. numBlocks + 2]: the batch's coherence words, the last one its mini-pool K (0 = not estimated yet, read as 1):
+            // written by the dispatch-order prediction of the batch's first launch, or by the coherence probe of its refresh launches
+            NTR_HIP(hipMalloc((void**)&hint->order, ((size_t)numBlocks + 3) * sizeof(unsigned int)));
             NTR_HIP(hipMalloc((void**)&hint->cost, (size_t)numBlocks * sizeof(unsigned int)));
             hint->numBlocks = numBlocks;
             hint->device = dev;
@@ -681,7 +686,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         // costs measured under the natural order differ from those under the derived order, so the first
         // launches all refresh; afterwards every 8th does (slowly drifting rays keep their schedule)
         if (hint->uses == 0) {   // a hint that starts over (new, or an automatic one recycled for another batch) forgets its K
-            const hipError_t zk = ntr_launch_zero_words(hint->order + numBlocks, 1, s);
+            const hipError_t zk = ntr_launch_zero_words(hint->order + numBlocks, 3, s);
             if (zk != hipSuccess) return hip_fail(zk, "zero_words launch");
         }
         const int every = tun.schedRefreshEvery;
@@ -719,6 +724,15 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         }
     }
 
+    // A hinted batch is predicted once (its hint then holds a measured order); its coherence words -- the mini-pool K -- are estimated again
+    // on the hint's refresh launches by a probe of their own (three small launches, every 16th launch): rays drift.
+    const bool probeCoherence = !predScratch && hint && refresh && variant == NTR_VARIANT_PERRAY && !anyHit && tun.minipool < 0 && p.flatFetch &&
+                                tun.predict != 0 && numRays >= tun.predictMinRays && nodesBytes >= (int64_t)tun.predictMinNodes * 64;
+    if (probeCoherence) {
+        rc = top_table_get(d_nodes, nodesBytes, s, false, &predTable);
+        if (rc != NTR_OK) return rc;
+    }
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (seconds) {
         NTR_HIP(hipEventCreate(&ev0));
@@ -729,8 +743,12 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     if (predScratch) {  // inside the timed bracket: the prediction is part of what the launch costs
         const hipError_t pe = ntr_launch_predict(d_rays, numRays, orderBlocks, predTable->table, predTable->count, predScratch->classCount,
                                                  predScratch->classList, predScratch->order,
-                                                 (hint && variant == NTR_VARIANT_PERRAY) ? hint->order + numBlocks : nullptr, minipool_wide(tun, nodesBytes), s);
+                                                 (hint && variant == NTR_VARIANT_PERRAY) ? hint->order + numBlocks + 2 : nullptr, minipool_wide(tun, nodesBytes, numRays), s);
         if (pe != hipSuccess) return hip_fail(pe, "predict launch");
+    } else if (probeCoherence) {   // (also inside the bracket)
+        const hipError_t ce = ntr_launch_coherence(d_rays, numRays, orderBlocks, predTable->table, predTable->count, hint->order + numBlocks,
+                                                  minipool_wide(tun, nodesBytes, numRays), s);
+        if (ce != hipSuccess) return hip_fail(ce, "coherence launch");
     }
     // Workgroup size of the per-ray kernel: smaller workgroups retire (and are replaced) sooner.  The dispatch order and the cost
     // feedback stay in units of 256 rays: numBlocks counts those, the launch has 4 / waves workgroups per unit.
@@ -755,7 +773,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
                 p.poolKConst = tun.minipool > 0 ? tun.minipool : 1;
                 if (tun.minipool < 0) {
                     if (predScratch) p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 2;
-                    else if (hint && hint->numBlocks == numBlocks && hint->order) p.poolK = hint->order + numBlocks;
+                    else if (hint && hint->numBlocks == numBlocks && hint->order) p.poolK = hint->order + numBlocks + 2;
                 }
             }
         }
@@ -859,7 +877,7 @@ int ntr_predict_batch_coherence(int32_t numRays, const NtrRay* d_rays, const voi
     TopTable* t = nullptr;
     const int rc = top_table_get(d_nodes, nodesBytes, (hipStream_t)stream, false, &t);
     if (rc != NTR_OK) return rc;
-    const hipError_t e = ntr_launch_coherence(d_rays, numRays, (numRays + 255) / 256, t->table, t->count, d_out, minipool_wide(tunables(), nodesBytes),
+    const hipError_t e = ntr_launch_coherence(d_rays, numRays, (numRays + 255) / 256, t->table, t->count, d_out, minipool_wide(tunables(), nodesBytes, numRays),
                                               (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "coherence launch");
     return NTR_OK;

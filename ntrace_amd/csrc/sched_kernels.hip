@@ -165,17 +165,15 @@ __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* 
 // when a captured HIP graph is replayed; kernels do).
 constexpr int FLATTEN_THREADS = 1024;
 
-// Rays a wave of the mini-pool kernel owns / 64, from the batch's incoherent blocks: scattered origins in at least half of the blocks ->
-// poolKWide (4 on big trees, else 2); otherwise, on big trees, scattered directions (or origins) in at least a quarter of them (two
-// cosine-distributed bounce directions are more than 60 degrees apart about half of the time, two camera rays never) -> 2; else 1.
-// Measured (profiles/r03_minipool_matrix.txt): 2^21 box rays +29-33 % on the 2.8 M / 10 M-triangle LBVHs with K = 4, +9 % on the
-// 262 k SAH tree with K = 2 (K = 4: +4 %); diffuse bounce batches +4 % on the big trees with K = 2, -1 % on the small one;
-// camera rays lose with any K > 1 (-15 % to -50 %).
+// Rays a wave of the mini-pool kernel owns / 64: scattered origins in at least half of the batch's blocks -> poolKWide (the host's choice
+// by tree and batch size, ntr_api.cpp minipool_wide), else 1.  Measured (profiles/r03_minipool_matrix.txt): 2^21 box rays +29-33 % on the
+// 2.8 M / 10 M-triangle LBVHs with K = 4, +9-12 % on the 262 k / 331 k SAH trees with K = 2; camera rays lose with any K > 1 (-15 % to
+// -50 %).  Blocks whose rays start together but point apart (bounce rays: 44 % of the blocks of a diffuse batch) are counted and reported,
+// not acted on: K = 2 for such batches measured between 0 and +4 %, inside the run-to-run noise.
 __device__ __forceinline__ unsigned int pool_k(unsigned int originApart, unsigned int dirApart, int numBlocks, int poolKWide)
 {
-    if (originApart > 0u && 2u * originApart >= (unsigned int)numBlocks) return (unsigned int)poolKWide;
-    if (poolKWide == 4 && originApart + dirApart > 0u && 4u * (originApart + dirApart) >= (unsigned int)numBlocks) return 2u;
-    return 1u;
+    (void)dirApart;
+    return (originApart > 0u && 2u * originApart >= (unsigned int)numBlocks) ? (unsigned int)poolKWide : 1u;
 }
 __global__ __launch_bounds__(FLATTEN_THREADS) void flatten_kernel(unsigned int* __restrict__ classCount, const unsigned int* __restrict__ classList,
                                                                   int numBlocks, unsigned int* __restrict__ order,

@@ -405,23 +405,28 @@ def test_wave_private_mini_pool_changes_no_record(monkeypatch, tree):
     monkeypatch.delenv("NTR_TRACE_MINIPOOL", raising=False)
     monkeypatch.delenv("NTR_TRACE_MINIPOOL_THRESHOLD", raising=False)
     nt.set_tunables()
-    for rays, want in ((scenes.random_rays(30000, seed=11), None), (allrays, ref)):
-        if want is None:
-            want, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
-        d_rays = up(rays)
-        d_res = torch.zeros(rays.shape[0] * 16, dtype=torch.uint8, device="cuda:0")
-        for rep in range(5):
-            d_res.zero_()
-            dbvh.view.trace("fermi_speculative_while_while", rays.shape[0], False, d_rays.data_ptr(), d_res.data_ptr())
-            torch.cuda.synchronize()
-            assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), want, "%s mini-pool, hinted launch %d" % (tree, rep))
+    # (first with the batch's first launch predicted, then with batches too small to be predicted: their K comes from the coherence probe
+    # of the hint's refresh launches)
+    rnd = scenes.random_rays(30000, seed=11)
+    rnd_ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rnd, any_hit=False, threads=8)
+    for min_rays in ("1", "100000000"):
+        monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", min_rays)
+        nt.set_tunables()
+        for rays, want in ((rnd, rnd_ref), (allrays, ref)):
+            d_rays = up(rays)
+            d_res = torch.zeros(rays.shape[0] * 16, dtype=torch.uint8, device="cuda:0")
+            for rep in range(5):
+                d_res.zero_()
+                dbvh.view.trace("fermi_speculative_while_while", rays.shape[0], False, d_rays.data_ptr(), d_res.data_ptr())
+                torch.cuda.synchronize()
+                assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), want, "%s mini-pool, hinted launch %d, predict from %s rays" % (tree, rep, min_rays))
 
 
 def test_batch_coherence_estimate_separates_camera_rays_from_scattered_ones(soup, monkeypatch):
     """ntr_predict_batch_coherence (the words the dispatch-order prediction derives on the device): rays from one camera start together
     and point alike -- no incoherent block, K = 1; rays that start anywhere in the scene's box are incoherent in nearly every block --
-    K = the wide pool (2 on a small tree, 4 when asked for); rays that start together and point anywhere count as direction-incoherent
-    -- K = 2 where the wide pool is 4, else 1; an empty batch is coherent."""
+    K = the wide pool (2 on a small tree, 4 when asked for); rays that start together and point anywhere are counted as direction-incoherent
+    and stay at K = 1; an empty batch is coherent."""
     import torch
     from gpu_util import up
     dbvh, cam = soup
@@ -446,7 +451,7 @@ def test_batch_coherence_estimate_separates_camera_rays_from_scattered_ones(soup
     assert o == 0 and d >= 0.6 * blocks and k == 1, (o, d, k)
     monkeypatch.setenv("NTR_TRACE_MINIPOOL_WIDE", "4")
     nt.set_tunables()
-    assert query(rnd)[2] == 4 and query(fan)[2] == 2 and query(prim)[2] == 1
+    assert query(rnd)[2] == 4 and query(fan)[2] == 1 and query(prim)[2] == 1
     assert query(prim[:0]) == [0, 0, 1]
 
 
