@@ -601,8 +601,13 @@ __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs&
 template <bool FLATF>
 __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int K, lds_int* stackBase);
 
+#if defined(NTR_AB) && defined(NTR_OCC8)
+#define NTR_PERRAY_BOUNDS(W) __launch_bounds__((W) * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define NTR_PERRAY_BOUNDS(W) __launch_bounds__((W) * 64, NTR_TRACE_MIN_WAVES_PER_SIMD)
+#endif
 template <int WAVES, bool STATS, bool COOP, bool UNIFIED = false, bool FLATF = true, bool MINI = false>
-__global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_perray(TraceParams p)
+__global__ NTR_PERRAY_BOUNDS(WAVES) void trace_bvh_perray(TraceParams p)
 {
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     if constexpr (MINI) {
