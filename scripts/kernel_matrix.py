@@ -20,11 +20,10 @@ from ntrace_amd import scenes  # noqa: E402
 from workloads import lbvh, scene_of, up  # noqa: E402
 
 dev = torch.device("cuda:0")
-VARIANTS = [("fermi_speculative_while_while", {}),
-            ("fermi_speculative_while_while", {"NTR_TRACE_LDS_PAD": "2560"}),
-            ("fermi_speculative_while_while", {"NTR_TRACE_LDS_PAD": "4000"}),
-            ("fermi_speculative_while_while", {"NTR_TRACE_LDS_PAD": "6100"}),
-            ("fermi_speculative_while_while", {"NTR_TRACE_LDS_PAD": "9500"})]
+VARIANTS = [("fermi_speculative_while_while", {"NTR_TRACE_MINIPOOL": "0"}),   # the plain per-ray kernel
+            ("fermi_speculative_while_while", {}),                            # default: mini-pool depth decided per batch on the device
+            ("kepler_dynamic_fetch", {}),
+            ("tesla_persistent_while_while", {})]
 EXTRA = [e for e in os.environ.get("KM_EXTRA_ENV", "").split(";") if e]   # e.g. "NTR_TRACE_CHUNK=128;NTR_TRACE_POOL_HEADS=256"
 
 
