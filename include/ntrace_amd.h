@@ -199,7 +199,7 @@ NTR_API int ntr_predict_block_costs(int32_t numRays, const NtrRay* d_rays, const
 /* Coherence estimate of a batch, without tracing it, from two sample rays (the 100th and the 227th) of every 256-ray block:
  * d_out[0] = blocks whose samples start further apart than 1/8 of the scene's extent, d_out[1] = blocks whose samples start together
  * but point more than 60 degrees apart (reported only), d_out[2] = the pool K large closest-hit launches of the per-ray kernel derive
- * on the device (1 = one ray per lane; 2 or 4 = a wave owns K x 64 rays and refills its finished lanes from them: chosen when origins
+ * on the device (1 = one ray per lane; K > 1 = a wave owns K x 64 rays and refills its finished lanes from them: chosen when origins
  * are scattered in at least half of the blocks -- 4 on trees of 32 MB of nodes and more for batches of 1.5 M rays and more, else 2;
  * DESIGN.md 4.1).  The launch itself does not call this -- its dispatch-order prediction computes the same words -- it is the query
  * for tests and for hosts that plan batches.  No counterpart in the reference.  d_out: 3 words.  Asynchronous on `stream`. */

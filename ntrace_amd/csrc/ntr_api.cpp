@@ -547,7 +547,7 @@ static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, i
 //   atrium-262k    2^19: .230 / .217 / .276   2^20: .374 / .375 / .349   1.5 M: .520 / .483 / .520   2^21: .670 / .598 / .627   2^22: 1.24 / 1.04 / 1.03
 static int minipool_wide(const Tunables& tun, int64_t nodesBytes, int numRays)
 {
-    if (tun.minipoolWide == 2 || tun.minipoolWide == 4) return tun.minipoolWide;
+    if (tun.minipoolWide >= 2 && tun.minipoolWide <= NTR_MINIPOOL_MAX_K) return tun.minipoolWide;
     return (nodesBytes >= (int64_t)32 << 20 && numRays >= (3 << 19)) ? 4 : 2;
 }
 

@@ -20,6 +20,7 @@
 #define NTR_VARIANT_PERRAY_W1 4    // per-ray kernel in 64-thread workgroups
 #define NTR_VARIANT_PERSISTENT_UNIFIED 5  // persistent waves, unified-step loop (every live lane advances each iteration)
 #define NTR_VARIANT_PERRAY_UNIFIED_W1 6   // per-ray kernel, 64-thread workgroups, unified-step loop
+#define NTR_MINIPOOL_MAX_K 16             // a wave's private pool: at most this many 64-ray chunks
 #define NTR_VARIANT_PERRAY_UNIFIED_MINI 7 // the same launch, which runs as the wave-private mini-pool instead when the batch's pool K (TraceParams::poolK,
                                           // decided on the device) is 2 or 4: a wave owns K x 64 rays and refills its finished lanes from them
 
@@ -56,7 +57,7 @@ struct TraceParams {
                                    // hands the 256-ray blocks out in this order
     unsigned int* cost;            // per-ray kernel: cost[block] = max wave lifetime in 10 ns ticks (null = off)
     unsigned long long* stats;  // STATS variant: {innerVisits, triTests, leafVisits, hits}
-    const unsigned int* poolK;  // mini-pool kernel: device word holding the rays a wave owns / 64 (1, 2 or 4; anything else reads as 1),
+    const unsigned int* poolK;  // mini-pool kernel: device word holding the rays a wave owns / 64 (1 .. NTR_MINIPOOL_MAX_K; anything else reads as 1),
                                 // written by the dispatch-order prediction of this launch or kept in the launch's hint; null = poolKConst
     int32_t poolKConst;
 };

@@ -614,7 +614,7 @@ __global__ NTR_PERRAY_BOUNDS(WAVES) void trace_bvh_perray(TraceParams p)
         static_assert(WAVES == 1 && UNIFIED && !STATS && !COOP, "the mini-pool shares the one-wave unified-step launch");
         unsigned int K = (unsigned int)p.poolKConst;
         if (p.poolK) K = *p.poolK;   // wave-uniform (scalar load)
-        if (K == 2u || K == 4u) {
+        if (K >= 2u && K <= (unsigned int)NTR_MINIPOOL_MAX_K) {
             minipool_body<FLATF>(p, K, (lds_int*)&s_stack[0][0][threadIdx.x]);
             return;
         }
@@ -901,18 +901,22 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
 template <bool FLATF>
 __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int K, lds_int* stackBase)
 {
-    // The launch has one wave per 64 rays (the per-ray kernel's grid): four consecutive workgroups per 256-ray block, of which only 4 / K
-    // have rays here.  WHICH of the four must not follow a power-of-two pattern: workgroups are dealt round-robin to XCDs, shader
-    // engines and CUs, and "every 4th workgroup" put all live waves on a quarter of the chip (measured 2.7x slower, with the XCD bits
-    // excluded just the same).  So the parts are rotated per block by a golden-ratio hash of the block's position.
+    // The launch has one wave per 64-ray chunk (the per-ray kernel's grid); K consecutive chunks of the dispatch order form a pool, and one
+    // workgroup of every K owns it, the others exit at once.  WHICH one must not follow a regular pattern: workgroups are dealt round-robin
+    // to XCDs, shader engines and CUs, and "every 4th workgroup" put all live waves on a quarter of the chip (measured 2.7x slower, with the
+    // XCD bits excluded just the same).  So the live member of a group is picked by a golden-ratio hash of the group's position.
     const int lane = threadIdx.x;
-    const unsigned int g = blockIdx.x >> 2;
-    const unsigned int part = ((blockIdx.x & 3u) - ((g * 0x9E3779B1u) >> 30)) & 3u;
-    if (part & (K - 1u)) return;
-    const unsigned int block = p.order ? p.order[g] : g;
-    int poolNext = (int)(block * 256 + part * 64);                              // wave-uniform
-    const int poolEnd = min(poolNext + (int)K * 64, p.numRays);
-    if (poolNext >= poolEnd) return;
+    const unsigned int numChunks = gridDim.x;                                    // 4 per 256-ray block of the order, the last block's empty ones included
+    const unsigned int q = blockIdx.x / K;                                       // wave-uniform (one software division per wave)
+    const unsigned int members = min(K, numChunks - q * K);                      // (the last group may be short)
+    if (blockIdx.x - q * K != ((((q * 0x9E3779B1u) >> 16) * members) >> 16)) return;
+    unsigned int chunk = q * K;
+    const unsigned int chunkEnd = min(chunk + K, numChunks);
+    if (chunk >= chunkEnd) return;
+    // chunk c of the order = quarter (c & 3) of block order[c >> 2]
+    unsigned int block = p.order ? p.order[chunk >> 2] : (chunk >> 2);
+    int poolNext = (int)(block * 256u + (chunk & 3u) * 64u);                     // wave-uniform: the unstarted rays of the current chunk
+    int poolEnd = min(poolNext + 64, p.numRays);
     const bool anyHit = p.anyHit != 0;
     const bool bvhFast = (p.bvhFlags & NTR_BVH_FASTDIV) != 0;
     const UnifiedBufs ub = unified_bufs(p);
@@ -930,7 +934,13 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
     bool nice = true;
 
     for (;;) {
-        // ---- start the wave's next rays on its empty lanes --------------------------------------------------------------------
+        // ---- start the wave's next rays on its empty lanes (from the current chunk; what it cannot fill is filled next time round) --
+        while (poolNext >= poolEnd && chunk + 1u < chunkEnd) {
+            chunk++;
+            block = p.order ? p.order[chunk >> 2] : (chunk >> 2);
+            poolNext = (int)(block * 256u + (chunk & 3u) * 64u);
+            poolEnd = min(poolNext + 64, p.numRays);
+        }
         const unsigned long long empty = __ballot(rayIdx < 0);
         if (empty != 0ull && poolNext < poolEnd) {
             const int prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(empty >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)empty, 0));
@@ -946,7 +956,7 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
             }
             poolNext += min(__popcll(empty), avail);
         }
-        const bool poolEmpty = poolNext >= poolEnd;
+        const bool poolEmpty = poolNext >= poolEnd && chunk + 1u >= chunkEnd;
         // ---- unified-step traversal until every lane is done, or until enough lanes are free to be worth a refill -------------
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
         if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
@@ -958,8 +968,10 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
         }
         if (poolEmpty && __ballot(rayIdx >= 0) == 0ull) break;
     }
-    if (p.cost && lane == 0)  // scheduling feedback: a block's cost is the lifetime of its longest wave
-        atomicMax(&p.cost[block], (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0));
+    if (p.cost && lane == 0) {  // scheduling feedback: a block's cost is the lifetime of the longest wave that traced a part of it
+        const unsigned int life = (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0);
+        for (unsigned int c = q * K; c < chunkEnd; c += 4u - (c & 3u)) atomicMax(&p.cost[p.order ? p.order[c >> 2] : (c >> 2)], life);
+    }
 }
 
 // ---------------------------------------------------------------------------------

@@ -29,11 +29,11 @@ for scene in sys.argv[1].split(","):
         view = nt.BvhView(keep[0].data_ptr(), best.nodesBytes, keep[1].data_ptr(), best.triWoopBytes, keep[2].data_ptr())
     view.validate()
     prim = scenes.primary_rays(cam, 1920, 1080)[0]
-    for n in (1 << 17, 1 << 19, 3 << 18, 1 << 20, 3 << 19, 1 << 21, 3 << 20, 1 << 22):
+    for n in (1 << 19, 1 << 20, 3 << 19, 1 << 21, 3 << 20, 1 << 22):
         rays = scenes.box_rays(pos, n, seed=21)
         out = dict(scene=scene, batch="incoherent", rays=n)
         ref = None
-        for mode in ("1", "2", "4", None):
+        for mode in ("1", "2", "3", "4", "5", "6", "8", "10", None):
             nt.set_tunables(NTR_TRACE_MINIPOOL=mode)
             d_rays = up(rays)   # (a new buffer: a new hint)
             d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)

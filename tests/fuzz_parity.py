@@ -188,7 +188,7 @@ def main(argv=None):
             loop = dict(NTR_TRACE_PERRAY_UNIFIED=int(rng.choice([-1, 0, 1])), NTR_TRACE_UNIFIED=int(rng.choice([1, 1, 0])),
                         NTR_TRACE_FETCH_THRESHOLD=int(rng.choice([-1, -1, 1, 16, 33, 64])), NTR_TRACE_FLAT_FETCH=int(rng.choice([1, 1, 0])),
                         # wave-private mini-pool of the closest-hit per-ray launches: by the device's coherence estimate, off, or forced
-                        NTR_TRACE_MINIPOOL=int(rng.choice([-1, -1, 0, 1, 2, 4])), NTR_TRACE_MINIPOOL_THRESHOLD=int(rng.choice([48, 48, 1, 33, 64])))
+                        NTR_TRACE_MINIPOOL=int(rng.choice([-1, -1, 0, 1, 2, 3, 4, 5, 8, 16])), NTR_TRACE_MINIPOOL_THRESHOLD=int(rng.choice([48, 48, 1, 33, 64])))
             nt.set_tunables(**loop)
             tot["loop_%s" % "_".join(str(v) for v in loop.values())] = tot.get("loop_%s" % "_".join(str(v) for v in loop.values()), 0) + 1
             hint = nt.SchedHint() if sched == 2 else None

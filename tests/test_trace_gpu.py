@@ -363,7 +363,7 @@ def test_unified_step_loop_changes_no_record(soup, monkeypatch, tree):
 def test_wave_private_mini_pool_changes_no_record(monkeypatch, tree):
     """The wave-private mini-pool (a wave owns K x 64 rays of a 256-ray block and refills its finished lanes from them; closest-hit
     launches of the per-ray kernel, K decided on the device) changes which lane traces which ray and when, nothing else: K forced to
-    1 / 2 / 4 and left to the device, refill thresholds from 'only when the wave is empty' to 'at once', ragged counts around the
+    1 ... 16 (pools that end inside a block, that span blocks of the dispatch order, whose last group is short) and left to the device, refill thresholds from 'only when the wave is empty' to 'at once', ragged counts around the
     64 / 128 / 256 boundaries, natural, predicted and measured (hinted) dispatch orders, coherent + edge-case + random rays."""
     import torch
     from gpu_util import DeviceBvh, assert_parity, gpu_trace, up
@@ -388,7 +388,8 @@ def test_wave_private_mini_pool_changes_no_record(monkeypatch, tree):
         monkeypatch.setenv("NTR_TRACE_PREDICT", predict)
         monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
         monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
-        for env in ({"NTR_TRACE_MINIPOOL": "1"}, {"NTR_TRACE_MINIPOOL": "2"}, {"NTR_TRACE_MINIPOOL": "4"},
+        for env in ({"NTR_TRACE_MINIPOOL": "1"}, {"NTR_TRACE_MINIPOOL": "2"}, {"NTR_TRACE_MINIPOOL": "4"}, {"NTR_TRACE_MINIPOOL": "3"},
+                    {"NTR_TRACE_MINIPOOL": "5"}, {"NTR_TRACE_MINIPOOL": "7", "NTR_TRACE_MINIPOOL_THRESHOLD": "33"}, {"NTR_TRACE_MINIPOOL": "16"},
                     {"NTR_TRACE_MINIPOOL": "4", "NTR_TRACE_MINIPOOL_THRESHOLD": "1"}, {"NTR_TRACE_MINIPOOL": "2", "NTR_TRACE_MINIPOOL_THRESHOLD": "64"},
                     {"NTR_TRACE_MINIPOOL": "-1", "NTR_TRACE_MINIPOOL_WIDE": "4"}, {"NTR_TRACE_MINIPOOL": "-1", "NTR_TRACE_MINIPOOL_WIDE": "2"},
                     {"NTR_TRACE_MINIPOOL": "0"}):
