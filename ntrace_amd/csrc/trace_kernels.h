@@ -22,7 +22,7 @@
 #define NTR_VARIANT_PERRAY_UNIFIED_W1 6   // per-ray kernel, 64-thread workgroups, unified-step loop
 #define NTR_MINIPOOL_MAX_K 16             // a wave's private pool: at most this many 64-ray chunks
 #define NTR_VARIANT_PERRAY_UNIFIED_MINI 7 // the same launch, which runs as the wave-private mini-pool instead when the batch's pool K (TraceParams::poolK,
-                                          // decided on the device) is 2 or 4: a wave owns K x 64 rays and refills its finished lanes from them
+                                          // decided on the device) is 2 ... 16: a wave owns K x 64 rays and refills its finished lanes from them
 
 // bits of the device status word
 #define NTR_STATUS_STACK_OVERFLOW 1u
