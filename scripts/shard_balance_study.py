@@ -60,12 +60,16 @@ def study(scene):
     streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
     main = torch.cuda.Stream(device=dev)
 
-    def rank_time(lo, hi):
-        """(protocol_ms, overlap_ms) of the rank that owns primary slots [lo, hi)."""
-        m = hi - lo
+    def rank_time(lo, hi, slots=None):
+        """(protocol_ms, overlap_ms) of the rank that owns primary slots [lo, hi) -- or the slots `slots` (a striped plan), gathered
+        into a buffer of their own."""
+        m = hi - lo if slots is None else int(slots.numel())
         if m <= 0:
             return 0.0, 0.0
-        r_ptr = full.data_ptr() + lo * 32
+        own = None
+        if slots is not None:
+            own = full.view(-1, 32).index_select(0, slots).contiguous().view(-1)
+        r_ptr = full.data_ptr() + lo * 32 if own is None else own.data_ptr()
         res = torch.zeros(m * 16, dtype=torch.uint8, device=dev)
         per = (1 << 20) // ns
         view.trace(K, m, False, r_ptr, res.data_ptr())
@@ -122,6 +126,13 @@ def study(scene):
             plans["balanced-%g" % f] = ntd.balanced_cuts(cost, n, N, f)
         if flat_fit is not None and flat_fit > 0:
             plans["balanced-fit(%.2f)" % flat_fit] = ntd.balanced_cuts(cost, n, N, flat_fit)
+        for stripe in (1024, 4096, 16384, 65536):   # rank r owns the stripes s with s % N == r (stripe = that many consecutive PixelTable slots)
+            idx = torch.arange(n, device=dev)
+            tt = [rank_time(0, 0, idx[((idx // stripe) % N) == r]) for r in range(N)]
+            tp = [x[0] for x in tt]
+            to = [x[1] for x in tt]
+            print(json.dumps(dict(scene=scene, ranks=N, plan="striped-%d" % stripe, max_ms=max(tp), mean_ms=float(np.mean(tp)), min_ms=min(tp),
+                                  efficiency=one_p / max(tp) / N, overlap_max_ms=max(to), overlap_efficiency=one_o / max(to) / N)), flush=True)
         for name, cuts in plans.items():
             tt = [rank_time(cuts[r], cuts[r + 1]) for r in range(N)]
             tp = [x[0] for x in tt]
