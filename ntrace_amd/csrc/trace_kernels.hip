@@ -32,10 +32,13 @@
 //            sign of zero, which no later comparison can observe.
 //   ntr_selftest_division() checks FAST == GENERIC bit for bit on the device.
 //
-// DATA PATH.  Nodes and Woop triangles are fetched with buffer loads through
-// wave-uniform resource descriptors (voffset = the Compact layout's own byte offsets, so
-// no 64-bit address arithmetic; out-of-range reads return 0 instead of faulting, which
-// lets a leaf fetch its triangle and the following terminator word in one round trip).
+// DATA PATH.  The while-while loop (traverse) fetches nodes and Woop triangles with buffer
+// loads through wave-uniform resource descriptors (voffset = the Compact layout's own byte
+// offsets, so no 64-bit address arithmetic; out-of-range reads return 0 instead of faulting,
+// which lets a leaf fetch its triangle and the following terminator word in one round trip).
+// The unified-step loop (traverse_unified: every live lane advances by one node OR one
+// triangle per iteration) fetches 64 bytes per lane with ONE group of global loads from the
+// lane's own buffer, descriptor loads only for the lanes within 64 bytes of a buffer's end.
 // The traversal stack lives in LDS ([entry][lane], conflict-free), spilling to scratch
 // beyond LDS_DEPTH.  No MFMA: there is no dense contraction on this path.
 //
@@ -44,6 +47,9 @@
 //   * trace_bvh_perray maps workgroup i to ray block order[i] when an order is given -- predicted
 //     (sched_kernels.hip, automatic for large closest-hit launches) or learned from the previous launch of
 //     the batch (NtrSchedHint: per-block cost recording here, sched_order_kernel below);
+//   * the closest-hit instantiation of trace_bvh_perray runs a batch as wave-private mini-pools (minipool_body: a
+//     wave owns K 64-ray chunks of the dispatch order and refills its finished lanes from them) when the pool
+//     depth K the device derived for the batch (coherence estimate in sched_kernels.hip) is above 1;
 //   * every per-launch counter is cleared by a kernel, so an asynchronous launch can be captured in a HIP
 //     graph and replayed.
 
