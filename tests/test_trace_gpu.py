@@ -421,6 +421,22 @@ def test_wave_private_mini_pool_changes_no_record(monkeypatch, tree):
                 dbvh.view.trace("fermi_speculative_while_while", rays.shape[0], False, d_rays.data_ptr(), d_res.data_ptr())
                 torch.cuda.synchronize()
                 assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), want, "%s mini-pool, hinted launch %d, predict from %s rays" % (tree, rep, min_rays))
+    # the rays of a batch change under its hint (same buffer, same count): camera rays become scattered ones and back; the hint's refresh
+    # launches re-estimate the coherence words, and whatever K a launch runs with, the records are the oracle's
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+    monkeypatch.setenv("NTR_SCHED_REFRESH_EVERY", "2")
+    nt.set_tunables()
+    m = rnd.shape[0]
+    cam_rays, cam_ref = allrays[:m], ref[:m]
+    d_rays = up(cam_rays)
+    d_res = torch.zeros(m * 16, dtype=torch.uint8, device="cuda:0")
+    for phase, (rays, want) in enumerate(((cam_rays, cam_ref), (rnd, rnd_ref), (cam_rays, cam_ref))):
+        d_rays.copy_(up(rays))
+        for rep in range(6):
+            d_res.zero_()
+            dbvh.view.trace("fermi_speculative_while_while", m, False, d_rays.data_ptr(), d_res.data_ptr())
+            torch.cuda.synchronize()
+            assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), want, "%s mini-pool, batch contents changed (phase %d), launch %d" % (tree, phase, rep))
 
 
 def test_batch_coherence_estimate_separates_camera_rays_from_scattered_ones(soup, monkeypatch):
