@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Measured numbers for the five BASELINE.json configurations (seeded stand-ins for the named scenes):
-BVH build time, primary and 8xAO (radius 5) trace rates at 1920x1080, on one GPU.  Prints a markdown table."""
+BVH build time, primary, 8xAO (radius 5, any hit) and 8x diffuse (closest hit, to the camera's far plane: Renderer.cpp:533-537) trace rates at
+1920x1080 on one GPU, rays / sum of per-batch kernel time as the reference counts them.  Config 3 names the persistent-threads traversal and
+config 4 diffuse rays: config 3 is also measured with the two persistent kernel names.  Prints a markdown table."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +13,7 @@ dev = torch.device("cuda:0")
 K = "fermi_speculative_while_while"
 def up(a): return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
 
-def measure(name, tri, pos, cam, builder):
+def measure(name, tri, pos, cam, builder, K=K):
     n = tri.shape[0]
     keep = []
     if builder == "sah":
@@ -38,24 +40,37 @@ def measure(name, tri, pos, cam, builder):
     hits = nt.count_hits(d_res.data_ptr(), npr)
     d_nrm = up(scenes.tri_normals(tri, pos))
     ns, per = 8, (1 << 20) // 8
-    ao_t, ao_live = 0.0, 0
     diag = float(np.linalg.norm(pos.max(0).astype(np.float64) - pos.min(0)))
     radius = 5.0 * diag / 4300.0  # config.conf's aoRadius 5 is in Sponza units; scaled to the scene's diagonal
-    for lo in range(0, npr, per):
-        cnt = min(per, npr - lo)
-        b_rays = torch.zeros(cnt * ns * 32, dtype=torch.uint8, device=dev); b_res = torch.zeros(cnt * ns * 16, dtype=torch.uint8, device=dev)
-        b_a = torch.zeros(cnt * ns, dtype=torch.int32, device=dev)
-        nt.raygen_ao(b_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(), d_res.data_ptr(), d_nrm.data_ptr(), lo, cnt, ns, radius, 0xFFF2D5E4)
-        view.trace(K, cnt * ns, True, b_rays.data_ptr(), b_res.data_ptr())
-        ao_t += float(np.median([view.trace(K, cnt * ns, True, b_rays.data_ptr(), b_res.data_ptr()) for _ in range(3)]))
-        ao_live += nt.count_hits(d_res.data_ptr() + lo * 16, cnt) * ns
-    print("| %s | %d | %s | %.0f | %.0f | %.1f %% |" % (name, n, build, npr / tp / 1e6, ao_live / ao_t / 1e6 if ao_t > 0 else 0, 100.0 * hits / npr), flush=True)
+    rate = {}
+    for kind, dist_, any_hit in (("ao", radius, True), ("diffuse", cam["far"], False)):
+        tt, live, launched = 0.0, 0, 0
+        for lo in range(0, npr, per):
+            cnt = min(per, npr - lo)
+            b_rays = torch.zeros(cnt * ns * 32, dtype=torch.uint8, device=dev); b_res = torch.zeros(cnt * ns * 16, dtype=torch.uint8, device=dev)
+            b_a = torch.zeros(cnt * ns, dtype=torch.int32, device=dev)
+            nt.raygen_ao(b_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(), d_res.data_ptr(), d_nrm.data_ptr(), lo, cnt, ns, dist_, 0xFFF2D5E4)
+            view.trace(K, cnt * ns, any_hit, b_rays.data_ptr(), b_res.data_ptr())
+            tt += float(np.median([view.trace(K, cnt * ns, any_hit, b_rays.data_ptr(), b_res.data_ptr()) for _ in range(3)]))
+            live += nt.count_hits(d_res.data_ptr() + lo * 16, cnt) * ns
+            launched += cnt * ns
+        rate[kind] = "%.0f (%.0f)" % (live / tt / 1e6, launched / tt / 1e6) if tt > 0 else "0"
+    print("| %s | %d | %s | %s | %.0f | %s | %s | %.1f %% |" % (name, n, build, K.split("_")[0] + ("" if K.startswith("fermi") else " (persistent)"), npr / tp / 1e6, rate["ao"],
+                                                                    rate["diffuse"], 100.0 * hits / npr), flush=True)
 
-print("| config (stand-in) | triangles | BVH build | primary Mrays/s | 8xAO Mrays/s | primary hit rate |")
-print("|---|---|---|---|---|---|")
+print("Secondary rates: the reference's count -- rays of primary HITS (Renderer::getTotalNumRays) / sum of per-batch kernel time --, and in brackets all rays of the\nbatches (the rays of missed pixels are degenerate and end at once) / the same time.\n")
+print("| config (stand-in) | triangles | BVH build | kernel name | primary Mrays/s | 8xAO Mrays/s | 8x diffuse Mrays/s | primary hit rate |")
+print("|---|---|---|---|---|---|---|---|")
+ONLY = os.environ.get("CFG_ONLY", "")   # e.g. "4": only that configuration (sweeps)
+if ONLY:
+    tri, pos, cam = {"2": scenes.atrium, "3": scenes.conference_room, "4": scenes.hairball, "5": scenes.courtyard}[ONLY]()
+    measure("%s (CFG_ONLY)" % ONLY, tri, pos, cam, "sah" if ONLY in ("2", "3") else "lbvh")
+    sys.exit(0)
 tri, pos, cam = scenes.cornell_box(); measure("1 Cornell box", tri, pos, cam, "sah")
 tri, pos, cam = scenes.atrium(); measure("2 Sponza (atrium-262k), SAH", tri, pos, cam, "sah"); measure("2 Sponza (atrium-262k), LBVH", tri, pos, cam, "lbvh")
-tri, pos, cam = scenes.conference_room(); measure("3 Conference (room-331k), SAH", tri, pos, cam, "sah")
+tri, pos, cam = scenes.conference_room()
+for kn in (K, "tesla_persistent_while_while", "kepler_dynamic_fetch"):
+    measure("3 Conference (room-331k), SAH", tri, pos, cam, "sah", kn)
 tri, pos, cam = scenes.hairball(); measure("4 Hairball (2.8 M), LBVH", tri, pos, cam, "lbvh")
 tri, pos, cam = scenes.courtyard(); measure("5 San Miguel (courtyard-10M), LBVH", tri, pos, cam, "lbvh")
 if "--sah-10m" in sys.argv:
