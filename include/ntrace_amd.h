@@ -144,6 +144,13 @@ NTR_API int ntr_trace_bvh(const char* kernelName, int32_t numRays, int32_t anyHi
  * (seconds != NULL) perform the same check themselves.  The word is shared by all streams of the device. */
 NTR_API int ntr_trace_status(void* stream, uint32_t* statusBits);
 
+/* Tail hand-off counters of the stream's most recent trace launch that ran as wave-private ray pools (closest-hit
+ * launches of incoherent batches): counts[0] = ray continuations appended to the queue by waves that
+ * left, counts[1] = continuations taken up by other waves (equal once the launch has completed: every ray handed
+ * off is finished by another wave -- its visiting order, and so its hit record, is untouched), counts[2] = queue
+ * capacity in continuations.  All zero when no such launch ran on `stream`.  Waits for `stream`.  Diagnostic. */
+NTR_API int ntr_trace_handoff_counts(void* stream, uint32_t counts[3]);
+
 /* HIP graphs.  An asynchronous ntr_trace_bvh (seconds == NULL) may be captured into a HIP graph.  Nothing can be allocated
  * during a capture, and the scratch of a captured launch must outlive the graph, so the library hands such a launch scratch
  * of its OWN from per-device stores that are filled outside captures and never recycled while pinned:
@@ -152,7 +159,9 @@ NTR_API int ntr_trace_status(void* stream, uint32_t* statusBits);
  *     (a replay on any stream never shares it with a live launch); every live launch of a size keeps 4 spares of that size
  *     ready, ntr_trace_graph_reserve(launches, numRays) provisions more (48 entries per process in all);
  *   - the top-of-tree table of a BVH (16 BVHs): trace the BVH once, or call ntr_bvh_validate, before capturing.
- * When a store is exhausted the capture-time call fails with NTR_ERR_NOMEM / NTR_ERR_INVALID and says so.  A host that
+ * The predicted order is an optimisation: a captured launch that finds no spare scratch is captured in buffer order
+ * (no error).  Captured launches never use the tail hand-off's continuation queue either.
+ * When one of the other stores is exhausted the capture-time call fails with NTR_ERR_NOMEM / NTR_ERR_INVALID and says so.  A host that
  * re-captures graphs (e.g. every frame) calls ntr_trace_graph_release_all() once the graphs holding earlier captures are
  * destroyed: it waits for the device and returns every pinned resource of the current device to its store. */
 NTR_API int ntr_trace_graph_reserve(int32_t launches, int32_t numRays);

@@ -81,6 +81,7 @@ SYMBOLS = [
     ("ntr_trace_bvh_hinted", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _u32, _vp,
                                        C.POINTER(C.c_float), _vp]),
     ("ntr_trace_status", C.c_int, [_vp, C.POINTER(_u32)]),
+    ("ntr_trace_handoff_counts", C.c_int, [_vp, C.POINTER(_u32 * 3)]),
     ("ntr_tunables_reload", C.c_int, []),
     ("ntr_predict_block_costs", C.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
     ("ntr_predict_batch_coherence", C.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
@@ -215,6 +216,13 @@ def trace_status(stream=0):
     bits = _u32(0)
     _check(lib().ntr_trace_status(_vp(stream), C.byref(bits)))
     return int(bits.value)
+
+
+def trace_handoff_counts(stream=0):
+    """ntr_trace_handoff_counts: (continuations appended, continuations taken up, queue capacity) of the stream's last pooled launch."""
+    c = (_u32 * 3)()
+    _check(lib().ntr_trace_handoff_counts(_vp(stream), C.byref(c)))
+    return int(c[0]), int(c[1]), int(c[2])
 
 
 def predict_batch_coherence(num_rays, d_rays, d_nodes, nodes_bytes, d_out, stream=0):

@@ -149,6 +149,11 @@ static void tunables_load_locked()
     t.minipool = env_int("NTR_TRACE_MINIPOOL", -1);              // closest-hit per-ray launches: rays owned by a wave / 64.  -1: decided per batch on the device (1, or minipoolWide when the prediction finds the batch incoherent); 0: the plain per-ray kernel; 1 ... 16: forced
     t.minipoolWide = env_int("NTR_TRACE_MINIPOOL_WIDE", -1);     // K of an incoherent batch: 2 / 4, or -1 = by tree size (4 from 32 MB of nodes up)
     t.minipoolThreshold = env_int("NTR_TRACE_MINIPOOL_THRESHOLD", 48);   // refill a wave's finished lanes when fewer than this many are live
+    t.handoff = env_int("NTR_TRACE_HANDOFF", 1);                  // mini-pool launches: tail hand-off through the continuation queue (0 = off)
+    t.handoffBelow = env_int("NTR_TRACE_HANDOFF_BELOW", 16);      // T: a pool wave with fewer live lanes (own rays all started) fills up from the queue or hands its rays off
+    t.handoffMinQueue = env_int("NTR_TRACE_HANDOFF_MIN_QUEUE", 64);   // M: waiting continuations needed to fill up rather than hand off (capped by the wave's free lanes)
+    t.handoffKeepWaves = env_int("NTR_TRACE_HANDOFF_KEEP_WAVES", 1024);   // A: with no more waves than this left in the launch nobody hands off
+    t.handoffFlags = env_int("NTR_TRACE_HANDOFF_FLAGS", 0);       // 1: raised priority for waves that took continuations; 2: batches with pool K = 1 run as one-chunk pools and hand their tails off too
     t.unified = env_int("NTR_TRACE_UNIFIED", 1);                  // kepler_dynamic_fetch: unified-step loop (0 = while-while loop + dynamic fetch)
     t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", -1);    // per-ray kernel with the unified-step loop: -1 = closest-hit launches always, any-hit launches on trees flagged NTR_BVH_WIDE_LEAVES; 0 / 1 = never / always
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/persist_diag.py)
@@ -324,6 +329,57 @@ static constexpr int kScratchSpares = 4;   // spares a live launch keeps ready (
 static constexpr int kScratchLive = 16;    // streams with an entry of their own before the least recently used one is recycled
 static PredictScratch g_scratch[kScratch];
 
+// Continuation queue of the tail hand-off (trace_kernels.hip): one per (device, stream) -- launches on one stream are ordered, two streams
+// must not share a queue.  A fixed number of entries, never evicted and never touched during a capture: a launch that finds none runs
+// without the hand-off (it is an optimisation, not a contract).
+struct ContScratch {
+    void* stream = nullptr;
+    int device = -1;
+    unsigned int* mem = nullptr;   // NTR_CONT_SHARDS control lines, then NTR_CONT_SHARDS x shardSlots slots
+    int shardSlots = 0;
+    bool used = false;
+};
+static constexpr int kContScratch = 16;
+static ContScratch g_cont[kContScratch];
+
+static size_t cont_bytes(int shardSlots)
+{
+    return ((size_t)NTR_CONT_SHARDS * NTR_CONT_CTL_WORDS + (size_t)NTR_CONT_SHARDS * shardSlots * NTR_CONT_SLOT_WORDS) * sizeof(unsigned int);
+}
+
+// the queue of stream `s` with room for a launch of numRays rays, or null (no entry free, or the stream is being captured)
+static int cont_scratch_get(hipStream_t s, int numRays, ContScratch** out)
+{
+    *out = nullptr;
+    if (stream_is_capturing(s)) return NTR_OK;
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    // a quarter of the rays can wait at once (the model's worst case is a third of the rays handed off over a whole launch, K = 1);
+    // producers that find their shard full keep their rays
+    const int shardSlots = ((numRays / 4 + NTR_CONT_SHARDS - 1) / NTR_CONT_SHARDS + 63) & ~63;
+    std::lock_guard<std::mutex> lk(g_mu);
+    ContScratch* c = nullptr;
+    for (auto& e : g_cont)
+        if (e.used && e.stream == (void*)s && e.device == dev) { c = &e; break; }
+    if (!c)
+        for (auto& e : g_cont)
+            if (!e.used) { c = &e; break; }
+    if (!c) return NTR_OK;
+    if (c->shardSlots < shardSlots) {
+        if (c->mem) {
+            NTR_HIP(hipStreamSynchronize(s));   // the stream's previous launch may still use the smaller queue
+            (void)hipFree(c->mem);
+            c->mem = nullptr; c->shardSlots = 0;
+        }
+        NTR_HIP(hipMalloc((void**)&c->mem, cont_bytes(shardSlots)));
+        NTR_HIP(hipMemsetAsync(c->mem, 0xFF, cont_bytes(shardSlots), s));   // every slot's flag word: -1 = empty (consumers put it back)
+        c->shardSlots = shardSlots;
+    }
+    c->used = true; c->stream = (void*)s; c->device = dev;
+    *out = c;
+    return NTR_OK;
+}
+
 static int top_table_get(const void* d_nodes, int64_t nodesBytes, hipStream_t s, bool rebuild, TopTable** out)
 {
     int dev = 0;
@@ -432,10 +488,9 @@ static int predict_scratch_get(hipStream_t s, int numBlocks, PredictScratch** ou
         PredictScratch* best = nullptr;
         for (auto& e : g_scratch)
             if (e.state == PredictScratch::SPARE && e.device == dev && e.capBlocks >= numBlocks && (!best || e.capBlocks < best->capBlocks)) best = &e;
-        if (!best)
-            return set_error(NTR_ERR_INVALID, "ntr_trace_bvh: no prediction scratch is ready for a captured launch of this size: trace a batch "
-                                              "of this size once outside the capture (it keeps %d spares ready), call ntr_trace_graph_reserve, or "
-                                              "release the captures of destroyed graphs (ntr_trace_graph_release_all)", kScratchSpares);
+        // no spare of this size: the launch is captured without a predicted order (an optimisation, not a contract);
+        // ntr_trace_graph_reserve provisions spares for graphs that want it
+        if (!best) { *out = nullptr; return NTR_OK; }
         best->state = PredictScratch::PINNED;
         best->lastUse = ++g_topClock;
         *out = best;
@@ -506,36 +561,67 @@ struct AutoHint {
     void* stream = nullptr;
     int numRays = 0, anyHit = 0, device = -1;
     bool used = false;
+    int sightings = 0;              // launches of this key: storage is allocated at the second one (a batch seen once pays nothing)
+    hipEvent_t lastLaunch = nullptr;   // recorded behind the last launch that read order[]: the entry is recycled only once it has completed
     unsigned long long lastUse = 0;
     NtrSchedHint hint;
 };
 static constexpr int kAutoHints = 96;
 static AutoHint g_auto[kAutoHints];
 
-static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, int anyHit, hipStream_t s, NtrSchedHint** out)
+// The hint of this batch, or null: the first launch of a key only registers it (no allocation, no hint); from the second on the key owns a
+// hint.  Nothing here ever synchronises or frees under a launch in flight: a victim is recycled only if the event behind its last launch
+// has completed, and if no entry can be had the launch simply goes without (buffer / predicted order).
+static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, int anyHit, hipStream_t s, int numBlocks, NtrSchedHint** out, AutoHint** entry)
 {
+    *out = nullptr;
+    *entry = nullptr;
     int dev = 0;
     NTR_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
-    AutoHint* lru = nullptr;
+    AutoHint* hit = nullptr;
+    AutoHint* freeE = nullptr;
     for (auto& e : g_auto) {
-        if (e.used && e.rays == d_rays && e.nodes == d_nodes && e.numRays == numRays && e.anyHit == anyHit && e.stream == (void*)s && e.device == dev) {
-            e.lastUse = ++g_topClock;
-            *out = &e.hint;
-            return NTR_OK;
+        if (e.used && e.rays == d_rays && e.nodes == d_nodes && e.numRays == numRays && e.anyHit == anyHit && e.stream == (void*)s && e.device == dev) { hit = &e; break; }
+        if (!e.used && !freeE) freeE = &e;
+    }
+    if (!hit) {
+        AutoHint* v = freeE;
+        if (!v) {   // least recently used entry whose last launch is known to be over
+            for (auto& e : g_auto) {
+                if (v && e.lastUse >= v->lastUse) continue;
+                if (e.lastLaunch && hipEventQuery(e.lastLaunch) != hipSuccess) { (void)hipGetLastError(); continue; }
+                v = &e;
+            }
+            if (!v) return NTR_OK;
+            sched_hint_release(&v->hint);   // (its launches are over: nothing reads the arrays)
         }
-        if (!e.used) { if (!lru || lru->used) lru = &e; }                       // a free entry first
-        else if (!lru || (lru->used && e.lastUse < lru->lastUse)) lru = &e;     // else the least recently used
+        v->rays = d_rays; v->nodes = d_nodes; v->numRays = numRays; v->anyHit = anyHit; v->stream = (void*)s; v->device = dev;
+        v->used = true;
+        v->sightings = 1;
+        v->lastUse = ++g_topClock;
+        v->hint.uses = 0; v->hint.valid = false;
+        return NTR_OK;   // first sighting: registered, not hinted
     }
-    if (lru->used) {
-        NTR_HIP(hipDeviceSynchronize());   // a launch in flight may still read the evicted order
-        sched_hint_release(&lru->hint);
+    hit->lastUse = ++g_topClock;
+    hit->sightings++;
+    NtrSchedHint* h = &hit->hint;
+    if (h->numBlocks != numBlocks || h->device != dev) {   // second sighting (or a resized batch): the storage
+        if (h->order && hit->lastLaunch && hipEventQuery(hit->lastLaunch) != hipSuccess) { (void)hipGetLastError(); return NTR_OK; }
+        sched_hint_release(h);
+        unsigned int* order = nullptr;
+        unsigned int* cost = nullptr;
+        // (failing here -- another thread capturing in global mode, memory -- only means: no hint for this launch)
+        if (hipMalloc((void**)&order, ((size_t)numBlocks + 3) * sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); return NTR_OK; }
+        if (hipMalloc((void**)&cost, (size_t)numBlocks * sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(order); return NTR_OK; }
+        h->order = order; h->cost = cost;
+        h->numBlocks = numBlocks;
+        h->device = dev;
+        h->uses = 0; h->valid = false;
     }
-    lru->rays = d_rays; lru->nodes = d_nodes; lru->numRays = numRays; lru->anyHit = anyHit; lru->stream = (void*)s; lru->device = dev;
-    lru->used = true;
-    lru->lastUse = ++g_topClock;
-    lru->hint.uses = 0; lru->hint.valid = false;
-    *out = &lru->hint;
+    if (!hit->lastLaunch && hipEventCreateWithFlags(&hit->lastLaunch, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); hit->lastLaunch = nullptr; return NTR_OK; }
+    *out = h;
+    *entry = hit;
     return NTR_OK;
 }
 
@@ -615,6 +701,12 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.cost = nullptr;
     p.poolK = nullptr;
     p.poolKConst = 1;
+    p.cont = nullptr;
+    p.contShardSlots = 0;
+    p.contBelow = tun.handoffBelow < 1 ? 1 : (tun.handoffBelow > 64 ? 64 : tun.handoffBelow);
+    p.contMinQueue = tun.handoffMinQueue < 1 ? 1 : tun.handoffMinQueue;
+    p.contKeepWaves = tun.handoffKeepWaves < 0 ? 0 : tun.handoffKeepWaves;
+    p.contFlags = tun.handoffFlags;
 #ifdef NTR_EXPERIMENTS
     p.timeline = g_expTimeline;
     p.order = g_expOrder;
@@ -664,8 +756,9 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     }
 
     // no hint from the caller: the library's own, keyed by (stream, batch, BVH)
+    AutoHint* autoEntry = nullptr;
     if (!hint && !stats && tun.autoHint != 0 && variant == NTR_VARIANT_PERRAY && numRays >= tun.autoHintMinRays && !stream_is_capturing(s)) {
-        rc = auto_hint_get(d_rays, d_nodes, numRays, anyHit ? 1 : 0, s, &hint);
+        rc = auto_hint_get(d_rays, d_nodes, numRays, anyHit ? 1 : 0, s, numBlocks, &hint, &autoEntry);
         if (rc != NTR_OK) return rc;
     }
     // Scheduling hint: the per-ray kernel dispatches blocks in the hint's order; on refresh launches it
@@ -717,10 +810,14 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         if (rc != NTR_OK) return rc;
         rc = predict_scratch_get(s, orderBlocks, &predScratch);
         if (rc != NTR_OK) return rc;
-        p.order = predScratch->order;
-        if (variant == NTR_VARIANT_PERSISTENT) {   // every head walks its share of the order: ranges of whole 256-ray blocks
-            p.orderBlocks = orderBlocks;
-            p.shardRays = ((orderBlocks + p.numHeads - 1) / p.numHeads) * 256;
+        if (predScratch) {
+            p.order = predScratch->order;
+            if (variant == NTR_VARIANT_PERSISTENT) {   // every head walks its share of the order: ranges of whole 256-ray blocks
+                p.orderBlocks = orderBlocks;
+                p.shardRays = ((orderBlocks + p.numHeads - 1) / p.numHeads) * 256;
+            }
+        } else {
+            predTable = nullptr;   // (a captured launch that found no spare scratch: buffer order)
         }
     }
 
@@ -733,7 +830,12 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         if (rc != NTR_OK) return rc;
     }
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct EventPair {   // destroyed on every return path of the timed bracket
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    hipEvent_t& ev0 = ev.a;
+    hipEvent_t& ev1 = ev.b;
     if (seconds) {
         NTR_HIP(hipEventCreate(&ev0));
         NTR_HIP(hipEventCreate(&ev1));
@@ -775,6 +877,18 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
                     if (predScratch) p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 2;
                     else if (hint && hint->numBlocks == numBlocks && hint->order) p.poolK = hint->order + numBlocks + 2;
                 }
+                // tail hand-off: the pool waves' continuation queue (used only if the launch runs as pools)
+                if (tun.handoff != 0 && (p.poolK || p.poolKConst >= 2 || (p.contFlags & NTR_CONT_FLAG_K1))) {
+                    ContScratch* cq = nullptr;
+                    rc = cont_scratch_get(s, numRays, &cq);
+                    if (rc != NTR_OK) return rc;   // (events not created yet: see below)
+                    if (cq) {
+                        const hipError_t ze = ntr_launch_zero_words(cq->mem, NTR_CONT_SHARDS * NTR_CONT_CTL_WORDS, s);
+                        if (ze != hipSuccess) return hip_fail(ze, "zero_words launch");
+                        p.cont = cq->mem;
+                        p.contShardSlots = cq->shardSlots;
+                    }
+                }
             }
         }
     }
@@ -786,13 +900,12 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         if (le != hipSuccess) return hip_fail(le, "sched_order launch");
         hint->valid = true;
     }
+    if (autoEntry && autoEntry->lastLaunch) NTR_HIP(hipEventRecord(autoEntry->lastLaunch, s));   // behind everything that reads or writes the entry's arrays
     if (seconds) {
         NTR_HIP(hipEventSynchronize(ev1));
         float ms = 0.0f;
         NTR_HIP(hipEventElapsedTime(&ms, ev0, ev1));
         *seconds = ms * 1e-3f;
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
         unsigned int st = 0;   // fetch-and-clear in one device-side step (the word is shared by all streams of the device)
         std::lock_guard<std::mutex> slk(g_statusMu);
         const hipError_t xe = ntr_launch_status_exchange(ds->status, ds->status + 8, s);
@@ -800,6 +913,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         NTR_HIP(hipMemcpyAsync(&st, ds->status + 8, sizeof(st), hipMemcpyDeviceToHost, s));
         NTR_HIP(hipStreamSynchronize(s));
         if (st & NTR_STATUS_STACK_OVERFLOW) return set_error(NTR_ERR_OVERFLOW, "trace_bvh: traversal stack overflow");
+        if (st & NTR_STATUS_HANDOFF_TIMEOUT) return set_error(NTR_ERR_HIP, "trace_bvh: a handed-off ray never arrived (continuation queue)");
     }
     if (stats) {
         unsigned long long h[4];
@@ -849,6 +963,34 @@ int ntr_trace_status(void* stream, uint32_t* statusBits)
     if (statusBits) *statusBits = st;
     if (st & NTR_STATUS_STACK_OVERFLOW)
         return set_error(NTR_ERR_OVERFLOW, "trace_bvh: traversal stack overflow in a launch since the last status check");
+    if (st & NTR_STATUS_HANDOFF_TIMEOUT)
+        return set_error(NTR_ERR_HIP, "trace_bvh: a handed-off ray never arrived (continuation queue) in a launch since the last status check");
+    return NTR_OK;
+}
+
+int ntr_trace_handoff_counts(void* stream, uint32_t counts[3])
+{
+    if (!counts) return set_error(NTR_ERR_INVALID, "ntr_trace_handoff_counts: null argument");
+    counts[0] = counts[1] = counts[2] = 0;
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    unsigned int* mem = nullptr;
+    int shardSlots = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& e : g_cont)
+            if (e.used && e.stream == stream && e.device == dev) { mem = e.mem; shardSlots = e.shardSlots; }
+    }
+    if (!mem) return NTR_OK;
+    static thread_local unsigned int ctl[NTR_CONT_SHARDS * NTR_CONT_CTL_WORDS];
+    NTR_HIP(hipMemcpyAsync(ctl, mem, sizeof(ctl), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    NTR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    for (int sh = 0; sh < NTR_CONT_SHARDS; sh++) {
+        const unsigned int reserved = ctl[sh * NTR_CONT_CTL_WORDS + 0], popped = ctl[sh * NTR_CONT_CTL_WORDS + 1];
+        counts[0] += reserved < (unsigned int)shardSlots ? reserved : (unsigned int)shardSlots;   // (reservations beyond the capacity are void)
+        counts[1] += popped < (unsigned int)shardSlots ? popped : (unsigned int)shardSlots;
+    }
+    counts[2] = (uint32_t)shardSlots * NTR_CONT_SHARDS;
     return NTR_OK;
 }
 
@@ -872,6 +1014,12 @@ int ntr_predict_batch_coherence(int32_t numRays, const NtrRay* d_rays, const voi
     if (numRays < 0) return set_error(NTR_ERR_INVALID, "ntr_predict_batch_coherence: numRays < 0");
     if (!d_out) return set_error(NTR_ERR_INVALID, "ntr_predict_batch_coherence: null argument");
     if (numRays > 0 && (!d_rays || !d_nodes)) return set_error(NTR_ERR_INVALID, "ntr_predict_batch_coherence: null argument");
+    if (numRays == 0) {   // nothing to look at: {0, 0, K = 1} without touching the node buffer
+        const unsigned int none[3] = {0u, 0u, 1u};
+        NTR_HIP(hipMemcpyAsync(d_out, none, sizeof(none), hipMemcpyHostToDevice, (hipStream_t)stream));
+        NTR_HIP(hipStreamSynchronize((hipStream_t)stream));
+        return NTR_OK;
+    }
     if (nodesBytes < 64 || (nodesBytes % 64) != 0 || nodesBytes > kMaxNodesBytes)
         return set_error(NTR_ERR_INVALID, "ntr_predict_batch_coherence: node buffer size must be a multiple of 64 in [64, 0x76543200]");
     TopTable* t = nullptr;

@@ -466,7 +466,7 @@ __device__ __forceinline__ void fetch64_two_buffers(u32x4 rsrcA, u32x4 rsrcB, in
         "s_waitcnt vmcnt(0)"
         : [a] "=&v"(va), [b] "=&v"(vb), [c] "=&v"(vc), [d] "=&v"(vd), [sav] "=&s"(sav)
         : [ofs] "v"(ofs), [ra] "s"(rsrcA), [rb] "s"(rsrcB), [ma] "s"(maskA), [mb] "s"(maskB)
-        : "memory");
+        : "memory", "scc");   // (s_and_b64 writes SCC)
     a = make_float4(__uint_as_float(va.x), __uint_as_float(va.y), __uint_as_float(va.z), __uint_as_float(va.w));
     b = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
     c = make_float4(__uint_as_float(vc.x), __uint_as_float(vc.y), __uint_as_float(vc.z), __uint_as_float(vc.w));
@@ -498,7 +498,7 @@ __device__ __forceinline__ void fetch64_two_buffers_into(u32x4 rsrcA, u32x4 rsrc
         "s_waitcnt vmcnt(0)"
         : [a] "+v"(va), [b] "+v"(vb), [c] "+v"(vc), [d] "+v"(vd), [sav] "=&s"(sav)
         : [ofs] "v"(ofs), [ra] "s"(rsrcA), [rb] "s"(rsrcB), [ma] "s"(maskA), [mb] "s"(maskB)
-        : "memory");
+        : "memory", "scc");   // (s_and_b64 writes SCC)
     a = make_float4(__uint_as_float(va.x), __uint_as_float(va.y), __uint_as_float(va.z), __uint_as_float(va.w));
     b = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
     c = make_float4(__uint_as_float(vc.x), __uint_as_float(vc.y), __uint_as_float(vc.z), __uint_as_float(vc.w));
@@ -613,14 +613,14 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
 #define NTR_PERRAY_BOUNDS(W) __launch_bounds__((W) * 64, NTR_TRACE_MIN_WAVES_PER_SIMD)
 #endif
 template <int WAVES, bool STATS, bool COOP, bool UNIFIED = false, bool FLATF = true, bool MINI = false>
-__global__ NTR_PERRAY_BOUNDS(WAVES) void trace_bvh_perray(TraceParams p)
+__device__ __forceinline__ void perray_body(const TraceParams& p)
 {
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     if constexpr (MINI) {
         static_assert(WAVES == 1 && UNIFIED && !STATS && !COOP, "the mini-pool shares the one-wave unified-step launch");
         unsigned int K = (unsigned int)p.poolKConst;
         if (p.poolK) K = *p.poolK;   // wave-uniform (scalar load)
-        if (K >= 2u && K <= (unsigned int)NTR_MINIPOOL_MAX_K) {
+        if ((K >= 2u && K <= (unsigned int)NTR_MINIPOOL_MAX_K) || (K == 1u && p.cont && (p.contFlags & NTR_CONT_FLAG_K1))) {
             minipool_body<FLATF>(p, K, (lds_int*)&s_stack[0][0][threadIdx.x]);
             return;
         }
@@ -716,6 +716,18 @@ __global__ NTR_PERRAY_BOUNDS(WAVES) void trace_bvh_perray(TraceParams p)
         atomicAdd(&p.stats[2], (unsigned long long)ls.leaves);
         atomicAdd(&p.stats[3], (unsigned long long)(hitAddr >= 0));
     }
+}
+
+template <int WAVES, bool STATS, bool COOP, bool UNIFIED = false, bool FLATF = true>
+__global__ NTR_PERRAY_BOUNDS(WAVES) void trace_bvh_perray(TraceParams p)
+{
+    perray_body<WAVES, STATS, COOP, UNIFIED, FLATF, false>(p);
+}
+// The one-wave unified-step launch that may run as mini-pools (K decided on the device).  It carries the out-of-line hand-off calls, whose
+// calling convention would push it to 74 registers: held to the 72 of seven waves per SIMD, what it needs without them.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void trace_bvh_perray_mini(TraceParams p)
+{
+    perray_body<1, false, false, true, true, true>(p);
 }
 
 // ---------------------------------------------------------------------------------
@@ -894,6 +906,142 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     }
 }
 
+// ---- tail hand-off (round 4): continuation queue of the mini-pool waves ------------------------------------------------------------
+// A pool wave whose own rays are all started and of which fewer than T are still live keeps a whole wave slot busy for a handful of
+// lanes (lane utilisation 0.15 on the 10 M-triangle tree, profiles/r03zz_courtyard10m_pmc_summary.json).  Such a wave now either FILLS
+// its free lanes with continuations other waves left in a queue, or -- while enough waves are still running to pick them up -- APPENDS
+// its own live rays to the queue and exits.  A continuation is the ray's complete traversal state (current node, shrunken tmax, hit so
+// far, stack), so the ray goes on exactly where it stood: its visiting order, and with it its hit record, cannot change.
+// Model first (scripts/studies/tail_handoff_model.py, profiles/r04_tail_handoff_model_*.jsonl): 1.8-3.4x fewer wave-iterations for K = 4.
+//
+// Queue: NTR_CONT_SHARDS independent shards (a wave uses shard = its ordinal % shards: the counters of one shard see 1/64 of the
+// traffic).  Shard control line (128 B): [0] reserved = slots producers took, [1] popped = slots consumers claimed, [2] exited = waves
+// of the shard that are gone.  Slot (128 B): [0] rayIdx -- doubling as the ready flag, -1 = empty --, node, tmax, hitAddr, hitU, hitV, sp,
+// tos, then up to CONT_STACK stack entries.  Every access is an agent-scope relaxed atomic (sc1: served by the coherent level, the
+// per-XCD L2s are not coherent with each other); a producer lane drains its stores (s_waitcnt vmcnt(0)) before it sets its slot's flag, a
+// consumer lane polls its slot's flag before it loads the slot (MI355X_MICROARCH, inter-workgroup visibility: sc1 both sides).
+//   producer: reserved += n (one atomic per wave); slots beyond the shard's capacity are VOID: the lane keeps its ray.
+//   consumer: CAS on popped, never beyond reserved (a claimed slot has a producer that will fill it without waiting for anyone).
+//   exit:     exited += 1 AFTER the wave's last reservation; the wave that completes its shard finds every reservation made and drains
+//             what nobody claimed.  No wave ever waits for a wave that could be waiting for it.
+// The counters are cleared by a kernel before the launch; slots are returned to -1 by their consumer.
+static constexpr int CONT_STACK = NTR_CONT_SLOT_WORDS - 8;
+
+struct ContShard {
+    unsigned int* ctl;            // this wave's shard
+    unsigned long long* slots;    // its slots, as 8-byte words
+    int capacity;                 // slots of the shard
+    int waves;                    // waves of the launch that use the shard
+};
+
+__device__ __forceinline__ unsigned int cont_ld(const unsigned int* a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long cont_ld64(const unsigned long long* a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cont_st64(unsigned long long* a, unsigned int lo, unsigned int hi)
+{
+    __hip_atomic_store(a, (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// A lane's traversal state, as the out-of-line hand-off routines see it (the kernel keeps these in registers; it packs them only around
+// the rare calls, so the cold code costs the hot loop no register).
+struct LaneState {
+    RayRegs r;
+    int rayIdx, node, hitAddr, sp, tos, nice;
+    float hitU, hitV;
+};
+
+// Appends the rays of the lanes in `mask` to the shard and empties those lanes (a lane whose slot lies beyond the shard's capacity keeps its ray).
+__device__ __noinline__ void cont_produce(unsigned int* ctl, unsigned long long* slots, int capacity, unsigned long long mask, LaneState& ls, lds_int* lds, int* spill)
+{
+    const int n = __popcll(mask);
+    unsigned int base = 0;
+    if (threadIdx.x == 0) base = __hip_atomic_fetch_add(ctl + 0, (unsigned int)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    base = __builtin_amdgcn_readfirstlane(base);
+    const bool mine = (mask >> threadIdx.x) & 1ull;
+    const unsigned int idx = base + (unsigned int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+    if (mine && idx < (unsigned int)capacity) {
+        unsigned long long* slot = slots + (size_t)idx * (NTR_CONT_SLOT_WORDS / 2);
+        cont_st64(slot + 1, __float_as_uint(ls.r.tmax), (unsigned int)ls.hitAddr);
+        cont_st64(slot + 2, __float_as_uint(ls.hitU), __float_as_uint(ls.hitV));
+        cont_st64(slot + 3, (unsigned int)ls.sp, (unsigned int)ls.tos);
+        for (int i = 0; i < ls.sp; i += 2) {
+            const int e0 = i < LDS_DEPTH ? lds[i * 64] : spill[i - LDS_DEPTH];
+            const int e1 = (i + 1 < ls.sp) ? ((i + 1) < LDS_DEPTH ? lds[(i + 1) * 64] : spill[i + 1 - LDS_DEPTH]) : 0;
+            cont_st64(slot + 4 + (i >> 1), (unsigned int)e0, (unsigned int)e1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slot has reached the coherent level before its flag says so
+        cont_st64(slot + 0, (unsigned int)ls.rayIdx, (unsigned int)ls.node);
+        ls.rayIdx = -1;
+        ls.node = kSentinel;
+        ls.sp = 0;
+        ls.tos = kSentinel;
+    }
+}
+
+// Fills up to `want` empty lanes (rayIdx < 0) with continuations of the shard.  Returns the number of lanes filled.
+__device__ __noinline__ int cont_consume(unsigned int* ctl, unsigned long long* slots, int capacity, const NtrRay* rays, uint32_t bvhFlags, unsigned int* status,
+                                         int want, LaneState& ls, lds_int* lds, int* spill)
+{
+    unsigned int base = 0;
+    int take = 0;
+    if (threadIdx.x == 0) {
+        for (int tries = 0; tries < 8; tries++) {
+            const unsigned int pp = cont_ld(ctl + 1);
+            const unsigned int rr = cont_ld(ctl + 0);   // read after popped: reserved only grows, so rr - pp never overstates what a claim from pp may take
+            const int avail = (int)(rr - pp);
+            if (avail <= 0) break;
+            const int t = min(want, avail);
+            unsigned int expected = pp;
+            if (__hip_atomic_compare_exchange_strong(ctl + 1, &expected, pp + (unsigned int)t, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                base = pp;
+                take = t;
+                break;
+            }
+        }
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    take = __builtin_amdgcn_readfirstlane(take);
+    if (take == 0) return 0;
+    const unsigned long long empty = __ballot(ls.rayIdx < 0);
+    const int prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(empty >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)empty, 0));
+    const unsigned int idx = base + (unsigned int)prefix;
+    const bool mine = ls.rayIdx < 0 && prefix < take && idx < (unsigned int)capacity;   // (a void slot holds nothing: its producer kept the ray)
+    if (mine) {
+        unsigned long long* slot = slots + (size_t)idx * (NTR_CONT_SLOT_WORDS / 2);
+        unsigned long long w0;
+        unsigned int spins = 0;
+        while ((int)(unsigned int)(w0 = cont_ld64(slot + 0)) < 0) {     // the producer reserved this slot before the claim: it is on its way
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 22)) { atomicOr(status, NTR_STATUS_HANDOFF_TIMEOUT); break; }
+        }
+        if ((int)(unsigned int)w0 >= 0) {
+            const unsigned long long w1 = cont_ld64(slot + 1), w2 = cont_ld64(slot + 2), w3 = cont_ld64(slot + 3);
+            ls.rayIdx = (int)(unsigned int)w0;
+            load_ray(rays, ls.rayIdx, ls.r);
+            ls.nice = ray_is_nice(ls.r, bvhFlags) ? 1 : 0;
+            ls.node = (int)(unsigned int)(w0 >> 32);
+            ls.r.tmax = __uint_as_float((unsigned int)w1);
+            ls.hitAddr = (int)(unsigned int)(w1 >> 32);
+            ls.hitU = __uint_as_float((unsigned int)w2);
+            ls.hitV = __uint_as_float((unsigned int)(w2 >> 32));
+            ls.sp = (int)(unsigned int)w3;
+            ls.tos = (int)(unsigned int)(w3 >> 32);
+            for (int i = 0; i < ls.sp; i += 2) {
+                const unsigned long long e = cont_ld64(slot + 4 + (i >> 1));
+                if (i < LDS_DEPTH) lds[i * 64] = (int)(unsigned int)e; else spill[i - LDS_DEPTH] = (int)(unsigned int)e;
+                if (i + 1 < ls.sp) { if (i + 1 < LDS_DEPTH) lds[(i + 1) * 64] = (int)(unsigned int)(e >> 32); else spill[i + 1 - LDS_DEPTH] = (int)(unsigned int)(e >> 32); }
+            }
+            cont_st64(slot + 0, 0xFFFFFFFFu, 0u);   // the slot is free again (for the next launch: a slot is used once per launch)
+        }
+    }
+    return __popcll(__ballot(mine && ls.rayIdx >= 0));
+}
+
+// packs / unpacks the register state around the out-of-line calls
+#define NTR_LANE_PACK(ls) do { (ls).r = r; (ls).rayIdx = rayIdx; (ls).node = node; (ls).hitAddr = hitAddr; (ls).sp = st.sp; (ls).tos = st.tos; \
+                               (ls).nice = nice ? 1 : 0; (ls).hitU = hitU; (ls).hitV = hitV; } while (0)
+#define NTR_LANE_UNPACK(ls) do { r = (ls).r; rayIdx = (ls).rayIdx; node = (ls).node; hitAddr = (ls).hitAddr; st.sp = (ls).sp; st.tos = (ls).tos; \
+                                 nice = (ls).nice != 0; hitU = (ls).hitU; hitV = (ls).hitV; } while (0)
+
 // ---------------------------------------------------------------------------------
 // Variant 3: per-ray kernel with a wave-private mini-pool (round 3).  A hardware-scheduled 64-thread workgroup owns K x 64 consecutive
 // rays instead of 64: its lanes start on the first 64, and a lane that finishes takes the wave's next unstarted ray (ballot + mbcnt
@@ -903,6 +1051,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
 // path per wave -- which is why the pool stays small and private: the global pool of the persistent kernels keeps every lane busy
 // until it runs dry, and then 6 144 waves each hold a few long rays (a tail of 60-70 % of their launch, profiles/r03_divergence_timelines.jsonl).
 // Unified-step loop, flat fetch; 256-ray blocks keep their role as the unit of the dispatch order and of the cost feedback.
+// With a continuation queue (p.cont, round 4) the tail of a pool is handed off: see above.
 // ---------------------------------------------------------------------------------
 template <bool FLATF>
 __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int K, lds_int* stackBase)
@@ -929,6 +1078,23 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
 
     unsigned long long tl0 = 0;
     if (p.cost) tl0 = __builtin_amdgcn_s_memrealtime();
+    unsigned int life = 0;                 // scheduling feedback: the wave's lifetime up to the hand-off of its tail (or its end)
+
+    // tail hand-off: this wave's shard of the continuation queue
+    ContShard cs = {nullptr, nullptr, 0, 0};
+    bool final = true;                     // wave-uniform: no (more) hand-off, the wave runs what it holds to completion
+    bool shardLast = false;                // wave-uniform: every other wave of the shard is gone; this one drains the shard
+    int keepWaves = 0;
+    if (p.cont) {
+        const unsigned int numWaves = (numChunks + K - 1u) / K;
+        const unsigned int shard = q & (unsigned int)(NTR_CONT_SHARDS - 1);
+        cs.ctl = p.cont + shard * NTR_CONT_CTL_WORDS;
+        cs.capacity = p.contShardSlots;
+        cs.slots = reinterpret_cast<unsigned long long*>(p.cont + NTR_CONT_SHARDS * NTR_CONT_CTL_WORDS) + (size_t)shard * cs.capacity * (NTR_CONT_SLOT_WORDS / 2);
+        cs.waves = (int)((numWaves - shard + (unsigned int)NTR_CONT_SHARDS - 1u) / (unsigned int)NTR_CONT_SHARDS);
+        keepWaves = max(p.contKeepWaves / NTR_CONT_SHARDS, 1);
+        final = false;
+    }
 
     LaneStack st;
     int spill[SPILL_DEPTH];
@@ -963,19 +1129,73 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
             poolNext += min(__popcll(empty), avail);
         }
         const bool poolEmpty = poolNext >= poolEnd && chunk + 1u >= chunkEnd;
+        // ---- tail: the wave's own rays are all started.  Below T live lanes: fill up from the queue, or hand the rays off ----------
+        bool stopEarly = !poolEmpty;               // leave the traversal when fewer than `stopBelow` lanes are live
+        int stopBelow = p.fetchThreshold;
+        if (poolEmpty && !final) {
+            int nlive = __popcll(__ballot(node != kSentinel));
+            if (nlive < p.contBelow) {
+                if (rayIdx >= 0 && node == kSentinel) {   // (rays that ended, degenerate ones just started: their lanes are free)
+                    store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
+                    rayIdx = -1;
+                }
+                if (p.cost && life == 0u) life = (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0);
+                unsigned int rr = 0, pp = 0, ex = 0;
+                if (lane == 0) { pp = cont_ld(cs.ctl + 1); rr = cont_ld(cs.ctl + 0); ex = cont_ld(cs.ctl + 2); }
+                const int queued = (int)(__builtin_amdgcn_readfirstlane(rr) - __builtin_amdgcn_readfirstlane(pp));
+                const int remaining = cs.waves - (int)__builtin_amdgcn_readfirstlane(ex);   // waves of the shard not yet gone, this one included
+                const int freeLanes = 64 - nlive;
+                const int need = min(freeLanes, p.contMinQueue);
+                if (shardLast || remaining <= keepWaves) {            // end game: nobody hands off any more; take what is left, then run to the end
+                    if (queued > 0 && freeLanes > 0) {
+                        LaneState ls; NTR_LANE_PACK(ls);
+                        cont_consume(cs.ctl, cs.slots, cs.capacity, p.rays, p.bvhFlags, p.status, min(queued, freeLanes), ls, st.lds, spill);
+                        NTR_LANE_UNPACK(ls);
+                    } else final = true;
+                } else if (queued >= need && queued > 0) {            // consumer
+                    LaneState ls; NTR_LANE_PACK(ls);
+                    const int got = cont_consume(cs.ctl, cs.slots, cs.capacity, p.rays, p.bvhFlags, p.status, min(queued, freeLanes), ls, st.lds, spill);
+                    NTR_LANE_UNPACK(ls);
+                    if (got > 0 && (p.contFlags & NTR_CONT_FLAG_PRIO)) __builtin_amdgcn_s_setprio(2);
+                } else if (nlive > 0) {                               // producer: the rays go on in another wave
+                    LaneState ls; NTR_LANE_PACK(ls);
+                    cont_produce(cs.ctl, cs.slots, cs.capacity, __ballot(node != kSentinel && st.sp <= CONT_STACK), ls, st.lds, spill);
+                    NTR_LANE_UNPACK(ls);
+                }
+                nlive = __popcll(__ballot(node != kSentinel));
+            }
+            if (!final) { stopEarly = true; stopBelow = min(p.contBelow, nlive); }   // look again as soon as a ray ends below T
+        }
         // ---- unified-step traversal until every lane is done, or until enough lanes are free to be worth a refill -------------
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
-        if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
-        else traverse_unified<false, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
+        if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, !stopEarly, stopBelow);
+        else traverse_unified<false, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, !stopEarly, stopBelow);
         // ---- retire finished rays ---------------------------------------------------------------------------------------------
         if (rayIdx >= 0 && node == kSentinel) {
             store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
             rayIdx = -1;
         }
-        if (poolEmpty && __ballot(rayIdx >= 0) == 0ull) break;
+        if (poolEmpty && __ballot(rayIdx >= 0) == 0ull) {
+            if (!p.cont) break;
+            // ---- leaving: a wave that holds nothing.  The one that completes its shard drains what nobody claimed ----------------------
+            if (!shardLast) {
+                unsigned int old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_add(cs.ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)__builtin_amdgcn_readfirstlane(old) + 1 < cs.waves) break;
+                shardLast = true;
+            }
+            unsigned int rr = 0, pp = 0;
+            if (lane == 0) { pp = cont_ld(cs.ctl + 1); rr = cont_ld(cs.ctl + 0); }
+            const int queued = (int)(__builtin_amdgcn_readfirstlane(rr) - __builtin_amdgcn_readfirstlane(pp));
+            if (queued <= 0) break;
+            final = false;   // (looks at the queue again whenever it runs empty)
+            LaneState ls; NTR_LANE_PACK(ls);
+            cont_consume(cs.ctl, cs.slots, cs.capacity, p.rays, p.bvhFlags, p.status, min(queued, 64), ls, st.lds, spill);
+            NTR_LANE_UNPACK(ls);
+        }
     }
     if (p.cost && lane == 0) {  // scheduling feedback: a block's cost is the lifetime of the longest wave that traced a part of it
-        const unsigned int life = (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0);
+        if (life == 0u) life = (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0);
         for (unsigned int c = q * K; c < chunkEnd; c += 4u - (c & 3u)) atomicMax(&p.cost[p.order ? p.order[c >> 2] : (c >> 2)], life);
     }
 }
@@ -1088,7 +1308,7 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
         else hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false, true, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_UNIFIED_MINI:   // numBlocks counts waves of 64 rays; needs flatFetch
-        hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false, true, true, true>), dim3(numBlocks), dim3(64), 0, stream, *p);
+        hipLaunchKernelGGL(ntr::trace_bvh_perray_mini, dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_STATS:
         hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);

@@ -52,7 +52,9 @@ def balanced_cuts(block_cost, num_rays, world, flat_share=1.0, block=256):
             b -= 1
         cuts.append(max(min(b, nb) * block, cuts[-1]))
     cuts.append(int(num_rays))
-    return [min(int(x), int(num_rays)) for x in cuts]
+    # interior cuts stay aligned: one that lands on (or beyond) a partial last block moves down to the last aligned position
+    top = (int(num_rays) // block) * block
+    return [min(int(x), top) for x in cuts[:-1]] + [int(num_rays)]
 
 
 def broadcast_cuts(cuts, world, device, src=0):

@@ -9,7 +9,7 @@ from ray_sets import edge_rays
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["fermi_speculative_while_while", "kepler_dynamic_fetch"]
+KERNELS = list(nt.KERNELS)   # every kernel name the reference selects by, the tesla_* while-while persistent bodies included
 
 
 @pytest.fixture(scope="module")
