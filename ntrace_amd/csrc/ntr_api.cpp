@@ -149,7 +149,7 @@ static void tunables_load_locked()
     t.minipool = env_int("NTR_TRACE_MINIPOOL", -1);              // closest-hit per-ray launches: rays owned by a wave / 64.  -1: decided per batch on the device (1, or minipoolWide when the prediction finds the batch incoherent); 0: the plain per-ray kernel; 1 ... 16: forced
     t.minipoolWide = env_int("NTR_TRACE_MINIPOOL_WIDE", -1);     // K of an incoherent batch: 2 / 4, or -1 = by tree size (4 from 32 MB of nodes up)
     t.minipoolThreshold = env_int("NTR_TRACE_MINIPOOL_THRESHOLD", 48);   // refill a wave's finished lanes when fewer than this many are live
-    t.handoff = env_int("NTR_TRACE_HANDOFF", 1);                  // mini-pool launches: tail hand-off through the continuation queue (0 = off)
+    t.handoff = env_int("NTR_TRACE_HANDOFF", 0);                  // mini-pool launches: tail hand-off through the continuation queue.  OFF: it cuts the wave-iterations 3x and the VALU work 2.2x as modelled, and the launch gets 5-10 % slower (profiles/r04_handoff_*; EXPERIMENTS.md)
     t.handoffBelow = env_int("NTR_TRACE_HANDOFF_BELOW", 16);      // T: a pool wave with fewer live lanes (own rays all started) fills up from the queue or hands its rays off
     t.handoffMinQueue = env_int("NTR_TRACE_HANDOFF_MIN_QUEUE", 64);   // M: waiting continuations needed to fill up rather than hand off (capped by the wave's free lanes)
     t.handoffKeepWaves = env_int("NTR_TRACE_HANDOFF_KEEP_WAVES", 1024);   // A: with no more waves than this left in the launch nobody hands off

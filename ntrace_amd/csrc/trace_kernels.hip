@@ -531,11 +531,22 @@ __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs&
                                                  int (&spill)[SPILL_DEPTH], bool anyHit, int& hitAddr, float& hitU, float& hitV,
                                                  unsigned int* status, bool poolEmpty, int fetchThreshold)
 {
+#if defined(NTR_AB) && defined(NTR_AGE_SHIFT)
+    unsigned int ageIt = 0;   // A/B experiment: waves that have been stepping for long (they hold the long rays: the launch's critical path) get issue priority
+#endif
     for (;;) {
         const unsigned long long live = __ballot(node != kSentinel);
         if (live == 0ull) break;
         // dynamic fetch (kepler_dynamic_fetch.cu:310): too few live lanes while rays remain in the pool -> refill
         if (!poolEmpty && __popcll(live) < fetchThreshold) break;
+#if defined(NTR_AB) && defined(NTR_AGE_SHIFT)
+        if ((++ageIt & ((1u << NTR_AGE_SHIFT) - 1u)) == 0u) {
+            const unsigned int a = ageIt >> NTR_AGE_SHIFT;
+            if (a == 1u) __builtin_amdgcn_s_setprio(1);
+            else if (a == 2u) __builtin_amdgcn_s_setprio(2);
+            else if (a == 3u) __builtin_amdgcn_s_setprio(3);
+        }
+#endif
         const bool inner = (unsigned)node < (unsigned)kSentinel;
         const bool atTri = node < 0;
         // one 64-byte fetch per lane from its own buffer: four loads under the inner lanes' mask and four under the triangle lanes'

@@ -80,11 +80,11 @@ def main():
                     ts = ("8", "16", "24", "32") if mode == "full" else ("16", "32")
                     ks = ("0", "1024", "3072") if mode == "full" else ("0", "1024")
                     for t, a in itertools.product(ts, ks):
-                        cfgs.append({"NTR_TRACE_MINIPOOL": k, "NTR_TRACE_HANDOFF_BELOW": t, "NTR_TRACE_HANDOFF_KEEP_WAVES": a,
+                        cfgs.append({"NTR_TRACE_HANDOFF": "1", "NTR_TRACE_MINIPOOL": k, "NTR_TRACE_HANDOFF_BELOW": t, "NTR_TRACE_HANDOFF_KEEP_WAVES": a,
                                      "NTR_TRACE_HANDOFF_FLAGS": "2" if k == "1" else "0"})
-                    cfgs.append({"NTR_TRACE_MINIPOOL": k, "NTR_TRACE_HANDOFF_BELOW": "24", "NTR_TRACE_HANDOFF_KEEP_WAVES": "1024", "NTR_TRACE_HANDOFF_MIN_QUEUE": "16",
+                    cfgs.append({"NTR_TRACE_HANDOFF": "1", "NTR_TRACE_MINIPOOL": k, "NTR_TRACE_HANDOFF_BELOW": "24", "NTR_TRACE_HANDOFF_KEEP_WAVES": "1024", "NTR_TRACE_HANDOFF_MIN_QUEUE": "16",
                                  "NTR_TRACE_HANDOFF_FLAGS": "2" if k == "1" else "0"})
-                    cfgs.append({"NTR_TRACE_MINIPOOL": k, "NTR_TRACE_HANDOFF_BELOW": "24", "NTR_TRACE_HANDOFF_KEEP_WAVES": "1024",
+                    cfgs.append({"NTR_TRACE_HANDOFF": "1", "NTR_TRACE_MINIPOOL": k, "NTR_TRACE_HANDOFF_BELOW": "24", "NTR_TRACE_HANDOFF_KEEP_WAVES": "1024",
                                  "NTR_TRACE_HANDOFF_FLAGS": "3" if k == "1" else "1"})
                 cfgs.append({})   # the defaults
             for env in cfgs:

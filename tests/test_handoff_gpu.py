@@ -1,4 +1,4 @@
-"""GPU parity of the tail hand-off (round 4): a pool wave whose own rays are all started and of which only a few are still live
+"""GPU parity of the tail hand-off (round 4; an opt-in, NTR_TRACE_HANDOFF=1: measured slower than leaving the tails alone): a pool wave whose own rays are all started and of which only a few are still live
 appends those rays' complete traversal state to a continuation queue and exits, or fills its free lanes from that queue.  A ray goes
 on exactly where it stood -- its visiting order cannot change -- so every record must stay the oracle's, whatever the thresholds."""
 import numpy as np
@@ -45,10 +45,10 @@ def test_tail_handoff_changes_no_record(monkeypatch, tree):
     configs = []
     for k, flags in (("1", 2), ("2", 0), ("4", 1), ("7", 3)):
         for below, minq, keep in (("16", "64", "0"), ("63", "1", "0"), ("2", "64", "0"), ("24", "8", "256"), ("33", "16", "100000")):
-            configs.append({"NTR_TRACE_MINIPOOL": k, "NTR_TRACE_HANDOFF_FLAGS": str(flags), "NTR_TRACE_HANDOFF_BELOW": below,
+            configs.append({"NTR_TRACE_HANDOFF": "1", "NTR_TRACE_MINIPOOL": k, "NTR_TRACE_HANDOFF_FLAGS": str(flags), "NTR_TRACE_HANDOFF_BELOW": below,
                             "NTR_TRACE_HANDOFF_MIN_QUEUE": minq, "NTR_TRACE_HANDOFF_KEEP_WAVES": keep})
     configs.append({"NTR_TRACE_MINIPOOL": "4", "NTR_TRACE_HANDOFF": "0"})
-    configs.append({"NTR_TRACE_MINIPOOL": "2", "NTR_TRACE_MINIPOOL_THRESHOLD": "64", "NTR_TRACE_HANDOFF_BELOW": "64", "NTR_TRACE_HANDOFF_KEEP_WAVES": "0"})
+    configs.append({"NTR_TRACE_HANDOFF": "1", "NTR_TRACE_MINIPOOL": "2", "NTR_TRACE_MINIPOOL_THRESHOLD": "64", "NTR_TRACE_HANDOFF_BELOW": "64", "NTR_TRACE_HANDOFF_KEEP_WAVES": "0"})
     for env in configs:
         for k in HANDOFF_ENV:
             monkeypatch.delenv(k, raising=False)
@@ -77,6 +77,7 @@ def test_tail_handoff_on_two_streams_and_repeated_launches(monkeypatch):
     dbvh = _lbvh_device_bvh(tri, pos)
     for k in HANDOFF_ENV:
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("NTR_TRACE_HANDOFF", "1")
     monkeypatch.setenv("NTR_TRACE_MINIPOOL", "2")
     monkeypatch.setenv("NTR_TRACE_HANDOFF_KEEP_WAVES", "0")
     monkeypatch.setenv("NTR_TRACE_AUTO_HINT_MIN_RAYS", "1")
