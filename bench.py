@@ -46,12 +46,13 @@ PEAK_CLOCK_GHZ = 2.4
 # kernel symbol a selector launches by default (ntr_api.cpp: 64-thread workgroups of the per-ray kernel; template arguments
 # <WAVES, STATS, COOP, UNIFIED> / <WAVES, COOP, TL, UNIFIED>), and the grid it is launched with for n rays
 def launched_symbol(kernel, wide_leaves=False, any_hit=False):
-    """<WAVES, STATS, COOP, UNIFIED, FLATF, MINI> / <WAVES, COOP, TL, UNIFIED, FLATF>: closest-hit launches of the per-ray kernel run the
-    unified-step loop on every tree (in the instantiation that can turn into the wave-private mini-pool), any-hit launches on trees of
-    multi-triangle leaves (ntr_api.cpp)."""
+    """Closest-hit launches of the per-ray kernel run trace_bvh_perray_mini (the unified-step loop in the instantiation that can turn into
+    wave-private ray pools); any-hit launches trace_bvh_perray<WAVES, STATS, COOP, UNIFIED, FLATF>, unified on trees of multi-triangle
+    leaves; the persistent selectors trace_bvh_persistent<WAVES, COOP, TL, UNIFIED, FLATF> (ntr_api.cpp)."""
     if kernel.startswith("fermi"):
-        return "trace_bvh_perray<1, false, false, %s, true, %s>" % ("true" if (wide_leaves or not any_hit) else "false",
-                                                                    "false" if any_hit else "true")
+        if not any_hit:
+            return "trace_bvh_perray_mini"
+        return "trace_bvh_perray<1, false, false, %s, true>" % ("true" if wide_leaves else "false")
     return "trace_bvh_persistent<4, false, false, %s, true>" % ("true" if kernel == "kepler_dynamic_fetch" else "false")
 
 
@@ -83,10 +84,20 @@ def load_pmc(symbol, grid, tag=None):
     return best, src
 
 
+def l1_roofline(alg_bytes, sec, cus):
+    """SURVEY 8(d) algorithmic bytes against the data path that actually serves a cache-resident BVH: the CUs' vector L1s, 64 bytes per
+    clock each at the peak clock.  Recomputable from the line alone: achieved = algorithmic_bytes_per_launch / launch_ms."""
+    peak = cus * 64.0 * PEAK_CLOCK_GHZ          # GB/s
+    ach = alg_bytes / sec / 1e9
+    return {"bound": "l1-data-path", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
+            "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": sec * 1e3,
+            "peak_definition": "%d CUs x 64 B/clk (vector L1) x %.1f GHz peak clock" % (cus, PEAK_CLOCK_GHZ)}
+
+
 def binding_roofs(pmc, pmc_src, sec, visits=None):
-    """Busy fractions of the units that can bind a trace launch, from per-dispatch PMC means of the same kernel symbol and launch
-    shape and THIS run's launch duration: VALU issue (a wave64 instruction occupies its SIMD-32 for two cycles), the texture-address
-    unit (one per CU), and -- where the bytes are not cache-served -- HBM traffic."""
+    """UTILISATION (busy shares, not bounds) of the units a trace launch keeps busy, from per-dispatch PMC means of the same kernel symbol
+    and launch shape (a committed rocprofv3 summary, named in `source`) and THIS run's launch duration: VALU issue (a wave64 instruction
+    occupies its SIMD-32 for two cycles), the texture-address unit (one per CU), HBM-side traffic, lanes per wave-iteration."""
     if not pmc:
         return None
     clk = pmc.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / sec / 1e9 if pmc.get("GRBM_GUI_ACTIVE") else None
@@ -110,11 +121,6 @@ def binding_roofs(pmc, pmc_src, sec, visits=None):
         b["lane_util"] = visits / (pmc["SQ_INSTS_VMEM_RD"] / 4.0 * 64.0)
     if "SQ_WAIT_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"] > 0:
         b["wave_wait_share"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
-    fr = {k: v for k, v in b.items() if k in ("valu_issue_frac", "ta_frac", "hbm_traffic_frac")}
-    if fr:
-        top = max(fr, key=fr.get)
-        b["bound"] = {"valu_issue_frac": "valu", "ta_frac": "ta", "hbm_traffic_frac": "hbm"}[top]
-        b["frac"] = fr[top]
     return b
 
 
@@ -432,6 +438,30 @@ def main():
         ao_alg += view.trace_stats(args.kernel, b["n"], True, b["rays"], b["res"], stream).algorithmic_bytes()
     ao_live = sum(b["live"] for b in batches[1:])
 
+    # ---- N > 1: the mode in which this design scales by construction, in the SAME driver-parsed line: every rank traces a whole frame of
+    # its own camera (no ray or record crosses a rank boundary), the same K steps
+    frame_per_rank = None
+    if world > 1 and args.scaling == "strong":
+        cam_r = dict(cam)
+        eye = np.array(cam_r["eye"], dtype=np.float64)
+        eye[2] += 2.0 * rank        # a slow camera move: the frames are distinct and about equally costly
+        cam_r["eye"] = tuple(eye)
+        frame_w = Frame(nt, torch, view, lambda d_rays: ntd.FramePlan(n_primary, 0, 1, ns, args.ao_batch_rays), cam_r, w, h, d_nrm, args, dev, stream, scenes)
+        for _ in range(args.warmup):
+            for b in frame_w.batches:
+                run_batch(b)
+        evw = [[(E(enable_timing=True), E(enable_timing=True)) for _ in frame_w.batches] for _ in range(args.steps)]
+        barrier()
+        for s_ in range(args.steps):
+            for bi, b in enumerate(frame_w.batches):
+                evw[s_][bi][0].record()
+                run_batch(b)
+                evw[s_][bi][1].record()
+        barrier()
+        wms = np.array([[e0.elapsed_time(e1) for (e0, e1) in step] for step in evw])
+        frame_per_rank = ntd.frame_per_rank_summary(frame_w.rays_per_step, float(wms.sum()) * 1e-3, args.steps, dev)
+        del frame_w, evw
+
     overlapped = None
     if world > 1 and not args.no_extras:
         # every rank's frame share on three streams (no graph: one capture per rank is not worth its set-up here), between barriers;
@@ -448,6 +478,8 @@ def main():
         except Exception as e:  # extras never invalidate the headline
             extras = {"error": repr(e)}
 
+    if frame_per_rank is not None and isinstance(extras, dict):
+        extras["frame_per_rank"] = frame_per_rank
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -499,33 +531,37 @@ def main():
         "extras": extras,
         "roofline": None,
     }
-    # roofline of the dominant kernel (the primary launch).  The 34 MB BVH of the headline workload is cache-resident, so the SURVEY
-    # 8(d) HBM figure (algorithmic bytes / time / 8 TB/s) exceeds 1 and is not an efficiency: it is kept as `hbm_algorithmic`
-    # ("cache-served"), and the top-level bound / frac name the unit that actually binds the launch, from the PMC passes of the same
-    # kernel symbol.  The launch whose bytes HBM really delivers is `roofline_hbm_resident` (10 M-triangle BVH, incoherent rays).
+    # Roofline.  The 34 MB BVH of the headline workload is cache-resident: the SURVEY 8(d) HBM figure (algorithmic bytes / time / 8 TB/s)
+    # exceeds 1 and is not an efficiency -- it is kept as `hbm_algorithmic` (cache_served).  The top-level fraction is the same algorithmic
+    # bytes against the data path that serves them, the CUs' vector L1s (64 B/clk each), for the primary launch and -- the larger part of
+    # the step -- for the AO batches; every figure is recomputable from this line.  Busy shares of TA / VALU from a committed PMC summary
+    # of the same kernel symbol and grid sit under `utilisation` (shares, not bounds); when no summary matches the launched symbol they
+    # are null and `utilisation_note` says so.  The launch whose bytes HBM really delivers is `roofline_hbm_resident`.
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
     hbm_alg = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                "cache_served": True, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic,
                "note": "SURVEY 8(d) accounting; frac > 1 because L1 / L2 / Infinity Cache serve the bytes (HBM-side bytes per launch in `traffic`)"}
-    roof = {"kernel": "%s (%s), primary batch of rank 0" % (symbol, args.kernel), "launch_ms": prim_ms,
-            "launch_includes": "predict_kernel + flatten_kernel (dispatch-order prediction, about 20 us) + the trace kernel; rocprofv3's "
-                               "per-kernel average for the trace kernel alone is in profiles/",
-            "traffic": traffic, "hbm_algorithmic": hbm_alg, "binding": binding,
-            "cache_ceilings": {"l2_gather_peak": L2_GATHER_PEAK_GBS, "frac_of_l2_gather": achieved / L2_GATHER_PEAK_GBS,
-                               "infinity_cache_gather_peak": MALL_GATHER_PEAK_GBS, "source": "MI355X_MICROARCH.md gather table"},
-            "ao": {"hbm_algorithmic_achieved": (ao_alg / (ao_ms * 1e-3) / 1e9) if ao_ms > 0 else None, "algorithmic_bytes_all_batches": ao_alg}}
-    if binding and binding.get("bound") in ("ta", "valu"):
-        clk = min(binding.get("effective_clock_ghz") or PEAK_CLOCK_GHZ, PEAK_CLOCK_GHZ)
-        if binding["bound"] == "ta":
-            roof.update({"bound": "ta", "unit": "Gcycles/s", "peak": NUM_TAS * clk,
-                         "achieved": pmc.get("TA_TA_BUSY_sum", pmc.get("TA_BUFFER_TOTAL_CYCLES_sum", 0.0)) / (prim_ms * 1e-3) / 1e9, "frac": binding["ta_frac"],
-                         "note": "texture-address unit busy cycles (TA_TA_BUSY, one TA per CU) over the launch; VALU issue is in binding"})
-        else:
-            roof.update({"bound": "valu", "unit": "Ginstr/s", "peak": NUM_SIMDS * clk / 2.0,
-                         "achieved": pmc["SQ_INSTS_VALU"] / (prim_ms * 1e-3) / 1e9, "frac": binding["valu_issue_frac"],
-                         "note": "wave64 VALU instructions (two cycles each on a SIMD-32) over the launch; the TA fraction is in binding"})
-    else:  # no PMC summary of this symbol committed: only the 8(d) figure is available
-        roof.update({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-                     "note": "cache-served (see hbm_algorithmic); no PMC summary of %s under profiles/" % symbol})
+    roof = l1_roofline(alg_bytes, prim_ms * 1e-3, cus)
+    roof.update({"kernel": "%s (%s), primary batch of rank 0" % (symbol, args.kernel),
+                 "launch_includes": "the dispatch-order work of the launch (prediction or cost feedback, a few small kernels) + the trace kernel, as the "
+                                    "HIP events around the library call see it; rocprofv3's per-kernel average for the trace kernel alone is in profiles/",
+                 "traffic": traffic, "hbm_algorithmic": hbm_alg,
+                 "utilisation": binding,
+                 "utilisation_note": None if binding else "no committed PMC summary under profiles/ matches the launched symbol %s with grid %d: "
+                                                           "utilisation not reported" % (symbol, launched_grid(args.kernel, b0["n"])),
+                 "cache_ceilings": {"l2_gather_peak": L2_GATHER_PEAK_GBS, "frac_of_l2_gather": achieved / L2_GATHER_PEAK_GBS,
+                                    "infinity_cache_gather_peak": MALL_GATHER_PEAK_GBS, "source": "MI355X_MICROARCH.md gather table"}})
+    if ao_ms > 0:
+        ao_sym = launched_symbol(args.kernel, wide, any_hit=True)
+        ao_roof = l1_roofline(ao_alg, ao_ms * 1e-3, cus)
+        ao_pmc, ao_src = load_pmc(ao_sym, launched_grid(args.kernel, batches[1]["n"]))
+        ao_bind = binding_roofs(ao_pmc, ao_src, ao_ms * 1e-3 / (len(batches) - 1)) if ao_pmc else None
+        ao_roof.update({"kernel": "%s (%s), the %d AO batches of rank 0 (any hit)" % (ao_sym, args.kernel, len(batches) - 1),
+                        "share_of_step": ao_ms / (ao_ms + prim_ms),
+                        "hbm_algorithmic": {"achieved": ao_alg / (ao_ms * 1e-3) / 1e9, "frac": ao_alg / (ao_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "cache_served": True},
+                        "utilisation": ao_bind,
+                        "utilisation_note": None if ao_bind else "no committed PMC summary under profiles/ matches %s with grid %d" % (ao_sym, launched_grid(args.kernel, batches[1]["n"]))})
+        roof["ao"] = ao_roof
     out["roofline"] = roof
     hp = extras.get("hbm_resident_point") if isinstance(extras, dict) else None
     if hp and hp.get("incoherent"):
@@ -685,6 +721,16 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
     extras["stream_copy_GBps"] = 2.0 * 4 * cp_src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del cp_src, cp_dst
 
+    # (3b) the practical roof of an HBM-resident BVH's fetches: dependent chains of random 64-byte records (ntr_selftest_gather_rate)
+    try:
+        g_waves, g_steps = 8192, 256
+        gsec = nt.selftest_gather_rate(768 << 20, g_waves, 64, g_steps, stream)
+        extras["gather_roof"] = {"what": "%d waves x 64 lanes, each a dependent chain of %d random 64-byte records of a 768 MB table (4 x 16-byte loads per record): "
+                                         "the memory side of a divergent traversal without its arithmetic" % (g_waves, g_steps),
+                                 "grecords_per_s": g_waves * 64 * g_steps / gsec / 1e9, "GBps": g_waves * 64 * g_steps * 64 / gsec / 1e9, "ms": gsec * 1e3}
+    except Exception as e:
+        extras["gather_roof"] = {"error": repr(e)}
+
     # (4) on-device LBVH build of the bench scene + primary rays on the built tree
     def lbvh_of(tri_, pos_, reps):
         capn, capw, capi = nt.lbvh_capacity(tri_.shape[0])
@@ -769,8 +815,16 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         sym = launched_symbol(best_kn, wide10)
         pmc_i, src_i = load_pmc(sym, launched_grid(best_kn, nr), tag="courtyard")
         bind_i = binding_roofs(pmc_i, src_i, secr, sr.numInnerVisits + sr.numTriTests) if pmc_i else None
+        gr = extras.get("gather_roof", {})
+        steps_i = sr.numInnerVisits + sr.numTriTests
         r_inc.update({"kernel": "%s (%s)" % (sym, best_kn), "launch_ms": secr * 1e3,
-                      "traffic": bind_i.get("hbm_traffic_bytes") if bind_i else None, "binding": bind_i,
+                      "traffic": bind_i.get("hbm_traffic_bytes") if bind_i else None, "utilisation": bind_i,
+                      "utilisation_note": None if bind_i else "no committed PMC summary under profiles/ matches %s with grid %d" % (sym, launched_grid(best_kn, nr)),
+                      "gather_roof": {"records_per_s": steps_i / secr, "roof_records_per_s": gr.get("grecords_per_s", 0) * 1e9 or None,
+                                      "frac": (steps_i / secr) / (gr["grecords_per_s"] * 1e9) if gr.get("grecords_per_s") else None,
+                                      "note": "node + triangle fetches of the launch (one 64-byte record per lane step) against the measured rate of dependent "
+                                              "random 64-byte fetches beyond the L2 (extras.gather_roof): what HBM + fabric deliver for this access pattern, "
+                                              "whatever the record size; part of the launch's fetches hit the L2 (see utilisation.l2_hit_rate)"},
                       "workload": "courtyard-10M device LBVH (0.75 GB), 2^21 incoherent closest-hit rays",
                       "note": "the launch whose bytes HBM really delivers: SURVEY 8(d) algorithmic bytes / time / 8 TB/s; `traffic` = PMC bytes of "
                               "the same kernel symbol (FETCH_SIZE x 2 + WRITE_SIZE) from profiles/"})

@@ -151,6 +151,13 @@ NTR_API int ntr_trace_status(void* stream, uint32_t* statusBits);
  * capacity in continuations.  All zero when no such launch ran on `stream`.  Waits for `stream`.  Diagnostic. */
 NTR_API int ntr_trace_handoff_counts(void* stream, uint32_t counts[3]);
 
+/* Measurement aid (bench.py extras.gather_roof; no counterpart in the reference): every one of `waves` x `lanesPerWave` lanes walks
+ * a dependent chain of `steps` random 64-byte records of a `tableBytes` table (four 16-byte loads per record, the next index a hash of
+ * the bytes just loaded) -- the memory side of a divergent traversal without its arithmetic.  *seconds = best of three launches;
+ * waves x lanesPerWave x steps / seconds is the record rate.  On a table larger than the Infinity Cache with a full grid this is the
+ * practical roof of an HBM-resident BVH's fetches (56 G records/s = 3.6 TB/s on MI355X, whatever the record size: DESIGN.md 4.1). */
+NTR_API int ntr_selftest_gather_rate(int64_t tableBytes, int32_t waves, int32_t lanesPerWave, int32_t steps, void* stream, float* seconds);
+
 /* HIP graphs.  An asynchronous ntr_trace_bvh (seconds == NULL) may be captured into a HIP graph.  Nothing can be allocated
  * during a capture, and the scratch of a captured launch must outlive the graph, so the library hands such a launch scratch
  * of its OWN from per-device stores that are filled outside captures and never recycled while pinned:

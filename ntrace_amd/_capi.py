@@ -82,6 +82,7 @@ SYMBOLS = [
                                        C.POINTER(C.c_float), _vp]),
     ("ntr_trace_status", C.c_int, [_vp, C.POINTER(_u32)]),
     ("ntr_trace_handoff_counts", C.c_int, [_vp, C.POINTER(_u32 * 3)]),
+    ("ntr_selftest_gather_rate", C.c_int, [_i64, _i32, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     ("ntr_tunables_reload", C.c_int, []),
     ("ntr_predict_block_costs", C.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
     ("ntr_predict_batch_coherence", C.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
@@ -223,6 +224,13 @@ def trace_handoff_counts(stream=0):
     c = (_u32 * 3)()
     _check(lib().ntr_trace_handoff_counts(_vp(stream), C.byref(c)))
     return int(c[0]), int(c[1]), int(c[2])
+
+
+def selftest_gather_rate(table_bytes, waves, lanes_per_wave=64, steps=256, stream=0):
+    """ntr_selftest_gather_rate: seconds of the best of three launches of waves x lanes dependent chains of `steps` random 64-byte records."""
+    sec = C.c_float(0.0)
+    _check(lib().ntr_selftest_gather_rate(int(table_bytes), int(waves), int(lanes_per_wave), int(steps), _vp(stream), C.byref(sec)))
+    return float(sec.value)
 
 
 def predict_batch_coherence(num_rays, d_rays, d_nodes, nodes_bytes, d_out, stream=0):

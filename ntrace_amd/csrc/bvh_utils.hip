@@ -54,7 +54,68 @@ __global__ __launch_bounds__(256) void bvh_validate_kernel(const float4* __restr
     }
 }
 
+// ---- measurement aid: the memory side of a divergent traversal without its arithmetic ----------------------------------------------
+// Every active lane walks a dependent chain of random 64-byte records (4 x global_load_dwordx4; the next index is a hash of the bytes
+// just loaded) -- what a ray does from node to node.  The records / s of a full grid on a table larger than the Infinity Cache is the
+// practical roof of an HBM-resident BVH's node and triangle fetches (scripts/microbench/chase64.hip; bench.py extras.gather_roof).
+__global__ __launch_bounds__(256) void gather_fill_kernel(unsigned int* __restrict__ t, size_t words)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256)
+        t[i] = (unsigned int)(i * 2654435761ull) ^ (unsigned int)(i >> 7) * 40503u;
+}
+__global__ __launch_bounds__(64) void gather_chase_kernel(const uint4* __restrict__ table, unsigned int mask, int steps, int activeLanes, unsigned int* __restrict__ out)
+{
+    const int tid = blockIdx.x * 64 + threadIdx.x;
+    if ((int)threadIdx.x >= activeLanes) return;
+    unsigned int rec = ((unsigned)tid * 2654435761u) & mask;
+    unsigned int acc = 0;
+    for (int s = 0; s < steps; s++) {
+        const uint4* q = table + (size_t)rec * 4;
+        const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+        const unsigned int h = a.x ^ b.y ^ c.z ^ d.w ^ a.w ^ d.x;
+        acc += h;
+        rec = ((h ^ (unsigned)tid * 0x9E3779B9u) * 2654435761u + (unsigned)s * 40503u) & mask;
+    }
+    out[tid] = acc;
+}
+
 }  // namespace ntr
+
+extern "C" int ntr_selftest_gather_rate(int64_t tableBytes, int32_t waves, int32_t lanesPerWave, int32_t steps, void* stream, float* seconds)
+{
+    using namespace ntr;
+    if (!seconds || tableBytes < 4096 || tableBytes > ((int64_t)1 << 34) || waves < 1 || waves > (1 << 20) || lanesPerWave < 1 || lanesPerWave > 64 || steps < 1)
+        return set_error(NTR_ERR_INVALID, "ntr_selftest_gather_rate: bad argument");
+    *seconds = 0.0f;
+    hipStream_t s = (hipStream_t)stream;
+    size_t recs = (size_t)tableBytes / 64, pow2 = 1;
+    while (pow2 * 2 <= recs) pow2 *= 2;
+    void* d_t = nullptr;
+    unsigned int* d_o = nullptr;
+    NTR_HIP(hipMalloc(&d_t, (size_t)tableBytes));
+    if (hipMalloc((void**)&d_o, (size_t)waves * 64 * sizeof(unsigned int)) != hipSuccess) { (void)hipFree(d_t); return set_error(NTR_ERR_NOMEM, "ntr_selftest_gather_rate: out of device memory"); }
+    hipLaunchKernelGGL(gather_fill_kernel, dim3(4096), dim3(256), 0, s, (unsigned int*)d_t, (size_t)tableBytes / 4);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3 && err == hipSuccess; rep++) {
+        err = hipEventRecord(e0, s);
+        hipLaunchKernelGGL(gather_chase_kernel, dim3(waves), dim3(64), 0, s, (const uint4*)d_t, (unsigned int)(pow2 - 1), steps, lanesPerWave, d_o);
+        if (err == hipSuccess) err = hipEventRecord(e1, s);
+        if (err == hipSuccess) err = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+        if (err == hipSuccess && ms < best) best = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_t);
+    (void)hipFree(d_o);
+    if (err != hipSuccess) return hip_fail(err, "ntr_selftest_gather_rate");
+    *seconds = best * 1e-3f;
+    return NTR_OK;
+}
 
 extern "C" int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_t* flags, void* stream)
 {

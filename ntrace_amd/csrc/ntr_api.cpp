@@ -562,20 +562,28 @@ struct AutoHint {
     int numRays = 0, anyHit = 0, device = -1;
     bool used = false;
     int sightings = 0;              // launches of this key: storage is allocated at the second one (a batch seen once pays nothing)
-    hipEvent_t lastLaunch = nullptr;   // recorded behind the last launch that read order[]: the entry is recycled only once it has completed
     unsigned long long lastUse = 0;
-    NtrSchedHint hint;
+    NtrSchedHint hint;              // (its arrays come from the stream-ordered allocator: hipMallocAsync / hipFreeAsync on `stream`)
 };
 static constexpr int kAutoHints = 96;
 static AutoHint g_auto[kAutoHints];
 
+// returns an automatic hint's arrays in stream order: behind every launch of `s` that reads them (no synchronisation, no event)
+static void auto_hint_release_async(NtrSchedHint* h, hipStream_t s)
+{
+    if (h->order) (void)hipFreeAsync(h->order, s);
+    if (h->cost) (void)hipFreeAsync(h->cost, s);
+    h->order = h->cost = nullptr;
+    h->numBlocks = 0; h->uses = 0; h->valid = false;
+}
+
 // The hint of this batch, or null: the first launch of a key only registers it (no allocation, no hint); from the second on the key owns a
-// hint.  Nothing here ever synchronises or frees under a launch in flight: a victim is recycled only if the event behind its last launch
-// has completed, and if no entry can be had the launch simply goes without (buffer / predicted order).
-static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, int anyHit, hipStream_t s, int numBlocks, NtrSchedHint** out, AutoHint** entry)
+// hint.  Nothing here synchronises, records an event or frees under a launch in flight: an entry is recycled only if it holds no storage
+// or belongs to THIS stream (its arrays are then freed in stream order, behind the launches that read them), and if no entry can be had
+// the launch simply goes without (buffer / predicted order).
+static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, int anyHit, hipStream_t s, int numBlocks, NtrSchedHint** out)
 {
     *out = nullptr;
-    *entry = nullptr;
     int dev = 0;
     NTR_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
@@ -587,14 +595,14 @@ static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, i
     }
     if (!hit) {
         AutoHint* v = freeE;
-        if (!v) {   // least recently used entry whose last launch is known to be over
+        if (!v) {   // least recently used among the entries this launch may recycle
             for (auto& e : g_auto) {
-                if (v && e.lastUse >= v->lastUse) continue;
-                if (e.lastLaunch && hipEventQuery(e.lastLaunch) != hipSuccess) { (void)hipGetLastError(); continue; }
-                v = &e;
+                const bool mine = e.stream == (void*)s && e.device == dev;
+                if (e.hint.order && !mine) continue;
+                if (!v || e.lastUse < v->lastUse) v = &e;
             }
             if (!v) return NTR_OK;
-            sched_hint_release(&v->hint);   // (its launches are over: nothing reads the arrays)
+            if (v->hint.order) auto_hint_release_async(&v->hint, s);
         }
         v->rays = d_rays; v->nodes = d_nodes; v->numRays = numRays; v->anyHit = anyHit; v->stream = (void*)s; v->device = dev;
         v->used = true;
@@ -606,22 +614,19 @@ static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, i
     hit->lastUse = ++g_topClock;
     hit->sightings++;
     NtrSchedHint* h = &hit->hint;
-    if (h->numBlocks != numBlocks || h->device != dev) {   // second sighting (or a resized batch): the storage
-        if (h->order && hit->lastLaunch && hipEventQuery(hit->lastLaunch) != hipSuccess) { (void)hipGetLastError(); return NTR_OK; }
-        sched_hint_release(h);
+    if (h->numBlocks != numBlocks || h->device != dev) {   // second sighting: the storage
+        if (h->order) auto_hint_release_async(h, s);
         unsigned int* order = nullptr;
         unsigned int* cost = nullptr;
         // (failing here -- another thread capturing in global mode, memory -- only means: no hint for this launch)
-        if (hipMalloc((void**)&order, ((size_t)numBlocks + 3) * sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); return NTR_OK; }
-        if (hipMalloc((void**)&cost, (size_t)numBlocks * sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(order); return NTR_OK; }
+        if (hipMallocAsync((void**)&order, ((size_t)numBlocks + 3) * sizeof(unsigned int), s) != hipSuccess) { (void)hipGetLastError(); return NTR_OK; }
+        if (hipMallocAsync((void**)&cost, (size_t)numBlocks * sizeof(unsigned int), s) != hipSuccess) { (void)hipGetLastError(); (void)hipFreeAsync(order, s); return NTR_OK; }
         h->order = order; h->cost = cost;
         h->numBlocks = numBlocks;
         h->device = dev;
         h->uses = 0; h->valid = false;
     }
-    if (!hit->lastLaunch && hipEventCreateWithFlags(&hit->lastLaunch, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); hit->lastLaunch = nullptr; return NTR_OK; }
     *out = h;
-    *entry = hit;
     return NTR_OK;
 }
 
@@ -756,9 +761,8 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     }
 
     // no hint from the caller: the library's own, keyed by (stream, batch, BVH)
-    AutoHint* autoEntry = nullptr;
     if (!hint && !stats && tun.autoHint != 0 && variant == NTR_VARIANT_PERRAY && numRays >= tun.autoHintMinRays && !stream_is_capturing(s)) {
-        rc = auto_hint_get(d_rays, d_nodes, numRays, anyHit ? 1 : 0, s, numBlocks, &hint, &autoEntry);
+        rc = auto_hint_get(d_rays, d_nodes, numRays, anyHit ? 1 : 0, s, numBlocks, &hint);
         if (rc != NTR_OK) return rc;
     }
     // Scheduling hint: the per-ray kernel dispatches blocks in the hint's order; on refresh launches it
@@ -900,7 +904,6 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         if (le != hipSuccess) return hip_fail(le, "sched_order launch");
         hint->valid = true;
     }
-    if (autoEntry && autoEntry->lastLaunch) NTR_HIP(hipEventRecord(autoEntry->lastLaunch, s));   // behind everything that reads or writes the entry's arrays
     if (seconds) {
         NTR_HIP(hipEventSynchronize(ev1));
         float ms = 0.0f;

@@ -147,6 +147,19 @@ def job_throughput(units, seconds, device):
     return float(u.item()), float(t.item())
 
 
+def frame_per_rank_summary(rays_this_rank, kernel_seconds_this_rank, steps, device):
+    """The frame-per-rank scaling mode of bench.py (every rank traces a whole frame of its own camera; no ray or record crosses a rank
+    boundary): rays of all ranks over `steps` frames each / MAX over ranks of the summed kernel time.  Returns the dict bench.py emits as
+    extras.frame_per_rank for N > 1 (same reduction as `value`: SUM of units, MAX of seconds)."""
+    rays, secs = job_throughput(rays_this_rank, kernel_seconds_this_rank, device)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    return {"what": "every rank traces a whole 1920x1080 primary + AO frame of its own camera against the replicated BVH (weak scaling): "
+                    "rays of all ranks / MAX over ranks of the summed per-batch kernel times",
+            "ranks": world, "steps": int(steps), "rays_per_frame_all_ranks": rays,
+            "mrays": rays * steps / secs / 1e6 if secs > 0 else None,
+            "ms_per_frame": secs / steps * 1e3 if steps > 0 else None}
+
+
 def broadcast_bytes(buf_u8, src, device):
     """Replicates a byte buffer from `src` (BVH replication: built once, broadcast).  `buf_u8` is a
     uint8 tensor on `src` and may be None elsewhere; returns the tensor on `device` on every rank."""

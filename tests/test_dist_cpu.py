@@ -83,6 +83,10 @@ def _sharded_frame_worker(rank, world, port, num_primary, samples, max_batch, ou
     full = ntd.gather_hit_records(torch.from_numpy(own.view(np.uint8).copy()), num_primary)
     ao_sum = ntd.all_sum_int64(ao_ck, cpu)
     units, secs = ntd.job_throughput(plan.num_own_primary * (1 + samples), 0.5 + rank, cpu)
+    # the frame-per-rank mode bench.py reports beside `value` for N > 1 (extras.frame_per_rank): SUM of rays, MAX of seconds
+    fpr = ntd.frame_per_rank_summary(1000 * (rank + 1), 0.25 * (rank + 1), 5, cpu)
+    ok = ok and fpr["ranks"] == world and fpr["steps"] == 5 and fpr["rays_per_frame_all_ranks"] == 1000 * world * (world + 1) // 2
+    ok = ok and abs(fpr["ms_per_frame"] - 0.25 * world / 5 * 1e3) < 1e-9 and abs(fpr["mrays"] - fpr["rays_per_frame_all_ranks"] * 5 / (0.25 * world) / 1e6) < 1e-12
     if rank == 0:
         ref = _standin_primary(0, num_primary)
         ok = ok and torch.equal(full, torch.from_numpy(ref.view(np.uint8).copy()))
@@ -206,6 +210,11 @@ def test_balanced_cuts_properties():
     # a large flat share tends to equal ray counts
     cuts = ntd.balanced_cuts(cost, n, 8, 1e6)
     assert all(abs((b - a) - n / 8) <= 512 for a, b in zip(cuts, cuts[1:]))
+    # an interior cut that lands on a partial last block stays aligned (it moves down to the last aligned position)
+    cuts = ntd.balanced_cuts(np.array([1.0, 1.0, 1.0, 50.0]), 1000, 8)
+    assert cuts[0] == 0 and cuts[-1] == 1000 and all(c % 64 == 0 for c in cuts[:-1]) and all(a <= b for a, b in zip(cuts, cuts[1:]))
+    for r in range(8):
+        ntd.FramePlan(1000, r, 8, 8, 1 << 20, cuts=cuts)
     # degenerate inputs
     assert ntd.balanced_cuts([], 0, 4) == [0, 0, 0, 0, 0]
     assert ntd.balanced_cuts([5.0], 100, 4)[-1] == 100
