@@ -683,6 +683,32 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
     ov_s, note, steps = overlapped_frame(args, nt, torch, view, frame, dev, stream)
     extras["overlapped_frame"] = {"how": note, "ms_per_frame": ov_s * 1e3, "mrays_wall": rays_per_step / ov_s / 1e6, "steps": steps}
 
+    # (1b) the reference's persistent-threads selectors on the SAME step (BASELINE config 3 names the persistent-threads traversal;
+    # the per-ray kernel is what `value` runs): one warm step, then `psteps` timed steps, per-batch HIP events as for `value`
+    pk = {}
+    psteps = max(3, min(args.steps, 10))
+    for kn in ("tesla_persistent_while_while", "kepler_dynamic_fetch"):
+        for b in batches:
+            view.trace(kn, b["n"], b["any_hit"], b["rays"], b["res"], stream, False)
+        pev = [[(E(enable_timing=True), E(enable_timing=True)) for _ in batches] for _ in range(psteps)]
+        for s_ in range(psteps):
+            for bi, b in enumerate(batches):
+                pev[s_][bi][0].record()
+                view.trace(kn, b["n"], b["any_hit"], b["rays"], b["res"], stream, False)
+                pev[s_][bi][1].record()
+        torch.cuda.synchronize()
+        pms = np.array([[e0.elapsed_time(e1) for (e0, e1) in st_] for st_ in pev])
+        pk[kn] = {"mrays": rays_per_step / (float(pms.sum(axis=1).mean()) * 1e-3) / 1e6,
+                  "primary_mrays": n_primary / (float(pms[:, 0].mean()) * 1e-3) / 1e6,
+                  "ao_mrays": (sum(b["live"] for b in batches[1:]) / (float(pms[:, 1:].sum(axis=1).mean()) * 1e-3) / 1e6) if len(batches) > 1 else None,
+                  "primary_ms": float(pms[:, 0].mean()), "steps": psteps}
+    pk["what"] = ("the same step traced by the persistent-threads selectors (tesla_persistent_while_while: while-while loop, whole-wave refill from "
+                  "128 pool heads; kepler_dynamic_fetch: unified step, ballot/mbcnt refill of finished lanes); identical hit records")
+    extras["persistent_kernels"] = pk
+    for b in batches:   # restore the per-ray kernel's records (identical bits, but keep one writer for what follows)
+        view.trace(args.kernel, b["n"], b["any_hit"], b["rays"], b["res"], stream, False)
+    torch.cuda.synchronize()
+
     # (2) opt-in scheduling hints (ntr_trace_bvh_hinted): block order learned from the previous trace of the same batch
     hints = [nt.SchedHint() for _ in batches]
     for _ in range(4):
