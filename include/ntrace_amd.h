@@ -346,6 +346,47 @@ NTR_API int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const i
                                 NtrRay* d_outRays, int32_t* d_outIDToSlot, int32_t* d_outSlotToID,
                                 void* stream, float* seconds);
 
+/* ---- multi-GPU (new design: the reference is single-device, its launches synchronous on one
+ * context, src/framework/gpu/CudaKernel.cpp:188-221) ----------------------------------------------------------------
+ * One process per GPU, or one host thread per GPU in one process.  Rays shard by screen tile: the primary-ray index
+ * space [0, W*H) -- already 8 x 8 pixel blocks in Morton order (PixelTable, src/rt/ray/PixelTable.cpp:77-122) -- is
+ * cut into `world` contiguous ranges of whole 64-ray blocks; a rank's AO / diffuse rays derive from its own primary
+ * hits, so no ray ever crosses a rank boundary.  The BVH is built once and replicated by broadcast; the ONLY
+ * collective of a frame is the final gather of hit records (16 B per primary ray) or of the RGBA8 framebuffer (4 B per
+ * pixel: 8.3 MB at 1080p) to the root, over RCCL (grouped point-to-point sends over xGMI).  RCCL is bound at run time
+ * (dlopen), only by the ntr_dist_* calls.  The group calls are collective: every rank makes the same call. */
+typedef struct NtrDist NtrDist;
+#define NTR_DIST_ID_BYTES 128
+/* The rank-th of `world` contiguous, align-ray-aligned ranges of [0, numPrimary) (the first ranges one block longer
+ * when the blocks do not divide), and the AO batches of a range as RayGen::batching cuts them (src/rt/ray/RayGen.cpp:
+ * 582-602; at most maxBatchRays output rays each): first[b], count[b] are input slots.  No device, no RCCL. */
+NTR_API int ntr_frame_shard(int32_t numPrimary, int32_t rank, int32_t world, int32_t align, int32_t* lo, int32_t* hi);
+NTR_API int ntr_frame_ao_batches(int32_t lo, int32_t hi, int32_t samples, int32_t maxBatchRays, int32_t* first, int32_t* count,
+                                 int32_t capacity, int32_t* numBatches);
+/* Group set-up.  Processes: the root calls ntr_dist_unique_id and hands the 128 bytes to every rank by any means (file,
+ * socket, MPI, environment); every rank then calls ntr_dist_init on ITS device (ntr_set_device first).  Threads of one
+ * process: ntr_dist_init_all creates one group object per device (devices == NULL: 0 .. numDevices - 1); thread i uses
+ * out[i] after ntr_set_device(devices[i]). */
+NTR_API int ntr_dist_unique_id(char id[NTR_DIST_ID_BYTES]);
+NTR_API int ntr_dist_init(const char id[NTR_DIST_ID_BYTES], int32_t rank, int32_t world, NtrDist** out);
+NTR_API int ntr_dist_init_all(int32_t numDevices, const int32_t* devices, NtrDist** out /* numDevices entries */);
+NTR_API int ntr_dist_info(const NtrDist* dist, int32_t* rank, int32_t* world);
+NTR_API int ntr_dist_destroy(NtrDist* dist);
+/* BVH replication: `bytes` of device memory from `root` to every rank (asynchronous on `stream`); _bvh does the three
+ * BVHLayout_Compact buffers (every rank passes buffers of the root's sizes). */
+NTR_API int ntr_dist_broadcast(NtrDist* dist, void* d_buf, int64_t bytes, int32_t root, void* stream);
+NTR_API int ntr_dist_broadcast_bvh(NtrDist* dist, void* d_nodes, int64_t nodesBytes, void* d_triWoop, int64_t triWoopBytes,
+                                   int32_t* d_triIndex, int64_t triIndexBytes, int32_t root, void* stream);
+/* The frame's one collective.  _records: rank r's hit records of its range (hi_r - lo_r records, d_ownRecords) land at
+ * d_fullRecords + lo_r on the root (numPrimary records; ignored elsewhere).  _pixels: rank r's pixels -- the tiles of
+ * its range inside its own W*H framebuffer d_ownPixels, as ntr_reconstruct wrote them -- land in the root's framebuffer
+ * d_fullPixels; d_slotToPixel is the PixelTable's index-to-pixel map (ntr_pixel_table), d_scratch numPrimary words on
+ * every rank.  Asynchronous on `stream`. */
+NTR_API int ntr_dist_gather_records(NtrDist* dist, const NtrRayResult* d_ownRecords, int32_t numPrimary, int32_t align,
+                                    NtrRayResult* d_fullRecords, int32_t root, void* stream);
+NTR_API int ntr_dist_gather_pixels(NtrDist* dist, const uint32_t* d_ownPixels, const int32_t* d_slotToPixel, int32_t numPrimary,
+                                   int32_t align, uint32_t* d_fullPixels, uint32_t* d_scratch, int32_t root, void* stream);
+
 /* ---- host-side BVH production (no device work) ---------------------------- */
 
 /* Host SAH build + Compact flatten: `BVH bvh(scene, platform, params);

@@ -83,6 +83,17 @@ SYMBOLS = [
     ("ntr_trace_status", C.c_int, [_vp, C.POINTER(_u32)]),
     ("ntr_trace_handoff_counts", C.c_int, [_vp, C.POINTER(_u32 * 3)]),
     ("ntr_selftest_gather_rate", C.c_int, [_i64, _i32, _i32, _i32, _vp, C.POINTER(C.c_float)]),
+    ("ntr_frame_shard", C.c_int, [_i32, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    ("ntr_frame_ao_batches", C.c_int, [_i32, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), _i32, C.POINTER(_i32)]),
+    ("ntr_dist_unique_id", C.c_int, [C.c_char_p]),
+    ("ntr_dist_init", C.c_int, [C.c_char_p, _i32, _i32, C.POINTER(_vp)]),
+    ("ntr_dist_init_all", C.c_int, [_i32, C.POINTER(_i32), C.POINTER(_vp)]),
+    ("ntr_dist_info", C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    ("ntr_dist_destroy", C.c_int, [_vp]),
+    ("ntr_dist_broadcast", C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    ("ntr_dist_broadcast_bvh", C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp]),
+    ("ntr_dist_gather_records", C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp]),
+    ("ntr_dist_gather_pixels", C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     ("ntr_tunables_reload", C.c_int, []),
     ("ntr_predict_block_costs", C.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
     ("ntr_predict_batch_coherence", C.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
@@ -231,6 +242,57 @@ def selftest_gather_rate(table_bytes, waves, lanes_per_wave=64, steps=256, strea
     sec = C.c_float(0.0)
     _check(lib().ntr_selftest_gather_rate(int(table_bytes), int(waves), int(lanes_per_wave), int(steps), _vp(stream), C.byref(sec)))
     return float(sec.value)
+
+
+def frame_shard(num_primary, rank, world, align=64):
+    """ntr_frame_shard: the rank-th of `world` contiguous align-aligned ranges of [0, num_primary)."""
+    lo, hi = _i32(0), _i32(0)
+    _check(lib().ntr_frame_shard(int(num_primary), int(rank), int(world), int(align), C.byref(lo), C.byref(hi)))
+    return int(lo.value), int(hi.value)
+
+
+def frame_ao_batches(lo, hi, samples, max_batch_rays):
+    """ntr_frame_ao_batches: [(first input slot, inputs)] of the AO batches of the input range [lo, hi)."""
+    n = _i32(0)
+    _check(lib().ntr_frame_ao_batches(int(lo), int(hi), int(samples), int(max_batch_rays), None, None, 0, C.byref(n)))
+    first, count = (_i32 * max(n.value, 1))(), (_i32 * max(n.value, 1))()
+    _check(lib().ntr_frame_ao_batches(int(lo), int(hi), int(samples), int(max_batch_rays), first, count, n.value, C.byref(n)))
+    return [(int(first[i]), int(count[i])) for i in range(n.value)]
+
+
+class DistGroup:
+    """ntr_dist_*: the native RCCL group of this process' GPU (one process per GPU).  `uid` = DistGroup.unique_id() of the root, handed to
+    every rank by the caller."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().ntr_dist_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, uid, rank, world):
+        h = _vp()
+        _check(lib().ntr_dist_init(C.c_char_p(uid), int(rank), int(world), C.byref(h)))
+        self._h, self.rank, self.world = h, int(rank), int(world)
+
+    def broadcast(self, d_buf, nbytes, root=0, stream=0):
+        _check(lib().ntr_dist_broadcast(self._h, _vp(d_buf), int(nbytes), int(root), _vp(stream)))
+
+    def broadcast_bvh(self, d_nodes, nodes_bytes, d_woop, woop_bytes, d_tri_index, tri_index_bytes, root=0, stream=0):
+        _check(lib().ntr_dist_broadcast_bvh(self._h, _vp(d_nodes), int(nodes_bytes), _vp(d_woop), int(woop_bytes), _vp(d_tri_index), int(tri_index_bytes),
+                                            int(root), _vp(stream)))
+
+    def gather_records(self, d_own, num_primary, d_full, root=0, stream=0, align=64):
+        _check(lib().ntr_dist_gather_records(self._h, _vp(d_own), int(num_primary), int(align), _vp(d_full), int(root), _vp(stream)))
+
+    def gather_pixels(self, d_own_pixels, d_slot_to_pixel, num_primary, d_full_pixels, d_scratch, root=0, stream=0, align=64):
+        _check(lib().ntr_dist_gather_pixels(self._h, _vp(d_own_pixels), _vp(d_slot_to_pixel), int(num_primary), int(align), _vp(d_full_pixels), _vp(d_scratch),
+                                            int(root), _vp(stream)))
+
+    def close(self):
+        if self._h:
+            lib().ntr_dist_destroy(self._h)
+            self._h = None
 
 
 def predict_batch_coherence(num_rays, d_rays, d_nodes, nodes_bytes, d_out, stream=0):

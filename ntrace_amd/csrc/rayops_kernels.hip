@@ -175,6 +175,31 @@ struct DevMem {
 };
 }  // namespace
 
+// Framebuffer gather of the multi-GPU path (ntr_dist.cpp): a rank's pixels packed in slot order / scattered back on the root.
+__global__ __launch_bounds__(256) void pixels_pack_kernel(const uint32_t* __restrict__ pixels, const int32_t* __restrict__ slotToPixel, int first, int count,
+                                                         uint32_t* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < count) out[i] = pixels[slotToPixel[first + i]];
+}
+__global__ __launch_bounds__(256) void pixels_unpack_kernel(const uint32_t* __restrict__ bySlot, const int32_t* __restrict__ slotToPixel, int count,
+                                                           uint32_t* __restrict__ pixels)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < count) pixels[slotToPixel[i]] = bySlot[i];
+}
+
+extern "C" hipError_t ntr_launch_pixels_pack(const uint32_t* d_pixels, const int32_t* d_slotToPixel, int first, int count, uint32_t* d_out, hipStream_t s)
+{
+    if (count > 0) hipLaunchKernelGGL(pixels_pack_kernel, dim3((count + 255) / 256), dim3(256), 0, s, d_pixels, d_slotToPixel, first, count, d_out);
+    return hipGetLastError();
+}
+extern "C" hipError_t ntr_launch_pixels_unpack(const uint32_t* d_bySlot, const int32_t* d_slotToPixel, int count, uint32_t* d_pixels, hipStream_t s)
+{
+    if (count > 0) hipLaunchKernelGGL(pixels_unpack_kernel, dim3((count + 255) / 256), dim3(256), 0, s, d_bySlot, d_slotToPixel, count, d_pixels);
+    return hipGetLastError();
+}
+
 extern "C" {
 
 int ntr_reconstruct(int32_t rayType, int32_t numRaysPerPrimary, int32_t firstPrimary, int32_t numPrimary,

@@ -16,11 +16,9 @@ def shard_range(num_rays, rank, world, align=64):
     """Contiguous slice [lo, hi) of the primary-ray index space for `rank`.  The index space is
     already 8x8-pixel blocks in Morton order (PixelTable), so a contiguous slice aligned to 64 rays
     is a compact set of screen tiles."""
-    blocks = (num_rays + align - 1) // align
-    per, extra = divmod(blocks, world)
-    lo_b = rank * per + min(rank, extra)
-    hi_b = lo_b + per + (1 if rank < extra else 0)
-    return min(lo_b * align, num_rays), min(hi_b * align, num_rays)
+    # the arithmetic lives in the C-ABI (ntr_frame_shard, ntr_dist.cpp), where the native multi-GPU driver and the C++ Renderer use it too
+    from ._capi import frame_shard
+    return frame_shard(num_rays, rank, world, align)
 
 
 def balanced_cuts(block_cost, num_rays, world, flat_share=1.0, block=256):
@@ -83,11 +81,8 @@ class FramePlan:
         else:
             self.lo, self.hi = shard_range(num_primary, rank, world, align)
         self.cuts = list(cuts) if cuts is not None else None
-        self.ao_batches = []
-        if samples > 0:
-            per = max(int(max_batch_rays) // samples, 1)
-            for first in range(self.lo, self.hi, per):
-                self.ao_batches.append((first, min(per, self.hi - first)))
+        from ._capi import frame_ao_batches
+        self.ao_batches = frame_ao_batches(self.lo, self.hi, samples, max(int(max_batch_rays), 1)) if samples > 0 else []
 
     @property
     def num_own_primary(self):

@@ -21,7 +21,13 @@ void CudaBVHTracer::setKernel(const String& kernelName)
 // CudaBVHTracer::traceBatch (CudaBVHTracer.cpp:88-168).
 F32 CudaBVHTracer::traceBatch(RayBuffer& rays)
 {
-    int numRays = rays.getSize();
+    return traceRange(rays, 0, rays.getSize());
+}
+
+F32 CudaBVHTracer::traceRange(RayBuffer& rays, S32 first, S32 count)
+{
+    if (first < 0 || count < 0 || first + count > rays.getSize()) fail("CudaBVHTracer: ray range out of bounds");
+    int numRays = count;
     if (!numRays) return 0.0f;
 
     if (!m_bvh) fail("CudaBVHTracer: No BVH!");
@@ -32,8 +38,8 @@ F32 CudaBVHTracer::traceBatch(RayBuffer& rays)
 
     float seconds = 0.0f;
     int rc = ntr_trace_bvh(m_kernelName.c_str(), numRays, rays.getNeedClosestHit() ? 0 : 1,
-                           (const NtrRay*)rays.getRayBuffer().getCudaPtr(),
-                           (NtrRayResult*)rays.getResultBuffer().getMutableCudaPtr(),
+                           (const NtrRay*)rays.getRayBuffer().getCudaPtr() + first,
+                           (NtrRayResult*)rays.getResultBuffer().getMutableCudaPtr() + first,
                            m_bvh->getNodeBuffer().getCudaPtr(), m_bvh->getNodeBuffer().getSize(),
                            m_bvh->getTriWoopBuffer().getCudaPtr(), m_bvh->getTriWoopBuffer().getSize(),
                            (const int32_t*)m_bvh->getTriIndexBuffer().getCudaPtr(), (int32_t)m_bvh->getLayout(),

@@ -17,6 +17,9 @@ public:
     virtual BVHLayout getDesiredBVHLayout(void) const { return (BVHLayout)m_kernelConfig.bvhLayout; }
     virtual void      setBVH(CudaAS* bvh) { m_bvh = bvh; }
     virtual F32       traceBatch(RayBuffer& rays);
+    // Multi-GPU extension (no counterpart in the reference): trace only the slots [first, first + count) of `rays` -- a rank's
+    // screen-tile range of the primary batch (Renderer::setShard).
+    F32               traceRange(RayBuffer& rays, S32 first, S32 count);
 
     const KernelConfig& getKernelConfig(void) const { return m_kernelConfig; }
 

@@ -52,13 +52,14 @@ bool RayGen::ao(RayBuffer& orays, RayBuffer& irays, Scene& scene, int numSamples
 
 bool RayGen::batching(S32 numInputRays, S32 numSamples, S32& startIdx, bool& newBatch, S32& lo, S32& hi)
 {
+    const S32 end = (m_inHi >= 0) ? FW::min(m_inHi, numInputRays) : numInputRays;   // (a rank's own input range, or everything)
     if (newBatch) {
         newBatch = false;
-        startIdx = 0;
+        startIdx = FW::min(m_inLo, end);
     }
-    if (startIdx == numInputRays) return false;
+    if (startIdx >= end) return false;
     lo = startIdx;
-    hi = FW::min(numInputRays, lo + m_maxBatchSize / numSamples);
+    hi = FW::min(end, lo + m_maxBatchSize / numSamples);
     startIdx = hi;
     return true;
 }

@@ -34,7 +34,11 @@ private:
 
 class RayGen {
 public:
-    explicit RayGen(S32 maxBatchSize = 8 * 1024 * 1024) : m_maxBatchSize(maxBatchSize), m_aoStartIdx(0) {}
+    explicit RayGen(S32 maxBatchSize = 8 * 1024 * 1024) : m_maxBatchSize(maxBatchSize), m_aoStartIdx(0), m_inLo(0), m_inHi(-1) {}
+
+    // Multi-GPU extension: secondary rays are generated from the input slots [lo, hi) only (a rank's own primary hits); hi < 0 = all.
+    void setInputRange(S32 lo, S32 hi) { m_inLo = lo; m_inHi = hi; }
+    PixelTable& getPixelTable(void) { return m_pixelTable; }
 
     // RayGen::primary (RayGen.cpp:45-74): no batching
     void primary(RayBuffer& orays, const Vec3f& origin, const Mat4f& nscreenToWorld, S32 w, S32 h, float maxDist, U32 randomSeed = 0);
@@ -47,6 +51,7 @@ private:
     S32        m_maxBatchSize;
     PixelTable m_pixelTable;
     S32        m_aoStartIdx;
+    S32        m_inLo, m_inHi;
 };
 
 }  // namespace FW

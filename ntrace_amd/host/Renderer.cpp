@@ -12,7 +12,8 @@ namespace FW {
 // Renderer::Renderer (Renderer.cpp:44-94): m_raygen(1 << 20), Platform("GPU") with leaf preferences (1,1).
 Renderer::Renderer(const String& builder)
     : m_builder(builder), m_raygen(1 << 20), m_enableRandom(false), m_scene(NULL), m_cameraFar(0.0f), m_newBatch(true),
-      m_batchRays(NULL), m_batchStart(0), m_accelStruct(NULL), m_cachePath("bvhcache"), m_cacheDataStructure(false)
+      m_batchRays(NULL), m_batchStart(0), m_accelStruct(NULL), m_cachePath("bvhcache"), m_cacheDataStructure(false),
+      m_shardRank(0), m_shardWorld(1), m_shardLo(0), m_shardHi(0)
 {
     m_cudaTracer = new CudaBVHTracer();
     m_cudaTracer->setScene(NULL);
@@ -33,6 +34,13 @@ void Renderer::setScene(Scene* scene)
     invalidateBVH();
     m_scene = scene;
     m_cudaTracer->setScene(scene);
+}
+
+void Renderer::setShard(int rank, int world)
+{
+    if (world < 1 || rank < 0 || rank >= world) fail("Renderer::setShard: rank %d of %d", rank, world);
+    m_shardRank = rank;
+    m_shardWorld = world;
 }
 
 void Renderer::setParams(const Params& params)  // Renderer.cpp:138-143
@@ -94,7 +102,14 @@ void Renderer::beginFrame(const CameraView& camera)
     if (!m_scene) fail("Renderer: no scene");
     m_cudaTracer->setBVH(getCudaBVH());
     m_raygen.primary(m_primaryRays, camera.position, camera.nscreenToWorld, camera.width, camera.height, camera.cameraFar, 0);
-    if (m_params.rayType != RayType_Primary) m_cudaTracer->traceBatch(m_primaryRays);  // :482-488
+    // this rank's screen tiles: a contiguous 64-aligned range of the primary slots (the whole frame for one rank)
+    int32_t lo = 0, hi = 0;
+    if (ntr_frame_shard(m_primaryRays.getSize(), m_shardRank, m_shardWorld, 64, &lo, &hi) != NTR_OK) fail("Renderer: %s", ntr_last_error());
+    m_shardLo = lo;
+    m_shardHi = hi;
+    m_raygen.setInputRange(lo, hi);
+    if (m_params.rayType != RayType_Primary)  // :482-488
+        static_cast<CudaBVHTracer*>(m_cudaTracer)->traceRange(m_primaryRays, lo, hi - lo);
     m_cameraFar = camera.cameraFar;
     m_newBatch = true;
     m_batchRays = NULL;
@@ -104,7 +119,7 @@ void Renderer::beginFrame(const CameraView& camera)
 // Renderer::nextBatch (Renderer.cpp:501-564)
 bool Renderer::nextBatch(void)
 {
-    if (m_batchRays) m_batchStart += m_batchRays->getSize();
+    if (m_batchRays) m_batchStart += (m_batchRays == &m_primaryRays) ? (m_shardHi - m_shardLo) : m_batchRays->getSize();
     m_batchRays = NULL;
     switch (m_params.rayType) {
     case RayType_Primary:
@@ -133,7 +148,9 @@ void Renderer::updateResult(Buffer& pixels, Buffer& triMaterialColor, Buffer& tr
 {
     if (!m_batchRays) fail("Renderer::updateResult: no batch");
     const int perPrimary = (m_params.rayType == RayType_Primary) ? 1 : m_params.numSamples;
-    int rc = ntr_reconstruct((int)m_params.rayType, perPrimary, m_batchStart / perPrimary, m_batchRays->getSize() / perPrimary,
+    // (the batch's first input slot counts from the start of this rank's range)
+    const int numInputs = (m_batchRays == &m_primaryRays) ? (m_shardHi - m_shardLo) : m_batchRays->getSize() / perPrimary;
+    int rc = ntr_reconstruct((int)m_params.rayType, perPrimary, m_shardLo + m_batchStart / perPrimary, numInputs,
                              (const int32_t*)m_primaryRays.getSlotToIDBuffer().getCudaPtr(),
                              (const NtrRayResult*)m_primaryRays.getResultBuffer().getCudaPtr(),
                              (const int32_t*)m_batchRays->getIDToSlotBuffer().getCudaPtr(),
@@ -147,14 +164,16 @@ void Renderer::updateResult(Buffer& pixels, Buffer& triMaterialColor, Buffer& tr
 F32 Renderer::traceBatch(void)  // Renderer.cpp:568-579
 {
     if (!m_batchRays) fail("Renderer::traceBatch: no batch");
+    if (m_batchRays == &m_primaryRays)   // the primary batch: this rank's range of it
+        return static_cast<CudaBVHTracer*>(m_cudaTracer)->traceRange(m_primaryRays, m_shardLo, m_shardHi - m_shardLo);
     return m_cudaTracer->traceBatch(*m_batchRays);
 }
 
 int Renderer::getTotalNumRays(void)  // Renderer.cpp:676-710
 {
-    if (m_params.rayType == RayType_Primary) return m_primaryRays.getSize();
+    if (m_params.rayType == RayType_Primary) return m_shardHi - m_shardLo;
     int32_t hits = 0;
-    if (ntr_count_hits((const NtrRayResult*)m_primaryRays.getResultBuffer().getCudaPtr(), m_primaryRays.getSize(), &hits, NULL) != NTR_OK)
+    if (ntr_count_hits((const NtrRayResult*)m_primaryRays.getResultBuffer().getCudaPtr() + m_shardLo, m_shardHi - m_shardLo, &hits, NULL) != NTR_OK)
         fail("Renderer: %s", ntr_last_error());
     return hits * m_params.numSamples;
 }

@@ -36,6 +36,15 @@ public:
     void   setEnableRandom(bool enable) { m_enableRandom = enable; }
     CudaVirtualTracer& getCudaTracer(void) { return *m_cudaTracer; }
     CudaAS* getCudaBVH(void);
+    // Multi-GPU (no counterpart in the reference, which is single-device).  setShard: this Renderer traces the rank-th of
+    // `world` screen-tile ranges of every frame -- contiguous 64-aligned ranges of the PixelTable index space (ntr_frame_shard) -- and
+    // the AO / diffuse rays of its own primary hits; (0, 1) = the whole frame.  adoptCudaBVH: use a BVH built elsewhere (the root's,
+    // replicated by DistGroup::broadcastBVH) instead of building one; the Renderer owns it from then on.
+    void   setShard(int rank, int world);
+    S32    getShardLo(void) const { return m_shardLo; }
+    S32    getShardHi(void) const { return m_shardHi; }
+    void   adoptCudaBVH(CudaAS* as) { delete m_accelStruct; m_accelStruct = as; }
+    RayGen& getRayGen(void) { return m_raygen; }
     // BVH cache files, "<cachePath>/<hash>_<builder>.dat" (Renderer.cpp:173-191, 293-299; format of CudaBVH::serialize).  Off by
     // default, like Renderer.cacheDataStructure in the reference's environment.
     void   setCachePath(const String& path) { m_cachePath = path; }
@@ -73,6 +82,8 @@ private:
     String             m_cachePath;
     bool               m_cacheDataStructure;
     CudaVirtualTracer* m_cudaTracer;
+    int                m_shardRank, m_shardWorld;
+    S32                m_shardLo, m_shardHi;   // this rank's range of the current frame's primary slots
 };
 
 }  // namespace FW

@@ -11,6 +11,7 @@
 #include <sstream>
 #include <vector>
 
+#include "DistGroup.hpp"
 #include "HLBVHBuilder.hpp"
 #include "Random.hpp"
 #include "Renderer.hpp"
@@ -221,6 +222,29 @@ static void cpuTests()
         std::remove(name.c_str());
         rmdir(dir);
     }
+    // multi-GPU partition arithmetic (ntr_frame_shard / ntr_frame_ao_batches): contiguous, 64-aligned ranges that cover the frame; AO
+    // batches of a range as RayGen::batching cuts them
+    for (int n : {0, 1, 63, 64, 65, 1000, 1920 * 1080}) {
+        for (int world : {1, 2, 3, 8}) {
+            int32_t prev = 0;
+            for (int r = 0; r < world; r++) {
+                int32_t lo = -1, hi = -1;
+                CHECK(ntr_frame_shard(n, r, world, 64, &lo, &hi) == NTR_OK && lo == prev && hi >= lo && (lo % 64 == 0 || lo == n));
+                prev = hi;
+                int32_t first[64], count[64], nb = 0;
+                CHECK(ntr_frame_ao_batches(lo, hi, 8, 1 << 20, first, count, 64, &nb) == NTR_OK);
+                int32_t covered = 0;
+                for (int b = 0; b < nb; b++) { CHECK(first[b] == lo + covered && count[b] * 8 <= (1 << 20) && count[b] > 0); covered += count[b]; }
+                CHECK(covered == hi - lo);
+            }
+            CHECK(prev == n);
+        }
+    }
+    {
+        int32_t lo, hi;
+        CHECK(ntr_frame_shard(1920 * 1080, 3, 8, 64, &lo, &hi) == NTR_OK && hi - lo == 259200 && lo % 64 == 0);
+        CHECK(ntr_frame_shard(100, 2, 2, 64, &lo, &hi) != NTR_OK);
+    }
     // sticky error model (Defs.hpp:142-151)
     clearError();
     setError("first %d", 1);
@@ -321,6 +345,84 @@ static void gpuTests()
         maxRel = std::fmax(maxRel, std::fabs(prim[0][i].t - prim[1][i].t) / prim[0][i].t);
     }
     CHECK(sameId > W * H * 0.995 && maxRel < 1e-4);
+
+    // multi-GPU path: Renderer::setShard + DistGroup.  This box has one GPU: the RCCL group has world size 1 (every call
+    // goes through RCCL: id, communicator, broadcast, the grouped gather), and the 3-way sharding is exercised by three Renderers that
+    // each trace their own range of the same frame on this GPU, compared with the unsharded frame.
+    {
+        char id[DistGroup::IdBytes];
+        DistGroup::uniqueId(id);
+        DistGroup group(id, 0, 1);
+        CHECK(group.getRank() == 0 && group.getWorld() == 1);
+        Renderer whole("SAHBVH");
+        whole.setScene(&scene);
+        Renderer::Params p;
+        p.kernelName = "fermi_speculative_while_while";
+        p.rayType = Renderer::RayType_AO;
+        p.numSamples = 8;
+        p.aoRadius = 2.0f;
+        whole.setParams(p);
+        whole.beginFrame(cam);
+        const int totalAO = whole.getTotalNumRays();
+        Buffer pixels, matCol, shCol, fullPixels, fullRecords;
+        pixels.resizeDiscard((S64)W * H * 4);
+        pixels.clear(0);
+        std::vector<U32> cols(tris.size(), 0xFF8090A0u);
+        matCol.set(cols.data(), (S64)cols.size() * 4);
+        shCol.set(cols.data(), (S64)cols.size() * 4);
+        while (whole.nextBatch()) { whole.traceBatch(); whole.updateResult(pixels, matCol, shCol); }
+        // BVH replication: a second BVH object receives the root's buffers through RCCL (root == the only rank: the buffers come back as sent)
+        CudaBVH* rootBvh = dynamic_cast<CudaBVH*>(whole.getCudaBVH());
+        CHECK(rootBvh != NULL);
+        const S64 nodesBefore = rootBvh->getNodeBuffer().getSize();
+        std::vector<U8> nodesCopy((size_t)nodesBefore);
+        std::memcpy(nodesCopy.data(), rootBvh->getNodeBuffer().getPtr(), (size_t)nodesBefore);
+        group.broadcastBVH(*rootBvh, 0);
+        CHECK(rootBvh->getNodeBuffer().getSize() == nodesBefore && std::memcmp(rootBvh->getNodeBuffer().getPtr(), nodesCopy.data(), (size_t)nodesBefore) == 0);
+        // the frame's collective at world size 1: records and pixels arrive as traced
+        group.gatherRecords(whole, fullRecords, 0);
+        CHECK(fullRecords.getSize() == (S64)W * H * 16 &&
+              std::memcmp(fullRecords.getPtr(), whole.getPrimaryRays().getResultBuffer().getPtr(), (size_t)W * H * 16) == 0);
+        group.gatherPixels(whole, pixels, fullPixels, 0);
+        CHECK(fullPixels.getSize() == (S64)W * H * 4 && std::memcmp(fullPixels.getPtr(), pixels.getPtr(), (size_t)W * H * 4) == 0);
+        // three ranks' worth of sharded Renderers on this one GPU: ranges partition the frame, records and pixels equal the whole frame's
+        int sumAO = 0, covered = 0;
+        std::vector<U32> assembled((size_t)W * H, 0u);
+        for (int r = 0; r < 3; r++) {
+            Renderer part("SAHBVH");
+            part.setScene(&scene);
+            part.setShard(r, 3);
+            part.setParams(p);
+            part.beginFrame(cam);
+            CHECK(part.getShardLo() == covered && part.getShardLo() % 64 == 0);
+            covered = part.getShardHi();
+            sumAO += part.getTotalNumRays();
+            Buffer px;
+            px.resizeDiscard((S64)W * H * 4);
+            px.clear(0);
+            S64 traced = 0;
+            while (part.nextBatch()) { part.traceBatch(); part.updateResult(px, matCol, shCol); traced += part.getBatchRays()->getSize(); }
+            CHECK(traced == (S64)(part.getShardHi() - part.getShardLo()) * 8);
+            const RayResult* own = (const RayResult*)part.getPrimaryRays().getResultBuffer().getPtr();
+            const RayResult* ref = (const RayResult*)whole.getPrimaryRays().getResultBuffer().getPtr();
+            int same = 0;
+            for (int i = part.getShardLo(); i < part.getShardHi(); i++) same += (own[i].id == ref[i].id && own[i].t == ref[i].t);
+            CHECK(same == part.getShardHi() - part.getShardLo());
+            const U32* ppx = (const U32*)px.getPtr();
+            for (int i = 0; i < W * H; i++) if (ppx[i]) { CHECK(assembled[(size_t)i] == 0u); assembled[(size_t)i] = ppx[i]; }
+            // the primary ray type on a shard: one batch of the range's size
+            Renderer::Params pp = p;
+            pp.rayType = Renderer::RayType_Primary;
+            part.setParams(pp);
+            part.beginFrame(cam);
+            CHECK(part.getTotalNumRays() == part.getShardHi() - part.getShardLo());
+            int nb = 0;
+            while (part.nextBatch()) { CHECK(part.traceBatch() > 0.0f); nb++; }
+            CHECK(nb == 1);
+        }
+        CHECK(covered == W * H && sumAO == totalAO);
+        CHECK(std::memcmp(assembled.data(), pixels.getPtr(), (size_t)W * H * 4) == 0);
+    }
 
     // layout mismatch is fatal (CudaBVHTracer.cpp:99-100)
     {

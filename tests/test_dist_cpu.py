@@ -136,6 +136,26 @@ def test_shard_ranges_cover_and_align():
     assert len(tiles) * 64 == hi - lo
 
 
+def test_partition_arithmetic_of_the_c_abi_equals_the_python_formulation():
+    """ntr_frame_shard / ntr_frame_ao_batches (ntr_dist.cpp: what FramePlan, the C++ Renderer::setShard and the native gather use)
+    against the formulation they replaced in this module."""
+    def py_range(n, rank, world, align=64):
+        blocks = (n + align - 1) // align
+        per, extra = divmod(blocks, world)
+        lo_b = rank * per + min(rank, extra)
+        hi_b = lo_b + per + (1 if rank < extra else 0)
+        return min(lo_b * align, n), min(hi_b * align, n)
+    for n in (0, 1, 63, 64, 65, 1000, 4097, 1920 * 1080, 3840 * 2160):
+        for world in (1, 2, 3, 5, 8):
+            for rank in range(world):
+                lo, hi = ntd.shard_range(n, rank, world)
+                assert (lo, hi) == py_range(n, rank, world)
+                for samples, mb in ((8, 1 << 20), (32, 1 << 20), (8, 4096), (1, 7)):
+                    per = max(mb // samples, 1)
+                    want = [(f, min(per, hi - f)) for f in range(lo, hi, per)]
+                    assert ntd.FramePlan(n, rank, world, samples, mb).ao_batches == want
+
+
 def test_two_rank_gather_gloo(tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, _free_port(), 1000, out), nprocs=2, join=True)
