@@ -385,9 +385,23 @@ static void gpuTests()
               std::memcmp(fullRecords.getPtr(), whole.getPrimaryRays().getResultBuffer().getPtr(), (size_t)W * H * 16) == 0);
         group.gatherPixels(whole, pixels, fullPixels, 0);
         CHECK(fullPixels.getSize() == (S64)W * H * 4 && std::memcmp(fullPixels.getPtr(), pixels.getPtr(), (size_t)W * H * 4) == 0);
+        // the whole frame's primary-type image (AO rays depend on where a batch starts -- the rotation hash takes the batch-local index,
+        // RayGenKernels.cu:179 -- so only the primary image is partition-invariant)
+        Buffer primPixels;
+        primPixels.resizeDiscard((S64)W * H * 4);
+        primPixels.clear(0);
+        {
+            Renderer::Params pp = p;
+            pp.rayType = Renderer::RayType_Primary;
+            whole.setParams(pp);
+            whole.beginFrame(cam);
+            while (whole.nextBatch()) { whole.traceBatch(); whole.updateResult(primPixels, matCol, shCol); }
+            whole.setParams(p);
+        }
         // three ranks' worth of sharded Renderers on this one GPU: ranges partition the frame, records and pixels equal the whole frame's
         int sumAO = 0, covered = 0;
         std::vector<U32> assembled((size_t)W * H, 0u);
+        std::vector<U32> tilesAO((size_t)W * H, 0u);
         for (int r = 0; r < 3; r++) {
             Renderer part("SAHBVH");
             part.setScene(&scene);
@@ -409,7 +423,9 @@ static void gpuTests()
             for (int i = part.getShardLo(); i < part.getShardHi(); i++) same += (own[i].id == ref[i].id && own[i].t == ref[i].t);
             CHECK(same == part.getShardHi() - part.getShardLo());
             const U32* ppx = (const U32*)px.getPtr();
-            for (int i = 0; i < W * H; i++) if (ppx[i]) { CHECK(assembled[(size_t)i] == 0u); assembled[(size_t)i] = ppx[i]; }
+            int overlap = 0;
+            for (int i = 0; i < W * H; i++) if (ppx[i]) { overlap += tilesAO[(size_t)i] != 0u; tilesAO[(size_t)i] = ppx[i]; }
+            CHECK(overlap == 0);
             // the primary ray type on a shard: one batch of the range's size
             Renderer::Params pp = p;
             pp.rayType = Renderer::RayType_Primary;
@@ -417,11 +433,19 @@ static void gpuTests()
             part.beginFrame(cam);
             CHECK(part.getTotalNumRays() == part.getShardHi() - part.getShardLo());
             int nb = 0;
-            while (part.nextBatch()) { CHECK(part.traceBatch() > 0.0f); nb++; }
+            Buffer px2;
+            px2.resizeDiscard((S64)W * H * 4);
+            px2.clear(0);
+            while (part.nextBatch()) { CHECK(part.traceBatch() > 0.0f); part.updateResult(px2, matCol, shCol); nb++; }
             CHECK(nb == 1);
+            const U32* p2 = (const U32*)px2.getPtr();
+            for (int i = 0; i < W * H; i++) if (p2[i]) assembled[(size_t)i] = p2[i];
         }
         CHECK(covered == W * H && sumAO == totalAO);
-        CHECK(std::memcmp(assembled.data(), pixels.getPtr(), (size_t)W * H * 4) == 0);
+        int written = 0;
+        for (int i = 0; i < W * H; i++) written += tilesAO[(size_t)i] != 0u;
+        CHECK(written == W * H);   // the ranks' AO tiles cover the image exactly once
+        CHECK(std::memcmp(assembled.data(), primPixels.getPtr(), (size_t)W * H * 4) == 0);
     }
 
     // layout mismatch is fatal (CudaBVHTracer.cpp:99-100)
