@@ -387,7 +387,7 @@ def main():
         nt.set_tunables(NTR_TRACE_AUTO_HINT=None)
 
     # ---- final framebuffer gather (hit records of the primary batch -> rank 0) over RCCL, timed separately ---------------
-    gather_ms, frame_check = None, None
+    gather_ms, frame_check, native_gather = None, None, None
     sharded = use_dist and not (args.scaling == "weak" and world > 1)
     if use_dist:
         barrier()
@@ -400,6 +400,20 @@ def main():
             full = None
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        # the same gather through the library's own multi-GPU entry points (ntr_dist_*: RCCL bound by the C-ABI, what a C++ host of the
+        # reference's shape uses -- INTEGRATION.md), opt-in: NTR_BENCH_NATIVE_GATHER=1.  The 128-byte group id travels over torch.distributed.
+        if sharded and os.environ.get("NTR_BENCH_NATIVE_GATHER") == "1" and plan.cuts is None:
+            uid = torch.frombuffer(bytearray(nt.DistGroup.unique_id() if rank == 0 else bytes(128)), dtype=torch.uint8).to(dev)
+            dist.broadcast(uid, 0)
+            grp = nt.DistGroup(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            full_n = torch.zeros(n_primary * 16, dtype=torch.uint8, device=dev) if rank == 0 else None
+            barrier()
+            n0 = time.perf_counter()
+            grp.gather_records(frame.own_primary_records().data_ptr(), n_primary, full_n.data_ptr() if rank == 0 else 0, 0, stream)
+            barrier()
+            native_gather = {"ms": (time.perf_counter() - n0) * 1e3, "equal_torch_gather": bool(torch.equal(full_n, full)) if rank == 0 else None,
+                             "how": "ntr_dist_gather_records: grouped ncclSend / ncclRecv of the ranks' 16-byte hit records to rank 0"}
+            grp.close()
         if sharded:
             # checksum of checksums over every AO record of the frame (wrapping 64-bit sums)
             ao_sum = ntd.all_sum_int64(ntd.wrap_i64(sum(ntd.records_checksum(b["res_t"]) for b in batches[1:])), dev)
@@ -523,6 +537,7 @@ def main():
         "ao_mrays": (ao_live_total * args.steps / ao_kernel_max / 1e6) if ao_kernel_max > 0 else None,
         "kernel_ms": {"primary": prim_ms, "ao_total": ao_ms, "per_step_rank0": float(kern_ms.sum(axis=1).mean())},
         "gather_ms": gather_ms,
+        "gather_native": native_gather,
         "sharded_frame_check": frame_check,
         "host_sah_build_s": sah_seconds,
         "trace_stats": st.as_dict(),

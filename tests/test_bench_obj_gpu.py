@@ -52,7 +52,7 @@ def test_bench_rccl_path_at_world_size_one():
     records to rank 0 and the assembled-frame check -- exercised on one GPU (NTR_BENCH_FORCE_DIST=1), so that the GPU test tier
     loads RCCL and runs every collective the 2 / 4 / 8-GPU runs use."""
     env = dict(os.environ, NTR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", NTR_BENCH_NATIVE_GATHER="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", "640", "--height", "360", "--steps", "2", "--warmup", "1",
                         "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -61,3 +61,5 @@ def test_bench_rccl_path_at_world_size_one():
     chk = out["sharded_frame_check"]
     assert chk and chk["primary_records_equal_single_gpu_frame"] and chk["ao_checksum_equal_single_gpu_frame"]
     assert chk["records_compared"] == 640 * 360
+    # the library's own gather (ntr_dist_gather_records, RCCL bound by the C-ABI) assembled the same frame
+    assert out["gather_native"] and out["gather_native"]["equal_torch_gather"] is True

@@ -586,3 +586,66 @@ def test_automatic_scheduling_feedback_changes_no_record(soup, monkeypatch, any_
     dbvh.view.trace("fermi_speculative_while_while", n, any_hit, d_rays.data_ptr(), d_res.data_ptr())
     torch.cuda.synchronize()
     assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), ref_a, "feedback off")
+
+
+def test_scheduling_feedback_with_two_bvhs_alternating_through_the_same_buffers(monkeypatch):
+    """Two DIFFERENT trees and ray sets traced alternately through the SAME node / triangle / ray / result buffers (a host that rebuilds
+    its BVH in place and regenerates its rays every frame): whatever the library remembers about a batch -- its top-of-tree table, the
+    dispatch order it measured, the pool depth it derived -- belongs to contents that are gone one launch later.  Stale knowledge may cost
+    time, never a record.  Also: more distinct batches than the library keeps entries for (it recycles them without waiting)."""
+    import torch
+    from gpu_util import assert_parity, up
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
+    monkeypatch.setenv("NTR_TRACE_AUTO_HINT_MIN_RAYS", "1000")
+    monkeypatch.setenv("NTR_SCHED_REFRESH_EVERY", "3")
+    nt.set_tunables()
+    trees, rays, refs = [], [], {}
+    for seed, ntri in ((61, 9000), (62, 9000)):   # same triangle count: SAH trees with one-triangle leaves have equal buffer sizes
+        tri, pos, cam = scenes.random_soup(ntri, seed=seed)
+        bvh = nt.sah_build(tri, pos, 1, 1)
+        trees.append(bvh)
+        rays.append(np.concatenate([scenes.primary_rays(cam, 300, 200)[0], scenes.random_rays(40000, seed=seed)]))
+    nbytes = [max(getattr(t, f).nbytes for t in trees) for f in ("nodes", "woop", "tri_index")]
+    d_nodes = torch.zeros(nbytes[0], dtype=torch.uint8, device="cuda:0")
+    d_woop = torch.zeros(nbytes[1], dtype=torch.uint8, device="cuda:0")
+    d_idx = torch.zeros(nbytes[2], dtype=torch.uint8, device="cuda:0")
+    n = rays[0].shape[0]
+    d_rays = torch.zeros(n * 32, dtype=torch.uint8, device="cuda:0")
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device="cuda:0")
+    for any_hit in (False, True):
+        for k in (0, 1):
+            refs[(k, any_hit)] = oracle.trace(trees[k].nodes, trees[k].woop, trees[k].tri_index, rays[k], any_hit=any_hit, threads=8)[0]
+    for gen in range(14):
+        k = gen % 2 if gen < 10 else (gen // 2) % 2     # strictly alternating, then in pairs
+        t = trees[k]
+        d_nodes[: t.nodes.nbytes].copy_(up(t.nodes))
+        d_woop[: t.woop.nbytes].copy_(up(t.woop))
+        d_idx[: t.tri_index.nbytes].copy_(up(t.tri_index))
+        d_rays.copy_(up(rays[k]))
+        torch.cuda.synchronize()
+        view = nt.BvhView(d_nodes.data_ptr(), t.nodes.nbytes, d_woop.data_ptr(), t.woop.nbytes, d_idx.data_ptr())
+        if gen % 3 == 0:
+            view.validate()      # a host may or may not re-validate after a rebuild: the top-of-tree table is stale otherwise
+        for any_hit in (False, True):
+            d_res.fill_(0xCD)
+            view.trace("fermi_speculative_while_while", n, any_hit, d_rays.data_ptr(), d_res.data_ptr(), 0, gen % 4 == 0)
+            torch.cuda.synchronize()
+            assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), refs[(k, any_hit)], "tree %d generation %d anyHit=%d" % (k, gen, any_hit))
+    # more distinct batches than the 96 feedback entries: ray counts that change every launch
+    t = trees[0]
+    d_nodes[: t.nodes.nbytes].copy_(up(t.nodes)); d_woop[: t.woop.nbytes].copy_(up(t.woop)); d_idx[: t.tri_index.nbytes].copy_(up(t.tri_index))
+    d_rays.copy_(up(rays[0]))
+    torch.cuda.synchronize()
+    view = nt.BvhView(d_nodes.data_ptr(), t.nodes.nbytes, d_woop.data_ptr(), t.woop.nbytes, d_idx.data_ptr())
+    view.validate()
+    for i in range(130):
+        m = n - 64 * i
+        d_res.fill_(0xCD)
+        for _ in range(2 if i % 5 == 0 else 1):
+            view.trace("fermi_speculative_while_while", m, False, d_rays.data_ptr(), d_res.data_ptr(), 0, False)
+        if i % 13 == 0:
+            torch.cuda.synchronize()
+            assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE)[:m], refs[(0, False)][:m], "changing count %d" % m)
+    torch.cuda.synchronize()
+    assert nt.trace_status() == 0
