@@ -188,9 +188,13 @@ def main(argv=None):
             loop = dict(NTR_TRACE_PERRAY_UNIFIED=int(rng.choice([-1, 0, 1])), NTR_TRACE_UNIFIED=int(rng.choice([1, 1, 0])),
                         NTR_TRACE_FETCH_THRESHOLD=int(rng.choice([-1, -1, 1, 16, 33, 64])), NTR_TRACE_FLAT_FETCH=int(rng.choice([1, 1, 0])),
                         # wave-private mini-pool of the closest-hit per-ray launches: by the device's coherence estimate, off, or forced
-                        NTR_TRACE_MINIPOOL=int(rng.choice([-1, -1, 0, 1, 2, 3, 4, 5, 8, 16])), NTR_TRACE_MINIPOOL_THRESHOLD=int(rng.choice([48, 48, 1, 33, 64])))
+                        NTR_TRACE_MINIPOOL=int(rng.choice([-1, -1, 0, 1, 2, 3, 4, 5, 8, 16])), NTR_TRACE_MINIPOOL_THRESHOLD=int(rng.choice([48, 48, 1, 33, 64])),
+                        # tail hand-off of the pool waves (an opt-in): every threshold drawn at random, pools of one chunk included
+                        NTR_TRACE_HANDOFF=int(rng.choice([0, 1, 1])), NTR_TRACE_HANDOFF_BELOW=int(rng.integers(1, 65)),
+                        NTR_TRACE_HANDOFF_MIN_QUEUE=int(rng.choice([1, 4, 16, 64])), NTR_TRACE_HANDOFF_KEEP_WAVES=int(rng.choice([0, 0, 64, 1024, 100000])),
+                        NTR_TRACE_HANDOFF_FLAGS=int(rng.integers(0, 4)))
             nt.set_tunables(**loop)
-            tot["loop_%s" % "_".join(str(v) for v in loop.values())] = tot.get("loop_%s" % "_".join(str(v) for v in loop.values()), 0) + 1
+            tot["handoff_rounds"] = tot.get("handoff_rounds", 0) + loop["NTR_TRACE_HANDOFF"]
             hint = nt.SchedHint() if sched == 2 else None
             tot["sched_%d_rounds" % sched] = tot.get("sched_%d_rounds" % sched, 0) + 1
             for any_hit in (False, True):
@@ -209,6 +213,10 @@ def main(argv=None):
                         view.trace(kernel, n, any_hit, d_rays.data_ptr(), d_res.data_ptr(), hint=hint)
                         torch.cuda.synchronize()
                         got2 = d_res.cpu().numpy().view(nt.RESULT_DTYPE)
+                        if loop["NTR_TRACE_HANDOFF"] and kernel == KERNELS[0] and not any_hit:
+                            pushed, popped, _ = nt.trace_handoff_counts(0)
+                            tot["rays_handed_off"] = tot.get("rays_handed_off", 0) + pushed
+                            bad += int(pushed != popped)
                         bad += int(((got2["id"] != exp["id"]) | (got2["t"].view(np.uint32) != exp["t"].view(np.uint32))).sum())
                         tot["rays_compared"] += n
                     tot["rays_compared"] += n
