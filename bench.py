@@ -136,7 +136,7 @@ def parse(argv=None):
                          "measured no better on the simulated ranks: profiles/r03_shard_balance_study.jsonl)")
     ap.add_argument("--flat-share", type=float, default=4.0,
                     help="balanced cuts: cost of a block that does not depend on where its rays go (ray load / store, its AO rays), "
-                         "as a multiple of the mean predicted cost (scripts/shard_balance_study.py)")
+                         "as a multiple of the mean predicted cost (scripts/studies/shard_balance_study.py)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--ao-samples", type=int, default=8)

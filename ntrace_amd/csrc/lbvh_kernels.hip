@@ -13,12 +13,13 @@
 //   + calcLeaf      :383-408                       position, the second to arrive forms the parent WITH its boxes -- and writes every node
 //                                                  word, Woop row, index and terminator once, to its final place; lbvh_runs_kernel adds the
 //                                                  reference's median subtrees for runs of equal codes.  (Section "Bottom-up emit" below.)
-// Fallback, top-down (scenes of at most NTR_LBVH_SPLIT = 3072 triangles, n <= leafSize, leaves of more than 32 triangles):
+// Fallback, top-down (scenes of at most NTR_LBVH_SPLIT = 3072 triangles, n <= leafSize, leaves of more than 32 triangles): lbvh_topdown.h --
 //   lbvh_gather_box_kernel (box terms in sorted order), lbvh_top_kernel (one workgroup splits ranges larger than the split size level
 //   by level), lbvh_subtree_kernel (one workgroup per smaller range: topology in an LDS entry list, one pair of global atomics, bottom-up
 //   refit), lbvh_top_refit_kernel, lbvh_place_kernel (Woop rows straight into the slots the leaves reserved).
-// The round-1 / round-2 A/B paths (one launch per level, three-kernel sort passes, cell-table top pass) are compiled only with
-// -DNTR_EXPERIMENTS into libntrace_amd_exp.so (`make exp`); tests/test_lbvh_gpu.py runs them against that library.
+// The round-1 / round-2 A/B paths (one launch per level, three-kernel sort passes, cell-table top pass) live in lbvh_kernels_exp.h and are
+// compiled only with -DNTR_EXPERIMENTS into libntrace_amd_exp.so (`make exp`); tests/test_lbvh_gpu.py runs them against that library.
+// This file is the shipped bottom-up pipeline and the build driver (ntr_lbvh_build); lbvh_workspace.h holds the driver's host helpers.
 //
 // The tree is the reference's tree: same split rule (highest differing Morton bit at or below the
 // level's bit, median when none), same leaf rule (count <= leafSize, or the level's bit is 0), same
@@ -72,29 +73,11 @@ struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
 struct __attribute__((packed, aligned(4))) TriVerts { V3 v[3]; };
 static_assert(sizeof(TriVerts) == 36, "TriVerts must be 36 bytes");
 
-#ifdef NTR_EXPERIMENTS // round-1 per-level path (A/B scaffolding: libntrace_amd_exp.so only)
-__global__ __launch_bounds__(256) void lbvh_morton_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
-                                                          F3 lo, F3 step, unsigned int* __restrict__ keys,
-                                                          int* __restrict__ idx)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-    const float l[3] = {lo.x, lo.y, lo.z}, s[3] = {step.x, step.y, step.z};
-    int cell[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float a = pos[3 * i0 + k], b = pos[3 * i1 + k], c = pos[3 * i2 + k];
-        const float mn = fminf(a, fminf(b, c)), mx = fmaxf(a, fmaxf(b, c));
-        const float mid = mn + (mx - mn) / 2.0f;
-        const int v = (int)floorf((mid - l[k]) / s[k]);
-        cell[k] = min(max(v, 0), 1023);
-    }
-    keys[t] = spread10(cell[0]) | (spread10(cell[1]) << 1) | (spread10(cell[2]) << 2);
-    idx[t] = t;
-}
-
-#endif  // NTR_EXPERIMENTS
+#ifdef NTR_EXPERIMENTS
+#define NTR_LBVH_EXP_SECTION 1
+#include "lbvh_kernels_exp.h"
+#undef NTR_LBVH_EXP_SECTION
+#endif
 // Morton codes as lbvh_morton_kernel, fused with everything else that one pass over the mesh can produce:
 //   * the digit histograms of all four radix passes (LDS, then one global add per non-empty bin and workgroup), so
 //     that the sort is four one-sweep launches and nothing else;
@@ -154,27 +137,6 @@ __global__ __launch_bounds__(MORTON_THREADS) void lbvh_morton_hist_kernel(int n,
     }
 }
 
-// After the sort: box terms in sorted order (one 24-byte gather per triangle) and the cell table of the top pass:
-// cellStart[c] = first sorted position whose key's upper TOP_CELL_BITS bits are >= c (cellStart[TOP_CELLS] = n).
-__global__ __launch_bounds__(256) void lbvh_gather_box_kernel(int n, const unsigned int* __restrict__ keys, const int* __restrict__ triSorted,
-                                                              const float2* __restrict__ boxMesh, float2* __restrict__ triBox,
-                                                              unsigned int* __restrict__ cellStart)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int t = triSorted[j];
-    const float2 a = boxMesh[3 * (size_t)t], b = boxMesh[3 * (size_t)t + 1], c = boxMesh[3 * (size_t)t + 2];
-    triBox[3 * (size_t)j] = a; triBox[3 * (size_t)j + 1] = b; triBox[3 * (size_t)j + 2] = c;
-#ifdef NTR_EXPERIMENTS
-    if (cellStart) {
-        const int c1 = (int)(keys[j] >> (30 - TOP_CELL_BITS));
-        const int c0 = j ? (int)(keys[j - 1] >> (30 - TOP_CELL_BITS)) : -1;
-        for (int cc = c0 + 1; cc <= c1; cc++) cellStart[cc] = (unsigned int)j;
-        if (j == n - 1)
-            for (int cc = c1 + 1; cc <= TOP_CELLS; cc++) cellStart[cc] = (unsigned int)n;
-    }
-#endif
-}
 
 // ---- Woop rows (emitTreeKernel.cu:574-635) ---------------------------------------------------------
 __device__ __forceinline__ void woop_rows_verts(float v0x, float v0y, float v0z, float v1x, float v1y, float v1z, float v2x, float v2y,
@@ -207,744 +169,35 @@ __device__ __forceinline__ void woop_rows(const int* __restrict__ tri, const flo
                     pos[3 * i2 + 1], pos[3 * i2 + 2], r0, r1, r2);
 }
 
-#ifdef NTR_EXPERIMENTS // round-1 per-level path
-__global__ __launch_bounds__(256) void lbvh_woop_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
-                                                        float4* __restrict__ out)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    float4 r0, r1, r2;
-    woop_rows(tri, pos, t, r0, r1, r2);
-    out[3 * t + 0] = r0;
-    out[3 * t + 1] = r1;
-    out[3 * t + 2] = r2;
-}
-
-#endif  // NTR_EXPERIMENTS
-
-// Subtree path, after the emit: Woop rows and original index of every triangle, written straight to the
-// slot its leaf reserved (triOut[j] = float4 index of sorted triangle j).
-__global__ __launch_bounds__(256) void lbvh_place_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
-                                                         const int* __restrict__ triSorted, const int* __restrict__ triOut,
-                                                         float4* __restrict__ outWoop, int* __restrict__ outIdx)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int t = triSorted[j], o = triOut[j];
-    float4 r0, r1, r2;
-    woop_rows(tri, pos, t, r0, r1, r2);
-    outWoop[o + 0] = r0;
-    outWoop[o + 1] = r1;
-    outWoop[o + 2] = r2;
-    outIdx[o + 0] = t;
-    outIdx[o + 1] = 0;
-    outIdx[o + 2] = 0;
-}
-
-#ifdef NTR_EXPERIMENTS // round-1 per-level emit / refit kernels
-// ---- tree emission, one level per launch (emitTreeKernel.cu:233-381) ------------------------------
-__device__ __forceinline__ int create_leaf(LbvhState* st, const float4* __restrict__ inWoop, const int* __restrict__ triSorted,
-                                           float4* __restrict__ outWoop, int* __restrict__ outIdx, int start, int end)
-{
-    const unsigned int numTris = end - start;
-    const unsigned long long add = ((unsigned long long)numTris << 32) + 1ull;
-    const unsigned long long p = atomicAdd(&st->leafPtr, add);
-    const unsigned int numLeafs = (unsigned int)(p & 0xFFFFFFFFull), allTris = (unsigned int)(p >> 32);
-    const int out = allTris * 3 + numLeafs;  // float4 index; one extra float4 per leaf for the terminator
-    for (unsigned int i = 0; i < numTris; i++) {
-        const int t = triSorted[start + i];
-        outWoop[out + 3 * i + 0] = inWoop[3 * t + 0];
-        outWoop[out + 3 * i + 1] = inWoop[3 * t + 1];
-        outWoop[out + 3 * i + 2] = inWoop[3 * t + 2];
-        outIdx[out + 3 * i + 0] = t;
-        outIdx[out + 3 * i + 1] = 0;
-        outIdx[out + 3 * i + 2] = 0;
-    }
-    const float nz = __uint_as_float(0x80000000u);
-    outWoop[out + 3 * numTris] = make_float4(nz, nz, nz, nz);
-    outIdx[out + 3 * numTris] = 0;
-    return ~out;
-}
-
-__global__ __launch_bounds__(256) void lbvh_emit_kernel(int lvl, int levelBit, int leafSize, LbvhState* __restrict__ st,
-                                                        const unsigned int* __restrict__ keys, const int* __restrict__ triSorted,
-                                                        const float4* __restrict__ inWoop, const int* __restrict__ qIn,
-                                                        int* __restrict__ qOut, int* __restrict__ nodes, unsigned int nodeCapacity,
-                                                        float4* __restrict__ outWoop, int* __restrict__ outIdx)
-{
-    const unsigned int inCount = st->lvlNodes[lvl];
-    const unsigned int inOfs = st->lvlStart[lvl] + inCount;  // index of the first node of the next level
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->lvlStart[lvl + 1] = inOfs;
-    const int lane = threadIdx.x & 63;
-    const unsigned int stride = gridDim.x * blockDim.x;
-    // all lanes of a wave run the same number of iterations (the wave-level scan needs them)
-    const unsigned int rounds = (inCount + stride - 1) / stride;
-    for (unsigned int it = 0; it < rounds; it++) {
-        const unsigned int e = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        const bool valid = e < inCount;
-        int nIdx = 0, nStart = 0, nEnd = 0, split = 0, level = levelBit;
-        bool leaf0 = false, leaf1 = false;
-        if (valid) {
-            nIdx = qIn[3 * e]; nStart = qIn[3 * e + 1]; nEnd = qIn[3 * e + 2];
-            const unsigned int kFirst = keys[nStart], kLast = keys[nEnd - 1];
-            while (level >= 0 && (((kFirst >> level) & 1) == ((kLast >> level) & 1))) level--;
-            if (level >= 0) {  // split where the bit flips (binary search, :263-280)
-                const unsigned int startBit = (kFirst >> level) & 1;
-                int a = nStart, b = nEnd;
-                for (;;) {
-                    split = (a + b) >> 1;
-                    const unsigned int splitBit = (keys[split] >> level) & 1;
-                    if (((keys[split - 1] >> level) & 1) != splitBit) break;
-                    if (splitBit == startBit) a = split; else b = split;
-                }
-            } else {
-                split = (nStart + nEnd) >> 1;  // identical keys: median (:282)
-            }
-            leaf0 = (split - nStart) <= leafSize || levelBit == 0;
-            leaf1 = (nEnd - split) <= leafSize || levelBit == 0;
-        }
-        // queue slots for the inner children: wave prefix sum + one atomic per wave (:296-303)
-        const int mine = valid ? ((leaf0 ? 0 : 1) + (leaf1 ? 0 : 1)) : 0;
-        int incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        const int total = __shfl(incl, 63);
-        unsigned int waveBase = 0;
-        if (lane == 63 && total > 0) waveBase = atomicAdd(&st->lvlNodes[lvl + 1], (unsigned int)total);
-        waveBase = __shfl(waveBase, 63);
-        if (!valid) continue;
-        unsigned int outOff = waveBase + (incl - mine);
-        unsigned int outIdxNode = inOfs + outOff;
-        if (outIdxNode + 2 > nodeCapacity) { atomicOr(&st->overflow, 1u); continue; }
-
-        int c0, c1;
-        int* nd = nodes + (size_t)nIdx * 16;
-        if (leaf0) {
-            c0 = create_leaf(st, inWoop, triSorted, outWoop, outIdx, nStart, split);
-            nd[0] = nStart; nd[1] = split;  // consumed by the refit pass
-        } else {
-            qOut[3 * outOff] = outIdxNode; qOut[3 * outOff + 1] = nStart; qOut[3 * outOff + 2] = split;
-            c0 = outIdxNode * 64;
-            outOff++; outIdxNode++;
-        }
-        if (leaf1) {
-            c1 = create_leaf(st, inWoop, triSorted, outWoop, outIdx, split, nEnd);
-            nd[4] = split; nd[5] = nEnd;
-        } else {
-            qOut[3 * outOff] = outIdxNode; qOut[3 * outOff + 1] = split; qOut[3 * outOff + 2] = nEnd;
-            c1 = outIdxNode * 64;
-        }
-        nd[12] = c0; nd[13] = c1; nd[14] = level % 3; nd[15] = 0;
-    }
-}
-
-// ---- bottom-up refit, one level per launch (emitTreeKernel.cu:417-562) ---------------------------
-__device__ __forceinline__ void calc_leaf(const int* __restrict__ tri, const float* __restrict__ pos,
-                                          const int* __restrict__ triSorted, int start, int end, float eps, float (&lo)[3], float (&hi)[3])
-{
-    for (int i = start; i < end; i++) {
-        const int t = triSorted[i];
-        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float a = pos[3 * i0 + k], b = pos[3 * i1 + k], c = pos[3 * i2 + k];
-            lo[k] = fminf(lo[k], fminf(a, fminf(b, c)) - eps);
-            hi[k] = fmaxf(hi[k], fmaxf(a, fmaxf(b, c)) + eps);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void lbvh_refit_kernel(int lvl, float eps, const LbvhState* __restrict__ st,
-                                                         const int* __restrict__ tri, const float* __restrict__ pos,
-                                                         const int* __restrict__ triSorted, int* __restrict__ nodes)
-{
-    const unsigned int cnt = st->lvlNodes[lvl], start = st->lvlStart[lvl];
-    for (unsigned int q = blockIdx.x * blockDim.x + threadIdx.x; q < cnt; q += gridDim.x * blockDim.x) {
-        int* ni = nodes + (size_t)(start + q) * 16;
-        float* nf = reinterpret_cast<float*>(ni);
-        const int ch[2] = {ni[12], ni[13]};
-        float box[2][6];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            if (ch[k] < 0) {
-                float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-                calc_leaf(tri, pos, triSorted, ni[4 * k], ni[4 * k + 1], eps, lo, hi);
-                box[k][0] = lo[0]; box[k][1] = hi[0]; box[k][2] = lo[1]; box[k][3] = hi[1]; box[k][4] = lo[2]; box[k][5] = hi[2];
-            } else {
-                const float4* cn = reinterpret_cast<const float4*>(nodes + (size_t)(ch[k] >> 6) * 16);
-                const float4 a = cn[0], b = cn[1], c = cn[2];
-                box[k][0] = fminf(a.x, b.x); box[k][1] = fmaxf(a.y, b.y);
-                box[k][2] = fminf(a.z, b.z); box[k][3] = fmaxf(a.w, b.w);
-                box[k][4] = fminf(c.x, c.z); box[k][5] = fmaxf(c.y, c.w);
-            }
-        }
-        reinterpret_cast<float4*>(nf)[0] = make_float4(box[0][0], box[0][1], box[0][2], box[0][3]);
-        reinterpret_cast<float4*>(nf)[1] = make_float4(box[1][0], box[1][1], box[1][2], box[1][3]);
-        reinterpret_cast<float4*>(nf)[2] = make_float4(box[0][4], box[0][5], box[1][4], box[1][5]);
-    }
-}
+#ifdef NTR_EXPERIMENTS
+#define NTR_LBVH_EXP_SECTION 2
+#include "lbvh_kernels_exp.h"
+#undef NTR_LBVH_EXP_SECTION
+#endif
 
 
-#endif  // NTR_EXPERIMENTS
-// ---- subtree path: emit + refit with workgroup barriers only ------------------------------------------
-// Position where bit `level` of the sorted keys flips inside [nStart, nEnd) (emitTreeKernel.cu:263-280).
-// keys[nStart] and keys[nEnd-1] differ in that bit and agree above it, so the flip is unique; K-1
-// independent probes per step shorten the dependent-load chain of the plain binary search.
-// `keys` is indexed relative to `base` (a subtree's keys live in LDS).
-template <int K>
-__device__ __forceinline__ int find_split(const unsigned int* keys, int base, int nStart, int nEnd, int level, unsigned int startBit)
-{
-    int a = nStart, b = nEnd - 1;
-    while (b - a > 1) {
-        const int len = b - a;
-        const int step = len / K;  // K is a power of two; any probes strictly inside (a, b) are valid
-        int na = a, nb = b;
-#pragma unroll
-        for (int j = 1; j < K; j++) {
-            const int p = step ? a + j * step : min(a + j, b - 1);
-            const unsigned int bit = (keys[p - base] >> level) & 1;
-            if (bit == startBit) na = max(na, p); else nb = min(nb, p);
-        }
-        a = na; b = nb;
-    }
-    return b;
-}
+#ifdef NTR_EXPERIMENTS
+#define NTR_LBVH_EXP_SECTION 3
+#include "lbvh_kernels_exp.h"
+#undef NTR_LBVH_EXP_SECTION
+#endif
+#define NTR_LBVH_TOPDOWN_PART 1
+#include "lbvh_topdown.h"   // the top-down fallback (small scenes, oversize leaves)
+#undef NTR_LBVH_TOPDOWN_PART
+#ifdef NTR_EXPERIMENTS
+#define NTR_LBVH_EXP_SECTION 4
+#include "lbvh_kernels_exp.h"
+#undef NTR_LBVH_EXP_SECTION
+#endif
 
-struct EmitCtx {
-    LbvhState* st;
-    const unsigned int* keys;
-    const float2* triBox;  // per sorted triangle: (lo, hi) per axis, epsilon applied (lbvh_tribox_kernel)
-    int* triOut;           // per sorted triangle: float4 index of its Woop rows (for lbvh_place_kernel)
-    int* nodes;
-    unsigned int nodeCap;
-    float4* outWoop;
-    int* outIdx;
-    int leafSize;
-    int4* subList;       // (node, start, end, level) of the ranges handed to lbvh_subtree_kernel
-    int spill;           // ranges of at most this many triangles are emitted by one workgroup each
-};
-
-struct EmitShared {      // LDS bookkeeping of one workgroup
-    unsigned long long leafCtr;   // (triangles << 32) | leaves reserved so far, like g_leafsPtr
-    unsigned long long leafBase;
-    unsigned int nodeCtr, nodeBase, numSub, item, maxLevel;
-    unsigned int cnt[3];          // queue lengths of three consecutive levels, rotating
-    unsigned int lvlOfs[34];
-};
-
-__device__ __forceinline__ void lds_barrier()
-{
-    // workgroup barrier that orders LDS traffic only: global stores of the emit stay in flight
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// createLeaf (emitTreeKernel.cu:170-231) without the copy: the leaf's triangles learn their slot, the
-// terminator is stored, and the leaf's box (calcLeaf :383-408, folded in stored order from FLT_MAX) goes
-// straight into child slot k of its parent.  lbvh_place_kernel fills the Woop rows afterwards.
-__device__ __forceinline__ void emit_leaf(const EmitCtx& c, int out, int start, int end, int* nd, int k)
-{
-    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    const float2* __restrict__ tb = c.triBox;
-    // eight triangles per round trip; indices past the end repeat the last triangle, which min/max ignore
-    for (int j = start; j < end; j += 8) {
-        float2 b[8][3];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int q = min(j + u, end - 1);
-            b[u][0] = tb[3 * q]; b[u][1] = tb[3 * q + 1]; b[u][2] = tb[3 * q + 2];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b[u][k].x); hi[k] = fmaxf(hi[k], b[u][k].y); }
-        }
-    }
-    for (int j = start; j < end; j++) c.triOut[j] = out + 3 * (j - start);
-    const int tpos = out + 3 * (end - start);
-    const float nz = __uint_as_float(0x80000000u);
-    c.outWoop[tpos] = make_float4(nz, nz, nz, nz);
-    c.outIdx[tpos] = 0;
-    float* nf = reinterpret_cast<float*>(nd);
-    reinterpret_cast<float4*>(nf)[k] = make_float4(lo[0], hi[0], lo[1], hi[1]);
-    reinterpret_cast<float2*>(nf)[4 + k] = make_float2(lo[2], hi[2]);
-}
-
-// Level-by-level emit by all threads of ONE workgroup that owns the node / leaf counters of the whole tree in LDS
-// (a level costs one barrier and no global atomic).  The queue holds (node, start, end, depth) entries -- `inCount` of
-// them are in qA on entry -- and every entry is split exactly as lbvh_emit_kernel splits it (its level bit is
-// 29 - depth); ranges of at most c.spill triangles are appended to c.subList (for lbvh_subtree_kernel) instead of the
-// next round's queue.  Returns the number of rounds that held nodes; lst receives the node indices round by round
-// (offsets in sh.lvlOfs) for the refit; sh.maxLevel = deepest depth that held a node, plus one.
-template <int THREADS, int K>
-__device__ __forceinline__ int emit_top(const EmitCtx& c, EmitShared& sh, int4* qA, int4* qB, int* lst, unsigned int firstCount)
-{
-    const int tid = threadIdx.x;
-    if (tid == 0) { sh.cnt[0] = firstCount; sh.cnt[1] = 0; sh.cnt[2] = 0; }
-    __syncthreads();
-    unsigned int total = 0;
-    int lv = 0;
-    for (; lv < 31; lv++) {
-        const unsigned int inCount = sh.cnt[lv % 3];
-        if (inCount == 0) break;
-        unsigned int* outCount = &sh.cnt[(lv + 1) % 3];
-        if (tid == 0) {
-            sh.cnt[(lv + 2) % 3] = 0;  // read one round ago, added to one round ahead
-            sh.lvlOfs[lv] = total;
-        }
-        for (unsigned int e = tid; e < inCount; e += THREADS) {
-            const int4 q = qA[e];
-            const int nIdx = q.x, nStart = q.y, nEnd = q.z, lvl = q.w;
-            const int levelBit = 29 - lvl;
-            const unsigned int kFirst = c.keys[nStart], kLast = c.keys[nEnd - 1];
-            const unsigned int diff = (kFirst ^ kLast) & ((2u << levelBit) - 1u);
-            const int level = diff ? 31 - __clz((int)diff) : -1;  // highest differing bit at or below the level's bit
-            const int split = level >= 0 ? find_split<K>(c.keys, 0, nStart, nEnd, level, (kFirst >> level) & 1)
-                                         : (nStart + nEnd) >> 1;  // identical keys: median (:282)
-            const int cs[2] = {nStart, split}, ce[2] = {split, nEnd};
-            const bool isLeaf[2] = {(split - nStart) <= c.leafSize || levelBit == 0, (nEnd - split) <= c.leafSize || levelBit == 0};
-            const unsigned int inner = (isLeaf[0] ? 0u : 1u) + (isLeaf[1] ? 0u : 1u);
-            const unsigned long long lf = (isLeaf[0] ? (((unsigned long long)(split - nStart) << 32) + 1ull) : 0ull) +
-                                          (isLeaf[1] ? (((unsigned long long)(nEnd - split) << 32) + 1ull) : 0ull);
-            unsigned int childNode = inner ? atomicAdd(&sh.nodeCtr, inner) : 0u;
-            unsigned long long lp = lf ? atomicAdd(&sh.leafCtr, lf) : 0ull;
-            lst[total + e] = nIdx;
-            atomicMax(&sh.maxLevel, (unsigned int)lvl + 1u);
-            if (childNode + inner > c.nodeCap) {  // cannot happen with ntr_lbvh_capacity() buffers
-                atomicOr(&c.st->overflow, 1u);
-                continue;
-            }
-            int* nd = c.nodes + (size_t)nIdx * 16;
-            int ch[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (isLeaf[k]) {
-                    const int out = (int)(lp >> 32) * 3 + (int)(lp & 0xFFFFFFFFull);  // createLeaf (:176-181)
-                    lp += ((unsigned long long)(ce[k] - cs[k]) << 32) + 1ull;
-                    ch[k] = ~out;
-                    emit_leaf(c, out, cs[k], ce[k], nd, k);
-                } else {
-                    if ((ce[k] - cs[k]) <= c.spill) {
-                        const unsigned int si = atomicAdd(&sh.numSub, 1u);
-                        c.subList[si] = make_int4((int)childNode, cs[k], ce[k], lvl + 1);
-                    } else {
-                        const unsigned int slot = atomicAdd(outCount, 1u);
-                        qB[slot] = make_int4((int)childNode, cs[k], ce[k], lvl + 1);
-                    }
-                    ch[k] = (int)childNode * 64;
-                    childNode++;
-                }
-            }
-            nd[12] = ch[0]; nd[13] = ch[1]; nd[14] = level % 3; nd[15] = 0;
-        }
-        total += inCount;
-        __syncthreads();
-        int4* t = qA; qA = qB; qB = t;
-    }
-    if (tid == 0) sh.lvlOfs[lv] = total;
-    return lv;
-}
-
-// calcAABB (emitTreeKernel.cu:417-562) for the inner children of one node: the child's box is the union of
-// that child's two stored boxes.  Leaf children received their boxes when they were emitted.
-__device__ __forceinline__ void refit_node(int* ni, const int* nodes)
-{
-    float* nf = reinterpret_cast<float*>(ni);
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int ch = ni[12 + k];
-        if (ch < 0) continue;
-        const float4* cn = reinterpret_cast<const float4*>(nodes + (size_t)(ch >> 6) * 16);
-        const float4 a = cn[0], b = cn[1], c = cn[2];
-        reinterpret_cast<float4*>(nf)[k] = make_float4(fminf(a.x, b.x), fmaxf(a.y, b.y), fminf(a.z, b.z), fmaxf(a.w, b.w));
-        reinterpret_cast<float2*>(nf)[4 + k] = make_float2(fminf(c.x, c.z), fmaxf(c.y, c.w));
-    }
-}
-
-template <int THREADS>
-__device__ __forceinline__ void refit_levels(const unsigned int* lvlOfs, int numLv, const int* lst, int* nodes)
-{
-    for (int lv = numLv - 1; lv >= 0; lv--) {
-        const unsigned int b = lvlOfs[lv], e = lvlOfs[lv + 1];
-        for (unsigned int q = b + threadIdx.x; q < e; q += THREADS)
-            refit_node(nodes + (size_t)lst[q] * 16, nodes);
-        __syncthreads();  // the level above reads these boxes (same workgroup, same CU)
-    }
-}
-
-constexpr int TOP_THREADS = 1024;
-
-__global__ __launch_bounds__(TOP_THREADS) void lbvh_top_kernel(EmitCtx c, int n, int4* qA, int4* qB, int* topLst)
-{
-    __shared__ EmitShared sh;
-    if (threadIdx.x == 0) {
-        sh.nodeCtr = 1; sh.nodeBase = 0;  // node 0 is the root
-        sh.leafCtr = 0ull; sh.leafBase = 0ull; sh.numSub = 0; sh.maxLevel = 0;
-        qA[0] = make_int4(0, 0, n, 0);  // the root: node 0 over all triangles, depth 0
-    }
-    __syncthreads();
-    const int lv = emit_top<TOP_THREADS, 16>(c, sh, qA, qB, topLst, 1u);
-    __syncthreads();
-    if ((int)threadIdx.x <= lv) c.st->topLvlOfs[threadIdx.x] = sh.lvlOfs[threadIdx.x];
-    if (threadIdx.x == 0) {
-        c.st->topLevels = (unsigned int)lv;
-        c.st->maxLevel = sh.maxLevel;
-        c.st->nodeCount = sh.nodeCtr;
-        c.st->leafPtr = sh.leafCtr;
-        c.st->numSub = sh.numSub;
-    }
-}
-
-#ifdef NTR_EXPERIMENTS // cell-table top pass (measured slower than the bottom-up emit; A/B only)
-// ---- top of the tree from the cell table ---------------------------------------------------------------------------------------
-// Above the cells (the keys' upper TOP_CELL_BITS bits) the tree is a function of the cell table alone: a tree node whose keys
-// first differ in bit 29 - L is the trie node (L, prefix) whose two halves are both non-empty, its range is the trie node's range
-// and its split is the boundary between the halves -- table look-ups, no key probes, no level-by-level dependency.  One workgroup
-// keeps the table and a heap-indexed node-index map in LDS and
-//   1. classifies all 2^(B+1) trie nodes in parallel: TOP NODE (both halves non-empty, more than `spill` triangles), HAND-OVER
-//      ROOT (a child of a top node with at most `spill` triangles: one subtree workgroup each) or OVERSIZE CELL (a single cell
-//      with more than `spill` triangles), and gives each a node index from an LDS counter;
-//   2. writes every top node (children = leaves, or the node indices of step 1) and the hand-over list;
-//   3. splits oversize cells level by level with key probes (emit_top) -- nothing to do for ordinary scenes.
-// The depth of a node (needed for the reference's level-bit-0 leaf rule and its level count) is the number of its trie ancestors
-// with two non-empty halves.  Heap index h = 2^L + prefix; the cells are the heap's last level.
-constexpr int TOP_HEAP = 2 * TOP_CELLS;  // heap indices 1 .. TOP_HEAP-1
-
-struct TopLds {
-    unsigned int cell[TOP_CELLS + 1];
-    unsigned short idx[TOP_HEAP];
-};
-
-__device__ __forceinline__ void trie_range(const unsigned int* cell, unsigned int h, int L, unsigned int& lo, unsigned int& hi)
-{
-    const unsigned int p = h - (1u << L);
-    lo = cell[p << (TOP_CELL_BITS - L)];
-    hi = cell[(p + 1) << (TOP_CELL_BITS - L)];
-}
-__device__ __forceinline__ bool trie_actual(const unsigned int* cell, unsigned int h, int L)  // both halves non-empty (L < TOP_CELL_BITS)
-{
-    const unsigned int p = h - (1u << L);
-    const unsigned int lo = cell[p << (TOP_CELL_BITS - L)], mid = cell[(2 * p + 1) << (TOP_CELL_BITS - L - 1)], hi = cell[(p + 1) << (TOP_CELL_BITS - L)];
-    return lo < mid && mid < hi;
-}
-__device__ __forceinline__ int trie_depth(const unsigned int* cell, unsigned int h, int L)  // trie ancestors with two non-empty halves
-{
-    int d = 0;
-    for (int l = L - 1; l >= 0; l--) {
-        h >>= 1;
-        d += trie_actual(cell, h, l) ? 1 : 0;
-    }
-    return d;
-}
-
-__global__ __launch_bounds__(TOP_THREADS) void lbvh_top_cells_kernel(EmitCtx c, int n, const unsigned int* __restrict__ cellStart,
-                                                                     int* __restrict__ topIdx, int4* qA, int4* qB, int* topLst)
-{
-    extern __shared__ int smem[];
-    TopLds& t = *reinterpret_cast<TopLds*>(smem);
-    __shared__ EmitShared sh;
-    __shared__ unsigned int s_over, s_trieLevels;
-    const int tid = threadIdx.x;
-    for (int i = tid; i <= TOP_CELLS; i += TOP_THREADS) t.cell[i] = cellStart[i];
-    for (int i = tid; i < TOP_HEAP; i += TOP_THREADS) t.idx[i] = 0xFFFFu;
-    if (tid == 0) {
-        sh.nodeCtr = 1; sh.nodeBase = 0;  // node 0 is the root
-        sh.leafCtr = 0ull; sh.leafBase = 0ull; sh.numSub = 0; sh.maxLevel = 0;
-        s_over = 0; s_trieLevels = 0;
-    }
-    __syncthreads();
-    const unsigned int spill = (unsigned int)c.spill, leafSize = (unsigned int)c.leafSize;
-
-    // ---- 1. classify, allocate node indices ------------------------------------------------------------------------------
-    for (unsigned int h = 1 + tid; h < (unsigned int)TOP_HEAP; h += TOP_THREADS) {
-        const int L = 31 - __clz((int)h);
-        unsigned int lo, hi;
-        trie_range(t.cell, h, L, lo, hi);
-        const unsigned int cnt = hi - lo;
-        if (cnt <= leafSize) continue;                                     // a leaf of its parent, or empty
-        const bool isCell = L == TOP_CELL_BITS;
-        if (!isCell && !trie_actual(t.cell, h, L)) continue;               // one empty half: no tree node here
-        // the tree parent: nearest ancestor holding more triangles (its other half is non-empty)
-        unsigned int pcnt = 0xFFFFFFFFu;                                   // none: this is the root
-        {
-            unsigned int a = h;
-            for (int l = L - 1; l >= 0; l--) {
-                a >>= 1;
-                unsigned int alo, ahi;
-                trie_range(t.cell, a, l, alo, ahi);
-                if (ahi - alo != cnt) { pcnt = ahi - alo; break; }
-            }
-        }
-        const bool top = !isCell && cnt > spill;
-        if (!top && pcnt != 0xFFFFFFFFu && pcnt <= spill) continue;       // inside some hand-over root's subtree
-        const unsigned int nIdx = pcnt == 0xFFFFFFFFu ? 0u : atomicAdd(&sh.nodeCtr, 1u);
-        t.idx[h] = (unsigned short)nIdx;
-        if (!top) {
-            const int depth = trie_depth(t.cell, h, L);
-            if (cnt <= spill) {                                            // hand-over root
-                const unsigned int si = atomicAdd(&sh.numSub, 1u);
-                c.subList[si] = make_int4((int)nIdx, (int)lo, (int)hi, depth);
-            } else {                                                       // oversize cell
-                const unsigned int qi = atomicAdd(&s_over, 1u);
-                qA[qi] = make_int4((int)nIdx, (int)lo, (int)hi, depth);
-            }
-        }
-    }
-    __syncthreads();
-    if (sh.nodeCtr > c.nodeCap) {  // cannot happen with ntr_lbvh_capacity() buffers
-        if (tid == 0) atomicOr(&c.st->overflow, 1u);
-        return;
-    }
-
-    // ---- 2. write the top nodes ------------------------------------------------------------------------------------------
-    for (unsigned int h = 1 + tid; h < (unsigned int)TOP_CELLS; h += TOP_THREADS) {
-        const unsigned int nIdx = t.idx[h];
-        const int L = 31 - __clz((int)h);
-        unsigned int lo, hi;
-        trie_range(t.cell, h, L, lo, hi);
-        const bool isTop = nIdx != 0xFFFFu && hi - lo > spill;            // else: nothing, or a hand-over root (its workgroup writes it)
-        topIdx[h] = isTop ? (int)nIdx : -1;                                // every entry of the map is written: no clearing pass
-        if (!isTop) continue;
-        atomicMax(&sh.maxLevel, (unsigned int)trie_depth(t.cell, h, L) + 1u);
-        atomicMax(&s_trieLevels, (unsigned int)L + 1u);
-        int* nd = c.nodes + (size_t)nIdx * 16;
-        int ch[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            unsigned int d = 2 * h + k;
-            int dl = L + 1;
-            unsigned int clo, chi;
-            trie_range(t.cell, d, dl, clo, chi);
-            if (chi - clo <= leafSize) {                                   // createLeaf (:170-231)
-                const unsigned long long lp = atomicAdd(&sh.leafCtr, ((unsigned long long)(chi - clo) << 32) + 1ull);
-                const int out = (int)(lp >> 32) * 3 + (int)(lp & 0xFFFFFFFFull);
-                ch[k] = ~out;
-                emit_leaf(c, out, (int)clo, (int)chi, nd, k);
-                continue;
-            }
-            while (dl < TOP_CELL_BITS && !trie_actual(t.cell, d, dl)) {  // skip trie nodes with an empty half
-                unsigned int llo, lhi;
-                trie_range(t.cell, 2 * d, dl + 1, llo, lhi);
-                d = 2 * d + (lhi > llo ? 0u : 1u);
-                dl++;
-            }
-            ch[k] = (int)t.idx[d] * 64;
-        }
-        nd[12] = ch[0]; nd[13] = ch[1]; nd[14] = (29 - L) % 3; nd[15] = 0;
-    }
-    __syncthreads();
-
-    // ---- 3. oversize cells: level by level with key probes -----------------------------------------------------------------
-    const unsigned int over = s_over;
-    int lv = 0;
-    if (over) lv = emit_top<TOP_THREADS, 16>(c, sh, qA, qB, topLst, over);
-    __syncthreads();
-    if ((int)tid <= lv) c.st->topLvlOfs[tid] = over ? sh.lvlOfs[tid] : 0u;
-    if (tid == 0) {
-        c.st->topLevels = (unsigned int)lv;
-        c.st->maxLevel = sh.maxLevel;
-        c.st->nodeCount = sh.nodeCtr;
-        c.st->leafPtr = sh.leafCtr;
-        c.st->numSub = sh.numSub;
-        c.st->topTrieLevels = s_trieLevels;
-    }
-}
-
-#endif  // NTR_EXPERIMENTS
-
-// Split position as find_split, for ranges of fewer than 2^16 keys held in LDS: 32-bit probe arithmetic.
-template <int LOGK>
-__device__ __forceinline__ int find_split_small(const unsigned int* keys, int nStart, int nEnd, int level, unsigned int startBit)
-{
-    int a = nStart, b = nEnd - 1;
-    while (b - a > 1) {
-        const int len = b - a;
-        int na = a, nb = b;
-#pragma unroll
-        for (int j = 1; j < (1 << LOGK); j++) {
-            const int p = a + ((len * j) >> LOGK);
-            const unsigned int bit = (keys[p] >> level) & 1;
-            if (bit == startBit) na = max(na, p); else nb = min(nb, p);
-        }
-        a = na; b = nb;
-    }
-    return b;
-}
-
-// One entry of a subtree's node list in LDS (positions are relative to the subtree's first triangle, which keeps
-// every field below 2^16 for the subtree sizes a workgroup's LDS can hold).
-struct SubEntry {
-    unsigned int range;   // start | end << 16
-    unsigned int split;   // split | (level + 1) << 16 | leaf0 << 24 | leaf1 << 25
-    unsigned int child;   // entry position of inner child 0 | of inner child 1 << 16
-    unsigned int leaf;    // triangles | leaves << 16 reserved by this subtree before this entry's leaves
-};
-
-// One workgroup per range of at most `cap` triangles.
-//   1. topology, level by level, entirely in LDS (keys, the entry list that doubles as the queue): splits, leaf
-//      decisions, positions of the children in the list, leaf storage offsets;
-//   2. ONE pair of global atomics reserves the subtree's node indices and leaf storage;
-//   3. every entry is written in parallel (node words, leaf boxes and slots): no level dependency any more;
-//   4. bottom-up refit over the levels, children found through the LDS list.
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void lbvh_subtree_kernel(EmitCtx c, int cap)
-{
-    extern __shared__ int smem[];
-    __shared__ EmitShared sh;
-    __shared__ unsigned int s_entCount, s_leafCtr;
-    unsigned int* sKeys = reinterpret_cast<unsigned int*>(smem);           // [cap]
-    SubEntry* ent = reinterpret_cast<SubEntry*>(smem + cap);               // [cap]: a subtree over m triangles has < m inner nodes
-    const unsigned int numSub = c.st->numSub;
-    const int tid = threadIdx.x;
-    unsigned int deepest = 0;
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) sh.item = atomicAdd(&c.st->subNext, 1u);
-        __syncthreads();
-        const unsigned int item = sh.item;
-        if (item >= numSub) break;
-        const int4 root = c.subList[item];
-        const int m = root.z - root.y;
-        for (int k = tid; k < m; k += THREADS) sKeys[k] = c.keys[root.y + k];
-        if (tid == 0) {
-            ent[0].range = (unsigned int)m << 16;  // [0, m)
-            s_entCount = 1; s_leafCtr = 0;
-            sh.lvlOfs[0] = 0;
-        }
-        lds_barrier();
-
-        // ---- 1. topology ------------------------------------------------------------------------------
-        int lv = 0;
-        unsigned int lvlBegin = 0, lvlEnd = 1;
-        for (int lvl = root.w; lvl < 30 && lvlBegin < lvlEnd; lvl++, lv++) {
-            const int levelBit = 29 - lvl;
-            for (unsigned int e = lvlBegin + tid; e < lvlEnd; e += THREADS) {
-                const unsigned int rg = ent[e].range;
-                const int nStart = (int)(rg & 0xFFFFu), nEnd = (int)(rg >> 16);
-                const unsigned int kFirst = sKeys[nStart], kLast = sKeys[nEnd - 1];
-                const unsigned int diff = (kFirst ^ kLast) & ((2u << levelBit) - 1u);
-                const int level = diff ? 31 - __clz((int)diff) : -1;
-                const int split = level >= 0 ? find_split_small<3>(sKeys, nStart, nEnd, level, (kFirst >> level) & 1)
-                                             : (nStart + nEnd) >> 1;  // identical keys: median (:282)
-                const bool leaf0 = (split - nStart) <= c.leafSize || levelBit == 0;
-                const bool leaf1 = (nEnd - split) <= c.leafSize || levelBit == 0;
-                const unsigned int inner = (leaf0 ? 0u : 1u) + (leaf1 ? 0u : 1u);
-                const unsigned int lf = (leaf0 ? ((unsigned int)(split - nStart) + 0x10000u) : 0u) +
-                                        (leaf1 ? ((unsigned int)(nEnd - split) + 0x10000u) : 0u);
-                unsigned int pos = inner ? atomicAdd(&s_entCount, inner) : 0u;
-                const unsigned int leafOfs = lf ? atomicAdd(&s_leafCtr, lf) : 0u;
-                unsigned int child = 0;
-                if (!leaf0) { ent[pos].range = (unsigned int)nStart | ((unsigned int)split << 16); child = pos; pos++; }
-                if (!leaf1) { ent[pos].range = (unsigned int)split | ((unsigned int)nEnd << 16); child |= pos << 16; }
-                ent[e].split = (unsigned int)split | ((unsigned int)(level + 1) << 16) | (leaf0 ? (1u << 24) : 0u) | (leaf1 ? (1u << 25) : 0u);
-                ent[e].child = child;
-                ent[e].leaf = leafOfs;
-            }
-            lds_barrier();
-            lvlBegin = lvlEnd;
-            lvlEnd = s_entCount;
-            if (tid == 0) sh.lvlOfs[lv + 1] = lvlBegin;
-            lds_barrier();  // every thread has read s_entCount before the next level adds to it
-        }
-        const unsigned int numEnt = lvlBegin;  // every entry of the subtree
-        deepest = max(deepest, (unsigned int)(root.w + lv));
-
-        // ---- 2. node indices and leaf storage of the whole subtree ---------------------------------------
-        if (tid == 0) {
-            const unsigned int lc = s_leafCtr;
-            sh.nodeBase = numEnt > 1 ? atomicAdd(&c.st->nodeCount, numEnt - 1) : 0u;
-            sh.leafBase = lc ? atomicAdd(&c.st->leafPtr, ((unsigned long long)(lc & 0xFFFFu) << 32) | (unsigned long long)(lc >> 16)) : 0ull;
-        }
-        __syncthreads();
-        const unsigned int nodeBase = sh.nodeBase;
-        const unsigned long long leafBase = sh.leafBase;
-        const bool overflow = numEnt > 1 && nodeBase + (numEnt - 1) > c.nodeCap;  // cannot happen with ntr_lbvh_capacity() buffers
-        if (overflow && tid == 0) atomicOr(&c.st->overflow, 1u);
-
-        // ---- 3. all entries at once ------------------------------------------------------------------------
-        for (unsigned int e = tid; e < numEnt && !overflow; e += THREADS) {
-            const SubEntry en = ent[e];
-            const int nIdx = e == 0 ? root.x : (int)(nodeBase + e - 1);
-            const int nStart = root.y + (int)(en.range & 0xFFFFu), nEnd = root.y + (int)(en.range >> 16);
-            const int split = root.y + (int)(en.split & 0xFFFFu);
-            const int level = (int)((en.split >> 16) & 0xFFu) - 1;
-            const bool isLeaf[2] = {((en.split >> 24) & 1u) != 0u, ((en.split >> 25) & 1u) != 0u};
-            const int cs[2] = {nStart, split}, ce[2] = {split, nEnd};
-            const unsigned int cpos[2] = {en.child & 0xFFFFu, en.child >> 16};
-            unsigned long long lp = leafBase + (((unsigned long long)(en.leaf & 0xFFFFu) << 32) | (unsigned long long)(en.leaf >> 16));
-            int* nd = c.nodes + (size_t)nIdx * 16;
-            int ch[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (isLeaf[k]) {
-                    const int out = (int)(lp >> 32) * 3 + (int)(lp & 0xFFFFFFFFull);  // createLeaf (:176-181)
-                    lp += ((unsigned long long)(ce[k] - cs[k]) << 32) + 1ull;
-                    ch[k] = ~out;
-                    emit_leaf(c, out, cs[k], ce[k], nd, k);
-                } else {
-                    ch[k] = (int)(nodeBase + cpos[k] - 1) * 64;
-                }
-            }
-            nd[12] = ch[0]; nd[13] = ch[1]; nd[14] = level % 3; nd[15] = 0;
-        }
-        __syncthreads();  // the leaf boxes are visible to the whole workgroup from here
-
-        // ---- 4. refit, deepest level first: an inner child's box is the union of that child's two boxes ---------
-        for (int l = lv - 1; l >= 0 && !overflow; l--) {
-            const unsigned int b0 = sh.lvlOfs[l], b1 = sh.lvlOfs[l + 1];
-            for (unsigned int e = b0 + tid; e < b1; e += THREADS) {
-                const SubEntry en = ent[e];
-                const int nIdx = e == 0 ? root.x : (int)(nodeBase + e - 1);
-                float* nf = reinterpret_cast<float*>(c.nodes + (size_t)nIdx * 16);
-                const unsigned int cpos[2] = {en.child & 0xFFFFu, en.child >> 16};
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    if ((en.split >> (24 + k)) & 1u) continue;
-                    const float4* cn = reinterpret_cast<const float4*>(c.nodes + (size_t)(nodeBase + cpos[k] - 1) * 16);
-                    const float4 a = cn[0], b = cn[1], cc = cn[2];
-                    reinterpret_cast<float4*>(nf)[k] = make_float4(fminf(a.x, b.x), fmaxf(a.y, b.y), fminf(a.z, b.z), fmaxf(a.w, b.w));
-                    reinterpret_cast<float2*>(nf)[4 + k] = make_float2(fminf(cc.x, cc.z), fmaxf(cc.y, cc.w));
-                }
-            }
-            __syncthreads();  // the level above reads these boxes (same workgroup, same CU)
-        }
-    }
-    if (tid == 0 && deepest) atomicMax(&c.st->maxLevel, deepest);
-}
-
-__global__ __launch_bounds__(TOP_THREADS) void lbvh_top_refit_kernel(const LbvhState* __restrict__ st, const int* __restrict__ topLst,
-                                                                     int* nodes)
-{
-    __shared__ unsigned int ofs[34];
-    const int lv = (int)st->topLevels;
-    if ((int)threadIdx.x <= lv) ofs[threadIdx.x] = st->topLvlOfs[threadIdx.x];
-    __syncthreads();
-    refit_levels<TOP_THREADS>(ofs, lv, topLst, nodes);
-}
-
-#ifdef NTR_EXPERIMENTS // cell-table top pass
-// Refit of the cell-table top: the oversize cells' levels first (deepest first), then the trie levels bottom-up, each
-// level's top nodes found through the heap-indexed map.
-__global__ __launch_bounds__(TOP_THREADS) void lbvh_top_cells_refit_kernel(const LbvhState* __restrict__ st, const int* __restrict__ topLst,
-                                                                           const int* __restrict__ topIdx, int* nodes)
-{
-    __shared__ unsigned int ofs[34];
-    const int lv = (int)st->topLevels;
-    if ((int)threadIdx.x <= lv) ofs[threadIdx.x] = st->topLvlOfs[threadIdx.x];
-    __syncthreads();
-    if (lv) refit_levels<TOP_THREADS>(ofs, lv, topLst, nodes);
-    for (int L = (int)st->topTrieLevels - 1; L >= 0; L--) {
-        for (unsigned int h = (1u << L) + threadIdx.x; h < (2u << L); h += TOP_THREADS) {
-            const int nIdx = topIdx[h];
-            if (nIdx >= 0) refit_node(nodes + (size_t)nIdx * 16, nodes);
-        }
-        __syncthreads();  // the level above reads these boxes (same workgroup, same CU)
-    }
-}
-
-#endif  // NTR_EXPERIMENTS
+#define NTR_LBVH_TOPDOWN_PART 2
+#include "lbvh_topdown.h"   // the top-down fallback (small scenes, oversize leaves)
+#undef NTR_LBVH_TOPDOWN_PART
+#ifdef NTR_EXPERIMENTS
+#define NTR_LBVH_EXP_SECTION 5
+#include "lbvh_kernels_exp.h"
+#undef NTR_LBVH_EXP_SECTION
+#endif
 
 
 // =====================================================================================================================
@@ -1785,72 +1038,12 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
 
 using namespace ntr;
 
-namespace {
-// Phase boundaries are recorded as events on the stream and read back after ONE synchronisation at
-// the end of the build, so the timed build has no host round trips inside it.
-struct PhaseEvents {
-    enum { N = 7 };
-    hipEvent_t ev[N] = {};
-    hipStream_t s;
-    explicit PhaseEvents(hipStream_t st) : s(st) { for (auto& e : ev) (void)hipEventCreate(&e); }
-    ~PhaseEvents() { for (auto& e : ev) (void)hipEventDestroy(e); }
-    void mark(int i) { (void)hipEventRecord(ev[i], s); }
-    float ms(int a, int b) { float v = 0; (void)hipEventElapsedTime(&v, ev[a], ev[b]); return v; }
-};
-
-// Grow-only scratch memory of the builder, kept between builds: a rebuild per frame must not pay nine
-// hipMalloc/hipFree pairs.  One workspace PER DEVICE (one caller per device at a time, as the rest of the
-// C-ABI; host threads driving different devices never touch each other's workspace).  A workspace is only
-// regrown after the device has drained, so a build still in flight on another stream keeps its memory.
-struct Workspace {
-    void* p = nullptr;
-    size_t bytes = 0;
-};
-constexpr int kMaxDevices = 64;
-Workspace g_ws[kMaxDevices];
-std::mutex g_wsMu;
-
-int workspace_reserve(size_t bytes, void** out)
-{
-    int dev = 0;
-    NTR_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= kMaxDevices) return set_error(NTR_ERR_INVALID, "device index %d out of range", dev);
-    std::lock_guard<std::mutex> lk(g_wsMu);
-    Workspace& w = g_ws[dev];
-    if (w.p && w.bytes < bytes) {
-        NTR_HIP(hipDeviceSynchronize());
-        NTR_HIP(hipFree(w.p));
-        w.p = nullptr; w.bytes = 0;
-    }
-    if (!w.p) {
-        NTR_HIP(hipMalloc(&w.p, bytes));
-        w.bytes = bytes;
-    }
-    *out = w.p;
-    return NTR_OK;
-}
-
-int workspace_release()
-{
-    int dev = 0;
-    NTR_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= kMaxDevices) return set_error(NTR_ERR_INVALID, "device index %d out of range", dev);
-    std::lock_guard<std::mutex> lk(g_wsMu);
-    Workspace& w = g_ws[dev];
-    if (w.p) {
-        NTR_HIP(hipDeviceSynchronize());
-        NTR_HIP(hipFree(w.p));
-        w.p = nullptr; w.bytes = 0;
-    }
-    return NTR_OK;
-}
-
-struct Carver {  // 256-byte aligned slices of the workspace
-    size_t off = 0;
-    size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
-};
-
-}  // namespace
+#include "lbvh_workspace.h"   // PhaseEvents, the per-device workspace, Carver
+#ifdef NTR_EXPERIMENTS
+#define NTR_LBVH_EXP_SECTION 6
+#include "lbvh_kernels_exp.h"
+#undef NTR_LBVH_EXP_SECTION
+#endif
 
 extern "C" {
 
@@ -2038,39 +1231,9 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     LbvhState h;
 #ifdef NTR_EXPERIMENTS
     if (levelSync) {
-        LbvhState init;
-        memset(&init, 0, sizeof(init));
-        init.lvlNodes[0] = 1;
-        init.nodeCount = 1;
-        NTR_HIP(hipMemcpyAsync(state, &init, sizeof(init), hipMemcpyHostToDevice, s));
-        int* q0 = (int*)(ws + oQ0);
-        int* q1 = (int*)(ws + oQ1);
-        const int root[3] = {0, 0, n};
-        NTR_HIP(hipMemcpyAsync(q0, root, 12, hipMemcpyHostToDevice, s));
-        int emitBlocks = (n / 2 + 255) / 256;
-        if (emitBlocks < 1) emitBlocks = 1;
-        if (emitBlocks > 2048) emitBlocks = 2048;
-        int* qIn = q0;
-        int* qOut = q1;
-        for (int lvl = 0; lvl < 30; lvl++) {  // kernel bit = 29 - lvl (HLBVHBuilder.cpp:344)
-            hipLaunchKernelGGL(lbvh_emit_kernel, dim3(emitBlocks), dim3(256), 0, s, lvl, 29 - lvl, leafSize, state, keys, triSorted,
-                               (const float4*)(ws + oWoop), qIn, qOut, (int*)d_nodes, nodeCap, (float4*)d_triWoop, d_triIndex);
-            int* t = qIn; qIn = qOut; qOut = t;
-        }
-        pe.mark(4);
-        // the refit launches are sized from the level counts: one read-back, as the reference does per level
-        NTR_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, s));
-        NTR_HIP(hipStreamSynchronize(s));
-        int numLevels = 0;
-        while (numLevels < 31 && h.lvlNodes[numLevels] > 0) numLevels++;
-        for (int lvl = numLevels - 1; lvl >= 0; lvl--) {
-            int blocks = (int)((h.lvlNodes[lvl] + 255) / 256);
-            if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(lbvh_refit_kernel, dim3(blocks), dim3(256), 0, s, lvl, epsilon, (const LbvhState*)state, d_triVtxIndex,
-                               d_vtxPos, triSorted, (int*)d_nodes);
-        }
-        pe.mark(5);
-        pe.mark(6);
+        const int rc = lbvh_levelsync_emit_refit(s, n, leafSize, epsilon, state, h, keys, triSorted, ws, oWoop, oQ0, oQ1, d_nodes, nodeCap, d_triWoop, d_triIndex,
+                                                 d_triVtxIndex, d_vtxPos, pe);
+        if (rc != NTR_OK) return rc;
     } else
 #endif
     {
@@ -2080,7 +1243,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         c.leafSize = leafSize; c.subList = (int4*)(ws + oSubList);
         // ranges of at most `spill` triangles become one workgroup's subtree: about 1.5 n / spill of them
         // as large as a workgroup's LDS entry list allows: the LDS levels of a subtree are cheaper than the top pass's
-        // global ones (sweep: scripts/lbvh_split_sweep.sh)
+        // global ones (sweep: scripts/studies/lbvh_split_sweep.sh)
         c.spill = spillSize;
         int4* q0 = (int4*)(ws + oQ0);
         int4* q1 = (int4*)(ws + oQ1);

@@ -156,7 +156,7 @@ static void tunables_load_locked()
     t.handoffFlags = env_int("NTR_TRACE_HANDOFF_FLAGS", 0);       // 1: raised priority for waves that took continuations; 2: batches with pool K = 1 run as one-chunk pools and hand their tails off too
     t.unified = env_int("NTR_TRACE_UNIFIED", 1);                  // kepler_dynamic_fetch: unified-step loop (0 = while-while loop + dynamic fetch)
     t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", -1);    // per-ray kernel with the unified-step loop: -1 = closest-hit launches always, any-hit launches on trees flagged NTR_BVH_WIDE_LEAVES; 0 / 1 = never / always
-    t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/persist_diag.py)
+    t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/studies/persist_diag.py)
     t.autoHint = env_int("NTR_TRACE_AUTO_HINT", 1);               // dispatch order learned from the previous launch of the same batch (stream, rays, count, BVH)
     t.autoHintMinRays = env_int("NTR_TRACE_AUTO_HINT_MIN_RAYS", 1 << 17);
     t.predict = env_int("NTR_TRACE_PREDICT", 1);
@@ -195,7 +195,7 @@ extern "C" int ntr_tunables_reload(void)
 }
 
 #ifdef NTR_EXPERIMENTS
-// Diagnostic hooks of scripts/timeline*.py and scripts/order_experiment.py; compiled only into experiment builds
+// Diagnostic hooks of scripts/timeline*.py and scripts/studies/order_experiment.py; compiled only into experiment builds
 // (`make exp` -> libntrace_amd_exp.so).  The shipped library has no way to inject a device pointer into a launch.
 static unsigned long long* g_expTimeline = nullptr;
 static const unsigned int* g_expOrder = nullptr;
@@ -632,7 +632,7 @@ static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, i
 
 // Pool K of an incoherent batch.  Long rays (big trees) amortise a deeper private pool, and the batch must oversubscribe the machine
 // (rays / 64 / K waves against 7 168 wave slots): below that a launch is bound by its longest rays, and fewer, longer-lived waves only
-// lengthen that path.  Box rays, K = 1 / 2 / 4 (scripts/small_batch_minipool.py, profiles/r03_minipool_batch_sizes.jsonl), ms:
+// lengthen that path.  Box rays, K = 1 / 2 / 4 (scripts/studies/small_batch_minipool.py, profiles/r03_minipool_batch_sizes.jsonl), ms:
 //   courtyard-10M  2^19: 2.81 / 3.12 / 3.52   2^20: 3.74 / 3.33 / 3.55   1.5 M: 5.23 / 4.36 / 3.84   2^21: 6.79 / 5.38 / 4.73   2^22: 12.8 / 9.9 / 7.8
 //   hairball-2.8M  2^19: 1.76 / 1.50 / 1.69   2^20: 2.79 / 2.38 / 2.39   1.5 M: 3.92 / 3.10 / 3.28   2^21: 5.04 / 3.77 / 3.80   2^22: 9.5 / 6.6 / 6.4
 //   atrium-262k    2^19: .230 / .217 / .276   2^20: .374 / .375 / .349   1.5 M: .520 / .483 / .520   2^21: .670 / .598 / .627   2^22: 1.24 / 1.04 / 1.03
@@ -688,7 +688,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.numHeads = 8;
     p.numBlocks = 0;
     p.orderBlocks = 0;
-    // persistent kernels (scripts/persist_sweep.py): 64-ray chunks, 6 workgroups per CU; dynamic fetch only for the kernel
+    // persistent kernels (scripts/studies/persist_sweep.py): 64-ray chunks, 6 workgroups per CU; dynamic fetch only for the kernel
     // named after it (it costs about 10 % here: refilled lanes de-cohere a wave's node fetches)
     const Tunables tun = tunables();
     p.chunk = tun.chunk;

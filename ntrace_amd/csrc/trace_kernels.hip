@@ -1057,7 +1057,7 @@ __device__ __noinline__ int cont_consume(unsigned int* ctl, unsigned long long* 
 // Variant 3: per-ray kernel with a wave-private mini-pool (round 3).  A hardware-scheduled 64-thread workgroup owns K x 64 consecutive
 // rays instead of 64: its lanes start on the first 64, and a lane that finishes takes the wave's next unstarted ray (ballot + mbcnt
 // prefix over the wave's OWN range: no atomic, no shared head).  On divergent batches the per-ray kernel's waves live as long as their
-// longest ray while most lanes idle (lane utilisation 0.22-0.48 on the LBVH scenes, scripts/divergence_study.py); list scheduling K x 64
+// longest ray while most lanes idle (lane utilisation 0.22-0.48 on the LBVH scenes, scripts/studies/divergence_study.py); list scheduling K x 64
 // rays on 64 lanes lifts that to 0.33-0.63 (K = 2) / 0.49-0.77 (K = 4) by the per-ray step counts, at the price of a longer critical
 // path per wave -- which is why the pool stays small and private: the global pool of the persistent kernels keeps every lane busy
 // until it runs dry, and then 6 144 waves each hold a few long rays (a tail of 60-70 % of their launch, profiles/r03_divergence_timelines.jsonl).
@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(256) void selftest_division_kernel(const float* __r
 // that the long-lived waves start early instead of forming the tail of the launch.  Blocks are
 // only CLASSIFIED (NTR_SCHED_CLASSES linear classes of the maximum cost) and keep their original
 // order inside a class: neighbouring blocks trace neighbouring rays, and a full sort by cost was
-// measured slower than the coarse one because it gives that locality up (scripts/order_experiment.py).
+// measured slower than the coarse one because it gives that locality up (scripts/studies/order_experiment.py).
 // One workgroup; stable counting sort with a per-thread segment of the block range.
 // ---------------------------------------------------------------------------------
 constexpr int SCHED_THREADS = 256;   // 64 classes x 256 threads x 4 B = the 64 KB of static LDS

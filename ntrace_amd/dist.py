@@ -30,7 +30,7 @@ def balanced_cuts(block_cost, num_rays, world, flat_share=1.0, block=256):
     flat_share   the part of a block's cost that does not depend on where its rays go -- ray load / result store and the AO
                  rays of its hits, which are short and cost about the same everywhere -- as a multiple of the MEAN predicted
                  cost: a block weighs cost[b] + flat_share * mean(cost).  0 balances the predictor alone; a large value tends
-                 to equal ray counts (shard_range).  Fitted on the simulated ranks of scripts/shard_balance_study.py.
+                 to equal ray counts (shard_range).  Fitted on the simulated ranks of scripts/studies/shard_balance_study.py.
     The ranges stay contiguous in the PixelTable index space, so a rank still owns a compact set of screen tiles."""
     import numpy as np
     c = np.asarray(block_cost, dtype=np.float64).reshape(-1)

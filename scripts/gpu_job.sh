@@ -11,11 +11,11 @@
 #   configs          scripts/config_table.py
 #   profile[:what]   scripts/profile_round.sh <tag> [lbvh|trace|hbm ...] (':' separated list)
 #   prof_bench       rocprofv3 --kernel-trace --stats of the bench command itself
-#   shard            scripts/shard_balance_study.py
-#   lbvh             scripts/lbvh_sweep3.py
+#   shard            scripts/studies/shard_balance_study.py
+#   lbvh             scripts/studies/lbvh_sweep3.py
 #   fuzz:<seconds>   tests/fuzz_parity.py for that long
 #   ab:<reps>        scripts/ab_bench.sh: bench.py alternately against libntrace_amd.so and libntrace_amd_ab.so
-#   py:<script>[:args...]   python3 scripts/<script>.py args (':' separated); pyexp: the same with libntrace_amd_exp.so
+#   py:<script>[:args...]   python3 scripts/<script>.py (or scripts/studies/<script>.py) args (':' separated); pyexp: the same with libntrace_amd_exp.so
 set -u
 TAG=${1:?tag}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
@@ -52,18 +52,20 @@ EOF
     python3 scripts/summarize_rocprof.py trace $OUT/prof_bench > $OUT/bench_kernel_summary.txt 2>&1; head -n 12 $OUT/bench_kernel_summary.txt
     find $OUT/prof_bench -name "*.csv" -size +8M -delete ;;
   shard)
-    timeout -k 5 1200 python3 scripts/shard_balance_study.py ${ARG//:/ } > $OUT/shard_balance.jsonl 2> $OUT/shard_balance.err; echo "rc=$?"; cat $OUT/shard_balance.jsonl; tail -n 3 $OUT/shard_balance.err ;;
+    timeout -k 5 1200 python3 scripts/studies/shard_balance_study.py ${ARG//:/ } > $OUT/shard_balance.jsonl 2> $OUT/shard_balance.err; echo "rc=$?"; cat $OUT/shard_balance.jsonl; tail -n 3 $OUT/shard_balance.err ;;
   lbvh)
-    timeout -k 5 900 python3 scripts/lbvh_sweep3.py ${ARG//:/ } > $OUT/lbvh_sweep.jsonl 2> $OUT/lbvh_sweep.err; echo "rc=$?"; cat $OUT/lbvh_sweep.jsonl; tail -n 3 $OUT/lbvh_sweep.err ;;
+    timeout -k 5 900 python3 scripts/studies/lbvh_sweep3.py ${ARG//:/ } > $OUT/lbvh_sweep.jsonl 2> $OUT/lbvh_sweep.err; echo "rc=$?"; cat $OUT/lbvh_sweep.jsonl; tail -n 3 $OUT/lbvh_sweep.err ;;
   fuzz)
     timeout -k 5 $((ARG + 120)) python3 tests/fuzz_parity.py --seconds $ARG --seed ${FUZZ_SEED:-41} > $OUT/fuzz.json 2> $OUT/fuzz.err; echo "rc=$?"; tail -c 1500 $OUT/fuzz.json; tail -n 3 $OUT/fuzz.err ;;
   ab)      # interleaved A/B of libntrace_amd.so and libntrace_amd_ab.so: ab:<reps>
     AB_OUT=$OUT bash scripts/ab_bench.sh ${ARG:-3} 2>&1 | tail -n 4 ;;
   pyexp)   # py: with the experiment build of the library (diagnostic hooks)
     SCRIPT=${ARG%%:*}; REST=""; [[ "$ARG" == *:* ]] && REST=${ARG#*:}
+    [ -f scripts/$SCRIPT.py ] || SCRIPT=studies/$SCRIPT; mkdir -p $OUT/studies
     NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_exp.so timeout -k 5 1500 python3 scripts/$SCRIPT.py ${REST//:/ } > $OUT/$SCRIPT.out 2> $OUT/$SCRIPT.err; echo "rc=$?"; tail -n 40 $OUT/$SCRIPT.out | cut -c1-1500; tail -n 5 $OUT/$SCRIPT.err ;;
   py)
     SCRIPT=${ARG%%:*}; REST=""; [[ "$ARG" == *:* ]] && REST=${ARG#*:}
+    [ -f scripts/$SCRIPT.py ] || SCRIPT=studies/$SCRIPT; mkdir -p $OUT/studies
     timeout -k 5 1500 python3 scripts/$SCRIPT.py ${REST//:/ } > $OUT/$SCRIPT.out 2> $OUT/$SCRIPT.err; echo "rc=$?"; tail -n 40 $OUT/$SCRIPT.out; tail -n 5 $OUT/$SCRIPT.err ;;
   *) echo "unknown step $STEP" ;;
   esac

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-wave timelines of the per-ray and the dynamic-fetch kernel on divergent batches (device LBVH scenes): when does the
 ray pool run dry (first wave to end), how long is the tail after it, how many waves are resident over time.
-Needs the experiment build: make -C ntrace_amd/csrc exp; NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_exp.so python3 scripts/divergence_timeline.py courtyard
+Needs the experiment build: make -C ntrace_amd/csrc exp; NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_exp.so python3 scripts/studies/divergence_timeline.py courtyard
 usage: divergence_timeline.py <scene> [batch ...]      batches: primary diffuse incoherent"""
 import json
 import os
@@ -9,7 +9,8 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))                    # scripts/ (workloads.py)
 import torch  # noqa: E402
 
 import ntrace_amd as nt  # noqa: E402

@@ -3,7 +3,8 @@
 Per mode the per-launch times by torch events (asynchronous launches, as bench.py issues them)."""
 import json, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))                    # scripts/ (workloads.py)
 import torch
 import ntrace_amd as nt
 from ntrace_amd import scenes

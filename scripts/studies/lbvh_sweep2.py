@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""LBVH build time of the three scene sizes over the emit paths: bottom-up emit (LDS meetings on / off), cell-table top +
-subtree workgroups, round-1 top / sort.  One JSON line per configuration (best of 6 builds)."""
+"""LBVH build time of the three scene sizes over the subtree size (NTR_LBVH_SPLIT), the subtree workgroup size and the
+round-1 sort / top pass, one JSON line per configuration (best of 6 builds)."""
 import json
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))                    # scripts/ (workloads.py)
 import torch  # noqa: E402
 
 import ntrace_amd as nt  # noqa: E402
@@ -30,7 +31,10 @@ for name in which:
     dw = torch.zeros(capw, dtype=torch.uint8, device=dev)
     di = torch.zeros(capi, dtype=torch.uint8, device=dev)
     mn, mx = pos.min(0), pos.max(0)
-    configs = [dict(), dict(NTR_LBVH_AGG_STAGED=0), dict(NTR_LBVH_AGG_STAGED=1), dict(NTR_LBVH_AGG_LDS=0), dict(NTR_LBVH_LEGACY_SORT=1), dict(NTR_LBVH_EMIT=1), dict(NTR_LBVH_LEGACY_TOP=1, NTR_LBVH_LEGACY_SORT=1)]
+    configs = [dict(NTR_LBVH_LEGACY_TOP=1, NTR_LBVH_LEGACY_SORT=1), dict(NTR_LBVH_LEGACY_TOP=1), dict(NTR_LBVH_LEGACY_SORT=1)]
+    for spill in (256, 512, 1024, 2048, 3072, 5120):
+        for thr in (64, 128, 256):
+            configs.append(dict(NTR_LBVH_SPLIT=spill, NTR_LBVH_SUB_THREADS=thr))
     for cfg in configs:
         nt.set_tunables(**cfg)
         best = None
@@ -40,5 +44,4 @@ for name in which:
             best = r if best is None or r.seconds < best.seconds else best
         nt.set_tunables(**{k: None for k in cfg})
         print(json.dumps(dict(scene=name, triangles=n, cfg=cfg, ms=best.seconds * 1e3, phases=dict(morton=best.mortonMs, sort=best.sortMs, box=best.woopMs,
-                                                                                               emit=best.emitMs, rest=best.refitMs), nodes=best.numNodes,
-                              leaves=best.numLeaves, levels=best.numLevels)), flush=True)
+                                                                                               top=best.emitMs, rest=best.refitMs), nodes=best.numNodes)), flush=True)

@@ -3,14 +3,15 @@
 one launch of each kernel on the 1080p primary batch and on one 2^20-ray AO batch of atrium-262k, reduced to
   * the number of waves resident over time (10 us bins) -- is the machine full?
   * wave lifetimes, and for the persistent kernel the share of a wave's life spent refilling.
-Needs the experiment build: make -C ntrace_amd/csrc exp; NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_exp.so python scripts/persist_diag.py"""
+Needs the experiment build: make -C ntrace_amd/csrc exp; NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_exp.so python scripts/studies/persist_diag.py"""
 import json
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))                    # scripts/ (workloads.py)
 import torch  # noqa: E402
 
 import ntrace_amd as nt  # noqa: E402

@@ -4,7 +4,8 @@ nodes of depth <= D whose boxes a sample ray segment intersects.  Predictor comp
 (numpy); the launch is re-timed under the derived order (NTR_TRACE_ORDER)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))                    # scripts/ (workloads.py)
 import torch
 import ntrace_amd as nt
 from ntrace_amd import scenes

@@ -3,7 +3,8 @@
 wall-clock cost of the bookkeeping, on the bench workload's primary batch and one AO batch."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))                    # scripts/ (workloads.py)
 import torch
 import ntrace_amd as nt
 from ntrace_amd import scenes

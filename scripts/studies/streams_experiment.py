@@ -3,7 +3,8 @@
 (tails of one batch overlap the start of the next) and compare wall-clock per step with the single-stream order."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))                    # scripts/ (workloads.py)
 import torch
 import ntrace_amd as nt
 from ntrace_amd import scenes

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """In-process A/B of tracer variants and tunables on the bench workload (interleaved rounds,
-median + min of per-launch HIP-event times).  Usage: python scripts/trace_sweep.py [--ao-radius R]"""
+median + min of per-launch HIP-event times).  Usage: python scripts/studies/trace_sweep.py [--ao-radius R]"""
 import argparse
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))                    # scripts/ (workloads.py)
 import torch  # noqa: E402
 
 import ntrace_amd as nt  # noqa: E402
