@@ -137,7 +137,6 @@ __global__ __launch_bounds__(MORTON_THREADS) void lbvh_morton_hist_kernel(int n,
     }
 }
 
-
 // ---- Woop rows (emitTreeKernel.cu:574-635) ---------------------------------------------------------
 __device__ __forceinline__ void woop_rows_verts(float v0x, float v0y, float v0z, float v1x, float v1y, float v1z, float v2x, float v2y,
                                                 float v2z, float4& r0, float4& r1, float4& r2)
@@ -175,7 +174,6 @@ __device__ __forceinline__ void woop_rows(const int* __restrict__ tri, const flo
 #undef NTR_LBVH_EXP_SECTION
 #endif
 
-
 #ifdef NTR_EXPERIMENTS
 #define NTR_LBVH_EXP_SECTION 3
 #include "lbvh_kernels_exp.h"
@@ -198,7 +196,6 @@ __device__ __forceinline__ void woop_rows(const int* __restrict__ tri, const flo
 #include "lbvh_kernels_exp.h"
 #undef NTR_LBVH_EXP_SECTION
 #endif
-
 
 // =====================================================================================================================
 // Bottom-up ("agglomerative") emit + refit in one pass, indices by prefix counts.
@@ -286,6 +283,8 @@ struct AggCtx {
     AggSlotG* slotG;             // [n + 1][2] meeting slots in memory
     const unsigned int* abortFlag;     // non-zero: the sort gave up (a look-back timed out) -- the keys are not sorted, and the meeting
                                        // protocol (exactly two arrivals per boundary) only terminates on sorted keys: emit nothing
+    unsigned long long* holeNodeBits;  // bit i: node index i was set aside inside a leaf the depth rule enlarged and stays unused (zeroed per build)
+    unsigned long long* holeSlotBits;  // bit o: triWoop / triIndex slot o likewise (the terminator slots of the leaves that were merged)
 };
 
 // exclusive rank of position p (set bits before p) = count before its 1024-block + count inside the block before its 256-tile
@@ -787,6 +786,7 @@ __device__ __forceinline__ void agg_rewrite_big_leaf(const AggCtx& c, int rootSp
             const int idx = agg_node_index(c, j, rootSplit);
             int4* nd = reinterpret_cast<int4*>(c.nodes + (size_t)idx * 16);
             nd[0] = nd[1] = nd[2] = nd[3] = make_int4(0, 0, 0, 0);
+            atomicOr(&c.holeNodeBits[idx >> 6], 1ull << (idx & 63));
         }
         const unsigned long long rm = __ballot(reserved);
         if (lane == 0 && rm) atomicAdd(&c.st->holes, (unsigned int)__popcll(rm));
@@ -796,6 +796,7 @@ __device__ __forceinline__ void agg_rewrite_big_leaf(const AggCtx& c, int rootSp
     for (int o = term + lane; o < endAll; o += 64) {
         c.outWoop[o] = o == term ? make_float4(nz, nz, nz, nz) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         c.outIdx[o] = 0;
+        if (o != term) atomicOr(&c.holeSlotBits[o >> 6], 1ull << (o & 63));
     }
 }
 
@@ -1039,6 +1040,7 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
 using namespace ntr;
 
 #include "lbvh_workspace.h"   // PhaseEvents, the per-device workspace, Carver
+#include "lbvh_compact.h"     // hole compaction (rare)
 #ifdef NTR_EXPERIMENTS
 #define NTR_LBVH_EXP_SECTION 6
 #include "lbvh_kernels_exp.h"
@@ -1126,6 +1128,10 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oArrive = takeIf(bottomUp, ((size_t)n + 1) * 4);
     const size_t oExportCount = takeIf(bottomUp, (size_t)aggTiles * 4);
     const size_t oAggMisc = takeIf(bottomUp, 64);           // [0] number of runs of more than leafSize equal keys
+    // hole bitmasks (node indices / storage slots left unused inside leaves the depth rule enlarged), in whole 512-bit chunks
+    const size_t holeNodeWords = ((((size_t)n + 2 + 63) / 64 + HOLE_CHUNK_WORDS - 1) / HOLE_CHUNK_WORDS) * HOLE_CHUNK_WORDS;
+    const size_t holeSlotWords = ((((size_t)n * 4 + 4 + 63) / 64 + HOLE_CHUNK_WORDS - 1) / HOLE_CHUNK_WORDS) * HOLE_CHUNK_WORDS;
+    const size_t oHoleNodeBits = takeIf(bottomUp, holeNodeWords * 8), oHoleSlotBits = takeIf(bottomUp, holeSlotWords * 8);
     const int cntTiles = (n + 1 + RANK_BLOCK - 1) / RANK_BLOCK;    // prefix-count blocks
     const size_t oAggZeroEnd = cv.off;
     const size_t oOsState = cv.take((size_t)osTiles * 256 * 4);
@@ -1276,6 +1282,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             a.runs = (int4*)(ws + oRuns); a.runCount = aggMisc; a.st = state; a.useLds = tun.lbvhAggLds;
             a.exports = (AggExport*)(ws + oExports); a.exportCount = (unsigned int*)(ws + oExportCount); a.slotG = (AggSlotG*)(ws + oSlot);
             a.abortFlag = osMisc + 4;
+            a.holeNodeBits = (unsigned long long*)(ws + oHoleNodeBits); a.holeSlotBits = (unsigned long long*)(ws + oHoleSlotBits);
             // leaf starts and their prefix counts first: everything after it writes to final places
             hipLaunchKernelGGL(lbvh_leafmark_kernel, dim3(cntTiles), dim3(MARK_THREADS), 0, s, n, leafSize, keys, (unsigned long long*)(ws + oLeafBits),
                                (unsigned long long*)(ws + oRunBits), (unsigned int*)(ws + oTileCount), (unsigned int*)(ws + oSubBase), state);
@@ -1369,10 +1376,20 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     if ((unsigned long long)numNodes * 64ull > 0x76543200ull)
         return set_error(NTR_ERR_OVERFLOW, "ntr_lbvh_build: %u nodes exceed what BVHLayout_Compact's 32-bit child offsets address", numNodes);
     // Bottom-up path: where the depth rule (level bit 0) made a leaf of more than leafSize equal keys, the node indices and terminator
-    // slots the leaf marks had set aside inside it stay unused (zero-filled): the buffers' extents include them, the counts do not.
-    const unsigned int leafs = (unsigned int)(h.leafPtr & 0xFFFFFFFFull);
-    result->numNodes = (int32_t)(numNodes - h.holes);
-    result->numLeaves = (int32_t)(leafs - h.holes);
+    // slots the leaf marks had set aside inside it stay unused (zero-filled).  They are squeezed out here (rare; NTR_LBVH_COMPACT=0 keeps
+    // them: the buffers' extents then include them, the counts do not), so that the extents equal the reference's exact sizes.
+    unsigned int leafs = (unsigned int)(h.leafPtr & 0xFFFFFFFFull);
+    unsigned int holesLeft = h.holes;
+    if (bottomUp && h.holes > 0 && tun.lbvhCompact != 0) {
+        const int rc = lbvh_compact_holes(s, n, numNodes, leafs, h.holes, (const unsigned long long*)(ws + oHoleNodeBits), holeNodeWords,
+                                          (const unsigned long long*)(ws + oHoleSlotBits), holeSlotWords, d_nodes, d_triWoop, d_triIndex);
+        if (rc != NTR_OK) return rc;
+        numNodes -= h.holes;
+        leafs -= h.holes;
+        holesLeft = 0;
+    }
+    result->numNodes = (int32_t)(numNodes - holesLeft);
+    result->numLeaves = (int32_t)(leafs - holesLeft);
     result->numLevels = numLevels;
     result->nodesBytes = (int64_t)numNodes * 64;                // HLBVHBuilder.cpp:382-386
     result->triWoopBytes = ((int64_t)n * 3 + leafs) * 16;

@@ -61,6 +61,11 @@ int workspace_release()
     return NTR_OK;
 }
 
+struct DevMem {   // a temporary device allocation of the rare paths (hole compaction)
+    void* p = nullptr;
+    ~DevMem() { if (p) (void)hipFree(p); }
+};
+
 struct Carver {  // 256-byte aligned slices of the workspace
     size_t off = 0;
     size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }

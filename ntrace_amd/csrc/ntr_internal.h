@@ -14,7 +14,7 @@ struct Tunables {
     int handoff, handoffBelow, handoffMinQueue, handoffKeepWaves, handoffFlags;
     int autoHint, autoHintMinRays, predict, predictPersistent, predictDepth, predictMinRays, predictMinNodes;
     int schedRefreshEvery, schedClasses;
-    int lbvhLevelSync, lbvhSplit, lbvhSubThreads, lbvhLegacyTop, lbvhLegacySort, lbvhEmit, lbvhAggLds, lbvhAggStaged;
+    int lbvhLevelSync, lbvhSplit, lbvhSubThreads, lbvhLegacyTop, lbvhLegacySort, lbvhEmit, lbvhAggLds, lbvhAggStaged, lbvhCompact;
 };
 Tunables tunables();
 

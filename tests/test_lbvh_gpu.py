@@ -86,7 +86,9 @@ def gpu_lbvh(tri, pos, leaf_size=8, epsilon=0.001):
     return nodes, woop, idx, res, (d_nodes, d_woop, d_idx)
 
 
-def check_against_oracle(tri, pos, leaf_size=8, epsilon=0.001, allow_holes=True):
+def check_against_oracle(tri, pos, leaf_size=8, epsilon=0.001, allow_holes=False):
+    """allow_holes: with NTR_LBVH_COMPACT=0 the bottom-up path leaves the slots it had set aside inside leaves the depth rule enlarged; by
+    default they are squeezed out and every extent equals the oracle's (the reference's exact sizes, HLBVHBuilder.cpp:382-386)."""
     nodes, woop, idx, res, keep = gpu_lbvh(tri, pos, leaf_size, epsilon)
     ref = oracle.lbvh_build(tri, pos, leaf_size, epsilon)
     assert res.numNodes == ref["num_inner"] and res.numLeaves == ref["num_leaves"] and res.numLevels == ref["num_levels"]
@@ -125,7 +127,7 @@ def test_lbvh_duplicate_morton_codes_median_split_and_depth_limit():
     far = np.array([[-10, -10, -10], [10, -10, -10], [-10, 10, 10], [10, 10, 10], [9, 10, 10], [10, 9, 10]], dtype=np.float64)
     pos = np.concatenate([p, far]).astype(np.float32)
     tri = np.concatenate([np.arange(n * 3).reshape(-1, 3), np.array([[n * 3, n * 3 + 1, n * 3 + 2], [n * 3 + 3, n * 3 + 4, n * 3 + 5]])]).astype(np.int32)
-    nodes, woop, idx, res, ref, _ = check_against_oracle(tri, pos, leaf_size=2, allow_holes=True)
+    nodes, woop, idx, res, ref, _ = check_against_oracle(tri, pos, leaf_size=2)
     assert res.numLevels >= 12  # ~log2(6000 / 2) median levels below the split that isolates the cluster
 
 
@@ -156,8 +158,17 @@ def test_lbvh_depth_limit_forces_oversized_leaves():
     pos = np.concatenate([p, corner]).astype(np.float32)
     nt_ = len(cells)
     tri = np.concatenate([np.arange(nt_ * 3).reshape(-1, 3), [[nt_ * 3, nt_ * 3 + 1, nt_ * 3 + 2], [nt_ * 3 + 3, nt_ * 3 + 4, nt_ * 3 + 5]]]).astype(np.int32)
-    nodes, woop, idx, res, ref, _ = check_against_oracle(tri, pos, leaf_size=2, allow_holes=True)
+    nodes, woop, idx, res, ref, _ = check_against_oracle(tri, pos, leaf_size=2)
     assert res.numLevels == 30
+    # the bvhcache file written from this tree has the reference's size: S32 layout + 3 x (S64 size + bytes), exact extents
+    assert 4 + 3 * 8 + nodes.nbytes + woop.nbytes + idx.nbytes == 4 + 3 * 8 + ref["nodes"].nbytes + ref["woop"].nbytes + ref["tri_index"].nbytes
+    # the uncompacted form (NTR_LBVH_COMPACT=0): one unused node index and one unused terminator slot per hole, same canonical tree
+    nt.set_tunables(NTR_LBVH_COMPACT=0)
+    try:
+        n2, w2, i2, res2, _, _ = check_against_oracle(tri, pos, leaf_size=2, allow_holes=True)
+        assert n2.nbytes > nodes.nbytes and (n2.nbytes - nodes.nbytes) // 64 == (w2.nbytes - woop.nbytes) // 16
+    finally:
+        nt.set_tunables(NTR_LBVH_COMPACT=None)
     w = woop.view(np.uint32).reshape(-1, 4)
     sizes, a, cur = [], 0, 0
     while a < w.shape[0]:
