@@ -28,14 +28,12 @@
 // leaf placement depend on atomic order in the reference (emitTreeKernel.cu:176,303) and are position ranks here; parity is
 // checked on the canonical (numbering-independent) form.
 #include <hip/hip_runtime.h>
-#include <stdint.h>
 #include <float.h>
-#include <string.h>
-#include <stdlib.h>
 #include <math.h>
-
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include <mutex>
-
 #include "ntr_internal.h"
 #include "radix_sort.h"
 
