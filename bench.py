@@ -455,7 +455,7 @@ def main():
     # ---- N > 1: the mode in which this design scales by construction, in the SAME driver-parsed line: every rank traces a whole frame of
     # its own camera (no ray or record crosses a rank boundary), the same K steps
     frame_per_rank = None
-    if world > 1 and args.scaling == "strong":
+    if (world > 1 or use_dist) and args.scaling == "strong":   # (also at world size 1 under NTR_BENCH_FORCE_DIST=1: the GPU test tier runs this code)
         cam_r = dict(cam)
         eye = np.array(cam_r["eye"], dtype=np.float64)
         eye[2] += 2.0 * rank        # a slow camera move: the frames are distinct and about equally costly

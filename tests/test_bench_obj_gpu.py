@@ -63,3 +63,6 @@ def test_bench_rccl_path_at_world_size_one():
     assert chk["records_compared"] == 640 * 360
     # the library's own gather (ntr_dist_gather_records, RCCL bound by the C-ABI) assembled the same frame
     assert out["gather_native"] and out["gather_native"]["equal_torch_gather"] is True
+    # the frame-per-rank mode reported beside `value` for N > 1 (here: one rank, one whole frame)
+    fpr = out["extras"]["frame_per_rank"]
+    assert fpr["ranks"] == 1 and fpr["steps"] == 2 and fpr["mrays"] > 0 and fpr["ms_per_frame"] > 0
