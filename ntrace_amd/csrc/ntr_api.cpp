@@ -142,6 +142,7 @@ static void tunables_load_locked()
     t.coop = env_int("NTR_TRACE_COOP", 0);
     t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", -1);     // -1: 32 for closest-hit, 24 for any-hit launches (bench-protocol sweep, scripts/jobs/gpu_job_r02ls.sh)
     t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 6);
+    t.blocksPerCUIncoherent = env_int("NTR_TRACE_BLOCKS_PER_CU_INCOHERENT", 3);   // persistent kernels, batches the device finds incoherent (scattered origins): fewer rays in flight = less queueing per step (scripts/studies/inflight_sweep.py)
     t.octant = env_int("NTR_TRACE_OCTANT", 1);
     t.closestWaves = env_int("NTR_TRACE_CLOSEST_WAVES", 1);      // likewise for closest-hit launches: primary +2.1 % with 1
     t.anyHitWaves = env_int("NTR_TRACE_ANYHIT_WAVES", 1);        // waves per workgroup of plain any-hit launches of the per-ray kernel (1, 2, 4): AO +1.7 % with 1
@@ -688,6 +689,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.shardRays = 0;
     p.numHeads = 8;
     p.numBlocks = 0;
+    p.numBlocksIncoherent = 0;
     p.orderBlocks = 0;
     // persistent kernels (scripts/studies/persist_sweep.py): 64-ray chunks, 6 workgroups per CU; dynamic fetch only for the kernel
     // named after it (it costs about 10 % here: refilled lanes de-cohere a wave's node fetches)
@@ -756,6 +758,12 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         int heads = tun.poolHeads < 8 ? 8 : (tun.poolHeads > kPoolHeadsMax ? kPoolHeadsMax : tun.poolHeads & ~7);
         p.numHeads = heads;
         p.numBlocks = numBlocks;
+        // (only the dynamic-fetch kernel: its waves stay full from the pool; the while-while persistent kernel refills a wave only when it is
+        // empty and loses with fewer waves -- hairball box rays 9.3 -> 14.7 ms)
+        if (dynamicFetch && tun.blocksPerCUIncoherent > 0 && tun.blocksPerCUIncoherent < blocksPerCU) {
+            p.numBlocksIncoherent = ds->numCUs * tun.blocksPerCUIncoherent;
+            if (p.numBlocksIncoherent > numBlocks) p.numBlocksIncoherent = numBlocks;
+        }
         p.shardRays = ((chunksTotal + heads - 1) / heads) * p.chunk;
     } else {
         numBlocks = (numRays + blockThreads - 1) / blockThreads;
@@ -820,6 +828,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
             if (variant == NTR_VARIANT_PERSISTENT) {   // every head walks its share of the order: ranges of whole 256-ray blocks
                 p.orderBlocks = orderBlocks;
                 p.shardRays = ((orderBlocks + p.numHeads - 1) / p.numHeads) * 256;
+                p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 2;   // the batch's coherence word: an incoherent batch runs on the smaller grid
             }
         } else {
             predTable = nullptr;   // (a captured launch that found no spare scratch: buffer order)

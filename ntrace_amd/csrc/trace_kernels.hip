@@ -769,6 +769,14 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     lds_char* stage = (lds_char*)&s_stage[__builtin_amdgcn_readfirstlane(wave)][0];
     const bool anyHit = p.anyHit != 0;
     const bool bvhFast = (p.bvhFlags & NTR_BVH_FASTDIV) != 0;
+    // How many rays should be in flight?  Beyond the L2 the chip serves ~56 G requests/s from ~64 k requests in flight on; more in flight
+    // only adds queueing delay, which every ray -- the batch's longest included -- pays per step (EXPERIMENTS.md, gather roof).  A batch the
+    // device found incoherent (pool word > 1: scattered origins, every step a cache miss) is therefore traced by HALF the grid:
+    // courtyard-10M box rays 5.12 -> 4.60 ms, hairball 4.16 -> 3.43 ms; coherent batches keep the full grid (atrium primary 0.57 against
+    // 0.67 ms with half).  Workgroups beyond the effective grid leave at once; everything below counts with the effective grid.
+    int numBlocksEff = p.numBlocks;   // wave-uniform
+    if (p.poolK && *p.poolK > 1u && p.numBlocksIncoherent > 0 && p.numBlocksIncoherent < numBlocksEff) numBlocksEff = p.numBlocksIncoherent;
+    if ((int)blockIdx.x >= numBlocksEff) return;
 
     LaneStack st;
     int spill[SPILL_DEPTH];
@@ -795,7 +803,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     auto range_beg = [&](int h) { return order ? h * p.shardRays : ((h & 7) * (numHeads >> 3) + (h >> 3)) * p.shardRays; };
     int chunkHead = 0;                // wave-uniform: the head the current chunk was taken from
     // chunks of head h handed out statically: one per wave of every block with blockIdx % numHeads == h
-    auto static_rays = [&](int h) { return ((p.numBlocks - h + numHeads - 1) / numHeads) * WAVES * p.chunk; };
+    auto static_rays = [&](int h) { return ((numBlocksEff - h + numHeads - 1) / numHeads) * WAVES * p.chunk; };
     LaneStats ls = {0u, 0u, 0u};
 
     // diagnostic stamps (NTR_TRACE_TIMELINE): wave start, end, cycles spent refilling, refill count
