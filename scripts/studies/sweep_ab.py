@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Sparse leaf sweep A/B on one box: NTR_TRACE_SWEEP_BELOW = 0 / 4 / 8 on the divergent batches (courtyard-10M, hairball-2.8M: 2^21 box rays,
+one diffuse batch, the 1080p primary batch) and on the atrium's primary + AO batch (coherent: must not move), per-ray kernel and
+kepler_dynamic_fetch; records compared with the sweep-free launch.  usage: sweep_ab.py [scene,scene]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import ntrace_amd as nt  # noqa: E402
+from ntrace_amd import scenes  # noqa: E402
+from workloads import lbvh, scene_of, up  # noqa: E402
+
+dev = torch.device("cuda:0")
+names = (sys.argv[1] if len(sys.argv) > 1 else "hairball,courtyard,atrium").split(",")
+for scene in names:
+    tri, pos, cam = scene_of(scene)
+    if scene in ("atrium", "conference"):
+        bvh = nt.sah_build(tri, pos, 1, 1)
+        keep = [up(bvh.nodes), up(bvh.woop), up(bvh.tri_index)]
+        view = nt.BvhView(keep[0].data_ptr(), bvh.nodes.nbytes, keep[1].data_ptr(), bvh.woop.nbytes, keep[2].data_ptr())
+    else:
+        best, keep = lbvh(tri, pos, 1)
+        view = nt.BvhView(keep[0].data_ptr(), best.nodesBytes, keep[1].data_ptr(), best.triWoopBytes, keep[2].data_ptr())
+    view.validate()
+    prim = scenes.primary_rays(cam, 1920, 1080)[0]
+    npr = prim.shape[0]
+    d_prim = up(prim)
+    d_pres = torch.zeros(npr * 16, dtype=torch.uint8, device=dev)
+    nt.set_tunables(NTR_TRACE_SWEEP_BELOW="0")
+    view.trace("fermi_speculative_while_while", npr, False, d_prim.data_ptr(), d_pres.data_ptr())
+    d_nrm = up(scenes.tri_normals(tri, pos))
+    ns, cnt = 8, (1 << 20) // 8
+    diag = float(np.linalg.norm(pos.max(0).astype(np.float64) - pos.min(0)))
+    b_diff = torch.zeros(cnt * ns * 32, dtype=torch.uint8, device=dev)
+    b_ao = torch.zeros(cnt * ns * 32, dtype=torch.uint8, device=dev)
+    b_a = torch.zeros(cnt * ns, dtype=torch.int32, device=dev)
+    first = min(900000, npr - cnt)
+    nt.raygen_ao(b_diff.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_prim.data_ptr(), d_pres.data_ptr(), d_nrm.data_ptr(), first, cnt, ns, cam["far"], 0xFFF2D5E4)
+    nt.raygen_ao(b_ao.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_prim.data_ptr(), d_pres.data_ptr(), d_nrm.data_ptr(), first, cnt, ns,
+                 5.0 if scene == "atrium" else 5.0 * diag / 4300.0, 0xFFF2D5E4)
+    torch.cuda.synchronize()
+    batches = [("primary", d_prim, npr, False), ("ao", b_ao, cnt * ns, True), ("diffuse", b_diff, cnt * ns, False)]
+    if scene not in ("atrium", "conference"):
+        batches.append(("incoherent", up(scenes.box_rays(pos, 1 << 21, seed=21)), 1 << 21, False))
+    for bname, d_rays, n, any_hit in batches:
+        d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        for kernel in ("fermi_speculative_while_while", "kepler_dynamic_fetch"):
+            ref = None
+            row = dict(scene=scene, batch=bname, kernel=kernel)
+            for sw in ("0", "8", "4", "0", "8"):
+                nt.set_tunables(NTR_TRACE_SWEEP_BELOW=sw)
+                rr = d_rays.clone()   # a new buffer: a new scheduling-feedback entry per setting
+                ts = [view.trace(kernel, n, any_hit, rr.data_ptr(), d_res.data_ptr()) * 1e3 for _ in range(7)]
+                got = d_res.cpu().numpy().view(nt.RESULT_DTYPE).copy()
+                if ref is None:
+                    ref = got
+                eq = bool((got["id"] == ref["id"]).all() and (got["t"].view(np.uint32) == ref["t"].view(np.uint32)).all())
+                row.setdefault("ms_sweep_" + sw, []).append(round(min(ts[3:]), 4))
+                row["records_equal"] = row.get("records_equal", True) and eq
+            print(json.dumps(row), flush=True)
+    nt.set_tunables(NTR_TRACE_SWEEP_BELOW=None)
+    assert nt.trace_status() == 0
