@@ -86,3 +86,32 @@ def test_sched_hint_object_lifecycle_without_device():
     assert L.ntr_sched_hint_create(None) != 0
     assert L.ntr_sched_hint_destroy(h) == 0
     assert L.ntr_sched_hint_destroy(None) == 0
+
+
+def test_multi_gpu_partition_and_diagnostics_argument_checks():
+    """The round-4 entry points check their arguments before any device or RCCL work: the partition arithmetic is pure host code, the
+    diagnostics reject null / out-of-range arguments, and a group call without a group fails with a message instead of crashing."""
+    L = nt.lib()
+    lo, hi = C.c_int32(-1), C.c_int32(-1)
+    assert L.ntr_frame_shard(1000, 0, 4, 64, C.byref(lo), C.byref(hi)) == 0 and (lo.value, hi.value) == (0, 256)
+    assert L.ntr_frame_shard(1000, 3, 4, 64, C.byref(lo), C.byref(hi)) == 0 and (lo.value, hi.value) == (768, 1000)
+    for bad in ((1000, 4, 4, 64), (1000, -1, 4, 64), (1000, 0, 0, 64), (-1, 0, 1, 64), (1000, 0, 1, 0)):
+        assert L.ntr_frame_shard(*bad, C.byref(lo), C.byref(hi)) == -1
+    assert L.ntr_frame_shard(1000, 0, 1, 64, None, C.byref(hi)) == -1
+    n = C.c_int32(-1)
+    assert L.ntr_frame_ao_batches(0, 1000, 8, 1 << 20, None, None, 0, C.byref(n)) == 0 and n.value == 1
+    assert L.ntr_frame_ao_batches(0, 1000, 0, 1 << 20, None, None, 0, C.byref(n)) == 0 and n.value == 0     # no samples: no batches
+    assert L.ntr_frame_ao_batches(10, 5, 8, 1 << 20, None, None, 0, C.byref(n)) == -1
+    assert L.ntr_frame_ao_batches(0, 1000, 8, 1 << 20, None, None, 4, C.byref(n)) == -1                     # capacity without arrays
+    assert nt.frame_ao_batches(64, 1064, 8, 4096) == [(64, 512), (576, 488)]
+    # diagnostics
+    assert L.ntr_trace_handoff_counts(None, None) == -1
+    sec = C.c_float(0.0)
+    assert L.ntr_selftest_gather_rate(16, 1, 64, 1, None, C.byref(sec)) == -1          # table too small
+    assert L.ntr_selftest_gather_rate(1 << 20, 1, 65, 1, None, C.byref(sec)) == -1     # more lanes than a wave has
+    assert L.ntr_selftest_gather_rate(1 << 20, 1, 64, 1, None, None) == -1
+    # group calls without a group
+    assert L.ntr_dist_info(None, None, None) == -1 and "null group" in nt.lib().ntr_last_error().decode()
+    assert L.ntr_dist_broadcast(None, None, 0, 0, None) == -1
+    assert L.ntr_dist_gather_records(None, None, 0, 64, None, 0, None) == -1
+    assert L.ntr_dist_destroy(None) == 0
