@@ -155,7 +155,12 @@ extern "C" int ntr_dist_init_all(int32_t numDevices, const int32_t* devices, Ntr
     NTR_RCCL(g_rccl.commInitAll(comms, numDevices, devs));   // one process: a communicator per device, used by one host thread each
     for (int i = 0; i < numDevices; i++) {
         NtrDist* d = new (std::nothrow) NtrDist();
-        if (!d) return ntr::set_error(NTR_ERR_NOMEM, "ntr_dist_init_all: out of memory");
+        if (!d) {   // give everything back: the groups made so far (with their communicators) and the communicators not yet wrapped
+            for (int j = 0; j < i; j++) { (void)ntr_dist_destroy(out[j]); out[j] = nullptr; }
+            for (int j = i; j < numDevices; j++) (void)g_rccl.commDestroy(comms[j]);
+            (void)hipSetDevice(prev);
+            return ntr::set_error(NTR_ERR_NOMEM, "ntr_dist_init_all: out of memory");
+        }
         d->comm = comms[i]; d->rank = i; d->world = numDevices; d->device = devs[i];
         out[i] = d;
     }
@@ -213,13 +218,16 @@ static int gather_slices(NtrDist* d, const void* d_own, int32_t numPrimary, int3
         if (hi > lo && (const char*)d_own != (const char*)d_full + (size_t)lo * elemBytes)
             NTR_HIP(hipMemcpyAsync((char*)d_full + (size_t)lo * elemBytes, d_own, (size_t)(hi - lo) * elemBytes, hipMemcpyDeviceToDevice, s));
         NTR_RCCL(g_rccl.groupStart());
-        for (int r = 0; r < d->world; r++) {
+        ncclResult_t re = ncclSuccess;   // (a group once started is always ended)
+        for (int r = 0; r < d->world && re == ncclSuccess; r++) {
             if (r == root) continue;
             int32_t l = 0, h = 0;
             (void)ntr_frame_shard(numPrimary, r, d->world, align, &l, &h);
-            if (h > l) NTR_RCCL(g_rccl.recv((char*)d_full + (size_t)l * elemBytes, (size_t)(h - l) * elemBytes, ncclUint8, r, d->comm, s));
+            if (h > l) re = g_rccl.recv((char*)d_full + (size_t)l * elemBytes, (size_t)(h - l) * elemBytes, ncclUint8, r, d->comm, s);
         }
-        NTR_RCCL(g_rccl.groupEnd());
+        const ncclResult_t ge = g_rccl.groupEnd();
+        if (re != ncclSuccess) return rccl_fail(re, "ncclRecv");
+        if (ge != ncclSuccess) return rccl_fail(ge, "ncclGroupEnd");
     } else if (hi > lo) {
         NTR_RCCL(g_rccl.send(d_own, (size_t)(hi - lo) * elemBytes, ncclUint8, root, d->comm, s));
     }

@@ -56,7 +56,7 @@ EOF
   lbvh)
     timeout -k 5 900 python3 scripts/studies/lbvh_sweep3.py ${ARG//:/ } > $OUT/lbvh_sweep.jsonl 2> $OUT/lbvh_sweep.err; echo "rc=$?"; cat $OUT/lbvh_sweep.jsonl; tail -n 3 $OUT/lbvh_sweep.err ;;
   fuzz)
-    timeout -k 5 $((ARG + 120)) python3 tests/fuzz_parity.py --seconds $ARG --seed ${FUZZ_SEED:-41} > $OUT/fuzz.json 2> $OUT/fuzz.err; echo "rc=$?"; tail -c 1500 $OUT/fuzz.json; tail -n 3 $OUT/fuzz.err ;;
+    timeout -k 5 $((ARG + 120)) python3 tests/fuzz_parity.py --seconds $ARG --seed ${FUZZ_SEED:-41} --progress $OUT/fuzz_progress.json > $OUT/fuzz.json 2> $OUT/fuzz.err; echo "rc=$?"; tail -c 1500 $OUT/fuzz.json; tail -n 3 $OUT/fuzz.err ;;
   ab)      # interleaved A/B of libntrace_amd.so and libntrace_amd_ab.so: ab:<reps>
     AB_OUT=$OUT bash scripts/ab_bench.sh ${ARG:-3} 2>&1 | tail -n 4 ;;
   pyexp)   # py: with the experiment build of the library (diagnostic hooks)

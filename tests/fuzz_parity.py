@@ -125,6 +125,7 @@ def main(argv=None):
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--rays", type=int, default=200000)
+    ap.add_argument("--progress", default=None, help="file that receives the running totals about once a minute (survives a killed run)")
     args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
     cores = os.cpu_count() or 1
@@ -132,7 +133,13 @@ def main(argv=None):
     tot = dict(rounds=0, sah_rounds=0, lbvh_rounds=0, lbvh_tree_mismatch=0, rays_compared=0, record_mismatches=0, counter_mismatches=0,
                fast_path_rounds=0, triangles=0)
     failures = []
+    t_progress = time.time()
     while time.time() < t_end:
+        if args.progress and time.time() - t_progress > 60.0:
+            t_progress = time.time()
+            with open(args.progress + ".tmp", "w") as pf:
+                json.dump(dict(tot, failures=len(failures), seed=args.seed, elapsed=round(args.seconds - (t_end - t_progress))), pf)
+            os.replace(args.progress + ".tmp", args.progress)
         tri, pos, scale = make_scene(rng)
         use_lbvh = rng.random() < 0.5
         leaf = int(rng.choice([1, 2, 4, 8, 16]))
