@@ -265,6 +265,11 @@ NTR_API int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_t* 
  * hardware `/` (must be 0 inside the FASTDIV range).  Diagnostic, blocking. */
 NTR_API int ntr_selftest_division(const float* d_x, int32_t nx, const float* d_d, int32_t nd,
                                   uint32_t* mismatches, void* stream);
+/* The same on the quotients that are hardest to round: for every significand D in [2^23, 2^24) the significands X whose quotient X / D
+ * lies within 8 / (2^24 D) of a midpoint of two neighbouring floats (enumerated on the device, both quotient binades; what
+ * scripts/studies/div_one_correction_check.py checks in exact integer arithmetic), as x = X 2^(xExp + i - 23), d = +-D 2^(dExp + j - 23),
+ * i, j = 0..3.  pairs = quotients tested, mismatches = FAST differs from `/` (must be 0).  Diagnostic, blocking. */
+NTR_API int ntr_selftest_division_hard(int32_t xExp, int32_t dExp, uint64_t* pairs, uint64_t* mismatches, void* stream);
 
 /* ---- ray production (callers of the hot path) -------- */
 

@@ -104,6 +104,7 @@ SYMBOLS = [
     ("ntr_sched_hint_destroy", C.c_int, [_vp]),
     ("ntr_sched_hint_reset", C.c_int, [_vp]),
     ("ntr_selftest_division", C.c_int, [_vp, _i32, _vp, _i32, C.POINTER(_u32), _vp]),
+    ("ntr_selftest_division_hard", C.c_int, [_i32, _i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _vp]),
     ("ntr_trace_bvh_stats", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _u32, _vp,
                                       C.POINTER(TraceStats)]),
     ("ntr_bvh_validate", C.c_int, [_vp, _i64, C.POINTER(_u32), _vp]),
@@ -344,6 +345,13 @@ def selftest_division(d_x, nx, d_d, nd, stream=0):
     m = _u32(0)
     _check(lib().ntr_selftest_division(_vp(d_x), int(nx), _vp(d_d), int(nd), C.byref(m), _vp(stream)))
     return int(m.value)
+
+
+def selftest_division_hard(x_exp, d_exp, stream=0):
+    """(pairs tested, mismatches) of the FAST divide on the enumerated near-midpoint quotients (ntr_selftest_division_hard)"""
+    n, m = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().ntr_selftest_division_hard(int(x_exp), int(d_exp), C.byref(n), C.byref(m), _vp(stream)))
+    return int(n.value), int(m.value)
 
 
 def trace_bvh_stats(kernel, num_rays, any_hit, d_rays, d_results, d_nodes, nodes_bytes, d_woop, woop_bytes,

@@ -1127,4 +1127,24 @@ int ntr_selftest_division(const float* d_x, int32_t nx, const float* d_d, int32_
     return NTR_OK;
 }
 
+int ntr_selftest_division_hard(int32_t xExp, int32_t dExp, uint64_t* pairs, uint64_t* mismatches, void* stream)
+{
+    // FASTDIV range of the operands the kernel forms (x = X 2^(xExp .. xExp + 3 - 23), d = D 2^(dExp .. dExp + 3 - 23), X, D in [2^23, 2^24))
+    if (!pairs || !mismatches || xExp < -84 || xExp > 51 || dExp < -40 || dExp > 16)
+        return set_error(NTR_ERR_INVALID, "ntr_selftest_division_hard: bad argument (x exponents in [-84, 51], d exponents in [-40, 16])");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* d_c = nullptr;
+    NTR_HIP(hipMalloc((void**)&d_c, 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_c, 0, 2 * sizeof(unsigned long long), s);
+    if (e == hipSuccess) e = ntr_launch_selftest_division_hard(xExp, dExp, d_c, s);
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d_c, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_c);
+    if (e != hipSuccess) return hip_fail(e, "ntr_selftest_division_hard");
+    *pairs = h[0];
+    *mismatches = h[1];
+    return NTR_OK;
+}
+
 }  // extern "C"

@@ -105,3 +105,4 @@ extern "C" hipError_t ntr_launch_sched_order(const unsigned int* d_cost, int num
                                              hipStream_t stream);
 extern "C" hipError_t ntr_launch_selftest_division(const float* d_x, const float* d_d, int nx, int nd,
                                                    unsigned int* d_mismatches, hipStream_t stream);
+extern "C" hipError_t ntr_launch_selftest_division_hard(int xe0, int de0, unsigned long long* d_counts, hipStream_t stream);

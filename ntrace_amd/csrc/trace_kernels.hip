@@ -23,14 +23,17 @@
 //            v_div_fmas / v_div_fixup) and select-form min/max.  Valid for every input
 //            (zero direction components, NaN, infinities, denormals).
 //   FAST     for waves whose rays are all "nice" (see ray_is_nice) over a BVH flagged
-//            NTR_BVH_FASTDIV: in that range v_div_scale never rescales and v_div_fixup is the
-//            identity, so the hardware divide reduces to  rcp(d) refined once (per ray) and,
-//            per quotient,  q0=x*r; e1=fma(-d,q0,x); q1=fma(e1,r,q0); e2=fma(-d,q1,x);
-//            q=fma(e2,r,q1)  -- the same five operations the GENERIC path executes after
-//            its scaling steps, hence the same correctly rounded bits.  No NaN/inf can
-//            arise there either, so v_min3/v_max3 equal the select-form folds up to the
-//            sign of zero, which no later comparison can observe.
-//   ntr_selftest_division() checks FAST == GENERIC bit for bit on the device.
+//            NTR_BVH_FASTDIV: in that range nothing over- or underflows and v_div_scale never
+//            rescales, so a quotient is  r = RN(1/d)  (the IEEE divide, once per ray and axis) and,
+//            per quotient,  q0 = x*r;  e = fma(-d,q0,x);  q = fma(e,r,q0)  -- three operations.
+//            With the CORRECTLY ROUNDED reciprocal one residual correction gives RN(x/d), the
+//            GENERIC path's bits (exact_rcp below: why, and how every quotient that could differ
+//            was checked).  Rounds 1-3 used the hardware divide's own chain instead -- v_rcp
+//            refined once, which is not always RN(1/d), and therefore TWO corrections: five
+//            operations per quotient, sixty of the ~100 vector instructions of an inner-node step.
+//            No NaN/inf can arise in the range either, so v_min3/v_max3 equal the select-form
+//            folds up to the sign of zero, which no later comparison can observe.
+//   ntr_selftest_division() / ntr_selftest_division_hard() check FAST == GENERIC bit for bit on the device.
 //
 // DATA PATH.  The while-while loop (traverse) fetches nodes and Woop triangles with buffer
 // loads through wave-uniform resource descriptors (voffset = the Compact layout's own byte
@@ -100,7 +103,7 @@ __device__ __forceinline__ float sel_max(float a, float b) { return (a > b) ? a 
 struct RayRegs {
     float ox, oy, oz, tmin;
     float dx, dy, dz, tmax;  // tmax shrinks to the closest accepted t (CudaBVH.cpp:1215)
-    float rx, ry, rz;        // FAST path: refined reciprocals of dx,dy,dz
+    float rx, ry, rz;        // FAST path: correctly rounded reciprocals of dx,dy,dz
 };
 
 // ---- FAST-path preconditions ---------------------------------------------------------
@@ -124,21 +127,33 @@ __device__ __forceinline__ bool ray_is_nice(const RayRegs& r, uint32_t bvhFlags)
     return nice_dir(r.dx) && nice_dir(r.dy) && nice_dir(r.dz) && nice_pos(r.ox, zeroOk) && nice_pos(r.oy, zeroOk) &&
            nice_pos(r.oz, zeroOk);
 }
-// rcp refined by one Newton step: the value hipcc's f32 divide expansion builds from the
-// denominator (v_rcp_f32, fma(-d,r0,1), fma(e0,r0,r0)) when v_div_scale does not rescale.
-__device__ __forceinline__ float refined_rcp(float d)
+// The CORRECTLY ROUNDED reciprocal of a direction component (the IEEE divide 1 / d: once per ray and axis).  With it ONE residual
+// correction makes a quotient correctly rounded:  q0 = x r;  e = fma(-d, q0, x);  q = fma(e, r, q0)  ==  RN(x / d).
+// Why: q0 + e r = x/d (1 + theta) exactly, |theta| <~ 4 u^2 (u = 2^-24), so q can differ from RN(x/d) only when x/d lies within that
+// distance of a midpoint of two neighbouring floats -- and those pairs are enumerable: for significands X, D and a midpoint Mo / 2^24 the
+// distance is |2^24 X - D Mo| / (2^24 D), a non-zero integer over 2^24 D.  scripts/studies/div_one_correction_check.py checks every such
+// pair (all D, both quotient binades, |numerator| <= 8: 46.5 M pairs) in exact integer arithmetic: none differs; with a reciprocal one ulp
+// off 14 % of them do (which is why the hardware divide's own chain -- v_rcp refined once, NOT always correctly rounded -- needs the two
+// corrections this path used until round 4).  ntr_selftest_division() checks FAST == GENERIC on the device, those pairs included.
+#if defined(NTR_AB) && defined(NTR_DIV_TWO_CORRECTIONS)   // A/B build: the chain of rounds 1-3 (v_rcp refined once, two corrections)
+__device__ __forceinline__ float exact_rcp(float d)
 {
     const float r0 = __builtin_amdgcn_rcpf(d);
-    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
-    return __builtin_fmaf(e0, r0, r0);
+    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
 }
+#else
+__device__ __forceinline__ float exact_rcp(float d) { return 1.0f / d; }
+#endif
 __device__ __forceinline__ float fast_div(float x, float d, float r)
 {
     const float q0 = x * r;
     const float e1 = __builtin_fmaf(-d, q0, x);
     const float q1 = __builtin_fmaf(e1, r, q0);
-    const float e2 = __builtin_fmaf(-d, q1, x);
-    return __builtin_fmaf(e2, r, q1);
+#if defined(NTR_AB) && defined(NTR_DIV_TWO_CORRECTIONS)
+    return __builtin_fmaf(__builtin_fmaf(-d, q1, x), r, q1);
+#else
+    return q1;
+#endif
 }
 
 // Intersect::RayBox for BOTH children of a node (Util.cpp:34-46).  The FAST form evaluates
@@ -165,10 +180,12 @@ __device__ __forceinline__ void ray_box2(const RayRegs& r, const float4& n0, con
         for (int k = 0; k < 12; k++) e[k] = __builtin_fmaf(-d[(k % 6) >> 1], q[k], x[k]);
 #pragma unroll
         for (int k = 0; k < 12; k++) q[k] = __builtin_fmaf(e[k], rc[(k % 6) >> 1], q[k]);
+#if defined(NTR_AB) && defined(NTR_DIV_TWO_CORRECTIONS)
 #pragma unroll
         for (int k = 0; k < 12; k++) e[k] = __builtin_fmaf(-d[(k % 6) >> 1], q[k], x[k]);
 #pragma unroll
         for (int k = 0; k < 12; k++) q[k] = __builtin_fmaf(e[k], rc[(k % 6) >> 1], q[k]);
+#endif
         if (OCT < 8) {
             constexpr int sx = OCT & 1, sy = (OCT >> 1) & 1, sz = (OCT >> 2) & 1;   // 1: the hi plane is the near one
             mn0 = fmaxf(fmaxf(q[0 + sx], q[2 + sy]), q[4 + sz]);
@@ -385,7 +402,7 @@ __device__ __forceinline__ void load_ray(const NtrRay* __restrict__ rays, int ra
     const float4 d = reinterpret_cast<const float4*>(rays)[rayIdx * 2 + 1];
     r.ox = o.x; r.oy = o.y; r.oz = o.z; r.tmin = o.w;
     r.dx = d.x; r.dy = d.y; r.dz = d.z; r.tmax = d.w;
-    r.rx = refined_rcp(d.x); r.ry = refined_rcp(d.y); r.rz = refined_rcp(d.z);
+    r.rx = exact_rcp(d.x); r.ry = exact_rcp(d.y); r.rz = exact_rcp(d.z);
 }
 
 // While-while traversal of the lanes' current rays until every lane is done (or, in the
@@ -1233,11 +1250,57 @@ __global__ __launch_bounds__(256) void selftest_division_kernel(const float* __r
     for (int j = 0; j < nd; j++) {
         const float dv = d[j];
         const float q0 = xv / dv;
-        const float q1 = fast_div(xv, dv, refined_rcp(dv));
+        const float q1 = fast_div(xv, dv, exact_rcp(dv));
         // the sign of a zero quotient is not observable by the tracer's comparisons
         bad += (__float_as_uint(q0) != __float_as_uint(q1)) && !(q0 == 0.0f && q1 == 0.0f);
     }
     if (bad) atomicAdd(mismatches, bad);
+}
+
+// The hardest quotients for the one-correction divide, enumerated on the device: for every significand D in [2^23, 2^24) the X whose
+// quotient X / D lies closest to a rounding boundary -- 2^b X - D Mo = N for a midpoint Mo (odd, 25 bits), b = 24 (X >= D) or 25 (X < D),
+// every N with |N| <= 8 the equation admits -- what scripts/studies/div_one_correction_check.py checks in exact integer arithmetic.
+// Here the hardware runs them: FAST divide against `/`, with x and d scaled by the powers of two [xe0, xe0 + 3] x [de0, de0 + 3]
+// (the result may not depend on them inside the FASTDIV range).  One thread per D; counts[0] += pairs tested, counts[1] += mismatches.
+__global__ __launch_bounds__(256) void selftest_division_hard_kernel(int xe0, int de0, unsigned long long* __restrict__ counts)
+{
+    const unsigned int D = (1u << 23) + blockIdx.x * 256u + threadIdx.x;   // grid: 2^23 / 256 workgroups
+    const int k = __builtin_ctz(D);
+    unsigned long long tested = 0, bad = 0;
+    if (k <= 6) {
+        const unsigned int Dp = D >> k;
+        unsigned int inv = Dp;   // Dp^-1 mod 2^32 (Newton: every step doubles the valid bits, 3 to start with)
+        for (int it = 0; it < 5; it++) inv *= 2u - Dp * inv;
+        for (int b = 24; b <= 25; b++) {
+            const unsigned long long mod = 1ull << (b - k);
+            for (int Np = -8; Np <= 8; Np++) {
+                if (Np == 0 || (Np << k) > 8 || (Np << k) < -8) continue;
+                const long long N = (long long)Np << k;
+                const unsigned long long base = ((unsigned long long)(unsigned int)(-Np) * inv) & (mod - 1ull);   // Dp Mo = -N' (mod 2^(b-k))
+                for (unsigned int j = 0; j < (1u << k); j++) {
+                    unsigned long long Mo = base + j * mod;
+                    while (Mo < (1ull << 24)) Mo += 1ull << b;
+                    if (Mo >= (1ull << 25) || !(Mo & 1ull)) continue;
+                    const long long num = (long long)((unsigned long long)D * Mo) + N;
+                    if (num & ((1ll << b) - 1ll)) continue;
+                    const long long X = num >> b;
+                    if (b == 24 ? (X < (long long)D || X >= (1ll << 24)) : (X < (1ll << 23) || X >= (long long)D)) continue;
+                    for (int e = 0; e < 16; e++) {
+                        const float xv = ldexpf((float)X, xe0 + (e & 3) - 23), dv = ldexpf((float)D, de0 + (e >> 2) - 23);
+                        for (int sgn = 0; sgn < 2; sgn++) {
+                            const float dd = sgn ? -dv : dv;
+                            const float q0 = xv / dd;
+                            const float q1 = fast_div(xv, dd, exact_rcp(dd));
+                            tested++;
+                            bad += __float_as_uint(q0) != __float_as_uint(q1);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (tested) atomicAdd(&counts[0], tested);
+    if (bad) atomicAdd(&counts[1], bad);
 }
 
 
@@ -1361,5 +1424,11 @@ extern "C" hipError_t ntr_launch_selftest_division(const float* d_x, const float
                                                    unsigned int* d_mismatches, hipStream_t stream)
 {
     hipLaunchKernelGGL(ntr::selftest_division_kernel, dim3((nx + 255) / 256), dim3(256), 0, stream, d_x, d_d, nx, nd, d_mismatches);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ntr_launch_selftest_division_hard(int xe0, int de0, unsigned long long* d_counts, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ntr::selftest_division_hard_kernel, dim3((1u << 23) / 256u), dim3(256), 0, stream, xe0, de0, d_counts);
     return hipGetLastError();
 }

@@ -110,6 +110,10 @@ def test_multi_gpu_partition_and_diagnostics_argument_checks():
     assert L.ntr_selftest_gather_rate(16, 1, 64, 1, None, C.byref(sec)) == -1          # table too small
     assert L.ntr_selftest_gather_rate(1 << 20, 1, 65, 1, None, C.byref(sec)) == -1     # more lanes than a wave has
     assert L.ntr_selftest_gather_rate(1 << 20, 1, 64, 1, None, None) == -1
+    pairs, bad = C.c_uint64(0), C.c_uint64(0)
+    assert L.ntr_selftest_division_hard(0, 0, None, C.byref(bad), None) == -1
+    assert L.ntr_selftest_division_hard(52, 0, C.byref(pairs), C.byref(bad), None) == -1    # operands would leave the FASTDIV range
+    assert L.ntr_selftest_division_hard(0, -41, C.byref(pairs), C.byref(bad), None) == -1
     # group calls without a group
     assert L.ntr_dist_info(None, None, None) == -1 and "null group" in nt.lib().ntr_last_error().decode()
     assert L.ntr_dist_broadcast(None, None, 0, 0, None) == -1

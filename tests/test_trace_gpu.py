@@ -125,8 +125,8 @@ def test_golden_fixtures_on_gpu(kernel):
 
 
 def test_fast_division_equals_hardware_division():
-    """FAST path precondition: inside the FASTDIV range the refactored divide (per-ray refined
-    reciprocal + 5 ops per quotient) is bit-identical to the hardware `/`; and the hardware `/`
+    """FAST path precondition: inside the FASTDIV range the refactored divide (per-ray correctly rounded
+    reciprocal + 3 ops per quotient) is bit-identical to the hardware `/`; and the hardware `/`
     is IEEE correctly rounded (checked against numpy binary32 division on a subsample)."""
     import torch
     rng = np.random.default_rng(123)
@@ -147,6 +147,25 @@ def test_fast_division_equals_hardware_division():
     with np.errstate(all="ignore"):
         ref = x[:20000, None] / d[None, :256]
     assert np.array_equal(q.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("x_exp,d_exp", [(0, 0), (-84, -20), (51, 16), (10, -40), (-30, 12)])
+def test_fast_division_on_the_hardest_quotients(x_exp, d_exp):
+    """One residual correction is enough only because the reciprocal is correctly rounded -- and only if NO quotient close to a rounding
+    boundary goes wrong.  Those quotients are enumerable (scripts/studies/div_one_correction_check.py checks all 46.5 M significand pairs
+    in exact integer arithmetic); here the device forms every one of them, at 16 exponent combinations and both signs, and compares the
+    FAST divide with the hardware `/`."""
+    pairs, bad = nt.selftest_division_hard(x_exp, d_exp)
+    assert pairs == 46_517_418 * 32, pairs      # every significand pair of the exact check x 16 exponent pairs x 2 signs
+    assert bad == 0, (pairs, bad)
+
+
+def test_hard_quotient_enumeration_matches_the_exact_check():
+    """The device enumerates the near-midpoint significand pairs itself: their number must be the one the exact-arithmetic script finds
+    (profiles/r04_div_one_correction_check.txt: 46 517 418)."""
+    pairs, bad = nt.selftest_division_hard(-3, 5)
+    assert bad == 0
+    assert pairs == 46_517_418 * 32
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
