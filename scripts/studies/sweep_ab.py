@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Sparse leaf sweep A/B on one box: NTR_TRACE_SWEEP_BELOW = 0 / 4 / 8 on the divergent batches (courtyard-10M, hairball-2.8M: 2^21 box rays,
-one diffuse batch, the 1080p primary batch) and on the atrium's primary + AO batch (coherent: must not move), per-ray kernel and
-kepler_dynamic_fetch; records compared with the sweep-free launch.  usage: sweep_ab.py [scene,scene]"""
+"""A/B of one run-time tunable on one box: the values of an NTR_* environment variable, interleaved (first value = the reference), on the
+batches of a scene (1080p primary, one AO batch, one diffuse batch; 2^21 box rays on the LBVH scenes), per-ray kernel and
+kepler_dynamic_fetch; records compared with the first value's.  First used for the sparse leaf sweep (round 4, rejected), then for
+NTR_TRACE_UNIFIED_TRI_MIN.   usage: sweep_ab.py [scene,scene] [NTR_VARIABLE] [v0,v1,...]"""
 import json
 import os
 import sys
@@ -18,6 +19,8 @@ from workloads import lbvh, scene_of, up  # noqa: E402
 
 dev = torch.device("cuda:0")
 names = (sys.argv[1] if len(sys.argv) > 1 else "hairball,courtyard,atrium").split(",")
+VAR = sys.argv[2] if len(sys.argv) > 2 else "NTR_TRACE_UNIFIED_TRI_MIN"
+VALUES = (sys.argv[3] if len(sys.argv) > 3 else "0,4,8").split(",")
 for scene in names:
     tri, pos, cam = scene_of(scene)
     if scene in ("atrium", "conference"):
@@ -32,7 +35,7 @@ for scene in names:
     npr = prim.shape[0]
     d_prim = up(prim)
     d_pres = torch.zeros(npr * 16, dtype=torch.uint8, device=dev)
-    nt.set_tunables(NTR_TRACE_SWEEP_BELOW="0")
+    nt.set_tunables(**{VAR: VALUES[0]})
     view.trace("fermi_speculative_while_while", npr, False, d_prim.data_ptr(), d_pres.data_ptr())
     d_nrm = up(scenes.tri_normals(tri, pos))
     ns, cnt = 8, (1 << 20) // 8
@@ -53,16 +56,16 @@ for scene in names:
         for kernel in ("fermi_speculative_while_while", "kepler_dynamic_fetch"):
             ref = None
             row = dict(scene=scene, batch=bname, kernel=kernel)
-            for sw in ("0", "8", "4", "0", "8"):
-                nt.set_tunables(NTR_TRACE_SWEEP_BELOW=sw)
+            for sw in VALUES + VALUES:
+                nt.set_tunables(**{VAR: sw})
                 rr = d_rays.clone()   # a new buffer: a new scheduling-feedback entry per setting
                 ts = [view.trace(kernel, n, any_hit, rr.data_ptr(), d_res.data_ptr()) * 1e3 for _ in range(7)]
                 got = d_res.cpu().numpy().view(nt.RESULT_DTYPE).copy()
                 if ref is None:
                     ref = got
                 eq = bool((got["id"] == ref["id"]).all() and (got["t"].view(np.uint32) == ref["t"].view(np.uint32)).all())
-                row.setdefault("ms_sweep_" + sw, []).append(round(min(ts[3:]), 4))
+                row.setdefault("ms_" + sw, []).append(round(min(ts[3:]), 4))
                 row["records_equal"] = row.get("records_equal", True) and eq
             print(json.dumps(row), flush=True)
-    nt.set_tunables(NTR_TRACE_SWEEP_BELOW=None)
+    nt.set_tunables(**{VAR: None})
     assert nt.trace_status() == 0
