@@ -156,7 +156,7 @@ static void tunables_load_locked()
     t.handoffKeepWaves = env_int("NTR_TRACE_HANDOFF_KEEP_WAVES", 1024);   // A: with no more waves than this left in the launch nobody hands off
     t.handoffFlags = env_int("NTR_TRACE_HANDOFF_FLAGS", 0);       // 1: raised priority for waves that took continuations; 2: batches with pool K = 1 run as one-chunk pools and hand their tails off too
     t.unified = env_int("NTR_TRACE_UNIFIED", 1);                  // kepler_dynamic_fetch: unified-step loop (0 = while-while loop + dynamic fetch)
-    t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", -1);    // per-ray kernel with the unified-step loop: -1 = closest-hit launches always, any-hit launches on trees flagged NTR_BVH_WIDE_LEAVES; 0 / 1 = never / always
+    t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", 1);     // per-ray kernel with the unified-step loop: 1 = always (the default since the one-correction divide: AO batches on one-triangle-leaf trees -4 %), 0 = never, -1 = closest-hit launches always, any-hit launches only on trees flagged NTR_BVH_WIDE_LEAVES (the rule of round 3)
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/studies/persist_diag.py)
     t.autoHint = env_int("NTR_TRACE_AUTO_HINT", 1);               // dispatch order learned from the previous launch of the same batch (stream, rays, count, BVH)
     t.autoHintMinRays = env_int("NTR_TRACE_AUTO_HINT_MIN_RAYS", 1 << 17);
@@ -876,8 +876,9 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         launchVariant = waves == 1 ? NTR_VARIANT_PERRAY_W1 : NTR_VARIANT_PERRAY_W2;
         launchBlocks = numBlocks * (4 / waves);
         // unified-step loop (one node OR one triangle per lane and iteration, one group of loads): closest-hit launches on any tree
-        // (atrium primary +5 %, conference +21 %, LBVH trees +50 %), any-hit launches where leaves hold several triangles (short AO rays
-        // in one-triangle-leaf trees rarely reach a leaf: the while-while loop is 2-3 % ahead there)
+        // (atrium primary +5 %, conference +21 %, LBVH trees +50 %) and any-hit launches (multi-triangle leaves: always ahead; short AO
+        // rays in one-triangle-leaf trees: the while-while loop was 2-3 % ahead while a step cost ~100 vector instructions, the unified
+        // loop is 4 % ahead since the one-correction divide -- profiles/r04_perray_unified_anyhit_knob.txt)
         if (tun.perrayUnified > 0 || (tun.perrayUnified < 0 && (!anyHit || (bvhFlags & NTR_BVH_WIDE_LEAVES)))) {
             launchVariant = NTR_VARIANT_PERRAY_UNIFIED_W1;
             launchBlocks = numBlocks * 4;
