@@ -1267,15 +1267,15 @@ __global__ __launch_bounds__(256) void selftest_division_hard_kernel(int xe0, in
     const unsigned int D = (1u << 23) + blockIdx.x * 256u + threadIdx.x;   // grid: 2^23 / 256 workgroups
     const int k = __builtin_ctz(D);
     unsigned long long tested = 0, bad = 0;
-    if (k <= 6) {
+    if (k <= 3) {   // (a D divisible by 16 admits no |N| <= 8)
         const unsigned int Dp = D >> k;
         unsigned int inv = Dp;   // Dp^-1 mod 2^32 (Newton: every step doubles the valid bits, 3 to start with)
         for (int it = 0; it < 5; it++) inv *= 2u - Dp * inv;
         for (int b = 24; b <= 25; b++) {
             const unsigned long long mod = 1ull << (b - k);
             for (int Np = -8; Np <= 8; Np++) {
-                if (Np == 0 || (Np << k) > 8 || (Np << k) < -8) continue;
-                const long long N = (long long)Np << k;
+                const long long N = (long long)Np * (1ll << k);
+                if (Np == 0 || N > 8 || N < -8) continue;
                 const unsigned long long base = ((unsigned long long)(unsigned int)(-Np) * inv) & (mod - 1ull);   // Dp Mo = -N' (mod 2^(b-k))
                 for (unsigned int j = 0; j < (1u << k); j++) {
                     unsigned long long Mo = base + j * mod;
