@@ -150,6 +150,8 @@ def parse(argv=None):
                     help="maxBatchSize of RayGen (the reference constructs it with 1 << 20, Renderer.cpp:45)")
     ap.add_argument("--ao-streams", type=int, default=3, help="HIP streams of the overlapped-frame figure (extras)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (profiling runs)")
+    ap.add_argument("--no-ao-prediction", action="store_true",
+                    help="trace the AO batches without the leaf-depth dispatch hint made beside ray generation (buffer order until a launch has measured)")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the 10 M-triangle HBM-resident roofline point (extras)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold-order", action="store_true", help="skip the extra K steps with the scheduling feedback off")
@@ -231,8 +233,29 @@ class Frame:
             live = nt.count_hits(self.d_res.data_ptr() + first * 16, cnt, stream) * ns
             self.keep.append((b_rays, b_res, b_a))
             self.batches.append(dict(name="ao", n=cnt * ns, any_hit=True, rays=b_rays.data_ptr(), res=b_res.data_ptr(), live=live,
-                                     res_t=b_res, rays_t=b_rays))
+                                     res_t=b_res, rays_t=b_rays, first=first, count=cnt))
+        # Dispatch hints of the secondary batches, made beside ray generation (untimed like it): a block's cost class from the depth in the
+        # tree of the leaves its pixels' primary rays hit (ntr_bvh_leaf_depths once per BVH, ntr_secondary_block_costs per batch).
+        self.nt, self.stream, self.ns = nt, stream, ns
+        self.d_depth = None
+        if not args.no_ao_prediction and args.kernel.startswith("fermi") and len(self.batches) > 1:
+            self.num_tris = int(tri_normals.numel() * tri_normals.element_size() // 12)   # (three float32 per triangle)
+            self.d_depth = torch.zeros(self.num_tris, dtype=i32, device=dev)
+            nt.bvh_leaf_depths(view.d_nodes, view.nodes_bytes, view.d_woop, view.woop_bytes, view.d_tri_index, self.num_tris, self.d_depth.data_ptr(), stream)
+            for b in self.batches[1:]:
+                b["cost_t"] = torch.zeros((b["n"] + 255) // 256, dtype=i32, device=dev)
+                b["hint"] = nt.SchedHint()
+            self.predict_hints()
         torch.cuda.synchronize()
+
+    def predict_hints(self):
+        """(Re)starts every secondary batch's hint from its predicted block costs -- what a renderer does when it generates the batch."""
+        if self.d_depth is None:
+            return
+        for b in self.batches[1:]:
+            self.nt.secondary_block_costs(self.d_res.data_ptr(), b["first"], b["count"], self.ns, self.d_depth.data_ptr(), self.num_tris,
+                                          b["cost_t"].data_ptr(), self.stream)
+            b["hint"].predict(b["cost_t"].data_ptr(), b["cost_t"].numel(), self.stream)
 
     @property
     def rays_per_step(self):  # the metric counts non-degenerate rays only (Renderer::getTotalNumRays, Renderer.cpp:676-709)
@@ -334,7 +357,7 @@ def main():
     batches = frame.batches
 
     def run_batch(b, timed=False, s=stream):
-        return view.trace(args.kernel, b["n"], b["any_hit"], b["rays"], b["res"], s, timed)
+        return view.trace(args.kernel, b["n"], b["any_hit"], b["rays"], b["res"], s, timed, hint=b.get("hint"))
 
     for _ in range(args.warmup):
         for b in batches:
@@ -374,6 +397,7 @@ def main():
         evc = [[(E(enable_timing=True), E(enable_timing=True)) for _ in batches] for _ in range(args.steps)]
         barrier()
         for s_ in range(args.steps):
+            frame.predict_hints()   # every step as if the batches were new: the AO hints start over from their prediction (untimed, like ray generation)
             for bi, b in enumerate(batches):
                 evc[s_][bi][0].record()
                 run_batch(b)
@@ -381,7 +405,8 @@ def main():
         barrier()
         cms = np.array([[e0.elapsed_time(e1) for (e0, e1) in step] for step in evc])
         _, cold_kernel_max = ntd.job_throughput(0, float(cms.sum()) * 1e-3, dev)
-        cold = {"what": "the same steps with NTR_TRACE_AUTO_HINT=0: no dispatch order learned from earlier launches of a batch",
+        cold = {"what": "the same steps with nothing learned from earlier launches of a batch (NTR_TRACE_AUTO_HINT=0; the AO batches' hints restarted "
+                        "from their leaf-depth prediction before every step%s)" % ("" if frame.d_depth is not None else ": --no-ao-prediction, buffer order"),
                 "mrays": total_rays_per_step * args.steps / cold_kernel_max / 1e6,
                 "primary_ms": float(cms[:, 0].mean()), "ao_total_ms": float(cms[:, 1:].sum(axis=1).mean()) if len(batches) > 1 else 0.0}
         nt.set_tunables(NTR_TRACE_AUTO_HINT=None)
@@ -532,7 +557,9 @@ def main():
                    "kernel": args.kernel, "bvh_flags": view.flags, "triangles": int(tri.shape[0]),
                    "rays_per_step": int(total_rays_per_step), "rays_per_step_rank0": rays_per_step,
                    "primary_rays_rank0": b0["n"], "primary_hits_rank0": frame.own_hits, "ao_rays_nondegenerate_rank0": ao_live,
-                   "ao_batches_rank0": len(batches) - 1, "parallelism": par, "frame_cut": cut_info},
+                   "ao_batches_rank0": len(batches) - 1, "parallelism": par, "frame_cut": cut_info,
+                   "ao_dispatch_hint": ("leaf-depth prediction made beside ray generation (ntr_bvh_leaf_depths, ntr_secondary_block_costs, ntr_sched_hint_predict), "
+                                        "refined by every launch's measurement (ntr_trace_bvh_hinted)") if frame.d_depth is not None else "none (library's automatic feedback)"},
         "primary_mrays": prim_live_total * args.steps / prim_kernel_max / 1e6,
         "ao_mrays": (ao_live_total * args.steps / ao_kernel_max / 1e6) if ao_kernel_max > 0 else None,
         "kernel_ms": {"primary": prim_ms, "ao_total": ao_ms, "per_step_rank0": float(kern_ms.sum(axis=1).mean())},

@@ -204,6 +204,22 @@ NTR_API int ntr_trace_bvh_hinted(const char* kernelName, int32_t numRays, int32_
                                  int32_t layout, uint32_t bvhFlags, void* stream, float* seconds,
                                  NtrSchedHint* hint);
 
+/* A hint can also start from a PREDICTION instead of a measurement: ntr_sched_hint_predict binds the hint to a batch of numBlocks 256-ray
+ * blocks and orders them by the caller's per-block cost estimates (any monotone score; heaviest class first).  The next launch with the
+ * hint uses that order, measures, and refines it as usual.  For secondary batches the estimate comes from the tree itself:
+ *   ntr_bvh_leaf_depths        once per BVH: d_depthByTri[t] = depth of the leaf that holds triangle t (number of inner nodes from the
+ *                              root down; triangles in no leaf: 0).  One small launch per tree level; blocking.  *levels = levels walked.
+ *   ntr_secondary_block_costs  per batch, beside ray generation: d_blockCost[b] = the deepest leaf among the input rays (primary hits
+ *                              d_inResults[first .. first + count)) whose numSamples output rays fall into block b; misses count 0.
+ * Short secondary rays mostly pay for descending to where they start: on the bench frame's AO batches this order recovers what the
+ * order learned from a previous launch gives (-9 % launch time), without a previous launch (EXPERIMENTS.md).  No counterpart in the
+ * reference, which generates secondary rays (RayGen::ao, src/rt/ray/RayGen.cpp) and traces them in buffer order. */
+NTR_API int ntr_sched_hint_predict(NtrSchedHint* hint, const uint32_t* d_blockCost, int32_t numBlocks, void* stream);
+NTR_API int ntr_bvh_leaf_depths(const void* d_nodes, int64_t nodesBytes, const void* d_triWoop, int64_t triWoopBytes,
+                                const int32_t* d_triIndex, int32_t numTris, int32_t* d_depthByTri, int32_t* levels, void* stream);
+NTR_API int ntr_secondary_block_costs(const NtrRayResult* d_inResults, int32_t first, int32_t count, int32_t numSamples,
+                                      const int32_t* d_depthByTri, int32_t numTris, uint32_t* d_blockCost, void* stream);
+
 /* Cost estimate of every 256-ray block of a batch, without tracing it: d_blockCost[b] = number of boxes of the BVH's top-of-tree
  * table (the child boxes of the nodes of depth <= 9) that the block's sample ray (its 100th) intersects -- the predictor behind
  * the dispatch order of large closest-hit launches (Spearman 0.86-0.89 against the true block cost on primary batches).  No

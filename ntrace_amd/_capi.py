@@ -103,6 +103,9 @@ SYMBOLS = [
     ("ntr_sched_hint_create", C.c_int, [C.POINTER(_vp)]),
     ("ntr_sched_hint_destroy", C.c_int, [_vp]),
     ("ntr_sched_hint_reset", C.c_int, [_vp]),
+    ("ntr_sched_hint_predict", C.c_int, [_vp, _vp, _i32, _vp]),
+    ("ntr_secondary_block_costs", C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    ("ntr_bvh_leaf_depths", C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, C.POINTER(_i32), _vp]),
     ("ntr_selftest_division", C.c_int, [_vp, _i32, _vp, _i32, C.POINTER(_u32), _vp]),
     ("ntr_selftest_division_hard", C.c_int, [_i32, _i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _vp]),
     ("ntr_trace_bvh_stats", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _u32, _vp,
@@ -195,6 +198,10 @@ class SchedHint:
 
     def reset(self):
         _check(lib().ntr_sched_hint_reset(self._h))
+
+    def predict(self, d_block_cost, num_blocks, stream=0):
+        """ntr_sched_hint_predict: dispatch the batch's next launch by these per-block cost estimates (device pointer, uint32 per block)"""
+        _check(lib().ntr_sched_hint_predict(self._h, _vp(d_block_cost), int(num_blocks), _vp(stream)))
 
     def close(self):
         if self._h:
@@ -339,6 +346,20 @@ def experiment_hooks(timeline=0, order=0):
     L.ntr_experiment_hooks.restype = C.c_int
     L.ntr_experiment_hooks.argtypes = [_vp, _vp]
     _check(L.ntr_experiment_hooks(_vp(timeline), _vp(order)))
+
+
+def bvh_leaf_depths(d_nodes, nodes_bytes, d_woop, woop_bytes, d_tri_index, num_tris, d_depth_by_tri, stream=0):
+    """ntr_bvh_leaf_depths: depth of every triangle's leaf into d_depth_by_tri (int32 per triangle); returns the number of levels walked"""
+    m = _i32(0)
+    _check(lib().ntr_bvh_leaf_depths(_vp(d_nodes), int(nodes_bytes), _vp(d_woop), int(woop_bytes), _vp(d_tri_index), int(num_tris),
+                                     _vp(d_depth_by_tri), C.byref(m), _vp(stream)))
+    return int(m.value)
+
+
+def secondary_block_costs(d_in_results, first, count, num_samples, d_depth_by_tri, num_tris, d_block_cost, stream=0):
+    """ntr_secondary_block_costs: predicted cost of the 256-ray blocks of a secondary batch (deepest leaf among a block's input rays)"""
+    _check(lib().ntr_secondary_block_costs(_vp(d_in_results), int(first), int(count), int(num_samples), _vp(d_depth_by_tri), int(num_tris),
+                                           _vp(d_block_cost), _vp(stream)))
 
 
 def selftest_division(d_x, nx, d_d, nd, stream=0):

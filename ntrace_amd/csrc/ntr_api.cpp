@@ -540,6 +540,7 @@ struct NtrSchedHint {
     int device = -1;
     int uses = 0;                   // launches since the hint was (re)bound
     bool valid = false;             // order[] holds a permutation
+    bool predicted = false;         // order[] comes from ntr_sched_hint_predict and has not been used yet
 };
 
 static void sched_hint_release(NtrSchedHint* h)
@@ -547,7 +548,7 @@ static void sched_hint_release(NtrSchedHint* h)
     if (h->order) (void)hipFree(h->order);
     if (h->cost) (void)hipFree(h->cost);
     h->order = h->cost = nullptr;
-    h->numBlocks = 0; h->uses = 0; h->valid = false;
+    h->numBlocks = 0; h->uses = 0; h->valid = false; h->predicted = false;
 }
 
 // Automatic scheduling feedback.  The launch time of the per-ray kernel is set by where its long-lived blocks start;
@@ -576,7 +577,7 @@ static void auto_hint_release_async(NtrSchedHint* h, hipStream_t s)
     if (h->order) (void)hipFreeAsync(h->order, s);
     if (h->cost) (void)hipFreeAsync(h->cost, s);
     h->order = h->cost = nullptr;
-    h->numBlocks = 0; h->uses = 0; h->valid = false;
+    h->numBlocks = 0; h->uses = 0; h->valid = false; h->predicted = false;
 }
 
 // The hint of this batch, or null: the first launch of a key only registers it (no allocation, no hint); from the second on the key owns a
@@ -791,12 +792,15 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         }
         // costs measured under the natural order differ from those under the derived order, so the first
         // launches all refresh; afterwards every 8th does (slowly drifting rays keep their schedule)
-        if (hint->uses == 0) {   // a hint that starts over (new, or an automatic one recycled for another batch) forgets its K
+        const bool firstOfPrediction = hint->predicted && hint->valid;   // (ntr_sched_hint_predict cleared the K words itself)
+        if (hint->uses == 0 && !firstOfPrediction) {   // a hint that starts over (new, or an automatic one recycled for another batch) forgets its K
             const hipError_t zk = ntr_launch_zero_words(hint->order + numBlocks, 3, s);
             if (zk != hipSuccess) return hip_fail(zk, "zero_words launch");
         }
         const int every = tun.schedRefreshEvery;
         refresh = hint->uses < 3 || every <= 1 || (hint->uses % every) == 0;
+        if (firstOfPrediction) refresh = false;   // the first launch of a predicted order just runs it (a batch traced once pays nothing for feedback)
+        hint->predicted = false;
         hint->uses++;
         if (hint->valid) p.order = hint->order;
         if (refresh) {
@@ -1098,6 +1102,89 @@ int ntr_sched_hint_reset(NtrSchedHint* hint)
     if (!hint) return set_error(NTR_ERR_INVALID, "ntr_sched_hint_reset: null hint");
     hint->uses = 0;
     hint->valid = false;
+    hint->predicted = false;
+    return NTR_OK;
+}
+
+int ntr_sched_hint_predict(NtrSchedHint* hint, const uint32_t* d_blockCost, int32_t numBlocks, void* stream)
+{
+    if (!hint || !d_blockCost || numBlocks < 1) return set_error(NTR_ERR_INVALID, "ntr_sched_hint_predict: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    if (hint->numBlocks != numBlocks || hint->device != dev) {   // (the binding ntr_trace_bvh_hinted would make on first use)
+        sched_hint_release(hint);
+        NTR_HIP(hipMalloc((void**)&hint->order, ((size_t)numBlocks + 3) * sizeof(unsigned int)));
+        NTR_HIP(hipMalloc((void**)&hint->cost, (size_t)numBlocks * sizeof(unsigned int)));
+        hint->numBlocks = numBlocks;
+        hint->device = dev;
+    }
+    NTR_HIP(hipMemcpyAsync(hint->cost, d_blockCost, (size_t)numBlocks * sizeof(unsigned int), hipMemcpyDeviceToDevice, s));
+    hipError_t le = ntr_launch_sched_order(hint->cost, numBlocks, tunables().schedClasses, hint->order, s);
+    if (le == hipSuccess) le = ntr_launch_zero_words(hint->order + numBlocks, 3, s);   // the batch's coherence words / pool K: not estimated yet
+    if (le != hipSuccess) return hip_fail(le, "sched_order launch");
+    hint->uses = 0;      // the next launch starts the hint's life: it runs this order; the launches after it measure and refine
+    hint->valid = true;
+    hint->predicted = true;
+    return NTR_OK;
+}
+
+int ntr_secondary_block_costs(const NtrRayResult* d_inResults, int32_t first, int32_t count, int32_t numSamples, const int32_t* d_depthByTri,
+                              int32_t numTris, uint32_t* d_blockCost, void* stream)
+{
+    if (first < 0 || count < 0 || numSamples < 1 || numTris < 0 || (count > 0 && (!d_inResults || !d_depthByTri || !d_blockCost)))
+        return set_error(NTR_ERR_INVALID, "ntr_secondary_block_costs: bad argument");
+    if (count == 0) return NTR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t blocks = ((int64_t)count * numSamples + 255) / 256;
+    if (blocks > 0x7FFFFFFF) return set_error(NTR_ERR_INVALID, "ntr_secondary_block_costs: batch too large");
+    hipError_t e = ntr_launch_zero_words(d_blockCost, (int)blocks, s);
+    if (e == hipSuccess) e = ntr_launch_secondary_block_costs(d_inResults, first, count, numSamples, d_depthByTri, numTris, d_blockCost, s);
+    if (e != hipSuccess) return hip_fail(e, "secondary_block_costs launch");
+    return NTR_OK;
+}
+
+int ntr_bvh_leaf_depths(const void* d_nodes, int64_t nodesBytes, const void* d_triWoop, int64_t triWoopBytes, const int32_t* d_triIndex,
+                        int32_t numTris, int32_t* d_depthByTri, int32_t* maxDepth, void* stream)
+{
+    if (maxDepth) *maxDepth = 0;
+    if (!d_nodes || nodesBytes < 64 || (nodesBytes % 64) != 0 || nodesBytes > 0x76543200ll || !d_triWoop || triWoopBytes < 16 || !d_triIndex ||
+        numTris < 1 || !d_depthByTri)
+        return set_error(NTR_ERR_INVALID, "ntr_bvh_leaf_depths: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned int capacity = (unsigned int)(nodesBytes / 64);
+    // two frontier queues + their counters (counter k of level L at counts[L & 1]; cleared before it is filled)
+    unsigned int* d_q = nullptr;
+    NTR_HIP(hipMalloc((void**)&d_q, (2 * (size_t)capacity + 2) * sizeof(unsigned int)));
+    unsigned int* q[2] = {d_q, d_q + capacity};
+    unsigned int* cnt = d_q + 2 * (size_t)capacity;
+    hipError_t e = hipMemsetAsync(d_depthByTri, 0, (size_t)numTris * sizeof(int32_t), s);
+    const unsigned int init[3] = {0u, 1u, 0u};   // q[0][0] = root offset 0; counts = {1, 0}
+    if (e == hipSuccess) e = hipMemcpyAsync(q[0], &init[0], sizeof(unsigned int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(cnt, &init[1], 2 * sizeof(unsigned int), hipMemcpyHostToDevice, s);
+    int depth = 0;
+    unsigned long long bound = 1;   // the frontier of level L holds at most min(2^L, capacity) nodes
+    unsigned int frontier = 1;
+    while (e == hipSuccess && frontier > 0 && depth < 4096) {
+        const int in = depth & 1, out = in ^ 1;
+        e = ntr_launch_zero_words(cnt + out, 1, s);
+        const unsigned int threads = (unsigned int)(bound < capacity ? bound : capacity);
+        if (e == hipSuccess)
+            e = ntr_launch_leaf_depth_level(d_nodes, (unsigned int)nodesBytes, d_triWoop, (unsigned int)(triWoopBytes / 16), d_triIndex, numTris, q[in], cnt + in,
+                                            q[out], cnt + out, capacity, threads, depth, d_depthByTri, s);
+        depth++;
+        bound = bound < capacity ? bound * 2 : bound;
+        if ((depth & 3) == 0 && e == hipSuccess) {   // every fourth level: has the frontier run empty?
+            e = hipMemcpyAsync(&frontier, cnt + (depth & 1), sizeof(frontier), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (frontier > capacity) frontier = capacity;
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_q);
+    if (e != hipSuccess) return hip_fail(e, "ntr_bvh_leaf_depths");
+    if (depth >= 4096) return set_error(NTR_ERR_INVALID, "ntr_bvh_leaf_depths: the tree is deeper than 4096 levels (a cycle in the child references?)");
+    if (maxDepth) *maxDepth = depth;
     return NTR_OK;
 }
 

@@ -98,6 +98,11 @@ extern "C" hipError_t ntr_launch_predict_costs(const void* d_rays, int numRays, 
 extern "C" hipError_t ntr_launch_coherence(const void* d_rays, int numRays, int numBlocks, const void* d_table, const unsigned int* d_tableCount,
                                            unsigned int* d_out, int poolKWide, hipStream_t stream);
 // clears 32-bit words with a kernel (graph-replay safe, unlike a memset node)
+extern "C" hipError_t ntr_launch_leaf_depth_level(const void* d_nodes, unsigned int nodesBytes, const void* d_woop, unsigned int woopVec4, const int* d_triIndex,
+                                                  int numTris, const unsigned int* d_qin, const unsigned int* d_nIn, unsigned int* d_qout, unsigned int* d_nOut,
+                                                  unsigned int capacity, unsigned int gridThreads, int depth, int* d_depthByTri, hipStream_t stream);
+extern "C" hipError_t ntr_launch_secondary_block_costs(const void* d_inResults, int first, int count, int numSamples, const int* d_depthByTri, int numTris,
+                                                       unsigned int* d_blockCost, hipStream_t stream);
 extern "C" hipError_t ntr_launch_zero_words(void* d_ptr, int words, hipStream_t stream);
 // out[0] = atomicExch(status, 0): fetch-and-clear of the sticky status word in one device-side step
 extern "C" hipError_t ntr_launch_status_exchange(unsigned int* d_status, unsigned int* d_out, hipStream_t stream);

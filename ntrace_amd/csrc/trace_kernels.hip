@@ -1313,13 +1313,14 @@ __global__ __launch_bounds__(256) void selftest_division_hard_kernel(int xe0, in
 // measured slower than the coarse one because it gives that locality up (scripts/studies/order_experiment.py).
 // One workgroup; stable counting sort with a per-thread segment of the block range.
 // ---------------------------------------------------------------------------------
-constexpr int SCHED_THREADS = 256;   // 64 classes x 256 threads x 4 B = the 64 KB of static LDS
+constexpr int SCHED_THREADS = 256;   // 64 classes x 256 threads x 4 B = 64 KB of static LDS (+ 1 KB of wave totals)
 constexpr int SCHED_MAX_CLASSES = 64;
 
 __global__ __launch_bounds__(SCHED_THREADS) void sched_order_kernel(const unsigned int* __restrict__ cost, int numBlocks, int classes,
                                                                     unsigned int* __restrict__ order)
 {
     __shared__ unsigned int s_cnt[SCHED_MAX_CLASSES][SCHED_THREADS];
+    __shared__ unsigned int s_tot[SCHED_MAX_CLASSES][SCHED_THREADS / 64];
     __shared__ unsigned int s_red[SCHED_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = (numBlocks + SCHED_THREADS - 1) / SCHED_THREADS;
@@ -1334,34 +1335,50 @@ __global__ __launch_bounds__(SCHED_THREADS) void sched_order_kernel(const unsign
     __syncthreads();
     mx = 0;
     for (int w = 0; w < SCHED_THREADS / 64; w++) mx = max(mx, s_red[w]);
-    const unsigned long long scale = (unsigned long long)classes;
-    const unsigned long long denom = (unsigned long long)mx + 1ull;
-    // class 0 = heaviest
-    auto cls = [&](unsigned int c) { return (classes - 1) - (int)(((unsigned long long)c * scale) / denom); };
+    // class 0 = heaviest.  Any monotone map of the cost onto [0, classes) will do -- the order only has to be a permutation, and both
+    // passes below use the same map -- so a float multiply stands in for the 64-bit division (a hundred instructions per block).
+    const float toClass = (float)classes / ((float)mx + 1.0f);
+    auto cls = [&](unsigned int c) { return (classes - 1) - min((int)((float)c * toClass), classes - 1); };
 
     for (int i = b0; i < b1; i++) s_cnt[cls(cost[i])][tid]++;
     __syncthreads();
-    // exclusive scan over (class major, thread minor): one class per iteration, block-wide
-    unsigned int running = 0;
-    for (int c = 0; c < classes; c++) {
-        const unsigned int v = s_cnt[c][tid];
-        unsigned int incl = v;
+    // Exclusive scan over (class major, thread minor).  Every lane scans all its classes' counts across the wave at once (independent
+    // shuffle chains), the waves exchange their totals once: three barriers in all instead of two per class.
+    unsigned int v[SCHED_MAX_CLASSES], incl[SCHED_MAX_CLASSES];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int u = (unsigned int)__shfl_up((int)incl, off);
-            if (lane >= off) incl += u;
-        }
-        if (lane == 63) s_red[wave] = incl;
-        __syncthreads();
-        unsigned int before = 0, total = 0;
-        for (int w = 0; w < SCHED_THREADS / 64; w++) {
-            if (w < wave) before += s_red[w];
-            total += s_red[w];
-        }
-        s_cnt[c][tid] = running + before + incl - v;
-        running += total;
-        __syncthreads();
+    for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
+        v[c] = c < classes ? s_cnt[c][tid] : 0u;
+        incl[c] = v[c];
     }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
+            const unsigned int u = (unsigned int)__shfl_up((int)incl[c], off);
+            if (lane >= off) incl[c] += u;
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < SCHED_MAX_CLASSES; c++) s_tot[c][wave] = incl[c];
+    }
+    __syncthreads();
+    unsigned int running = 0;
+#pragma unroll
+    for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
+        if (c < classes) {
+            unsigned int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < SCHED_THREADS / 64; w++) {
+                const unsigned int t = s_tot[c][w];
+                if (w < wave) before += t;
+                total += t;
+            }
+            s_cnt[c][tid] = running + before + incl[c] - v[c];
+            running += total;
+        }
+    }
+    // (every thread reads back only its own column of s_cnt: no barrier needed)
     for (int i = b0; i < b1; i++) {
         const int c = cls(cost[i]);
         order[s_cnt[c][tid]++] = (unsigned int)i;

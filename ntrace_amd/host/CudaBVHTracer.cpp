@@ -2,7 +2,7 @@
 
 namespace FW {
 
-CudaBVHTracer::CudaBVHTracer(void) : m_bvh(NULL)
+CudaBVHTracer::CudaBVHTracer(void) : m_bvh(NULL), m_hint(NULL)
 {
     m_scene = NULL;
     m_kernelConfig.bvhLayout = BVHLayout_Max;
@@ -37,13 +37,13 @@ F32 CudaBVHTracer::traceRange(RayBuffer& rays, S32 first, S32 count)
     if (CudaBVH* cb = dynamic_cast<CudaBVH*>(m_bvh)) flags = cb->getTraceFlags();
 
     float seconds = 0.0f;
-    int rc = ntr_trace_bvh(m_kernelName.c_str(), numRays, rays.getNeedClosestHit() ? 0 : 1,
+    int rc = ntr_trace_bvh_hinted(m_kernelName.c_str(), numRays, rays.getNeedClosestHit() ? 0 : 1,
                            (const NtrRay*)rays.getRayBuffer().getCudaPtr() + first,
                            (NtrRayResult*)rays.getResultBuffer().getMutableCudaPtr() + first,
                            m_bvh->getNodeBuffer().getCudaPtr(), m_bvh->getNodeBuffer().getSize(),
                            m_bvh->getTriWoopBuffer().getCudaPtr(), m_bvh->getTriWoopBuffer().getSize(),
                            (const int32_t*)m_bvh->getTriIndexBuffer().getCudaPtr(), (int32_t)m_bvh->getLayout(),
-                           flags, NULL, &seconds);
+                           flags, NULL, &seconds, m_hint);
     if (rc != NTR_OK) fail("CudaBVHTracer: %s", ntr_last_error());
     return seconds;
 }

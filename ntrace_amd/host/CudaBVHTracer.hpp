@@ -20,6 +20,8 @@ public:
     // Multi-GPU extension (no counterpart in the reference): trace only the slots [first, first + count) of `rays` -- a rank's
     // screen-tile range of the primary batch (Renderer::setShard).
     F32               traceRange(RayBuffer& rays, S32 first, S32 count);
+    // Dispatch hint for the next traceBatch / traceRange calls (ntr_trace_bvh_hinted; NULL = none).  No counterpart in the reference.
+    void              setSchedHint(NtrSchedHint* hint) { m_hint = hint; }
 
     const KernelConfig& getKernelConfig(void) const { return m_kernelConfig; }
 
@@ -27,6 +29,7 @@ private:
     String       m_kernelName;
     KernelConfig m_kernelConfig;
     CudaAS*      m_bvh;
+    NtrSchedHint* m_hint;
 };
 
 }  // namespace FW

@@ -13,7 +13,7 @@ namespace FW {
 Renderer::Renderer(const String& builder)
     : m_builder(builder), m_raygen(1 << 20), m_enableRandom(false), m_scene(NULL), m_cameraFar(0.0f), m_newBatch(true),
       m_batchRays(NULL), m_batchStart(0), m_accelStruct(NULL), m_cachePath("bvhcache"), m_cacheDataStructure(false),
-      m_shardRank(0), m_shardWorld(1), m_shardLo(0), m_shardHi(0)
+      m_predictSecondary(true), m_leafDepthOf(NULL), m_secondaryHint(NULL), m_shardRank(0), m_shardWorld(1), m_shardLo(0), m_shardHi(0)
 {
     m_cudaTracer = new CudaBVHTracer();
     m_cudaTracer->setScene(NULL);
@@ -24,6 +24,8 @@ Renderer::Renderer(const String& builder)
 
 Renderer::~Renderer(void)
 {
+    static_cast<CudaBVHTracer*>(m_cudaTracer)->setSchedHint(NULL);
+    if (m_secondaryHint) (void)ntr_sched_hint_destroy(m_secondaryHint);
     delete m_accelStruct;
     delete m_cudaTracer;
 }
@@ -141,7 +143,33 @@ bool Renderer::nextBatch(void)
     }
     // Renderer.cpp:559-563
     if (m_params.sortSecondary && m_params.rayType != RayType_Primary) m_batchRays->mortonSort();
+    // AO batches: a dispatch hint from the tree (not for sorted batches: their blocks no longer follow the input rays)
+    if (m_params.rayType == RayType_AO && m_predictSecondary && !m_params.sortSecondary && m_batchRays->getSize() > 0) predictSecondaryOrder();
     return true;
+}
+
+void Renderer::predictSecondaryOrder(void)
+{
+    CudaAS* as = getCudaBVH();
+    const int numTris = m_scene->getNumTriangles();
+    if (numTris < 1) return;
+    if (m_leafDepthOf != as || m_leafDepth.getSize() != (S64)numTris * 4) {   // once per BVH
+        m_leafDepth.resizeDiscard((S64)numTris * 4);
+        int rc = ntr_bvh_leaf_depths(as->getNodeBuffer().getCudaPtr(), as->getNodeBuffer().getSize(), as->getTriWoopBuffer().getCudaPtr(),
+                                     as->getTriWoopBuffer().getSize(), (const int32_t*)as->getTriIndexBuffer().getCudaPtr(), numTris,
+                                     (int32_t*)m_leafDepth.getMutableCudaPtr(), NULL, NULL);
+        if (rc != NTR_OK) fail("Renderer: %s", ntr_last_error());
+        m_leafDepthOf = as;
+    }
+    const int ns = m_params.numSamples;
+    const int first = m_shardLo + m_batchStart / ns, count = (int)(m_batchRays->getSize() / ns);
+    const int blocks = (int)((m_batchRays->getSize() + 255) / 256);
+    m_blockCost.resizeDiscard((S64)blocks * 4);
+    int rc = ntr_secondary_block_costs((const NtrRayResult*)m_primaryRays.getResultBuffer().getCudaPtr(), first, count, ns,
+                                       (const int32_t*)m_leafDepth.getCudaPtr(), numTris, (uint32_t*)m_blockCost.getMutableCudaPtr(), NULL);
+    if (rc == NTR_OK && !m_secondaryHint) rc = ntr_sched_hint_create(&m_secondaryHint);
+    if (rc == NTR_OK) rc = ntr_sched_hint_predict(m_secondaryHint, (const uint32_t*)m_blockCost.getCudaPtr(), blocks, NULL);
+    if (rc != NTR_OK) fail("Renderer: %s", ntr_last_error());
 }
 
 void Renderer::updateResult(Buffer& pixels, Buffer& triMaterialColor, Buffer& triShadedColor)
@@ -166,7 +194,11 @@ F32 Renderer::traceBatch(void)  // Renderer.cpp:568-579
     if (!m_batchRays) fail("Renderer::traceBatch: no batch");
     if (m_batchRays == &m_primaryRays)   // the primary batch: this rank's range of it
         return static_cast<CudaBVHTracer*>(m_cudaTracer)->traceRange(m_primaryRays, m_shardLo, m_shardHi - m_shardLo);
-    return m_cudaTracer->traceBatch(*m_batchRays);
+    CudaBVHTracer* tracer = static_cast<CudaBVHTracer*>(m_cudaTracer);
+    tracer->setSchedHint((m_params.rayType == RayType_AO && m_predictSecondary && !m_params.sortSecondary) ? m_secondaryHint : NULL);
+    const F32 sec = m_cudaTracer->traceBatch(*m_batchRays);
+    tracer->setSchedHint(NULL);
+    return sec;
 }
 
 int Renderer::getTotalNumRays(void)  // Renderer.cpp:676-710

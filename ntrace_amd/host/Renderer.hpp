@@ -31,7 +31,7 @@ public:
     Scene* getScene(void) const { return m_scene; }
     void   setBuildParams(const BVH::BuildParams& params) { invalidateBVH(); m_buildParams = params; }
     BVH::BuildParams& getBuildParams(void) { return m_buildParams; }
-    void   invalidateBVH(void) { delete m_accelStruct; m_accelStruct = NULL; }
+    void   invalidateBVH(void) { delete m_accelStruct; m_accelStruct = NULL; m_leafDepthOf = NULL; }
     void   setParams(const Params& params);
     void   setEnableRandom(bool enable) { m_enableRandom = enable; }
     CudaVirtualTracer& getCudaTracer(void) { return *m_cudaTracer; }
@@ -43,8 +43,12 @@ public:
     void   setShard(int rank, int world);
     S32    getShardLo(void) const { return m_shardLo; }
     S32    getShardHi(void) const { return m_shardHi; }
-    void   adoptCudaBVH(CudaAS* as) { delete m_accelStruct; m_accelStruct = as; }
+    void   adoptCudaBVH(CudaAS* as) { delete m_accelStruct; m_accelStruct = as; m_leafDepthOf = NULL; }
     RayGen& getRayGen(void) { return m_raygen; }
+    // Dispatch hint of the AO batches (no counterpart in the reference): beside generating a batch the Renderer predicts the cost of its
+    // 256-ray blocks from the depth of the leaves its pixels' primary rays hit (ntr_bvh_leaf_depths, ntr_secondary_block_costs) and hands
+    // the tracer a hint that starts from that order (ntr_sched_hint_predict).  On by default; hit records do not depend on it.
+    void   setPredictSecondaryOrder(bool enable) { m_predictSecondary = enable; }
     // BVH cache files, "<cachePath>/<hash>_<builder>.dat" (Renderer.cpp:173-191, 293-299; format of CudaBVH::serialize).  Off by
     // default, like Renderer.cacheDataStructure in the reference's environment.
     void   setCachePath(const String& path) { m_cachePath = path; }
@@ -62,6 +66,7 @@ public:
     RayBuffer* getBatchRays(void) { return m_batchRays; }
 
 private:
+    void predictSecondaryOrder(void);
     Renderer(const Renderer&);
     Renderer& operator=(const Renderer&);
 
@@ -82,6 +87,11 @@ private:
     String             m_cachePath;
     bool               m_cacheDataStructure;
     CudaVirtualTracer* m_cudaTracer;
+    bool               m_predictSecondary;
+    Buffer             m_leafDepth;            // S32 per triangle: depth of its leaf in m_leafDepthOf
+    CudaAS*            m_leafDepthOf;
+    Buffer             m_blockCost;            // U32 per 256-ray block of the current secondary batch
+    NtrSchedHint*      m_secondaryHint;
     int                m_shardRank, m_shardWorld;
     S32                m_shardLo, m_shardHi;   // this rank's range of the current frame's primary slots
 };

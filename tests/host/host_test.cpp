@@ -305,6 +305,24 @@ static void gpuTests()
                 batches++;
             }
             CHECK(traced == (S64)W * H * 8 && batches == 1);
+            // the AO batch was dispatched by the Renderer's leaf-depth hint; without it the records must be the same
+            {
+                std::vector<U8> withHint, without;
+                for (int pass = 0; pass < 2; pass++) {
+                    renderer.setPredictSecondaryOrder(pass == 0);
+                    renderer.beginFrame(cam);
+                    std::vector<U8>& dst = pass == 0 ? withHint : without;
+                    while (renderer.nextBatch()) {
+                        renderer.traceBatch();
+                        Buffer& rb = renderer.getBatchRays()->getResultBuffer();
+                        const size_t at = dst.size();
+                        dst.resize(at + (size_t)rb.getSize());
+                        std::memcpy(dst.data() + at, rb.getPtr(), (size_t)rb.getSize());
+                    }
+                }
+                renderer.setPredictSecondaryOrder(true);
+                CHECK(withHint.size() == (size_t)W * H * 8 * 16 && withHint == without);
+            }
             // sorted AO batches + image reconstruction: AO image = fraction of unoccluded samples
             {
                 p.sortSecondary = true;

@@ -114,6 +114,12 @@ def test_multi_gpu_partition_and_diagnostics_argument_checks():
     assert L.ntr_selftest_division_hard(0, 0, None, C.byref(bad), None) == -1
     assert L.ntr_selftest_division_hard(52, 0, C.byref(pairs), C.byref(bad), None) == -1    # operands would leave the FASTDIV range
     assert L.ntr_selftest_division_hard(0, -41, C.byref(pairs), C.byref(bad), None) == -1
+    # dispatch hints from a prediction: argument checks come before any device work
+    assert L.ntr_sched_hint_predict(None, None, 16, None) == -1
+    assert L.ntr_secondary_block_costs(None, 0, 0, 8, None, 0, None, None) == 0          # an empty batch: nothing to do
+    assert L.ntr_secondary_block_costs(None, 0, 16, 8, None, 0, None, None) == -1
+    assert L.ntr_secondary_block_costs(None, 0, 0, 0, None, 0, None, None) == -1          # no samples per input ray
+    assert L.ntr_bvh_leaf_depths(None, 64, None, 16, None, 1, None, None, None) == -1
     # group calls without a group
     assert L.ntr_dist_info(None, None, None) == -1 and "null group" in nt.lib().ntr_last_error().decode()
     assert L.ntr_dist_broadcast(None, None, 0, 0, None) == -1
