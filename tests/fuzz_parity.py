@@ -185,7 +185,7 @@ def main(argv=None):
             # traversal, so the traversal counters are defined over the other rays
             live = rays[rays["tmin"] < rays["tmax"]]
             # scheduling variants only permute blocks: plain, dispatch-order prediction forced on, caller-owned hint
-            sched = int(rng.integers(0, 3))
+            sched = int(rng.integers(0, 4))   # 3: a caller-owned hint that starts from PREDICTED block costs (random ones: any order is valid)
             if sched == 1:
                 nt.set_tunables(NTR_TRACE_PREDICT_MIN_RAYS=1, NTR_TRACE_PREDICT_MIN_NODES=1)
             else:
@@ -202,7 +202,11 @@ def main(argv=None):
                         NTR_TRACE_HANDOFF_FLAGS=int(rng.integers(0, 4)))
             nt.set_tunables(**loop)
             tot["handoff_rounds"] = tot.get("handoff_rounds", 0) + loop["NTR_TRACE_HANDOFF"]
-            hint = nt.SchedHint() if sched == 2 else None
+            hint = nt.SchedHint() if sched >= 2 else None
+            if sched == 3:
+                nbk = (n + 255) // 256
+                d_pc = torch.from_numpy(rng.integers(0, int(rng.choice([1, 2, 50, 1 << 20])), nbk).astype(np.int32)).to(DEV)
+                hint.predict(d_pc.data_ptr(), nbk)
             tot["sched_%d_rounds" % sched] = tot.get("sched_%d_rounds" % sched, 0) + 1
             for any_hit in (False, True):
                 exp, _ = oracle.trace(nodes, woop, idx, rays, any_hit=any_hit, threads=cores)
