@@ -211,6 +211,7 @@ NTR_API int ntr_trace_bvh_hinted(const char* kernelName, int32_t numRays, int32_
  *                              root down; triangles in no leaf: 0).  One small launch per tree level; blocking.  *levels = levels walked.
  *   ntr_secondary_block_costs  per batch, beside ray generation: d_blockCost[b] = the deepest leaf among the input rays (primary hits
  *                              d_inResults[first .. first + count)) whose numSamples output rays fall into block b; misses count 0.
+ *                              d_blockCost holds (count * numSamples + 255) / 256 words; the call clears them first.
  * Short secondary rays mostly pay for descending to where they start: on the bench frame's AO batches this order recovers what the
  * order learned from a previous launch gives (-9 % launch time), without a previous launch (EXPERIMENTS.md).  No counterpart in the
  * reference, which generates secondary rays (RayGen::ao, src/rt/ray/RayGen.cpp) and traces them in buffer order. */
