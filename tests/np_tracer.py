@@ -29,9 +29,11 @@ def _dot4(a, bx, by, bz, bw):
     return r
 
 
-def trace(nodes, woop, tri_index, rays, any_hit=False, max_stack=100, return_stats=False):
+def trace(nodes, woop, tri_index, rays, any_hit=False, max_stack=100, return_stats=False, inner_hook=None):
     """Returns (id, t); with return_stats also the counters (inner nodes visited, triangle tests, leaf terminators
-    read, hits) as the reference's RayStats defines them (CudaBVH.cpp:746-749, 1107-1111)."""
+    read, hits) as the reference's RayStats defines them (CudaBVH.cpp:746-749, 1107-1111).
+    inner_hook(ray indices, node visited (byte offset), node the ray holds afterwards): called once per lock-step inner step
+    (analysis scripts: which node follows which)."""
     n_inner = n_tri = n_leaf = 0
     nodes_f = np.frombuffer(np.ascontiguousarray(nodes).tobytes(), dtype=F)
     nodes_i = nodes_f.view(np.int32)
@@ -146,6 +148,8 @@ def trace(nodes, woop, tri_index, rays, any_hit=False, max_stack=100, return_sta
                 m = np.zeros(n, dtype=bool)
                 m[inner[none]] = True
                 pop(m)
+                if inner_hook is not None:
+                    inner_hook(inner, b * 4, node[inner].copy())
     if return_stats:
         return res_id, res_t, dict(numInnerVisits=n_inner, numTriTests=n_tri, numLeafVisits=n_leaf, numHits=int((res_id >= 0).sum()))
     return res_id, res_t
