@@ -2,6 +2,7 @@
 """Same-box A/B of two builds of the library on the trace batches: run as
    NTR_LIB_OVERRIDE=ntrace_amd/<lib>.so python3 scripts/studies/lib_ab.py <scene>[,<scene>] [kernel]
 once per library (scripts/studies/lib_ab.sh alternates them).  Prints min-of-last-4 launch times of 8 launches per batch."""
+import hashlib
 import json
 import os
 import sys
@@ -20,6 +21,7 @@ dev = torch.device("cuda:0")
 names = sys.argv[1].split(",")
 kernels = sys.argv[2].split(",") if len(sys.argv) > 2 else ["fermi_speculative_while_while", "kepler_dynamic_fetch"]
 out = {}
+sha = {}   # a digest of every batch's hit records: two builds must agree
 for scene in names:
     tri, pos, cam = scene_of(scene)
     if scene in ("atrium", "conference"):
@@ -54,4 +56,5 @@ for scene in names:
         for kernel in kernels:
             ts = [view.trace(kernel, n, any_hit, d_rays.data_ptr(), d_res.data_ptr()) * 1e3 for _ in range(8)]
             out["%s %s %s" % (scene, bname, kernel.split("_")[0])] = round(min(ts[4:]), 4)
-print(json.dumps(dict(lib=os.environ.get("NTR_LIB_OVERRIDE", "product"), sweep=os.environ.get("NTR_TRACE_SWEEP_BELOW", "default"), ms=out)))
+            sha["%s %s %s" % (scene, bname, kernel.split("_")[0])] = hashlib.sha1(d_res.cpu().numpy().tobytes()).hexdigest()[:12]
+print(json.dumps(dict(lib=os.environ.get("NTR_LIB_OVERRIDE", "product"), ms=out, sha=sha)))
