@@ -139,7 +139,6 @@ static void tunables_load_locked()
     Tunables t;
     t.chunk = env_int("NTR_TRACE_CHUNK", 64);
     t.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", -1);  // -1: 24 for kepler_dynamic_fetch, 0 otherwise
-    t.coop = env_int("NTR_TRACE_COOP", 0);
     t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", -1);     // -1: 32 for closest-hit, 24 for any-hit launches (bench-protocol sweep, scripts/jobs/gpu_job_r02ls.sh)
     t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 6);
     t.blocksPerCUIncoherent = env_int("NTR_TRACE_BLOCKS_PER_CU_INCOHERENT", 3);   // persistent kernels, batches the device finds incoherent (scattered origins): fewer rays in flight = less queueing per step (scripts/studies/inflight_sweep.py)
@@ -697,10 +696,9 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     const Tunables tun = tunables();
     p.chunk = tun.chunk;
     const bool dynamicFetch = strcmp(k->name, "kepler_dynamic_fetch") == 0;
-    const bool unified = dynamicFetch && tun.unified != 0 && !tun.coop;
+    const bool unified = dynamicFetch && tun.unified != 0;
     p.fetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (dynamicFetch ? (unified ? 48 : 24) : 0);
     p.bvhFlags = bvhFlags;
-    p.coop = tun.coop;
     p.flatFetch = (tun.flatFetch != 0 && nodesBytes >= 64 && triWoopBytes >= 64) ? 1 : 0;
     p.leafSwitchBelow = tun.leafSwitchBelow >= 0 ? tun.leafSwitchBelow : (anyHit ? 24 : 32);
     p.octant = tun.octant;
@@ -818,7 +816,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     // (a tree of a few hundred nodes is traced faster than it is predicted: Cornell-box class scenes are left alone)
     // The persistent kernels hand their pool out in the same predicted order (the heavy blocks' long rays start first instead of being
     // the chunks fetched last): there the prediction covers batches of all 256-ray blocks and needs pool chunks that divide 256.
-    const bool persistentOrder = variant == NTR_VARIANT_PERSISTENT && tun.predictPersistent != 0 && (256 % p.chunk) == 0 && !p.coop;
+    const bool persistentOrder = variant == NTR_VARIANT_PERSISTENT && tun.predictPersistent != 0 && (256 % p.chunk) == 0;
     const int orderBlocks = (numRays + 255) / 256;
     // (a launch whose hint holds no measured order yet -- the first one of a batch -- is predicted like an unhinted one)
     if (!(hint && hint->valid) && !p.order && (variant == NTR_VARIANT_PERRAY || persistentOrder) && !anyHit && numRays >= tun.predictMinRays &&
@@ -875,7 +873,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     int launchVariant = variant, launchBlocks = numBlocks;
     if (variant == NTR_VARIANT_PERSISTENT && unified) launchVariant = NTR_VARIANT_PERSISTENT_UNIFIED;
     const int wantWaves = anyHit ? tun.anyHitWaves : tun.closestWaves;
-    if (variant == NTR_VARIANT_PERRAY && !p.coop && wantWaves < NTR_TRACE_WAVES_PER_BLOCK) {
+    if (variant == NTR_VARIANT_PERRAY && wantWaves < NTR_TRACE_WAVES_PER_BLOCK) {
         const int waves = wantWaves <= 1 ? 1 : 2;
         launchVariant = waves == 1 ? NTR_VARIANT_PERRAY_W1 : NTR_VARIANT_PERRAY_W2;
         launchBlocks = numBlocks * (4 / waves);

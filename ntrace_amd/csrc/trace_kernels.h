@@ -59,7 +59,6 @@ struct TraceParams {
     uint32_t bvhFlags;
     int32_t leafSwitchBelow; // serve waiting leaves when fewer lanes than this still hold an inner node
     int32_t octant;          // per-ray kernel: specialise the slab test for waves whose rays share their direction signs
-    int32_t coop;            // quad-cooperative LDS-DMA node fetch instead of per-lane loads
     int32_t flatFetch;       // unified-step loop: one group of global loads for nodes and triangles (needs both extents >= 64 bytes)
     unsigned long long* timeline;  // diagnostic: per-wave realtime stamps (scripts/timeline*.py), or null
     const unsigned int* order;     // per-ray kernel: workgroup i traces ray block order[i] (null = identity); persistent kernels: the pool

@@ -72,12 +72,6 @@ static constexpr int SPILL_DEPTH = 1;
 static constexpr int SPILL_DEPTH = 88;        // 16 + 88 >= the reference CPU stack of 100 (CudaBVH.cpp:701)
 #endif
 
-// Node staging area of one wave in LDS for the quad-cooperative fetch: 4 pieces of
-// 64 lanes x 16 B, each piece skewed by 16 B so that the 4 lanes of a quad (which read
-// different pieces at the same in-piece offset) fall on different banks.
-static constexpr int STAGE_PIECE = 1024 + 16;
-static constexpr int STAGE_BYTES = 4 * STAGE_PIECE;
-
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -266,61 +260,20 @@ struct LaneStats {
     unsigned int inner, tris, leaves;
 };
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(3))) char lds_char;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-
-template <int K>
-__device__ __forceinline__ int quad_bcast(int v)  // value of lane (lane & ~3) + K
-{
-    return __builtin_amdgcn_mov_dpp(v, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true);
-}
-
-// Quad-cooperative node fetch.  A lane reading its own 64-B node with four 16-B loads costs
-// the L1 four tag look-ups per lane (measured: ~44 clk per divergent dwordx4 wave-instruction,
-// scripts/microbench/gather64.hip).  Here the 4 lanes of a quad fetch the 4 nodes of the quad
-// together: in load j every lane reads the 16-B piece (lane & 3) of the node of quad-lane j, so
-// 4 adjacent lanes cover one contiguous 64-B node (one look-up, ~16 clk per wave-instruction).
-// The loads go straight to LDS (buffer_load ... lds); each lane then reads its node back as
-// 4 x ds_read_b128.  Must be executed with all 64 lanes enabled; lanes without an inner node
-// pass an out-of-range offset (the range-checked load fetches nothing).
-__device__ __forceinline__ void fetch_node_coop(Rsrc nodes, lds_char* stage, int lane, int ofs,
-                                                float4& n0, float4& n1, float4& nz, float4& nc)
-{
-    const int piece = (lane & 3) << 4;
-    const int o0 = quad_bcast<0>(ofs) + piece, o1 = quad_bcast<1>(ofs) + piece;
-    const int o2 = quad_bcast<2>(ofs) + piece, o3 = quad_bcast<3>(ofs) + piece;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(nodes, (lds_void*)(stage + 0 * STAGE_PIECE), 16, o0, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(nodes, (lds_void*)(stage + 1 * STAGE_PIECE), 16, o1, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(nodes, (lds_void*)(stage + 2 * STAGE_PIECE), 16, o2, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(nodes, (lds_void*)(stage + 3 * STAGE_PIECE), 16, o3, 0, 0, 0);
-    // LDS-DMA completion is ordered for this wave's ds_read only by its own vmcnt.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const lds_f32x4* mine = (const lds_f32x4*)(stage + (lane & 3) * STAGE_PIECE + ((lane & ~3) << 4));
-    const f32x4 a = mine[0], b = mine[1], c = mine[2], d = mine[3];
-    n0 = make_float4(a.x, a.y, a.z, a.w); n1 = make_float4(b.x, b.y, b.z, b.w);
-    nz = make_float4(c.x, c.y, c.z, c.w); nc = make_float4(d.x, d.y, d.z, d.w);
-}
-
 static constexpr int kNoNode = (int)0xFFFFFF00u;  // buffer offset beyond any extent (< 4 GiB)
 
 // One inner-node step of trace<BVHLayout_Compact> (CudaBVH.cpp:721-775).  Executed by the whole
-// wave (cooperative fetch); only lanes whose current node is an inner node (`inner`) update
-// their state.
-template <bool FAST, bool COOP, int OCT = 8>
-__device__ __forceinline__ void inner_step(Rsrc nodes, lds_char* stage, int lane, bool inner, const RayRegs& r,
+// wave; only lanes whose current node is an inner node (`inner`) update their state.
+template <bool FAST, int OCT = 8>
+__device__ __forceinline__ void inner_step(Rsrc nodes, bool inner, const RayRegs& r,
                                            int& node, LaneStack& st, int (&spill)[SPILL_DEPTH], unsigned int* status)
 {
-    float4 n0, n1, nz, nc;
-    if (COOP) {
-        fetch_node_coop(nodes, stage, lane, inner ? node : kNoNode, n0, n1, nz, nc);
-    } else {  // every lane fetches its own node (4 x 16 B)
-        const int ofs = inner ? node : kNoNode;
-        n0 = ld4(nodes, ofs); n1 = ld4(nodes, ofs + 16); nz = ld4(nodes, ofs + 32);
-        nc = ld4(nodes, ofs + 48);   // (an 8-byte load of the two child words alone: 0.9 % slower, profiles/r03_ab_child_load_b64.jsonl)
-        keep(nc);
-    }
+    // every lane fetches its own node (4 x 16 B; the quad-cooperative LDS-DMA fetch of rounds 1-2 was 1.2-3.7x slower in this loop:
+    // scripts/studies/rejected_patches/coop_fetch.patch)
+    const int ofs = inner ? node : kNoNode;
+    const float4 n0 = ld4(nodes, ofs), n1 = ld4(nodes, ofs + 16), nz = ld4(nodes, ofs + 32);
+    float4 nc = ld4(nodes, ofs + 48);   // (an 8-byte load of the two child words alone: 0.9 % slower, profiles/r03_ab_child_load_b64.jsonl)
+    keep(nc);
 
     float mn0, mx0, mn1, mx1;
     ray_box2<FAST, OCT>(r, n0, n1, nz, mn0, mx0, mn1, mx1);
@@ -406,11 +359,10 @@ __device__ __forceinline__ void load_ray(const NtrRay* __restrict__ rays, int ra
 }
 
 // While-while traversal of the lanes' current rays until every lane is done (or, in the
-// persistent kernel, until too few lanes are live).  Both loops are wave-uniform (ballots), so
-// all 64 lanes stay enabled for the cooperative node fetch; per-ray visiting order is exactly
-// the CPU tracer's depth-first order, whatever the other lanes do.
-template <bool FAST, bool STATS, bool DYNAMIC_FETCH, bool COOP, int OCT = 8>
-__device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, lds_char* stage, int lane, RayRegs& r, int& node,
+// persistent kernel, until too few lanes are live).  Both loops are wave-uniform (ballots); per-ray
+// visiting order is exactly the CPU tracer's depth-first order, whatever the other lanes do.
+template <bool FAST, bool STATS, bool DYNAMIC_FETCH, int OCT = 8>
+__device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, RayRegs& r, int& node,
                                          LaneStack& st, int (&spill)[SPILL_DEPTH], bool anyHit,
                                          int& hitAddr, float& hitU, float& hitV, LaneStats& ls, unsigned int* status,
                                          bool poolEmpty, int fetchThreshold, int leafSwitchBelow)
@@ -425,7 +377,7 @@ __device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, lds_char* stage,
             // lanes still hold an inner node while others already wait at a leaf, serve the leaves first
             // instead of letting a handful of stragglers stall the wave.
             if (__popcll(innerMask) < leafSwitchBelow && __ballot(node < 0) != 0ull) break;
-            inner_step<FAST, COOP, OCT>(nodes, stage, lane, inner, r, node, st, spill, status);
+            inner_step<FAST, OCT>(nodes, inner, r, node, st, spill, status);
             if (STATS && inner) ls.inner++;
         }
         if (node < 0) {
@@ -640,12 +592,12 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
 #else
 #define NTR_PERRAY_BOUNDS(W) __launch_bounds__((W) * 64, NTR_TRACE_MIN_WAVES_PER_SIMD)
 #endif
-template <int WAVES, bool STATS, bool COOP, bool UNIFIED = false, bool FLATF = true, bool MINI = false>
+template <int WAVES, bool STATS, bool UNIFIED = false, bool FLATF = true, bool MINI = false>
 __device__ __forceinline__ void perray_body(const TraceParams& p)
 {
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     if constexpr (MINI) {
-        static_assert(WAVES == 1 && UNIFIED && !STATS && !COOP, "the mini-pool shares the one-wave unified-step launch");
+        static_assert(WAVES == 1 && UNIFIED && !STATS, "the mini-pool shares the one-wave unified-step launch");
         unsigned int K = (unsigned int)p.poolKConst;
         if (p.poolK) K = *p.poolK;   // wave-uniform (scalar load)
         if ((K >= 2u && K <= (unsigned int)NTR_MINIPOOL_MAX_K) || (K == 1u && p.cont && (p.contFlags & NTR_CONT_FLAG_K1))) {
@@ -653,7 +605,6 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
             return;
         }
     }
-    __shared__ __attribute__((aligned(16))) char s_stage[WAVES][COOP ? STAGE_BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // A "block" is 256 consecutive rays (the unit of the dispatch order and of the cost feedback) whatever the workgroup size: a
     // workgroup of WAVES waves traces one of its 4 / WAVES parts.
@@ -663,7 +614,6 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
     const int rayIdx = block * 256 + part * (WAVES * 64) + threadIdx.x;
     const bool valid = rayIdx < p.numRays;
     const Rsrc nodes = make_rsrc(p.nodes, p.nodesBytes), woop = make_rsrc(p.woop, p.woopBytes);
-    lds_char* stage = (lds_char*)&s_stage[__builtin_amdgcn_readfirstlane(wave)][0];
 
     unsigned long long tl0 = 0;
     if (p.timeline || p.cost) tl0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz; scheduling feedback / diagnostics
@@ -685,7 +635,7 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
     const bool fastWave = (p.bvhFlags & NTR_BVH_FASTDIV) && __ballot(node != kSentinel && !ray_is_nice(r, p.bvhFlags)) == 0ull;
     // direction signs shared by every live ray of the wave (a primary wave is an 8 x 8 pixel tile): the octant's own slab test
     int oct = 8;
-    if (!STATS && !COOP && fastWave && p.octant && (p.bvhFlags & NTR_BVH_ORDERED)) {
+    if (!STATS && fastWave && p.octant && (p.bvhFlags & NTR_BVH_ORDERED)) {
         const unsigned long long liveMask = __ballot(node != kSentinel);
         const unsigned long long sx = __ballot(node != kSentinel && r.dx < 0.0f), sy = __ballot(node != kSentinel && r.dy < 0.0f),
                                  sz = __ballot(node != kSentinel && r.dz < 0.0f);
@@ -711,8 +661,8 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
         else if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
         else traverse_unified<false, FLATF>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
     } else
-#define NTR_TRAVERSE_OCT(O) traverse<true, STATS, false, COOP, O>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow)
-    if (!STATS && !COOP && oct < 8) {
+#define NTR_TRAVERSE_OCT(O) traverse<true, STATS, false, O>(nodes, woop, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow)
+    if (!STATS && oct < 8) {
         switch (oct) {
             case 0: NTR_TRAVERSE_OCT(0); break;
             case 1: NTR_TRAVERSE_OCT(1); break;
@@ -725,8 +675,8 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
         }
     }
 #undef NTR_TRAVERSE_OCT
-    else if (fastWave) traverse<true, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
-    else traverse<false, STATS, false, COOP>(nodes, woop, stage, lane, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
+    else if (fastWave) traverse<true, STATS, false>(nodes, woop, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
+    else traverse<false, STATS, false>(nodes, woop, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
 
     if (p.timeline && lane == 0) {
         const unsigned int w = block * 4 + part * WAVES + wave;
@@ -746,16 +696,16 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
     }
 }
 
-template <int WAVES, bool STATS, bool COOP, bool UNIFIED = false, bool FLATF = true>
+template <int WAVES, bool STATS, bool UNIFIED = false, bool FLATF = true>
 __global__ NTR_PERRAY_BOUNDS(WAVES) void trace_bvh_perray(TraceParams p)
 {
-    perray_body<WAVES, STATS, COOP, UNIFIED, FLATF, false>(p);
+    perray_body<WAVES, STATS, UNIFIED, FLATF, false>(p);
 }
 // The one-wave unified-step launch that may run as mini-pools (K decided on the device).  It carries the out-of-line hand-off calls, whose
 // calling convention would push it to 74 registers: held to the 72 of seven waves per SIMD, what it needs without them.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void trace_bvh_perray_mini(TraceParams p)
 {
-    perray_body<1, false, false, true, true, true>(p);
+    perray_body<1, false, true, true, true>(p);
 }
 
 // ---------------------------------------------------------------------------------
@@ -775,15 +725,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
 // TL: the diagnostic stamps of NTR_TRACE_TIMELINE are compiled into their own instantiation -- they cost 18 VGPRs,
 // i.e. two waves of occupancy per SIMD, which the production kernel must not pay.
 // UNIFIED: the unified-step loop (traverse_unified) instead of the while-while loop -- what kepler_dynamic_fetch launches.
-template <int WAVES, bool COOP, bool TL, bool UNIFIED = false, bool FLATF = true>
+template <int WAVES, bool TL, bool UNIFIED = false, bool FLATF = true>
 __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_persistent(TraceParams p)
 {
     unsigned long long* const timeline = TL ? p.timeline : nullptr;
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
-    __shared__ __attribute__((aligned(16))) char s_stage[WAVES][COOP ? STAGE_BYTES : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Rsrc nodes = make_rsrc(p.nodes, p.nodesBytes), woop = make_rsrc(p.woop, p.woopBytes);
-    lds_char* stage = (lds_char*)&s_stage[__builtin_amdgcn_readfirstlane(wave)][0];
     const bool anyHit = p.anyHit != 0;
     const bool bvhFast = (p.bvhFlags & NTR_BVH_FASTDIV) != 0;
     // How many rays should be in flight?  Beyond the L2 the chip serves ~56 G requests/s from ~64 k requests in flight on; more in flight
@@ -921,8 +869,8 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
             const UnifiedBufs ub = unified_bufs(p);
             if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
             else traverse_unified<false, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
-        } else if (fastWave) traverse<true, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
-        else traverse<false, false, true, COOP>(nodes, woop, stage, lane, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
+        } else if (fastWave) traverse<true, false, true>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
+        else traverse<false, false, true>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
 
         // ---- retire finished rays ---------------------------------------------------
         if (rayIdx >= 0 && node == kSentinel) {
@@ -1393,34 +1341,32 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
     constexpr int WAVES = NTR_TRACE_WAVES_PER_BLOCK;
     switch (variant) {
     case NTR_VARIANT_PERRAY:
-        if (p->coop) hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, false, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
-        else hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, false, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_W2:   // smaller workgroups for short any-hit rays (numBlocks counts 128-ray blocks)
-        hipLaunchKernelGGL((ntr::trace_bvh_perray<2, false, false>), dim3(numBlocks), dim3(128), 0, stream, *p);
+        hipLaunchKernelGGL((ntr::trace_bvh_perray<2, false>), dim3(numBlocks), dim3(128), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_W1:
-        hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
+        hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_UNIFIED_W1:   // flatFetch 0: the two-group descriptor fetch (A/B; extents below 64 bytes)
-        if (p->flatFetch) hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false, true, true>), dim3(numBlocks), dim3(64), 0, stream, *p);
-        else hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, false, true, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
+        if (p->flatFetch) hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, true, true>), dim3(numBlocks), dim3(64), 0, stream, *p);
+        else hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, true, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_UNIFIED_MINI:   // numBlocks counts waves of 64 rays; needs flatFetch
         hipLaunchKernelGGL(ntr::trace_bvh_perray_mini, dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_STATS:
-        hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERSISTENT_UNIFIED:
-        if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
-        else if (p->flatFetch) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, false, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
-        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, false, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        else if (p->flatFetch) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERSISTENT:
-        if (p->coop) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
-        else if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
-        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     default:
         return hipErrorInvalidValue;

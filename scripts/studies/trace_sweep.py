@@ -73,7 +73,7 @@ def main():
     if args.configs:
         keep = set(args.configs.split(","))
         configs = [c for c in configs if c[0] in keep]
-    tunables = ("NTR_TRACE_LEAF_SWITCH", "NTR_TRACE_CHUNK", "NTR_TRACE_FETCH_THRESHOLD", "NTR_TRACE_BLOCKS_PER_CU", "NTR_TRACE_COOP")
+    tunables = ("NTR_TRACE_LEAF_SWITCH", "NTR_TRACE_CHUNK", "NTR_TRACE_FETCH_THRESHOLD", "NTR_TRACE_BLOCKS_PER_CU")
     times = {c[0]: ([], []) for c in configs}
     for rnd in range(args.rounds + 1):
         for name, kernel, env in configs:
