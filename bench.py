@@ -44,16 +44,16 @@ PEAK_CLOCK_GHZ = 2.4
 
 
 # kernel symbol a selector launches by default (ntr_api.cpp: 64-thread workgroups of the per-ray kernel; template arguments
-# <WAVES, STATS, COOP, UNIFIED> / <WAVES, COOP, TL, UNIFIED>), and the grid it is launched with for n rays
+# <WAVES, STATS, UNIFIED, FLATF> / <WAVES, TL, UNIFIED, FLATF>), and the grid it is launched with for n rays
 def launched_symbol(kernel, wide_leaves=False, any_hit=False):
     """Closest-hit launches of the per-ray kernel run trace_bvh_perray_mini (the unified-step loop in the instantiation that can turn into
-    wave-private ray pools); any-hit launches trace_bvh_perray<WAVES, STATS, COOP, UNIFIED, FLATF> with the unified-step loop as well;
-    the persistent selectors trace_bvh_persistent<WAVES, COOP, TL, UNIFIED, FLATF> (ntr_api.cpp)."""
+    wave-private ray pools); any-hit launches trace_bvh_perray<WAVES, STATS, UNIFIED, FLATF> with the unified-step loop as well;
+    the persistent selectors trace_bvh_persistent<WAVES, TL, UNIFIED, FLATF> (ntr_api.cpp)."""
     if kernel.startswith("fermi"):
         if not any_hit:
             return "trace_bvh_perray_mini"
-        return "trace_bvh_perray<1, false, false, true, true>"   # (unified-step loop for any-hit launches too since round 4; `wide_leaves` no longer matters)
-    return "trace_bvh_persistent<4, false, false, %s, true>" % ("true" if kernel == "kepler_dynamic_fetch" else "false")
+        return "trace_bvh_perray<1, false, true, true>"   # (unified-step loop for any-hit launches too since round 4; `wide_leaves` no longer matters)
+    return "trace_bvh_persistent<4, false, %s, true>" % ("true" if kernel == "kepler_dynamic_fetch" else "false")
 
 
 def launched_grid(kernel, n_rays, cus=256):

@@ -144,13 +144,6 @@ NTR_API int ntr_trace_bvh(const char* kernelName, int32_t numRays, int32_t anyHi
  * (seconds != NULL) perform the same check themselves.  The word is shared by all streams of the device. */
 NTR_API int ntr_trace_status(void* stream, uint32_t* statusBits);
 
-/* Tail hand-off counters of the stream's most recent trace launch that ran as wave-private ray pools (closest-hit
- * launches of incoherent batches): counts[0] = ray continuations appended to the queue by waves that
- * left, counts[1] = continuations taken up by other waves (equal once the launch has completed: every ray handed
- * off is finished by another wave -- its visiting order, and so its hit record, is untouched), counts[2] = queue
- * capacity in continuations.  All zero when no such launch ran on `stream`.  Waits for `stream`.  Diagnostic. */
-NTR_API int ntr_trace_handoff_counts(void* stream, uint32_t counts[3]);
-
 /* Measurement aid (bench.py extras.gather_roof; no counterpart in the reference): every one of `waves` x `lanesPerWave` lanes walks
  * a dependent chain of `steps` random 64-byte records of a `tableBytes` table (four 16-byte loads per record, the next index a hash of
  * the bytes just loaded) -- the memory side of a divergent traversal without its arithmetic.  *seconds = best of three launches;

@@ -81,7 +81,6 @@ SYMBOLS = [
     ("ntr_trace_bvh_hinted", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _u32, _vp,
                                        C.POINTER(C.c_float), _vp]),
     ("ntr_trace_status", C.c_int, [_vp, C.POINTER(_u32)]),
-    ("ntr_trace_handoff_counts", C.c_int, [_vp, C.POINTER(_u32 * 3)]),
     ("ntr_selftest_gather_rate", C.c_int, [_i64, _i32, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     ("ntr_frame_shard", C.c_int, [_i32, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     ("ntr_frame_ao_batches", C.c_int, [_i32, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), _i32, C.POINTER(_i32)]),
@@ -134,6 +133,8 @@ SYMBOLS = [
     ("ntr_host_bvh_wrap", C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.POINTER(_vp)]),
     ("ntr_host_bvh_trace", C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.POINTER(TraceStats)]),
 ]
+# entry points that exist only in the A/B build (libntrace_amd_ab.so; ntrace_amd/csrc/ntr_ab.h)
+AB_SYMBOLS = [("ntr_trace_handoff_counts", C.c_int, [_vp, C.POINTER(_u32 * 3)])]
 
 
 def _load(path):
@@ -153,6 +154,11 @@ def _load(path):
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        for name, res, args in AB_SYMBOLS:   # entry points of the A/B build only (ntrace_amd/csrc/ntr_ab.h)
+            fn = getattr(L, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         _libs[path] = L
     return _libs[path]
 
@@ -167,6 +173,11 @@ def lib():
 
 def exp_lib_path():
     return os.path.join(_HERE, "libntrace_amd_exp.so")
+
+
+def ab_lib_path():
+    """The A/B build (`make -C ntrace_amd/csrc ab`, -DNTR_AB): the product plus measured-and-rejected experiments (the tail hand-off)."""
+    return os.path.join(_HERE, "libntrace_amd_ab.so")
 
 
 def use_library(path=None):
@@ -239,7 +250,10 @@ def trace_status(stream=0):
 
 
 def trace_handoff_counts(stream=0):
-    """ntr_trace_handoff_counts: (continuations appended, continuations taken up, queue capacity) of the stream's last pooled launch."""
+    """ntr_trace_handoff_counts (A/B build only: use_library(ab_lib_path())): (continuations appended, continuations taken up, queue
+    capacity) of the stream's last pooled launch."""
+    if not hasattr(lib(), "ntr_trace_handoff_counts"):
+        raise NtrError(-1, "the tail hand-off lives in the A/B build only (make -C ntrace_amd/csrc ab; use_library(ab_lib_path()))")
     c = (_u32 * 3)()
     _check(lib().ntr_trace_handoff_counts(_vp(stream), C.byref(c)))
     return int(c[0]), int(c[1]), int(c[2])

@@ -16,6 +16,9 @@
 #include "ntrace_amd.h"
 #include "ntr_internal.h"
 #include "trace_kernels.h"
+#ifdef NTR_AB
+#include "ntr_ab.h"
+#endif
 
 namespace {
 
@@ -149,11 +152,13 @@ static void tunables_load_locked()
     t.minipool = env_int("NTR_TRACE_MINIPOOL", -1);              // closest-hit per-ray launches: rays owned by a wave / 64.  -1: decided per batch on the device (1, or minipoolWide when the prediction finds the batch incoherent); 0: the plain per-ray kernel; 1 ... 16: forced
     t.minipoolWide = env_int("NTR_TRACE_MINIPOOL_WIDE", -1);     // K of an incoherent batch: 2 / 4, or -1 = by tree size (4 from 32 MB of nodes up)
     t.minipoolThreshold = env_int("NTR_TRACE_MINIPOOL_THRESHOLD", 48);   // refill a wave's finished lanes when fewer than this many are live
+#ifdef NTR_AB
     t.handoff = env_int("NTR_TRACE_HANDOFF", 0);                  // mini-pool launches: tail hand-off through the continuation queue.  OFF: it cuts the wave-iterations 3x and the VALU work 2.2x as modelled, and the launch gets 5-10 % slower (profiles/r04_handoff_*; EXPERIMENTS.md)
     t.handoffBelow = env_int("NTR_TRACE_HANDOFF_BELOW", 16);      // T: a pool wave with fewer live lanes (own rays all started) fills up from the queue or hands its rays off
     t.handoffMinQueue = env_int("NTR_TRACE_HANDOFF_MIN_QUEUE", 64);   // M: waiting continuations needed to fill up rather than hand off (capped by the wave's free lanes)
     t.handoffKeepWaves = env_int("NTR_TRACE_HANDOFF_KEEP_WAVES", 1024);   // A: with no more waves than this left in the launch nobody hands off
     t.handoffFlags = env_int("NTR_TRACE_HANDOFF_FLAGS", 0);       // 1: raised priority for waves that took continuations; 2: batches with pool K = 1 run as one-chunk pools and hand their tails off too
+#endif
     t.unified = env_int("NTR_TRACE_UNIFIED", 1);                  // kepler_dynamic_fetch: unified-step loop (0 = while-while loop + dynamic fetch)
     t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", 1);     // per-ray kernel with the unified-step loop: 1 = always (the default since the one-correction divide: AO batches on one-triangle-leaf trees -4 %), 0 = never, -1 = closest-hit launches always, any-hit launches only on trees flagged NTR_BVH_WIDE_LEAVES (the rule of round 3)
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/studies/persist_diag.py)
@@ -330,6 +335,7 @@ static constexpr int kScratchSpares = 4;   // spares a live launch keeps ready (
 static constexpr int kScratchLive = 16;    // streams with an entry of their own before the least recently used one is recycled
 static PredictScratch g_scratch[kScratch];
 
+#ifdef NTR_AB
 // Continuation queue of the tail hand-off (trace_kernels.hip): one per (device, stream) -- launches on one stream are ordered, two streams
 // must not share a queue.  A fixed number of entries, never evicted and never touched during a capture: a launch that finds none runs
 // without the hand-off (it is an optimisation, not a contract).
@@ -380,6 +386,7 @@ static int cont_scratch_get(hipStream_t s, int numRays, ContScratch** out)
     *out = c;
     return NTR_OK;
 }
+#endif
 
 static int top_table_get(const void* d_nodes, int64_t nodesBytes, hipStream_t s, bool rebuild, TopTable** out)
 {
@@ -708,12 +715,14 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.cost = nullptr;
     p.poolK = nullptr;
     p.poolKConst = 1;
+#ifdef NTR_AB
     p.cont = nullptr;
     p.contShardSlots = 0;
     p.contBelow = tun.handoffBelow < 1 ? 1 : (tun.handoffBelow > 64 ? 64 : tun.handoffBelow);
     p.contMinQueue = tun.handoffMinQueue < 1 ? 1 : tun.handoffMinQueue;
     p.contKeepWaves = tun.handoffKeepWaves < 0 ? 0 : tun.handoffKeepWaves;
     p.contFlags = tun.handoffFlags;
+#endif
 #ifdef NTR_EXPERIMENTS
     p.timeline = g_expTimeline;
     p.order = g_expOrder;
@@ -894,6 +903,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
                     if (predScratch) p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 2;
                     else if (hint && hint->numBlocks == numBlocks && hint->order) p.poolK = hint->order + numBlocks + 2;
                 }
+#ifdef NTR_AB
                 // tail hand-off: the pool waves' continuation queue (used only if the launch runs as pools)
                 if (tun.handoff != 0 && (p.poolK || p.poolKConst >= 2 || (p.contFlags & NTR_CONT_FLAG_K1))) {
                     ContScratch* cq = nullptr;
@@ -906,6 +916,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
                         p.contShardSlots = cq->shardSlots;
                     }
                 }
+#endif
             }
         }
     }
@@ -929,7 +940,9 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         NTR_HIP(hipMemcpyAsync(&st, ds->status + 8, sizeof(st), hipMemcpyDeviceToHost, s));
         NTR_HIP(hipStreamSynchronize(s));
         if (st & NTR_STATUS_STACK_OVERFLOW) return set_error(NTR_ERR_OVERFLOW, "trace_bvh: traversal stack overflow");
+#ifdef NTR_AB
         if (st & NTR_STATUS_HANDOFF_TIMEOUT) return set_error(NTR_ERR_HIP, "trace_bvh: a handed-off ray never arrived (continuation queue)");
+#endif
     }
     if (stats) {
         unsigned long long h[4];
@@ -979,11 +992,14 @@ int ntr_trace_status(void* stream, uint32_t* statusBits)
     if (statusBits) *statusBits = st;
     if (st & NTR_STATUS_STACK_OVERFLOW)
         return set_error(NTR_ERR_OVERFLOW, "trace_bvh: traversal stack overflow in a launch since the last status check");
+#ifdef NTR_AB
     if (st & NTR_STATUS_HANDOFF_TIMEOUT)
         return set_error(NTR_ERR_HIP, "trace_bvh: a handed-off ray never arrived (continuation queue) in a launch since the last status check");
+#endif
     return NTR_OK;
 }
 
+#ifdef NTR_AB
 int ntr_trace_handoff_counts(void* stream, uint32_t counts[3])
 {
     if (!counts) return set_error(NTR_ERR_INVALID, "ntr_trace_handoff_counts: null argument");
@@ -1009,6 +1025,7 @@ int ntr_trace_handoff_counts(void* stream, uint32_t counts[3])
     counts[2] = (uint32_t)shardSlots * NTR_CONT_SHARDS;
     return NTR_OK;
 }
+#endif
 
 int ntr_predict_block_costs(int32_t numRays, const NtrRay* d_rays, const void* d_nodes, int64_t nodesBytes, uint32_t* d_blockCost, void* stream)
 {

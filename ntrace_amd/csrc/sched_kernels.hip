@@ -374,3 +374,97 @@ extern "C" hipError_t ntr_launch_zero_words(void* d_ptr, int words, hipStream_t 
     hipLaunchKernelGGL(ntr::zero_words_kernel, dim3(grid), dim3(256), 0, stream, (unsigned int*)d_ptr, words);
     return hipGetLastError();
 }
+
+namespace ntr {
+
+// ---------------------------------------------------------------------------------
+// Scheduling feedback (ntr_trace_bvh_hinted): turns the per-block costs one launch recorded into
+// the block order of the next launch of the same logical batch -- heaviest cost class first, so
+// that the long-lived waves start early instead of forming the tail of the launch.  Blocks are
+// only CLASSIFIED (NTR_SCHED_CLASSES linear classes of the maximum cost) and keep their original
+// order inside a class: neighbouring blocks trace neighbouring rays, and a full sort by cost was
+// measured slower than the coarse one because it gives that locality up (scripts/studies/order_experiment.py).
+// One workgroup; stable counting sort with a per-thread segment of the block range.
+// ---------------------------------------------------------------------------------
+constexpr int SCHED_THREADS = 256;   // 64 classes x 256 threads x 4 B = 64 KB of static LDS (+ 1 KB of wave totals)
+constexpr int SCHED_MAX_CLASSES = 64;
+
+__global__ __launch_bounds__(SCHED_THREADS) void sched_order_kernel(const unsigned int* __restrict__ cost, int numBlocks, int classes,
+                                                                    unsigned int* __restrict__ order)
+{
+    __shared__ unsigned int s_cnt[SCHED_MAX_CLASSES][SCHED_THREADS];
+    __shared__ unsigned int s_tot[SCHED_MAX_CLASSES][SCHED_THREADS / 64];
+    __shared__ unsigned int s_red[SCHED_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = (numBlocks + SCHED_THREADS - 1) / SCHED_THREADS;
+    const int b0 = min(tid * seg, numBlocks), b1 = min(b0 + seg, numBlocks);
+
+    unsigned int mx = 0;
+    for (int i = tid; i < numBlocks; i += SCHED_THREADS) mx = max(mx, cost[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, off));
+    if (lane == 0) s_red[wave] = mx;
+    for (int c = 0; c < classes; c++) s_cnt[c][tid] = 0;
+    __syncthreads();
+    mx = 0;
+    for (int w = 0; w < SCHED_THREADS / 64; w++) mx = max(mx, s_red[w]);
+    // class 0 = heaviest.  Any monotone map of the cost onto [0, classes) will do -- the order only has to be a permutation, and both
+    // passes below use the same map -- so a float multiply stands in for the 64-bit division (a hundred instructions per block).
+    const float toClass = (float)classes / ((float)mx + 1.0f);
+    auto cls = [&](unsigned int c) { return (classes - 1) - min((int)((float)c * toClass), classes - 1); };
+
+    for (int i = b0; i < b1; i++) s_cnt[cls(cost[i])][tid]++;
+    __syncthreads();
+    // Exclusive scan over (class major, thread minor).  Every lane scans all its classes' counts across the wave at once (independent
+    // shuffle chains), the waves exchange their totals once: three barriers in all instead of two per class.
+    unsigned int v[SCHED_MAX_CLASSES], incl[SCHED_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
+        v[c] = c < classes ? s_cnt[c][tid] : 0u;
+        incl[c] = v[c];
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
+            const unsigned int u = (unsigned int)__shfl_up((int)incl[c], off);
+            if (lane >= off) incl[c] += u;
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < SCHED_MAX_CLASSES; c++) s_tot[c][wave] = incl[c];
+    }
+    __syncthreads();
+    unsigned int running = 0;
+#pragma unroll
+    for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
+        if (c < classes) {
+            unsigned int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < SCHED_THREADS / 64; w++) {
+                const unsigned int t = s_tot[c][w];
+                if (w < wave) before += t;
+                total += t;
+            }
+            s_cnt[c][tid] = running + before + incl[c] - v[c];
+            running += total;
+        }
+    }
+    // (every thread reads back only its own column of s_cnt: no barrier needed)
+    for (int i = b0; i < b1; i++) {
+        const int c = cls(cost[i]);
+        order[s_cnt[c][tid]++] = (unsigned int)i;
+    }
+}
+
+}  // namespace ntr
+
+extern "C" hipError_t ntr_launch_sched_order(const unsigned int* d_cost, int numBlocks, int classes, unsigned int* d_order,
+                                             hipStream_t stream)
+{
+    if (classes < 1) classes = 1;
+    if (classes > ntr::SCHED_MAX_CLASSES) classes = ntr::SCHED_MAX_CLASSES;
+    hipLaunchKernelGGL(ntr::sched_order_kernel, dim3(1), dim3(ntr::SCHED_THREADS), 0, stream, d_cost, numBlocks, classes, d_order);
+    return hipGetLastError();
+}

@@ -61,6 +61,7 @@
 #include <float.h>
 
 #include "trace_kernels.h"
+#include "trace_arith.h"
 
 namespace ntr {
 
@@ -121,35 +122,6 @@ __device__ __forceinline__ bool ray_is_nice(const RayRegs& r, uint32_t bvhFlags)
     return nice_dir(r.dx) && nice_dir(r.dy) && nice_dir(r.dz) && nice_pos(r.ox, zeroOk) && nice_pos(r.oy, zeroOk) &&
            nice_pos(r.oz, zeroOk);
 }
-// The CORRECTLY ROUNDED reciprocal of a direction component (the IEEE divide 1 / d: once per ray and axis).  With it ONE residual
-// correction makes a quotient correctly rounded:  q0 = x r;  e = fma(-d, q0, x);  q = fma(e, r, q0)  ==  RN(x / d).
-// Why: q0 + e r = x/d (1 + theta) exactly, |theta| <~ 4 u^2 (u = 2^-24), so q can differ from RN(x/d) only when x/d lies within that
-// distance of a midpoint of two neighbouring floats -- and those pairs are enumerable: for significands X, D and a midpoint Mo / 2^24 the
-// distance is |2^24 X - D Mo| / (2^24 D), a non-zero integer over 2^24 D.  scripts/studies/div_one_correction_check.py checks every such
-// pair (all D, both quotient binades, |numerator| <= 8: 46.5 M pairs) in exact integer arithmetic: none differs; with a reciprocal one ulp
-// off 14 % of them do (which is why the hardware divide's own chain -- v_rcp refined once, NOT always correctly rounded -- needs the two
-// corrections this path used until round 4).  ntr_selftest_division() checks FAST == GENERIC on the device, those pairs included.
-#if defined(NTR_AB) && defined(NTR_DIV_TWO_CORRECTIONS)   // A/B build: the chain of rounds 1-3 (v_rcp refined once, two corrections)
-__device__ __forceinline__ float exact_rcp(float d)
-{
-    const float r0 = __builtin_amdgcn_rcpf(d);
-    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
-}
-#else
-__device__ __forceinline__ float exact_rcp(float d) { return 1.0f / d; }
-#endif
-__device__ __forceinline__ float fast_div(float x, float d, float r)
-{
-    const float q0 = x * r;
-    const float e1 = __builtin_fmaf(-d, q0, x);
-    const float q1 = __builtin_fmaf(e1, r, q0);
-#if defined(NTR_AB) && defined(NTR_DIV_TWO_CORRECTIONS)
-    return __builtin_fmaf(__builtin_fmaf(-d, q1, x), r, q1);
-#else
-    return q1;
-#endif
-}
-
 // Intersect::RayBox for BOTH children of a node (Util.cpp:34-46).  The FAST form evaluates
 // the twelve quotients stage by stage (all q0, then all e1, ...) so that consecutive
 // instructions are independent: a lone wave cannot issue a VALU op that depends on the
@@ -600,7 +572,11 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
         static_assert(WAVES == 1 && UNIFIED && !STATS, "the mini-pool shares the one-wave unified-step launch");
         unsigned int K = (unsigned int)p.poolKConst;
         if (p.poolK) K = *p.poolK;   // wave-uniform (scalar load)
-        if ((K >= 2u && K <= (unsigned int)NTR_MINIPOOL_MAX_K) || (K == 1u && p.cont && (p.contFlags & NTR_CONT_FLAG_K1))) {
+        bool pooled = K >= 2u && K <= (unsigned int)NTR_MINIPOOL_MAX_K;
+#ifdef NTR_AB
+        pooled = pooled || (K == 1u && p.cont && (p.contFlags & NTR_CONT_FLAG_K1));   // (hand-off experiment: one-chunk pools hand their tails off too)
+#endif
+        if (pooled) {
             minipool_body<FLATF>(p, K, (lds_int*)&s_stack[0][0][threadIdx.x]);
             return;
         }
@@ -701,9 +677,13 @@ __global__ NTR_PERRAY_BOUNDS(WAVES) void trace_bvh_perray(TraceParams p)
 {
     perray_body<WAVES, STATS, UNIFIED, FLATF, false>(p);
 }
-// The one-wave unified-step launch that may run as mini-pools (K decided on the device).  It carries the out-of-line hand-off calls, whose
-// calling convention would push it to 74 registers: held to the 72 of seven waves per SIMD, what it needs without them.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void trace_bvh_perray_mini(TraceParams p)
+// The one-wave unified-step launch that may run as mini-pools (K decided on the device).
+#ifdef NTR_AB   // with the out-of-line hand-off calls, whose calling convention would push it to 74 registers: held to the 72 of seven waves per SIMD
+#define NTR_MINI_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7)))
+#else
+#define NTR_MINI_BOUNDS __launch_bounds__(64)
+#endif
+__global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini(TraceParams p)
 {
     perray_body<1, false, true, true, true>(p);
 }
@@ -890,141 +870,9 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     }
 }
 
-// ---- tail hand-off (round 4): continuation queue of the mini-pool waves ------------------------------------------------------------
-// A pool wave whose own rays are all started and of which fewer than T are still live keeps a whole wave slot busy for a handful of
-// lanes (lane utilisation 0.15 on the 10 M-triangle tree, profiles/r03zz_courtyard10m_pmc_summary.json).  Such a wave now either FILLS
-// its free lanes with continuations other waves left in a queue, or -- while enough waves are still running to pick them up -- APPENDS
-// its own live rays to the queue and exits.  A continuation is the ray's complete traversal state (current node, shrunken tmax, hit so
-// far, stack), so the ray goes on exactly where it stood: its visiting order, and with it its hit record, cannot change.
-// Model first (scripts/studies/tail_handoff_model.py, profiles/r04_tail_handoff_model_*.jsonl): 1.8-3.4x fewer wave-iterations for K = 4.
-//
-// Queue: NTR_CONT_SHARDS independent shards (a wave uses shard = its ordinal % shards: the counters of one shard see 1/64 of the
-// traffic).  Shard control line (128 B): [0] reserved = slots producers took, [1] popped = slots consumers claimed, [2] exited = waves
-// of the shard that are gone.  Slot (128 B): [0] rayIdx -- doubling as the ready flag, -1 = empty --, node, tmax, hitAddr, hitU, hitV, sp,
-// tos, then up to CONT_STACK stack entries.  Every access is an agent-scope relaxed atomic (sc1: served by the coherent level, the
-// per-XCD L2s are not coherent with each other); a producer lane drains its stores (s_waitcnt vmcnt(0)) before it sets its slot's flag, a
-// consumer lane polls its slot's flag before it loads the slot (MI355X_MICROARCH, inter-workgroup visibility: sc1 both sides).
-//   producer: reserved += n (one atomic per wave); slots beyond the shard's capacity are VOID: the lane keeps its ray.
-//   consumer: CAS on popped, never beyond reserved (a claimed slot has a producer that will fill it without waiting for anyone).
-//   exit:     exited += 1 AFTER the wave's last reservation; the wave that completes its shard finds every reservation made and drains
-//             what nobody claimed.  No wave ever waits for a wave that could be waiting for it.
-// The counters are cleared by a kernel before the launch; slots are returned to -1 by their consumer.
-static constexpr int CONT_STACK = NTR_CONT_SLOT_WORDS - 8;
-
-struct ContShard {
-    unsigned int* ctl;            // this wave's shard
-    unsigned long long* slots;    // its slots, as 8-byte words
-    int capacity;                 // slots of the shard
-    int waves;                    // waves of the launch that use the shard
-};
-
-__device__ __forceinline__ unsigned int cont_ld(const unsigned int* a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long cont_ld64(const unsigned long long* a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void cont_st64(unsigned long long* a, unsigned int lo, unsigned int hi)
-{
-    __hip_atomic_store(a, (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// A lane's traversal state, as the out-of-line hand-off routines see it (the kernel keeps these in registers; it packs them only around
-// the rare calls, so the cold code costs the hot loop no register).
-struct LaneState {
-    RayRegs r;
-    int rayIdx, node, hitAddr, sp, tos, nice;
-    float hitU, hitV;
-};
-
-// Appends the rays of the lanes in `mask` to the shard and empties those lanes (a lane whose slot lies beyond the shard's capacity keeps its ray).
-__device__ __noinline__ void cont_produce(unsigned int* ctl, unsigned long long* slots, int capacity, unsigned long long mask, LaneState& ls, lds_int* lds, int* spill)
-{
-    const int n = __popcll(mask);
-    unsigned int base = 0;
-    if (threadIdx.x == 0) base = __hip_atomic_fetch_add(ctl + 0, (unsigned int)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    base = __builtin_amdgcn_readfirstlane(base);
-    const bool mine = (mask >> threadIdx.x) & 1ull;
-    const unsigned int idx = base + (unsigned int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-    if (mine && idx < (unsigned int)capacity) {
-        unsigned long long* slot = slots + (size_t)idx * (NTR_CONT_SLOT_WORDS / 2);
-        cont_st64(slot + 1, __float_as_uint(ls.r.tmax), (unsigned int)ls.hitAddr);
-        cont_st64(slot + 2, __float_as_uint(ls.hitU), __float_as_uint(ls.hitV));
-        cont_st64(slot + 3, (unsigned int)ls.sp, (unsigned int)ls.tos);
-        for (int i = 0; i < ls.sp; i += 2) {
-            const int e0 = i < LDS_DEPTH ? lds[i * 64] : spill[i - LDS_DEPTH];
-            const int e1 = (i + 1 < ls.sp) ? ((i + 1) < LDS_DEPTH ? lds[(i + 1) * 64] : spill[i + 1 - LDS_DEPTH]) : 0;
-            cont_st64(slot + 4 + (i >> 1), (unsigned int)e0, (unsigned int)e1);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slot has reached the coherent level before its flag says so
-        cont_st64(slot + 0, (unsigned int)ls.rayIdx, (unsigned int)ls.node);
-        ls.rayIdx = -1;
-        ls.node = kSentinel;
-        ls.sp = 0;
-        ls.tos = kSentinel;
-    }
-}
-
-// Fills up to `want` empty lanes (rayIdx < 0) with continuations of the shard.  Returns the number of lanes filled.
-__device__ __noinline__ int cont_consume(unsigned int* ctl, unsigned long long* slots, int capacity, const NtrRay* rays, uint32_t bvhFlags, unsigned int* status,
-                                         int want, LaneState& ls, lds_int* lds, int* spill)
-{
-    unsigned int base = 0;
-    int take = 0;
-    if (threadIdx.x == 0) {
-        for (int tries = 0; tries < 8; tries++) {
-            const unsigned int pp = cont_ld(ctl + 1);
-            const unsigned int rr = cont_ld(ctl + 0);   // read after popped: reserved only grows, so rr - pp never overstates what a claim from pp may take
-            const int avail = (int)(rr - pp);
-            if (avail <= 0) break;
-            const int t = min(want, avail);
-            unsigned int expected = pp;
-            if (__hip_atomic_compare_exchange_strong(ctl + 1, &expected, pp + (unsigned int)t, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                base = pp;
-                take = t;
-                break;
-            }
-        }
-    }
-    base = __builtin_amdgcn_readfirstlane(base);
-    take = __builtin_amdgcn_readfirstlane(take);
-    if (take == 0) return 0;
-    const unsigned long long empty = __ballot(ls.rayIdx < 0);
-    const int prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(empty >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)empty, 0));
-    const unsigned int idx = base + (unsigned int)prefix;
-    const bool mine = ls.rayIdx < 0 && prefix < take && idx < (unsigned int)capacity;   // (a void slot holds nothing: its producer kept the ray)
-    if (mine) {
-        unsigned long long* slot = slots + (size_t)idx * (NTR_CONT_SLOT_WORDS / 2);
-        unsigned long long w0;
-        unsigned int spins = 0;
-        while ((int)(unsigned int)(w0 = cont_ld64(slot + 0)) < 0) {     // the producer reserved this slot before the claim: it is on its way
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 22)) { atomicOr(status, NTR_STATUS_HANDOFF_TIMEOUT); break; }
-        }
-        if ((int)(unsigned int)w0 >= 0) {
-            const unsigned long long w1 = cont_ld64(slot + 1), w2 = cont_ld64(slot + 2), w3 = cont_ld64(slot + 3);
-            ls.rayIdx = (int)(unsigned int)w0;
-            load_ray(rays, ls.rayIdx, ls.r);
-            ls.nice = ray_is_nice(ls.r, bvhFlags) ? 1 : 0;
-            ls.node = (int)(unsigned int)(w0 >> 32);
-            ls.r.tmax = __uint_as_float((unsigned int)w1);
-            ls.hitAddr = (int)(unsigned int)(w1 >> 32);
-            ls.hitU = __uint_as_float((unsigned int)w2);
-            ls.hitV = __uint_as_float((unsigned int)(w2 >> 32));
-            ls.sp = (int)(unsigned int)w3;
-            ls.tos = (int)(unsigned int)(w3 >> 32);
-            for (int i = 0; i < ls.sp; i += 2) {
-                const unsigned long long e = cont_ld64(slot + 4 + (i >> 1));
-                if (i < LDS_DEPTH) lds[i * 64] = (int)(unsigned int)e; else spill[i - LDS_DEPTH] = (int)(unsigned int)e;
-                if (i + 1 < ls.sp) { if (i + 1 < LDS_DEPTH) lds[(i + 1) * 64] = (int)(unsigned int)(e >> 32); else spill[i + 1 - LDS_DEPTH] = (int)(unsigned int)(e >> 32); }
-            }
-            cont_st64(slot + 0, 0xFFFFFFFFu, 0u);   // the slot is free again (for the next launch: a slot is used once per launch)
-        }
-    }
-    return __popcll(__ballot(mine && ls.rayIdx >= 0));
-}
-
-// packs / unpacks the register state around the out-of-line calls
-#define NTR_LANE_PACK(ls) do { (ls).r = r; (ls).rayIdx = rayIdx; (ls).node = node; (ls).hitAddr = hitAddr; (ls).sp = st.sp; (ls).tos = st.tos; \
-                               (ls).nice = nice ? 1 : 0; (ls).hitU = hitU; (ls).hitV = hitV; } while (0)
-#define NTR_LANE_UNPACK(ls) do { r = (ls).r; rayIdx = (ls).rayIdx; node = (ls).node; hitAddr = (ls).hitAddr; st.sp = (ls).sp; st.tos = (ls).tos; \
-                                 nice = (ls).nice != 0; hitU = (ls).hitU; hitV = (ls).hitV; } while (0)
+#ifdef NTR_AB
+#include "trace_handoff_ab.h"   // continuation queue of the opt-in tail hand-off: A/B build only
+#endif
 
 // ---------------------------------------------------------------------------------
 // Variant 3: per-ray kernel with a wave-private mini-pool (round 3).  A hardware-scheduled 64-thread workgroup owns K x 64 consecutive
@@ -1035,7 +883,7 @@ __device__ __noinline__ int cont_consume(unsigned int* ctl, unsigned long long* 
 // path per wave -- which is why the pool stays small and private: the global pool of the persistent kernels keeps every lane busy
 // until it runs dry, and then 6 144 waves each hold a few long rays (a tail of 60-70 % of their launch, profiles/r03_divergence_timelines.jsonl).
 // Unified-step loop, flat fetch; 256-ray blocks keep their role as the unit of the dispatch order and of the cost feedback.
-// With a continuation queue (p.cont, round 4) the tail of a pool is handed off: see above.
+// A/B build only (-DNTR_AB): with a continuation queue (p.cont, round 4) the tail of a pool is handed off, trace_handoff_ab.h.
 // ---------------------------------------------------------------------------------
 template <bool FLATF>
 __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int K, lds_int* stackBase)
@@ -1062,8 +910,9 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
 
     unsigned long long tl0 = 0;
     if (p.cost) tl0 = __builtin_amdgcn_s_memrealtime();
-    unsigned int life = 0;                 // scheduling feedback: the wave's lifetime up to the hand-off of its tail (or its end)
+    unsigned int life = 0;                 // scheduling feedback: the wave's lifetime (A/B build: up to the hand-off of its tail)
 
+#ifdef NTR_AB
     // tail hand-off: this wave's shard of the continuation queue
     ContShard cs = {nullptr, nullptr, 0, 0};
     bool final = true;                     // wave-uniform: no (more) hand-off, the wave runs what it holds to completion
@@ -1079,6 +928,7 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
         keepWaves = max(p.contKeepWaves / NTR_CONT_SHARDS, 1);
         final = false;
     }
+#endif
 
     LaneStack st;
     int spill[SPILL_DEPTH];
@@ -1116,6 +966,7 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
         // ---- tail: the wave's own rays are all started.  Below T live lanes: fill up from the queue, or hand the rays off ----------
         bool stopEarly = !poolEmpty;               // leave the traversal when fewer than `stopBelow` lanes are live
         int stopBelow = p.fetchThreshold;
+#ifdef NTR_AB
         if (poolEmpty && !final) {
             int nlive = __popcll(__ballot(node != kSentinel));
             if (nlive < p.contBelow) {
@@ -1150,6 +1001,7 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
             }
             if (!final) { stopEarly = true; stopBelow = min(p.contBelow, nlive); }   // look again as soon as a ray ends below T
         }
+#endif
         // ---- unified-step traversal until every lane is done, or until enough lanes are free to be worth a refill -------------
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
         if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, !stopEarly, stopBelow);
@@ -1160,6 +1012,9 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
             rayIdx = -1;
         }
         if (poolEmpty && __ballot(rayIdx >= 0) == 0ull) {
+#ifndef NTR_AB
+            break;
+#else
             if (!p.cont) break;
             // ---- leaving: a wave that holds nothing.  The one that completes its shard drains what nobody claimed ----------------------
             if (!shardLast) {
@@ -1176,160 +1031,12 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
             LaneState ls; NTR_LANE_PACK(ls);
             cont_consume(cs.ctl, cs.slots, cs.capacity, p.rays, p.bvhFlags, p.status, min(queued, 64), ls, st.lds, spill);
             NTR_LANE_UNPACK(ls);
+#endif
         }
     }
     if (p.cost && lane == 0) {  // scheduling feedback: a block's cost is the lifetime of the longest wave that traced a part of it
         if (life == 0u) life = (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0);
         for (unsigned int c = q * K; c < chunkEnd; c += 4u - (c & 3u)) atomicMax(&p.cost[p.order ? p.order[c >> 2] : (c >> 2)], life);
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// Self test: FAST division == GENERIC division, bit for bit, on device.
-// mismatches += number of differing quotients among x[i] / d[j] for all i, j.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void selftest_division_kernel(const float* __restrict__ x, const float* __restrict__ d,
-                                                                int nx, int nd, unsigned int* __restrict__ mismatches)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nx) return;
-    const float xv = x[i];
-    unsigned int bad = 0;
-    for (int j = 0; j < nd; j++) {
-        const float dv = d[j];
-        const float q0 = xv / dv;
-        const float q1 = fast_div(xv, dv, exact_rcp(dv));
-        // the sign of a zero quotient is not observable by the tracer's comparisons
-        bad += (__float_as_uint(q0) != __float_as_uint(q1)) && !(q0 == 0.0f && q1 == 0.0f);
-    }
-    if (bad) atomicAdd(mismatches, bad);
-}
-
-// The hardest quotients for the one-correction divide, enumerated on the device: for every significand D in [2^23, 2^24) the X whose
-// quotient X / D lies closest to a rounding boundary -- 2^b X - D Mo = N for a midpoint Mo (odd, 25 bits), b = 24 (X >= D) or 25 (X < D),
-// every N with |N| <= 8 the equation admits -- what scripts/studies/div_one_correction_check.py checks in exact integer arithmetic.
-// Here the hardware runs them: FAST divide against `/`, with x and d scaled by the powers of two [xe0, xe0 + 3] x [de0, de0 + 3]
-// (the result may not depend on them inside the FASTDIV range).  One thread per D; counts[0] += pairs tested, counts[1] += mismatches.
-__global__ __launch_bounds__(256) void selftest_division_hard_kernel(int xe0, int de0, unsigned long long* __restrict__ counts)
-{
-    const unsigned int D = (1u << 23) + blockIdx.x * 256u + threadIdx.x;   // grid: 2^23 / 256 workgroups
-    const int k = __builtin_ctz(D);
-    unsigned long long tested = 0, bad = 0;
-    if (k <= 3) {   // (a D divisible by 16 admits no |N| <= 8)
-        const unsigned int Dp = D >> k;
-        unsigned int inv = Dp;   // Dp^-1 mod 2^32 (Newton: every step doubles the valid bits, 3 to start with)
-        for (int it = 0; it < 5; it++) inv *= 2u - Dp * inv;
-        for (int b = 24; b <= 25; b++) {
-            const unsigned long long mod = 1ull << (b - k);
-            for (int Np = -8; Np <= 8; Np++) {
-                const long long N = (long long)Np * (1ll << k);
-                if (Np == 0 || N > 8 || N < -8) continue;
-                const unsigned long long base = ((unsigned long long)(unsigned int)(-Np) * inv) & (mod - 1ull);   // Dp Mo = -N' (mod 2^(b-k))
-                for (unsigned int j = 0; j < (1u << k); j++) {
-                    unsigned long long Mo = base + j * mod;
-                    while (Mo < (1ull << 24)) Mo += 1ull << b;
-                    if (Mo >= (1ull << 25) || !(Mo & 1ull)) continue;
-                    const long long num = (long long)((unsigned long long)D * Mo) + N;
-                    if (num & ((1ll << b) - 1ll)) continue;
-                    const long long X = num >> b;
-                    if (b == 24 ? (X < (long long)D || X >= (1ll << 24)) : (X < (1ll << 23) || X >= (long long)D)) continue;
-                    for (int e = 0; e < 16; e++) {
-                        const float xv = ldexpf((float)X, xe0 + (e & 3) - 23), dv = ldexpf((float)D, de0 + (e >> 2) - 23);
-                        for (int sgn = 0; sgn < 2; sgn++) {
-                            const float dd = sgn ? -dv : dv;
-                            const float q0 = xv / dd;
-                            const float q1 = fast_div(xv, dd, exact_rcp(dd));
-                            tested++;
-                            bad += __float_as_uint(q0) != __float_as_uint(q1);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (tested) atomicAdd(&counts[0], tested);
-    if (bad) atomicAdd(&counts[1], bad);
-}
-
-
-// ---------------------------------------------------------------------------------
-// Scheduling feedback (ntr_trace_bvh_hinted): turns the per-block costs one launch recorded into
-// the block order of the next launch of the same logical batch -- heaviest cost class first, so
-// that the long-lived waves start early instead of forming the tail of the launch.  Blocks are
-// only CLASSIFIED (NTR_SCHED_CLASSES linear classes of the maximum cost) and keep their original
-// order inside a class: neighbouring blocks trace neighbouring rays, and a full sort by cost was
-// measured slower than the coarse one because it gives that locality up (scripts/studies/order_experiment.py).
-// One workgroup; stable counting sort with a per-thread segment of the block range.
-// ---------------------------------------------------------------------------------
-constexpr int SCHED_THREADS = 256;   // 64 classes x 256 threads x 4 B = 64 KB of static LDS (+ 1 KB of wave totals)
-constexpr int SCHED_MAX_CLASSES = 64;
-
-__global__ __launch_bounds__(SCHED_THREADS) void sched_order_kernel(const unsigned int* __restrict__ cost, int numBlocks, int classes,
-                                                                    unsigned int* __restrict__ order)
-{
-    __shared__ unsigned int s_cnt[SCHED_MAX_CLASSES][SCHED_THREADS];
-    __shared__ unsigned int s_tot[SCHED_MAX_CLASSES][SCHED_THREADS / 64];
-    __shared__ unsigned int s_red[SCHED_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int seg = (numBlocks + SCHED_THREADS - 1) / SCHED_THREADS;
-    const int b0 = min(tid * seg, numBlocks), b1 = min(b0 + seg, numBlocks);
-
-    unsigned int mx = 0;
-    for (int i = tid; i < numBlocks; i += SCHED_THREADS) mx = max(mx, cost[i]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, off));
-    if (lane == 0) s_red[wave] = mx;
-    for (int c = 0; c < classes; c++) s_cnt[c][tid] = 0;
-    __syncthreads();
-    mx = 0;
-    for (int w = 0; w < SCHED_THREADS / 64; w++) mx = max(mx, s_red[w]);
-    // class 0 = heaviest.  Any monotone map of the cost onto [0, classes) will do -- the order only has to be a permutation, and both
-    // passes below use the same map -- so a float multiply stands in for the 64-bit division (a hundred instructions per block).
-    const float toClass = (float)classes / ((float)mx + 1.0f);
-    auto cls = [&](unsigned int c) { return (classes - 1) - min((int)((float)c * toClass), classes - 1); };
-
-    for (int i = b0; i < b1; i++) s_cnt[cls(cost[i])][tid]++;
-    __syncthreads();
-    // Exclusive scan over (class major, thread minor).  Every lane scans all its classes' counts across the wave at once (independent
-    // shuffle chains), the waves exchange their totals once: three barriers in all instead of two per class.
-    unsigned int v[SCHED_MAX_CLASSES], incl[SCHED_MAX_CLASSES];
-#pragma unroll
-    for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
-        v[c] = c < classes ? s_cnt[c][tid] : 0u;
-        incl[c] = v[c];
-    }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-        for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
-            const unsigned int u = (unsigned int)__shfl_up((int)incl[c], off);
-            if (lane >= off) incl[c] += u;
-        }
-    }
-    if (lane == 63) {
-#pragma unroll
-        for (int c = 0; c < SCHED_MAX_CLASSES; c++) s_tot[c][wave] = incl[c];
-    }
-    __syncthreads();
-    unsigned int running = 0;
-#pragma unroll
-    for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
-        if (c < classes) {
-            unsigned int before = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < SCHED_THREADS / 64; w++) {
-                const unsigned int t = s_tot[c][w];
-                if (w < wave) before += t;
-                total += t;
-            }
-            s_cnt[c][tid] = running + before + incl[c] - v[c];
-            running += total;
-        }
-    }
-    // (every thread reads back only its own column of s_cnt: no barrier needed)
-    for (int i = b0; i < b1; i++) {
-        const int c = cls(cost[i]);
-        order[s_cnt[c][tid]++] = (unsigned int)i;
     }
 }
 
@@ -1371,27 +1078,5 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
     default:
         return hipErrorInvalidValue;
     }
-    return hipGetLastError();
-}
-
-extern "C" hipError_t ntr_launch_sched_order(const unsigned int* d_cost, int numBlocks, int classes, unsigned int* d_order,
-                                             hipStream_t stream)
-{
-    if (classes < 1) classes = 1;
-    if (classes > ntr::SCHED_MAX_CLASSES) classes = ntr::SCHED_MAX_CLASSES;
-    hipLaunchKernelGGL(ntr::sched_order_kernel, dim3(1), dim3(ntr::SCHED_THREADS), 0, stream, d_cost, numBlocks, classes, d_order);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t ntr_launch_selftest_division(const float* d_x, const float* d_d, int nx, int nd,
-                                                   unsigned int* d_mismatches, hipStream_t stream)
-{
-    hipLaunchKernelGGL(ntr::selftest_division_kernel, dim3((nx + 255) / 256), dim3(256), 0, stream, d_x, d_d, nx, nd, d_mismatches);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t ntr_launch_selftest_division_hard(int xe0, int de0, unsigned long long* d_counts, hipStream_t stream)
-{
-    hipLaunchKernelGGL(ntr::selftest_division_hard_kernel, dim3((1u << 23) / 256u), dim3(256), 0, stream, xe0, de0, d_counts);
     return hipGetLastError();
 }

@@ -28,6 +28,7 @@ from oracle import oracle  # noqa: E402
 
 KERNELS = ["fermi_speculative_while_while", "kepler_dynamic_fetch", "tesla_persistent_while_while"]
 DEV = "cuda:0"
+HAS_HANDOFF = hasattr(nt.lib(), "ntr_trace_handoff_counts")   # the A/B build of the library (NTR_LIB_OVERRIDE)
 
 
 def up(a):
@@ -196,8 +197,9 @@ def main(argv=None):
                         NTR_TRACE_FETCH_THRESHOLD=int(rng.choice([-1, -1, 1, 16, 33, 64])), NTR_TRACE_FLAT_FETCH=int(rng.choice([1, 1, 0])),
                         # wave-private mini-pool of the closest-hit per-ray launches: by the device's coherence estimate, off, or forced
                         NTR_TRACE_MINIPOOL=int(rng.choice([-1, -1, 0, 1, 2, 3, 4, 5, 8, 16])), NTR_TRACE_MINIPOOL_THRESHOLD=int(rng.choice([48, 48, 1, 33, 64])),
-                        # tail hand-off of the pool waves (an opt-in): every threshold drawn at random, pools of one chunk included
-                        NTR_TRACE_HANDOFF=int(rng.choice([0, 1, 1])), NTR_TRACE_HANDOFF_BELOW=int(rng.integers(1, 65)),
+                        # tail hand-off of the pool waves (A/B build only: run with NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_ab.so; the product
+                        # library ignores these): every threshold drawn at random, pools of one chunk included
+                        NTR_TRACE_HANDOFF=int(rng.choice([0, 1, 1])) if HAS_HANDOFF else 0, NTR_TRACE_HANDOFF_BELOW=int(rng.integers(1, 65)),
                         NTR_TRACE_HANDOFF_MIN_QUEUE=int(rng.choice([1, 4, 16, 64])), NTR_TRACE_HANDOFF_KEEP_WAVES=int(rng.choice([0, 0, 64, 1024, 100000])),
                         NTR_TRACE_HANDOFF_FLAGS=int(rng.integers(0, 4)))
             nt.set_tunables(**loop)

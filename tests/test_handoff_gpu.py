@@ -1,4 +1,5 @@
-"""GPU parity of the tail hand-off (round 4; an opt-in, NTR_TRACE_HANDOFF=1: measured slower than leaving the tails alone): a pool wave whose own rays are all started and of which only a few are still live
+"""GPU parity of the tail hand-off (round 4; measured 5-10 % slower than leaving the tails alone, so it lives in the A/B build of the
+library only -- libntrace_amd_ab.so, `make -C ntrace_amd/csrc ab` -- and these tests run against that library): a pool wave whose own rays are all started and of which only a few are still live
 appends those rays' complete traversal state to a continuation queue and exits, or fills its free lanes from that queue.  A ray goes
 on exactly where it stood -- its visiting order cannot change -- so every record must stay the oracle's, whatever the thresholds."""
 import numpy as np
@@ -11,6 +12,17 @@ from ray_sets import edge_rays
 
 pytestmark = pytest.mark.gpu
 K = "fermi_speculative_while_while"
+
+
+@pytest.fixture(autouse=True)
+def ab_library(request):
+    """Every test of this module calls the A/B build; the product library is restored afterwards."""
+    import os
+    if not os.path.exists(nt.ab_lib_path()):
+        pytest.fail("libntrace_amd_ab.so missing: __graft_entry__.build() makes it (make -C ntrace_amd/csrc ab)")
+    nt.use_library(nt.ab_lib_path())
+    request.addfinalizer(lambda: (nt.use_library(None), nt.set_tunables()))
+
 HANDOFF_ENV = ("NTR_TRACE_HANDOFF", "NTR_TRACE_HANDOFF_BELOW", "NTR_TRACE_HANDOFF_MIN_QUEUE", "NTR_TRACE_HANDOFF_KEEP_WAVES", "NTR_TRACE_HANDOFF_FLAGS",
                "NTR_TRACE_MINIPOOL", "NTR_TRACE_MINIPOOL_THRESHOLD")
 
