@@ -467,6 +467,81 @@ __device__ __forceinline__ UnifiedBufs unified_bufs(const TraceParams& p)
 // With FLAT every live lane forms the 64-bit address of its own 64 bytes and ONE group of four global loads serves nodes and triangles
 // alike (64 TA cycles).  Global loads are not range-checked: a lane whose 64 bytes would end beyond its buffer (an empty leaf's
 // terminator in the last 48 bytes of triWoop; a malformed child offset) takes the descriptor path instead, which reads zeros there.
+// One unified step, in two halves so that a wave can have the fetches of two independent rays per lane in flight (traverse_unified_pair).
+// unified_fetch: one 64-byte fetch per lane from its own buffer -- the node of a lane at an inner node, the triangle (48 B + the following
+// word) of a lane at a leaf.  Issues the loads and, apart from the rare end-of-buffer lanes, does not wait for them.
+template <bool FLAT>
+__device__ __forceinline__ void unified_fetch(const UnifiedBufs& ub, int node, float4& a, float4& b, float4& c, float4& d)
+{
+    const bool inner = (unsigned)node < (unsigned)kSentinel;
+    const bool atTri = node < 0;
+    // (Written as `inner ? ld4(nodes, ..) : ld4(woop, ..)` hipcc selects the descriptor per lane and wraps every load in a waterfall loop.)
+    const int ofs = inner ? node : (~node) * 16;
+    if (FLAT) {
+        const bool flatOk = (inner || atTri) && (unsigned)ofs <= (inner ? ub.nodesBytes : ub.woopBytes) - 64u;   // (extents are >= 64 here)
+        asm volatile("" : "=v"(a.x), "=v"(a.y), "=v"(a.z), "=v"(a.w), "=v"(b.x), "=v"(b.y), "=v"(b.z), "=v"(b.w));   // defined, whatever the lane
+        asm volatile("" : "=v"(c.x), "=v"(c.y), "=v"(c.z), "=v"(c.w), "=v"(d.x), "=v"(d.y), "=v"(d.z), "=v"(d.w));
+        if (flatOk) {
+            const float4* q = reinterpret_cast<const float4*>((inner ? ub.nodes : ub.woop) + (unsigned)ofs);
+            a = q[0]; b = q[1]; c = q[2]; d = q[3];
+        }
+        const unsigned long long odd = __ballot((inner || atTri) && !flatOk);
+        if (odd != 0ull)   // rare: range-checked descriptor loads, into the same registers, for the lanes at the very end of a buffer
+            fetch64_two_buffers_into(ub.rNodes, ub.rWoop, ofs, __ballot(inner && !flatOk), __ballot(atTri && !flatOk), a, b, c, d);
+    } else {   // four loads under the inner lanes' mask and four under the triangle lanes' mask into the SAME registers, one wait
+        fetch64_two_buffers(ub.rNodes, ub.rWoop, ofs, __ballot(inner), __ballot(atTri), a, b, c, d);
+    }
+}
+
+// unified_advance: the lane's ray takes the step its 64 bytes allow -- one inner node (trace<BVHLayout_Compact>, CudaBVH.cpp:721-775) or one
+// triangle (intersectTriangles + updateHit, CudaBVH.cpp:1084-1126, 1183-1225).
+template <bool FAST, int OCT>
+__device__ __forceinline__ void unified_advance(const float4& a, const float4& b, const float4& c, const float4& d, RayRegs& r, int& node,
+                                                LaneStack& st, int (&spill)[SPILL_DEPTH], bool anyHit, int& hitAddr, float& hitU, float& hitV,
+                                                unsigned int* status)
+{
+    const bool inner = (unsigned)node < (unsigned)kSentinel;
+    const bool atTri = node < 0;
+    if (inner) {
+        float mn0, mx0, mn1, mx1;
+        ray_box2<FAST, OCT>(r, a, b, c, mn0, mx0, mn1, mx1);
+        const bool i0 = (mn0 <= mx0) && (mx0 >= r.tmin) && (mn0 <= r.tmax);
+        const bool i1 = (mn1 <= mx1) && (mx1 >= r.tmin) && (mn1 <= r.tmax);
+        const int c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
+        const bool swp = i1 && (!i0 || mn0 > mn1);
+        const int nearC = swp ? c1 : c0, farC = swp ? c0 : c1;
+        if (i0 && i1) stack_push(st, spill, farC, status);
+        node = (i0 || i1) ? nearC : stack_pop(st, spill);
+    } else if (atTri) {
+        bool leafDone = __float_as_uint(a.x) == 0x80000000u;   // terminator: an empty leaf
+        if (!leafDone) {
+            const float Oz = a.w - r.ox * a.x - r.oy * a.y - r.oz * a.z;
+            const float ooDz = 1.0f / dot4(a, r.dx, r.dy, r.dz, 0.0f);
+            const float t = Oz * ooDz;
+            float tt = FLT_MAX, uu = 0.0f, vv = 0.0f;
+            if (t > r.tmin && t < r.tmax) {
+                const float u = dot4(b, r.ox, r.oy, r.oz, 1.0f) + t * dot4(b, r.dx, r.dy, r.dz, 0.0f);
+                if (u >= 0.0f) {
+                    const float v = dot4(c, r.ox, r.oy, r.oz, 1.0f) + t * dot4(c, r.dx, r.dy, r.dz, 0.0f);
+                    if (v >= 0.0f && (u + v) <= 1.0f) { tt = t; uu = u; vv = v; }
+                }
+            }
+            bool terminated = false;
+            if (tt > r.tmin && tt < r.tmax) {
+                r.tmax = tt;
+                hitAddr = ~node;
+                hitU = uu;
+                hitV = vv;
+                terminated = anyHit;
+            }
+            if (terminated) node = kSentinel;
+            else if (__float_as_uint(d.x) == 0x80000000u) leafDone = true;   // the terminator came with this triangle
+            else node -= 3;
+        }
+        if (leafDone) node = stack_pop(st, spill);
+    }
+}
+
 template <bool FAST, bool FLAT, int OCT = 8>
 __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs& r, int& node, LaneStack& st,
                                                  int (&spill)[SPILL_DEPTH], bool anyHit, int& hitAddr, float& hitU, float& hitV,
@@ -488,65 +563,35 @@ __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs&
             else if (a == 3u) __builtin_amdgcn_s_setprio(3);
         }
 #endif
-        const bool inner = (unsigned)node < (unsigned)kSentinel;
-        const bool atTri = node < 0;
-        // one 64-byte fetch per lane from its own buffer: four loads under the inner lanes' mask and four under the triangle lanes'
-        // mask into the SAME registers, one wait.  (Written as `inner ? ld4(nodes, ..) : ld4(woop, ..)` hipcc selects the
-        // descriptor per lane and wraps every load in a waterfall loop.)
-        const int ofs = inner ? node : (~node) * 16;
         float4 a, b, c, d;
-        if (FLAT) {
-            const bool flatOk = (inner || atTri) && (unsigned)ofs <= (inner ? ub.nodesBytes : ub.woopBytes) - 64u;   // (extents are >= 64 here)
-            asm volatile("" : "=v"(a.x), "=v"(a.y), "=v"(a.z), "=v"(a.w), "=v"(b.x), "=v"(b.y), "=v"(b.z), "=v"(b.w));   // defined, whatever the lane
-            asm volatile("" : "=v"(c.x), "=v"(c.y), "=v"(c.z), "=v"(c.w), "=v"(d.x), "=v"(d.y), "=v"(d.z), "=v"(d.w));
-            if (flatOk) {
-                const float4* q = reinterpret_cast<const float4*>((inner ? ub.nodes : ub.woop) + (unsigned)ofs);
-                a = q[0]; b = q[1]; c = q[2]; d = q[3];
-            }
-            keep(a); keep(b); keep(c); keep(d);
-            const unsigned long long odd = __ballot((inner || atTri) && !flatOk);
-            if (odd != 0ull)   // rare: range-checked descriptor loads, into the same registers, for the lanes at the very end of a buffer
-                fetch64_two_buffers_into(ub.rNodes, ub.rWoop, ofs, __ballot(inner && !flatOk), __ballot(atTri && !flatOk), a, b, c, d);
-        } else {
-            fetch64_two_buffers(ub.rNodes, ub.rWoop, ofs, __ballot(inner), __ballot(atTri), a, b, c, d);
+        unified_fetch<FLAT>(ub, node, a, b, c, d);
+        if (FLAT) { keep(a); keep(b); keep(c); keep(d); }
+        unified_advance<FAST, OCT>(a, b, c, d, r, node, st, spill, anyHit, hitAddr, hitU, hitV, status);
+    }
+}
+
+// Two independent rays per lane (round 5): the wave steps ray A and ray B of every lane in one iteration -- both
+// 64-byte fetches are issued before the wave waits for either, then A advances (while B's loads are still in flight), then B.  Each
+// ray's own visiting order is traverse_unified's, so every hit record is unchanged.  A slot whose 64 rays have all ended costs nothing
+// (wave-uniform skips).
+template <bool FAST, bool FLAT>
+__device__ __forceinline__ void traverse_unified_pair(const UnifiedBufs& ub, bool anyHit, unsigned int* status,
+                                                      RayRegs& rA, int& nodeA, LaneStack& stA, int (&spillA)[SPILL_DEPTH], int& hitAddrA, float& hitUA, float& hitVA,
+                                                      RayRegs& rB, int& nodeB, LaneStack& stB, int (&spillB)[SPILL_DEPTH], int& hitAddrB, float& hitUB, float& hitVB)
+{
+    for (;;) {
+        const bool liveA = __ballot(nodeA != kSentinel) != 0ull, liveB = __ballot(nodeB != kSentinel) != 0ull;   // wave-uniform
+        if (!liveA && !liveB) break;
+        float4 a0, b0, c0, d0, a1, b1, c1, d1;
+        if (liveA) unified_fetch<FLAT>(ub, nodeA, a0, b0, c0, d0);
+        if (liveB) unified_fetch<FLAT>(ub, nodeB, a1, b1, c1, d1);
+        if (liveA) {
+            if (FLAT) { keep(a0); keep(b0); keep(c0); keep(d0); }
+            unified_advance<FAST, 8>(a0, b0, c0, d0, rA, nodeA, stA, spillA, anyHit, hitAddrA, hitUA, hitVA, status);
         }
-        if (inner) {   // trace<BVHLayout_Compact>, one inner node (CudaBVH.cpp:721-775)
-            float mn0, mx0, mn1, mx1;
-            ray_box2<FAST, OCT>(r, a, b, c, mn0, mx0, mn1, mx1);
-            const bool i0 = (mn0 <= mx0) && (mx0 >= r.tmin) && (mn0 <= r.tmax);
-            const bool i1 = (mn1 <= mx1) && (mx1 >= r.tmin) && (mn1 <= r.tmax);
-            const int c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
-            const bool swp = i1 && (!i0 || mn0 > mn1);
-            const int nearC = swp ? c1 : c0, farC = swp ? c0 : c1;
-            if (i0 && i1) stack_push(st, spill, farC, status);
-            node = (i0 || i1) ? nearC : stack_pop(st, spill);
-        } else if (atTri) {   // intersectTriangles + updateHit, one triangle (CudaBVH.cpp:1084-1126, 1183-1225)
-            bool leafDone = __float_as_uint(a.x) == 0x80000000u;   // terminator: an empty leaf
-            if (!leafDone) {
-                const float Oz = a.w - r.ox * a.x - r.oy * a.y - r.oz * a.z;
-                const float ooDz = 1.0f / dot4(a, r.dx, r.dy, r.dz, 0.0f);
-                const float t = Oz * ooDz;
-                float tt = FLT_MAX, uu = 0.0f, vv = 0.0f;
-                if (t > r.tmin && t < r.tmax) {
-                    const float u = dot4(b, r.ox, r.oy, r.oz, 1.0f) + t * dot4(b, r.dx, r.dy, r.dz, 0.0f);
-                    if (u >= 0.0f) {
-                        const float v = dot4(c, r.ox, r.oy, r.oz, 1.0f) + t * dot4(c, r.dx, r.dy, r.dz, 0.0f);
-                        if (v >= 0.0f && (u + v) <= 1.0f) { tt = t; uu = u; vv = v; }
-                    }
-                }
-                bool terminated = false;
-                if (tt > r.tmin && tt < r.tmax) {
-                    r.tmax = tt;
-                    hitAddr = ~node;
-                    hitU = uu;
-                    hitV = vv;
-                    terminated = anyHit;
-                }
-                if (terminated) node = kSentinel;
-                else if (__float_as_uint(d.x) == 0x80000000u) leafDone = true;   // the terminator came with this triangle
-                else node -= 3;
-            }
-            if (leafDone) node = stack_pop(st, spill);
+        if (liveB) {
+            if (FLAT) { keep(a1); keep(b1); keep(c1); keep(d1); }
+            unified_advance<FAST, 8>(a1, b1, c1, d1, rB, nodeB, stB, spillB, anyHit, hitAddrB, hitUB, hitVB, status);
         }
     }
 }
@@ -686,6 +731,49 @@ __global__ NTR_PERRAY_BOUNDS(WAVES) void trace_bvh_perray(TraceParams p)
 __global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini(TraceParams p)
 {
     perray_body<1, false, true, true, true>(p);
+}
+
+// ---------------------------------------------------------------------------------
+// Variant 1b: two rays per lane (round 5).  A 64-thread workgroup traces 128 consecutive rays of a 256-ray block: lane l holds ray
+// base + l (slot A) and ray base + 64 + l (slot B), stepped together by traverse_unified_pair.  Half the waves of the per-ray launch,
+// two independent fetch groups in flight per wave.  The 256-ray block stays the unit of the dispatch order and of the cost feedback.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void trace_bvh_perray_pair(TraceParams p)
+{
+    __shared__ int s_stack[2][LDS_DEPTH][64];  // [slot][entry][lane]
+    const int lane = threadIdx.x;
+    const unsigned int g = blockIdx.x >> 1, part = blockIdx.x & 1u;
+    const unsigned int block = p.order ? p.order[g] : g;
+    const int rayA = block * 256 + part * 128 + lane, rayB = rayA + 64;
+    const bool validA = rayA < p.numRays, validB = rayB < p.numRays;
+
+    unsigned long long tl0 = 0;
+    if (p.cost) tl0 = __builtin_amdgcn_s_memrealtime();
+
+    RayRegs rA, rB;
+    load_ray(p.rays, validA ? rayA : 0, rA);
+    load_ray(p.rays, validB ? rayB : 0, rB);
+    LaneStack stA, stB;
+    int spillA[SPILL_DEPTH], spillB[SPILL_DEPTH];
+    stA.lds = (lds_int*)&s_stack[0][0][lane];
+    stB.lds = (lds_int*)&s_stack[1][0][lane];
+    NTR_STACK_RESET(stA);
+    NTR_STACK_RESET(stB);
+    int hitAddrA = -1, hitAddrB = -1;
+    float hitUA = 0.0f, hitVA = 0.0f, hitUB = 0.0f, hitVB = 0.0f;
+    // degenerate rays (Util.hpp:65) are misses without traversal
+    int nodeA = (validA && rA.tmin < rA.tmax) ? 0 : kSentinel;
+    int nodeB = (validB && rB.tmin < rB.tmax) ? 0 : kSentinel;
+
+    const bool fastWave = (p.bvhFlags & NTR_BVH_FASTDIV) &&
+                          __ballot((nodeA != kSentinel && !ray_is_nice(rA, p.bvhFlags)) || (nodeB != kSentinel && !ray_is_nice(rB, p.bvhFlags))) == 0ull;
+    const UnifiedBufs ub = unified_bufs(p);
+    if (fastWave) traverse_unified_pair<true, true>(ub, p.anyHit != 0, p.status, rA, nodeA, stA, spillA, hitAddrA, hitUA, hitVA, rB, nodeB, stB, spillB, hitAddrB, hitUB, hitVB);
+    else traverse_unified_pair<false, true>(ub, p.anyHit != 0, p.status, rA, nodeA, stA, spillA, hitAddrA, hitUA, hitVA, rB, nodeB, stB, spillB, hitAddrB, hitUB, hitVB);
+
+    if (p.cost && lane == 0) atomicMax(&p.cost[block], (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0));
+    if (validA) store_result(p.results, p.triIndex, rayA, hitAddrA, rA.tmax, hitUA, hitVA);
+    if (validB) store_result(p.results, p.triIndex, rayB, hitAddrB, rB.tmax, hitUB, hitVB);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1062,6 +1150,9 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
         break;
     case NTR_VARIANT_PERRAY_UNIFIED_MINI:   // numBlocks counts waves of 64 rays; needs flatFetch
         hipLaunchKernelGGL(ntr::trace_bvh_perray_mini, dim3(numBlocks), dim3(64), 0, stream, *p);
+        break;
+    case NTR_VARIANT_PERRAY_PAIR:   // numBlocks counts waves of 128 rays; needs flatFetch
+        hipLaunchKernelGGL(ntr::trace_bvh_perray_pair, dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_STATS:
         hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);

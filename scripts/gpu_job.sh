@@ -15,6 +15,7 @@
 #   lbvh             scripts/studies/lbvh_sweep3.py
 #   fuzz:<seconds>   tests/fuzz_parity.py for that long
 #   ab:<reps>        scripts/ab_bench.sh: bench.py alternately against libntrace_amd.so and libntrace_amd_ab.so
+#   knob:<VAR>:<v1>:<v2>...   scripts/studies/bench_knob.sh: the bench step under each value of one run-time tunable ("-" = unset), interleaved
 #   py:<script>[:args...]   python3 scripts/<script>.py (or scripts/studies/<script>.py) args (':' separated); pyexp: the same with libntrace_amd_exp.so
 set -u
 TAG=${1:?tag}; shift
@@ -59,6 +60,9 @@ EOF
     timeout -k 5 $((ARG + 120)) python3 tests/fuzz_parity.py --seconds $ARG --seed ${FUZZ_SEED:-41} --progress $OUT/fuzz_progress.json > $OUT/fuzz.json 2> $OUT/fuzz.err; echo "rc=$?"; tail -c 1500 $OUT/fuzz.json; tail -n 3 $OUT/fuzz.err ;;
   ab)      # interleaved A/B of libntrace_amd.so and libntrace_amd_ab.so: ab:<reps>
     AB_OUT=$OUT bash scripts/ab_bench.sh ${ARG:-3} 2>&1 | tail -n 4 ;;
+  knob)
+    VAR=${ARG%%:*}; VALS=${ARG#*:}
+    timeout -k 5 1500 bash scripts/studies/bench_knob.sh $OUT/knob_$VAR.jsonl $VAR ${VALS//:/ } > $OUT/knob_$VAR.txt 2>&1; echo "rc=$?"; cat $OUT/knob_$VAR.txt ;;
   pyexp)   # py: with the experiment build of the library (diagnostic hooks)
     SCRIPT=${ARG%%:*}; REST=""; [[ "$ARG" == *:* ]] && REST=${ARG#*:}
     [ -f scripts/$SCRIPT.py ] || SCRIPT=studies/$SCRIPT; mkdir -p $OUT/studies
