@@ -94,30 +94,67 @@ def l1_roofline(alg_bytes, sec, cus):
             "peak_definition": "%d CUs x 64 B/clk (vector L1) x %.1f GHz peak clock" % (cus, PEAK_CLOCK_GHZ)}
 
 
-def binding_roofs(pmc, pmc_src, sec, visits=None):
-    """UTILISATION (busy shares, not bounds) of the units a trace launch keeps busy, from per-dispatch PMC means of the same kernel symbol
-    and launch shape (a committed rocprofv3 summary, named in `source`) and THIS run's launch duration: VALU issue (a wave64 instruction
-    occupies its SIMD-32 for two cycles), the texture-address unit (one per CU), HBM-side traffic, lanes per wave-iteration."""
+def gather_like_for_like(lane_steps, sec, gr, pmc):
+    """The HBM-resident launch's fetch rates against the gather roofs measured in the same run, like with like:
+    * beyond_l2: the launch's L2 MISSES (TCC_MISS_sum of the profiled launch of the same symbol) per second of that PROFILED launch
+      (its own duration, `TCC_MISS_sum@ns`) against the roof of fetches that all go beyond the L2 (768 MB table);
+    * all_fetches: every lane step of this run's launch per second against the roof of fetches that all hit the L2 (2 MB table) --
+      an upper bound nobody reaches with 45 % misses, kept only beside that roof."""
+    out = {"all_fetches": {"records_per_s": lane_steps / sec, "roof_records_per_s": (gr.get("l2_resident_grecords_per_s") or 0) * 1e9 or None,
+                           "frac": (lane_steps / sec) / (gr["l2_resident_grecords_per_s"] * 1e9) if gr.get("l2_resident_grecords_per_s") else None,
+                           "roof": "dependent random 64-byte fetches, 2 MB table (L2-resident)"}}
+    miss, ns = (pmc or {}).get("TCC_MISS_sum"), (pmc or {}).get("TCC_MISS_sum@ns") or (pmc or {}).get("GRBM_GUI_ACTIVE@ns")
+    if miss and ns and gr.get("grecords_per_s"):
+        rate = miss / (ns * 1e-9)
+        out["beyond_l2"] = {"misses_per_launch": miss, "profiled_launch_ms": ns * 1e-6, "misses_per_s": rate, "roof_records_per_s": gr["grecords_per_s"] * 1e9,
+                            "frac": rate / (gr["grecords_per_s"] * 1e9), "roof": "dependent random 64-byte fetches, 768 MB table (every fetch beyond the L2)"}
+        out["frac"] = out["beyond_l2"]["frac"]
+    else:
+        out["beyond_l2"] = None
+        out["frac"] = None
+        out["note"] = "no PMC summary with TCC_MISS_sum and its launch duration (`@ns`, round-5 summaries) for this symbol: the like-for-like beyond-L2 fraction is not reported"
+    return out
+
+
+def profiled_shares(pmc, pmc_src, visits=None):
+    """Busy SHARES (not bounds) of the units a trace launch keeps busy, as ONE profiled launch measured them: the per-dispatch PMC means of
+    the same kernel symbol and launch shape from a committed rocprofv3 summary (named in `source`), every count divided by the cycles of
+    the SAME PMC pass (`<counter>@cycles` = that pass's GRBM_GUI_ACTIVE / 8; summaries older than round 5 carry one GRBM pass, used for all
+    counters and named in `cycles_from`).  Nothing here is divided by THIS run's launch time (that mixed two runs and read
+    an effective clock above the chip's 2.4 GHz).  VALU issue: a wave64 instruction occupies its SIMD-32 for two cycles; TA: one
+    texture-address unit per CU; wave_wait_share: SQ_WAIT_ANY / SQ_WAVE_CYCLES."""
     if not pmc:
         return None
-    clk = pmc.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / sec / 1e9 if pmc.get("GRBM_GUI_ACTIVE") else None
-    use_clk = min(clk, PEAK_CLOCK_GHZ) if clk else PEAK_CLOCK_GHZ
-    b = {"source": "profiles/" + pmc_src, "effective_clock_ghz": clk}
-    if "SQ_INSTS_VALU" in pmc:
-        b["valu_issue_frac"] = pmc["SQ_INSTS_VALU"] / sec / (NUM_SIMDS * use_clk * 1e9 / 2.0)
-    # texture-address unit: busy cycles over the launch.  TA_TA_BUSY counts every kind of vector-memory instruction (the unified-step loop
-    # fetches with global loads, which TA_BUFFER_TOTAL_CYCLES does not see); the buffer-only figure is kept where it is the larger part
-    if "TA_TA_BUSY_sum" in pmc:
-        b["ta_frac"] = pmc["TA_TA_BUSY_sum"] / NUM_TAS / (sec * use_clk * 1e9)
-    if "TA_BUFFER_TOTAL_CYCLES_sum" in pmc:
-        b["ta_buffer_frac"] = pmc["TA_BUFFER_TOTAL_CYCLES_sum"] / NUM_TAS / (sec * use_clk * 1e9)
-        b.setdefault("ta_frac", b["ta_buffer_frac"])
+
+    def cyc(counter):   # cycles of the pass that collected `counter`
+        return pmc.get(counter + "@cycles") or (pmc.get("GRBM_GUI_ACTIVE", 0.0) / 8.0) or None
+
+    def ns(counter):
+        return pmc.get(counter + "@ns") or pmc.get("GRBM_GUI_ACTIVE@ns")
+
+    b = {"source": "profiles/" + pmc_src,
+         "basis": "per-dispatch counts of the profiled launch / cycles of the same PMC pass (GRBM_GUI_ACTIVE / 8); this run's time is not used",
+         "cycles_from": "per pass" if any(k.endswith("@cycles") for k in pmc) else "the summary's one GRBM_GUI_ACTIVE pass"}
+    c_sq = cyc("SQ_INSTS_VALU")
+    if c_sq:
+        b["profiled_cycles"] = c_sq
+        if ns("SQ_INSTS_VALU"):
+            b["profiled_launch_us"] = ns("SQ_INSTS_VALU") * 1e-3
+            b["profiled_clock_ghz"] = c_sq / ns("SQ_INSTS_VALU")
+    if "SQ_INSTS_VALU" in pmc and c_sq:
+        b["valu_issue_frac"] = pmc["SQ_INSTS_VALU"] * 2.0 / (NUM_SIMDS * c_sq)
+    # TA_TA_BUSY counts every kind of vector-memory instruction (the unified-step loop fetches with global loads, which TA_BUFFER_TOTAL_CYCLES does not see)
+    if "TA_TA_BUSY_sum" in pmc and cyc("TA_TA_BUSY_sum"):
+        b["ta_frac"] = pmc["TA_TA_BUSY_sum"] / NUM_TAS / cyc("TA_TA_BUSY_sum")
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:  # KiB; gfx950: FETCH_SIZE counts 64 B per 128-B request
         b["hbm_traffic_bytes"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-        b["hbm_traffic_frac"] = b["hbm_traffic_bytes"] / sec / 1e9 / HBM_PEAK_GBS
+        if ns("FETCH_SIZE"):   # over the FETCH_SIZE pass's own launch duration
+            b["hbm_traffic_frac"] = b["hbm_traffic_bytes"] / (ns("FETCH_SIZE") * 1e-9) / 1e9 / HBM_PEAK_GBS
     if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc and (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]) > 0:
         b["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
-    if visits and "SQ_INSTS_VMEM_RD" in pmc:  # 4 buffer loads per wave-iteration (node: 4 x 16 B; triangle: 3 x 16 B + 4 B)
+        if "FETCH_SIZE" in pmc and pmc["TCC_MISS_sum"] > 0:   # bytes the fabric moved per byte a 64-byte record miss consumes (128-byte line fills)
+            b["line_overfetch"] = 2.0 * pmc["FETCH_SIZE"] * 1024.0 / (64.0 * pmc["TCC_MISS_sum"])
+    if visits and "SQ_INSTS_VMEM_RD" in pmc:  # 4 loads per wave-iteration (node: 4 x 16 B; triangle: 3 x 16 B + 4 B)
         b["lane_util"] = visits / (pmc["SQ_INSTS_VMEM_RD"] / 4.0 * 64.0)
     if "SQ_WAIT_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"] > 0:
         b["wave_wait_share"] = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]
@@ -149,6 +186,12 @@ def parse(argv=None):
     ap.add_argument("--ao-batch-rays", type=int, default=1 << 20,
                     help="maxBatchSize of RayGen (the reference constructs it with 1 << 20, Renderer.cpp:45)")
     ap.add_argument("--ao-streams", type=int, default=3, help="HIP streams of the overlapped-frame figure (extras)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default=os.environ.get("NTR_BENCH_DIST_BACKEND", "nccl"),
+                    help="process-group backend for N > 1: nccl (= RCCL over xGMI, one rank per GPU: what the driver runs), or gloo (host "
+                         "staging) -- with --one-device the way to execute the N > 1 path with real kernels on a ONE-GPU box")
+    ap.add_argument("--one-device", action="store_true", default=os.environ.get("NTR_BENCH_ONE_DEVICE") == "1",
+                    help="every rank uses cuda:0 (needs --dist-backend gloo: RCCL refuses two ranks on one GPU).  The ranks' kernels share "
+                         "the chip, so the line's times are NOT a scaling measurement; the sharded frame -> gather -> bit-compare flow is what runs")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (profiling runs)")
     ap.add_argument("--no-ao-prediction", action="store_true",
                     help="trace the AO batches without the leaf-depth dispatch hint made beside ray generation (buffer order until a launch has measured)")
@@ -284,6 +327,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the tracer has no CPU path)")
+    if args.one_device:
+        if world > 1 and args.dist_backend != "gloo":
+            raise SystemExit("bench.py: --one-device needs --dist-backend gloo (RCCL refuses two ranks on one GPU)")
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # NTR_BENCH_FORCE_DIST=1 runs the RCCL code path (init, barrier, all-reduce, broadcast, gather) at world size 1 too
@@ -295,7 +342,10 @@ def main():
             os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(sk.getsockname()[1]), "RANK": "0", "WORLD_SIZE": "1",
                                "LOCAL_RANK": "0"})
             sk.close()
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     nt.lib()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -421,15 +471,15 @@ def main():
             full = ntd.gather_hit_records(frame.own_primary_records(), n_primary, cuts=plan.cuts)
         else:
             outs = [torch.empty_like(frame.d_res) for _ in range(world)] if rank == 0 else None
-            dist.gather(frame.d_res, outs, dst=0)
+            ntd.gather_(frame.d_res, outs, 0)
             full = None
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
         # the same gather through the library's own multi-GPU entry points (ntr_dist_*: RCCL bound by the C-ABI, what a C++ host of the
         # reference's shape uses -- INTEGRATION.md), opt-in: NTR_BENCH_NATIVE_GATHER=1.  The 128-byte group id travels over torch.distributed.
-        if sharded and os.environ.get("NTR_BENCH_NATIVE_GATHER") == "1" and plan.cuts is None:
+        if sharded and os.environ.get("NTR_BENCH_NATIVE_GATHER") == "1" and plan.cuts is None and not (args.one_device and world > 1):
             uid = torch.frombuffer(bytearray(nt.DistGroup.unique_id() if rank == 0 else bytes(128)), dtype=torch.uint8).to(dev)
-            dist.broadcast(uid, 0)
+            ntd.broadcast_(uid, 0)
             grp = nt.DistGroup(bytes(uid.cpu().numpy().tobytes()), rank, world)
             full_n = torch.zeros(n_primary * 16, dtype=torch.uint8, device=dev) if rank == 0 else None
             barrier()
@@ -472,9 +522,11 @@ def main():
     prim_ms = float(kern_ms[:, 0].mean())
     ao_ms = float(kern_ms[:, 1:].sum(axis=1).mean()) if len(batches) > 1 else 0.0
     achieved = alg_bytes / (prim_ms * 1e-3) / 1e9
-    ao_alg = 0
+    ao_alg, ao_visits = 0, 0
     for b in batches[1:]:
-        ao_alg += view.trace_stats(args.kernel, b["n"], True, b["rays"], b["res"], stream).algorithmic_bytes()
+        st_b = view.trace_stats(args.kernel, b["n"], True, b["rays"], b["res"], stream)
+        ao_alg += st_b.algorithmic_bytes()
+        ao_visits += st_b.numInnerVisits + st_b.numTriTests
     ao_live = sum(b["live"] for b in batches[1:])
 
     # ---- N > 1: the mode in which this design scales by construction, in the SAME driver-parsed line: every rank traces a whole frame of
@@ -531,9 +583,10 @@ def main():
     symbol = launched_symbol(args.kernel, wide)
     pmc, pmc_src = load_pmc(symbol, launched_grid(args.kernel, b0["n"]))
     visits = st.numInnerVisits + st.numTriTests   # lane steps of the unified-step loop (a terminator arrives with its triangle)
-    binding = binding_roofs(pmc, pmc_src, prim_ms * 1e-3, visits)
+    binding = profiled_shares(pmc, pmc_src, visits)
     traffic = binding.get("hbm_traffic_bytes") if binding else None
-    par = ("one frame sharded by screen tile over %d ranks (PixelTable ranges), BVH built on rank 0 and broadcast, RCCL gather of hit records" % world
+    par = ("one frame sharded by screen tile over %d ranks (PixelTable ranges), BVH built on rank 0 and broadcast, %s gather of hit records"
+           % (world, "RCCL" if args.dist_backend == "nccl" else "gloo (host-staged)")
            if not (args.scaling == "weak" and world > 1) else "weak scaling: one full frame per rank (camera shifted per rank), BVH replicated")
     out = {
         "metric": "Mrays/sec (primary + 8xAO) on Crytek Sponza",
@@ -558,6 +611,10 @@ def main():
                    "rays_per_step": int(total_rays_per_step), "rays_per_step_rank0": rays_per_step,
                    "primary_rays_rank0": b0["n"], "primary_hits_rank0": frame.own_hits, "ao_rays_nondegenerate_rank0": ao_live,
                    "ao_batches_rank0": len(batches) - 1, "parallelism": par, "frame_cut": cut_info,
+                   "dist_backend": (args.dist_backend if use_dist else None), "one_device": bool(args.one_device and world > 1),
+                   **({"one_device_note": "all %d ranks share cuda:0 (gloo, host-staged collectives): the sharded frame -> gather -> bit-compare flow executed "
+                                          "with real kernels; the ranks' launches contend for one chip, so value / ms_per_step are NOT a scaling measurement" % world}
+                      if (args.one_device and world > 1) else {}),
                    "ao_dispatch_hint": ("leaf-depth prediction made beside ray generation (ntr_bvh_leaf_depths, ntr_secondary_block_costs, ntr_sched_hint_predict), "
                                         "refined by every launch's measurement (ntr_trace_bvh_hinted)") if frame.d_depth is not None else "none (library's automatic feedback)"},
         "primary_mrays": prim_live_total * args.steps / prim_kernel_max / 1e6,
@@ -587,7 +644,7 @@ def main():
     roof.update({"kernel": "%s (%s), primary batch of rank 0" % (symbol, args.kernel),
                  "launch_includes": "the dispatch-order work of the launch (prediction or cost feedback, a few small kernels) + the trace kernel, as the "
                                     "HIP events around the library call see it; rocprofv3's per-kernel average for the trace kernel alone is in profiles/",
-                 "traffic": traffic, "hbm_algorithmic": hbm_alg,
+                 "traffic": traffic, "hbm_frac": hbm_alg["frac"], "cache_served": True, "hbm_algorithmic": hbm_alg,
                  "utilisation": binding,
                  "utilisation_note": None if binding else "no committed PMC summary under profiles/ matches the launched symbol %s with grid %d: "
                                                            "utilisation not reported" % (symbol, launched_grid(args.kernel, b0["n"])),
@@ -597,7 +654,7 @@ def main():
         ao_sym = launched_symbol(args.kernel, wide, any_hit=True)
         ao_roof = l1_roofline(ao_alg, ao_ms * 1e-3, cus)
         ao_pmc, ao_src = load_pmc(ao_sym, launched_grid(args.kernel, batches[1]["n"]))
-        ao_bind = binding_roofs(ao_pmc, ao_src, ao_ms * 1e-3 / (len(batches) - 1)) if ao_pmc else None
+        ao_bind = profiled_shares(ao_pmc, ao_src, ao_visits // max(len(batches) - 1, 1)) if ao_pmc else None
         ao_roof.update({"kernel": "%s (%s), the %d AO batches of rank 0 (any hit)" % (ao_sym, args.kernel, len(batches) - 1),
                         "share_of_step": ao_ms / (ao_ms + prim_ms),
                         "hbm_algorithmic": {"achieved": ao_alg / (ao_ms * 1e-3) / 1e9, "frac": ao_alg / (ao_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "cache_served": True},
@@ -793,9 +850,12 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
     try:
         g_waves, g_steps = 8192, 256
         gsec = nt.selftest_gather_rate(768 << 20, g_waves, 64, g_steps, stream)
-        extras["gather_roof"] = {"what": "%d waves x 64 lanes, each a dependent chain of %d random 64-byte records of a 768 MB table (4 x 16-byte loads per record): "
-                                         "the memory side of a divergent traversal without its arithmetic" % (g_waves, g_steps),
-                                 "grecords_per_s": g_waves * 64 * g_steps / gsec / 1e9, "GBps": g_waves * 64 * g_steps * 64 / gsec / 1e9, "ms": gsec * 1e3}
+        gsec2 = nt.selftest_gather_rate(2 << 20, g_waves, 64, g_steps, stream)
+        extras["gather_roof"] = {"what": "%d waves x 64 lanes, each a dependent chain of %d random 64-byte records (4 x 16-byte loads per record): the memory side of a "
+                                         "divergent traversal without its arithmetic -- of a 768 MB table (every fetch beyond the L2: `grecords_per_s`) and of a "
+                                         "2 MB table (every fetch an L2 hit: `l2_resident_grecords_per_s`)" % (g_waves, g_steps),
+                                 "grecords_per_s": g_waves * 64 * g_steps / gsec / 1e9, "GBps": g_waves * 64 * g_steps * 64 / gsec / 1e9, "ms": gsec * 1e3,
+                                 "l2_resident_grecords_per_s": g_waves * 64 * g_steps / gsec2 / 1e9}
     except Exception as e:
         extras["gather_roof"] = {"error": repr(e)}
 
@@ -882,17 +942,13 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         r_inc = roof(sr, secr)
         sym = launched_symbol(best_kn, wide10)
         pmc_i, src_i = load_pmc(sym, launched_grid(best_kn, nr), tag="courtyard")
-        bind_i = binding_roofs(pmc_i, src_i, secr, sr.numInnerVisits + sr.numTriTests) if pmc_i else None
+        bind_i = profiled_shares(pmc_i, src_i, sr.numInnerVisits + sr.numTriTests) if pmc_i else None
         gr = extras.get("gather_roof", {})
         steps_i = sr.numInnerVisits + sr.numTriTests
         r_inc.update({"kernel": "%s (%s)" % (sym, best_kn), "launch_ms": secr * 1e3,
                       "traffic": bind_i.get("hbm_traffic_bytes") if bind_i else None, "utilisation": bind_i,
                       "utilisation_note": None if bind_i else "no committed PMC summary under profiles/ matches %s with grid %d" % (sym, launched_grid(best_kn, nr)),
-                      "gather_roof": {"records_per_s": steps_i / secr, "roof_records_per_s": gr.get("grecords_per_s", 0) * 1e9 or None,
-                                      "frac": (steps_i / secr) / (gr["grecords_per_s"] * 1e9) if gr.get("grecords_per_s") else None,
-                                      "note": "node + triangle fetches of the launch (one 64-byte record per lane step) against the measured rate of dependent "
-                                              "random 64-byte fetches beyond the L2 (extras.gather_roof): what HBM + fabric deliver for this access pattern, "
-                                              "whatever the record size; part of the launch's fetches hit the L2 (see utilisation.l2_hit_rate)"},
+                      "gather_roof": gather_like_for_like(steps_i, secr, gr, pmc_i),
                       "workload": "courtyard-10M device LBVH (0.75 GB), 2^21 incoherent closest-hit rays",
                       "note": "the launch whose bytes HBM really delivers: SURVEY 8(d) algorithmic bytes / time / 8 TB/s; `traffic` = PMC bytes of "
                               "the same kernel symbol (FETCH_SIZE x 2 + WRITE_SIZE) from profiles/"})

@@ -203,20 +203,22 @@ struct LaneStack {
 
 #define NTR_STACK_RESET(st) do { (st).sp = 0; (st).tos = kSentinel; } while (0)
 
+template <int LD = LDS_DEPTH>   // LD: the entries this stack has in LDS
 __device__ __forceinline__ void stack_push(LaneStack& st, int (&spill)[SPILL_DEPTH], int v, unsigned int* status)
 {
-    if (__builtin_expect(st.sp < LDS_DEPTH, 1)) st.lds[st.sp * 64] = st.tos;
-    else if (st.sp < LDS_DEPTH + SPILL_DEPTH) spill[st.sp - LDS_DEPTH] = st.tos;
+    if (__builtin_expect(st.sp < LD, 1)) st.lds[st.sp * 64] = st.tos;
+    else if (st.sp < LD + SPILL_DEPTH) spill[st.sp - LD] = st.tos;
     else { atomicOr(status, NTR_STATUS_STACK_OVERFLOW); return; }
     st.sp++;
     st.tos = v;
 }
+template <int LD = LDS_DEPTH>
 __device__ __forceinline__ int stack_pop(LaneStack& st, int (&spill)[SPILL_DEPTH])
 {
     const int r = st.tos;
     if (st.sp > 0) {
         st.sp--;
-        st.tos = __builtin_expect(st.sp < LDS_DEPTH, 1) ? st.lds[st.sp * 64] : spill[st.sp - LDS_DEPTH];
+        st.tos = __builtin_expect(st.sp < LD, 1) ? st.lds[st.sp * 64] : spill[st.sp - LD];
     } else {
         st.tos = kSentinel;
     }
@@ -495,7 +497,7 @@ __device__ __forceinline__ void unified_fetch(const UnifiedBufs& ub, int node, f
 
 // unified_advance: the lane's ray takes the step its 64 bytes allow -- one inner node (trace<BVHLayout_Compact>, CudaBVH.cpp:721-775) or one
 // triangle (intersectTriangles + updateHit, CudaBVH.cpp:1084-1126, 1183-1225).
-template <bool FAST, int OCT>
+template <bool FAST, int OCT, int LD = LDS_DEPTH>
 __device__ __forceinline__ void unified_advance(const float4& a, const float4& b, const float4& c, const float4& d, RayRegs& r, int& node,
                                                 LaneStack& st, int (&spill)[SPILL_DEPTH], bool anyHit, int& hitAddr, float& hitU, float& hitV,
                                                 unsigned int* status)
@@ -510,8 +512,8 @@ __device__ __forceinline__ void unified_advance(const float4& a, const float4& b
         const int c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
         const bool swp = i1 && (!i0 || mn0 > mn1);
         const int nearC = swp ? c1 : c0, farC = swp ? c0 : c1;
-        if (i0 && i1) stack_push(st, spill, farC, status);
-        node = (i0 || i1) ? nearC : stack_pop(st, spill);
+        if (i0 && i1) stack_push<LD>(st, spill, farC, status);
+        node = (i0 || i1) ? nearC : stack_pop<LD>(st, spill);
     } else if (atTri) {
         bool leafDone = __float_as_uint(a.x) == 0x80000000u;   // terminator: an empty leaf
         if (!leafDone) {
@@ -538,7 +540,7 @@ __device__ __forceinline__ void unified_advance(const float4& a, const float4& b
             else if (__float_as_uint(d.x) == 0x80000000u) leafDone = true;   // the terminator came with this triangle
             else node -= 3;
         }
-        if (leafDone) node = stack_pop(st, spill);
+        if (leafDone) node = stack_pop<LD>(st, spill);
     }
 }
 
@@ -571,27 +573,82 @@ __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs&
 }
 
 // Two independent rays per lane (round 5): the wave steps ray A and ray B of every lane in one iteration -- both
-// 64-byte fetches are issued before the wave waits for either, then A advances (while B's loads are still in flight), then B.  Each
-// ray's own visiting order is traverse_unified's, so every hit record is unchanged.  A slot whose 64 rays have all ended costs nothing
-// (wave-uniform skips).
-template <bool FAST, bool FLAT>
+// 64-byte fetches are issued before the wave waits for either, then A advances while B's loads are still in flight, then B.  Each
+// ray's own visiting order is traverse_unified's, so every hit record is unchanged.
+// The loads are written out (one asm statement: A's four, B's four, s_waitcnt vmcnt(4)): left to the compiler, loads issued under
+// divergent control flow make it wait with vmcnt(0) before A's arithmetic, and B's fetch would no longer overlap it.  Between that
+// statement and pair_wait_b the B registers hold loads in flight: nothing may read them (they are operands of nothing in between).
+static constexpr int PAIR_LDS_DEPTH = 12;   // LDS stack entries per ray of a pair (12 + 88 in scratch = the CPU tracer's 100): 6 KB per wave
+struct Fetched { u32x4 a, b, c, d; };
+__device__ __forceinline__ void pair_issue(const char* addrA, unsigned long long maskA, const char* addrB, unsigned long long maskB, Fetched& fa, Fetched& fb)
+{
+    unsigned long long sav;
+    asm volatile(
+        "s_mov_b64 %[sav], exec\n\t"
+        "s_and_b64 exec, %[sav], %[ma]\n\t"
+        "global_load_dwordx4 %[a0], %[pa], off\n\t"
+        "global_load_dwordx4 %[b0], %[pa], off offset:16\n\t"
+        "global_load_dwordx4 %[c0], %[pa], off offset:32\n\t"
+        "global_load_dwordx4 %[d0], %[pa], off offset:48\n\t"
+        "s_and_b64 exec, %[sav], %[mb]\n\t"
+        "global_load_dwordx4 %[a1], %[pb], off\n\t"
+        "global_load_dwordx4 %[b1], %[pb], off offset:16\n\t"
+        "global_load_dwordx4 %[c1], %[pb], off offset:32\n\t"
+        "global_load_dwordx4 %[d1], %[pb], off offset:48\n\t"
+        "s_mov_b64 exec, %[sav]\n\t"
+        "s_waitcnt vmcnt(4)"
+        : [a0] "=&v"(fa.a), [b0] "=&v"(fa.b), [c0] "=&v"(fa.c), [d0] "=&v"(fa.d), [a1] "=&v"(fb.a), [b1] "=&v"(fb.b), [c1] "=&v"(fb.c), [d1] "=&v"(fb.d),
+          [sav] "=&s"(sav)
+        : [pa] "v"(addrA), [pb] "v"(addrB), [ma] "s"(maskA), [mb] "s"(maskB)
+        : "memory", "scc");
+}
+__device__ __forceinline__ void pair_wait_b(Fetched& fb)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(fb.a), "+v"(fb.b), "+v"(fb.c), "+v"(fb.d) : : "memory");
+}
+__device__ __forceinline__ float4 as_f4(const u32x4& v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
+
+// where a lane's next 64 bytes are; ok = the plain global loads may fetch them (not within 64 bytes of the buffer's end: the descriptor form reads zeros there)
+__device__ __forceinline__ const char* unified_addr(const UnifiedBufs& ub, int node, bool& ok)
+{
+    const bool inner = (unsigned)node < (unsigned)kSentinel;
+    const bool atTri = node < 0;
+    const int ofs = inner ? node : (~node) * 16;
+    ok = (inner || atTri) && (unsigned)ofs <= (inner ? ub.nodesBytes : ub.woopBytes) - 64u;
+    return (inner ? ub.nodes : ub.woop) + (unsigned)ofs;
+}
+
+template <bool FAST>
 __device__ __forceinline__ void traverse_unified_pair(const UnifiedBufs& ub, bool anyHit, unsigned int* status,
                                                       RayRegs& rA, int& nodeA, LaneStack& stA, int (&spillA)[SPILL_DEPTH], int& hitAddrA, float& hitUA, float& hitVA,
                                                       RayRegs& rB, int& nodeB, LaneStack& stB, int (&spillB)[SPILL_DEPTH], int& hitAddrB, float& hitUB, float& hitVB)
 {
     for (;;) {
-        const bool liveA = __ballot(nodeA != kSentinel) != 0ull, liveB = __ballot(nodeB != kSentinel) != 0ull;   // wave-uniform
-        if (!liveA && !liveB) break;
-        float4 a0, b0, c0, d0, a1, b1, c1, d1;
-        if (liveA) unified_fetch<FLAT>(ub, nodeA, a0, b0, c0, d0);
-        if (liveB) unified_fetch<FLAT>(ub, nodeB, a1, b1, c1, d1);
-        if (liveA) {
-            if (FLAT) { keep(a0); keep(b0); keep(c0); keep(d0); }
-            unified_advance<FAST, 8>(a0, b0, c0, d0, rA, nodeA, stA, spillA, anyHit, hitAddrA, hitUA, hitVA, status);
+        const unsigned long long liveA = __ballot(nodeA != kSentinel), liveB = __ballot(nodeB != kSentinel);
+        if ((liveA | liveB) == 0ull) break;
+        bool okA, okB;
+        const char* pa = unified_addr(ub, nodeA, okA);
+        const char* pb = unified_addr(ub, nodeB, okB);
+        Fetched fa, fb;
+        pair_issue(pa, __ballot(okA), pb, __ballot(okB), fa, fb);
+        if (liveA != 0ull) {   // (wave-uniform)
+            float4 a = as_f4(fa.a), b = as_f4(fa.b), c = as_f4(fa.c), d = as_f4(fa.d);
+            const unsigned long long odd = __ballot(nodeA != kSentinel && !okA);
+            if (odd != 0ull) {   // rare: the lanes at the very end of a buffer (this also drains B's loads; harmless)
+                const bool inner = (unsigned)nodeA < (unsigned)kSentinel;
+                fetch64_two_buffers_into(ub.rNodes, ub.rWoop, inner ? nodeA : (~nodeA) * 16, __ballot(inner && !okA), __ballot(nodeA < 0 && !okA), a, b, c, d);
+            }
+            unified_advance<FAST, 8, PAIR_LDS_DEPTH>(a, b, c, d, rA, nodeA, stA, spillA, anyHit, hitAddrA, hitUA, hitVA, status);
         }
-        if (liveB) {
-            if (FLAT) { keep(a1); keep(b1); keep(c1); keep(d1); }
-            unified_advance<FAST, 8>(a1, b1, c1, d1, rB, nodeB, stB, spillB, anyHit, hitAddrB, hitUB, hitVB, status);
+        pair_wait_b(fb);
+        if (liveB != 0ull) {
+            float4 a = as_f4(fb.a), b = as_f4(fb.b), c = as_f4(fb.c), d = as_f4(fb.d);
+            const unsigned long long odd = __ballot(nodeB != kSentinel && !okB);
+            if (odd != 0ull) {
+                const bool inner = (unsigned)nodeB < (unsigned)kSentinel;
+                fetch64_two_buffers_into(ub.rNodes, ub.rWoop, inner ? nodeB : (~nodeB) * 16, __ballot(inner && !okB), __ballot(nodeB < 0 && !okB), a, b, c, d);
+            }
+            unified_advance<FAST, 8, PAIR_LDS_DEPTH>(a, b, c, d, rB, nodeB, stB, spillB, anyHit, hitAddrB, hitUB, hitVB, status);
         }
     }
 }
@@ -740,7 +797,7 @@ __global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini(TraceParams p)
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void trace_bvh_perray_pair(TraceParams p)
 {
-    __shared__ int s_stack[2][LDS_DEPTH][64];  // [slot][entry][lane]
+    __shared__ int s_stack[2][PAIR_LDS_DEPTH][64];  // [slot][entry][lane]
     const int lane = threadIdx.x;
     const unsigned int g = blockIdx.x >> 1, part = blockIdx.x & 1u;
     const unsigned int block = p.order ? p.order[g] : g;
@@ -768,8 +825,8 @@ __global__ __launch_bounds__(64) void trace_bvh_perray_pair(TraceParams p)
     const bool fastWave = (p.bvhFlags & NTR_BVH_FASTDIV) &&
                           __ballot((nodeA != kSentinel && !ray_is_nice(rA, p.bvhFlags)) || (nodeB != kSentinel && !ray_is_nice(rB, p.bvhFlags))) == 0ull;
     const UnifiedBufs ub = unified_bufs(p);
-    if (fastWave) traverse_unified_pair<true, true>(ub, p.anyHit != 0, p.status, rA, nodeA, stA, spillA, hitAddrA, hitUA, hitVA, rB, nodeB, stB, spillB, hitAddrB, hitUB, hitVB);
-    else traverse_unified_pair<false, true>(ub, p.anyHit != 0, p.status, rA, nodeA, stA, spillA, hitAddrA, hitUA, hitVA, rB, nodeB, stB, spillB, hitAddrB, hitUB, hitVB);
+    if (fastWave) traverse_unified_pair<true>(ub, p.anyHit != 0, p.status, rA, nodeA, stA, spillA, hitAddrA, hitUA, hitVA, rB, nodeB, stB, spillB, hitAddrB, hitUB, hitVB);
+    else traverse_unified_pair<false>(ub, p.anyHit != 0, p.status, rA, nodeA, stA, spillA, hitAddrA, hitUA, hitVA, rB, nodeB, stB, spillB, hitAddrB, hitUB, hitVB);
 
     if (p.cost && lane == 0) atomicMax(&p.cost[block], (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0));
     if (validA) store_result(p.results, p.triIndex, rayA, hitAddrA, rA.tmax, hitUA, hitVA);

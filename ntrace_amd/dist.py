@@ -12,6 +12,45 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(t):
+    """gloo moves host memory only: a device tensor takes part in a gloo collective through a host copy (the CPU test tier, and the
+    GPU-tier runs of bench.py with every rank on ONE device -- `--dist-backend gloo --one-device` -- where RCCL cannot be used: it
+    refuses two ranks on the same GPU)."""
+    return dist.get_backend() == "gloo" and t.is_cuda
+
+
+def broadcast_(t, src):
+    if _staged(t):
+        h = t.cpu()
+        dist.broadcast(h, src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src)
+    return t
+
+
+def all_reduce_(t, op):
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def gather_(buf, outs, dst):
+    """dist.gather with the staging above; `outs` (on dst) are filled in place."""
+    if _staged(buf):
+        h_outs = [torch.empty(o.shape, dtype=o.dtype) for o in outs] if outs is not None else None
+        dist.gather(buf.cpu(), h_outs, dst=dst)
+        if outs is not None:
+            for o, h in zip(outs, h_outs):
+                o.copy_(h)
+    else:
+        dist.gather(buf, outs, dst=dst)
+
+
 def shard_range(num_rays, rank, world, align=64):
     """Contiguous slice [lo, hi) of the primary-ray index space for `rank`.  The index space is
     already 8x8-pixel blocks in Morton order (PixelTable), so a contiguous slice aligned to 64 rays
@@ -59,7 +98,7 @@ def broadcast_cuts(cuts, world, device, src=0):
     """The planning rank's cut points to every rank (identity without a process group)."""
     t = torch.tensor([int(x) for x in cuts] if cuts is not None else [0] * (world + 1), dtype=torch.int64, device=device)
     if dist.is_initialized():
-        dist.broadcast(t, src)
+        broadcast_(t, src)
     return [int(x) for x in t.tolist()]
 
 
@@ -102,7 +141,7 @@ def gather_hit_records(local, num_rays, align=64, dst=0, cuts=None):
     buf = torch.zeros(pad, dtype=torch.uint8, device=local.device)
     buf[: local.numel()] = local
     outs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, outs, dst=dst)
+    gather_(buf, outs, dst)
     if rank != dst:
         return None
     return torch.cat([o[:s] for o, s in zip(outs, sizes)])
@@ -128,7 +167,7 @@ def all_sum_int64(value, device):
     """Wrapping int64 sum of `value` over the ranks (identity without a process group)."""
     t = torch.tensor([wrap_i64(value)], dtype=torch.int64, device=device)
     if dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        all_reduce_(t, dist.ReduceOp.SUM)
     return int(t.item())
 
 
@@ -137,8 +176,8 @@ def job_throughput(units, seconds, device):
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     u = torch.tensor([float(units)], dtype=torch.float64, device=device)
     if dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        all_reduce_(t, dist.ReduceOp.MAX)
+        all_reduce_(u, dist.ReduceOp.SUM)
     return float(u.item()), float(t.item())
 
 
@@ -161,7 +200,7 @@ def broadcast_bytes(buf_u8, src, device):
     if not dist.is_initialized():
         return buf_u8.to(device)
     n = torch.tensor([buf_u8.numel() if dist.get_rank() == src else 0], dtype=torch.int64, device=device)
-    dist.broadcast(n, src)
+    broadcast_(n, src)
     out = buf_u8.to(device) if dist.get_rank() == src else torch.empty(int(n.item()), dtype=torch.uint8, device=device)
-    dist.broadcast(out, src)
+    broadcast_(out, src)
     return out

@@ -12,111 +12,159 @@ CameraControls::CameraControls(void)
 {
 }
 
-// ---- signature codec (CameraControls.cpp:342-399, 471-545) ---------------------------------------
-static void encodeBits(String& dst, U32 v)
-{
-    int base = (v < 12) ? '/' : (v < 38) ? 'A' - 12 : 'a' - 38;
-    dst += (char)(v + base);
-}
-static U32 decodeBits(const char*& src)
-{
-    if (*src >= '/' && *src <= ':') return *src++ - '/';
-    if (*src >= 'A' && *src <= 'Z') return *src++ - 'A' + 12;
-    if (*src >= 'a' && *src <= 'z') return *src++ - 'a' + 38;
-    setError("CameraControls: Invalid signature!");
-    return 0;
-}
-static void encodeFloat(String& dst, F32 v)
-{
-    U32 bits = floatToBits(v);
-    for (int i = 0; i < 32; i += 6) encodeBits(dst, (bits >> i) & 0x3F);
-}
-static F32 decodeFloat(const char*& src)
-{
-    U32 bits = 0;
-    for (int i = 0; i < 32; i += 6) bits |= decodeBits(src) << i;
-    return bitsToFloat(bits);
-}
-static void encodeDirection(String& dst, const Vec3f& v)
-{
-    Vec3f a(std::fabs(v.x), std::fabs(v.y), std::fabs(v.z));
-    int axis = (a.x >= FW::max(a.y, a.z)) ? 0 : (a.y >= a.z) ? 1 : 2;
-    Vec3f tuv;
-    switch (axis) {
-    case 0: tuv = v; break;
-    case 1: tuv = Vec3f(v.y, v.z, v.x); break;
-    default: tuv = Vec3f(v.z, v.x, v.y); break;
+// ---- camera signature codec ------------------------------------------------------------------------
+// Wire format (what the reference's CameraControls::encodeSignature / decodeSignature exchange, framework/3d/CameraControls.cpp:342-399,
+// 471-545): a quoted string of base-64 digits, ALPHABET below (digit values 0..63 = '/', '0'..'9', ':', 'A'..'Z',
+// 'a'..'z').  A float is its 32 bits as six digits, least significant digit first (the last digit carries two bits).  A direction is one
+// digit -- bits 0-1: dominant axis d, bit 2: that component is negative, bit 3: the other two components are exactly zero -- followed,
+// unless bit 3 is set, by two floats: components d+1 and d+2 (cyclically) divided by |component d|.  Fields: position x y z, forward,
+// up, speed, fov, near, far, one digit keepAligned; the writer closes with `",`.
+namespace {
+
+const char ALPHABET[65] = "/0123456789:ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz";
+
+struct DigitTable {   // character -> digit value, -1 for characters outside the alphabet
+    signed char value[256];
+    DigitTable()
+    {
+        for (int c = 0; c < 256; c++) value[c] = -1;
+        for (int d = 0; d < 64; d++) value[(unsigned char)ALPHABET[d]] = (signed char)d;
     }
-    int face = axis | ((tuv.x >= 0.0f) ? 0 : 4);
-    if (tuv.y == 0.0f && tuv.z == 0.0f) {
-        encodeBits(dst, face | 8);
-        return;
+};
+
+class SignatureWriter {
+public:
+    void digit(U32 d) { m_text += ALPHABET[d & 63u]; }
+    void real(F32 v)
+    {
+        U32 rest = floatToBits(v);
+        for (int k = 0; k < 6; k++, rest >>= 6) digit(rest);
     }
-    encodeBits(dst, face);
-    encodeFloat(dst, tuv.y / std::fabs(tuv.x));
-    encodeFloat(dst, tuv.z / std::fabs(tuv.x));
-}
-static Vec3f normalized(const Vec3f& v)
-{
-    F32 len = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
-    return v * (1.0f * (1.0f / len));  // VectorBase::normalized (Math.hpp:141)
-}
-static Vec3f decodeDirection(const char*& src)
-{
-    int face = decodeBits(src);
-    Vec3f tuv;
-    tuv.x = ((face & 4) == 0) ? 1.0f : -1.0f;
-    tuv.y = ((face & 8) == 0) ? decodeFloat(src) : 0.0f;
-    tuv.z = ((face & 8) == 0) ? decodeFloat(src) : 0.0f;
-    tuv = normalized(tuv);
-    switch (face & 3) {
-    case 0: return tuv;
-    case 1: return Vec3f(tuv.z, tuv.x, tuv.y);
-    default: return Vec3f(tuv.y, tuv.z, tuv.x);
+    void direction(const Vec3f& v)
+    {
+        const F32 comp[3] = {v.x, v.y, v.z};
+        int d = 0;   // dominant axis; ties go to the earlier axis
+        for (int k = 1; k < 3; k++)
+            if (std::fabs(comp[k]) > std::fabs(comp[d])) d = k;
+        const F32 major = comp[d], u = comp[(d + 1) % 3], w = comp[(d + 2) % 3];
+        const U32 face = (U32)d | ((major >= 0.0f) ? 0u : 4u);
+        if (u == 0.0f && w == 0.0f) {   // axis-aligned: the face digit alone
+            digit(face | 8u);
+            return;
+        }
+        digit(face);
+        real(u / std::fabs(major));
+        real(w / std::fabs(major));
     }
-}
+    void raw(const char* t) { m_text += t; }
+    const String& text() const { return m_text; }
+
+private:
+    String m_text;
+};
+
+class SignatureReader {
+public:
+    explicit SignatureReader(const char* p) : m_at(p), m_bad(false) {}
+    void skipBlanks()
+    {
+        while (*m_at == ' ' || *m_at == '\t' || *m_at == '\n') m_at++;
+    }
+    void skipIf(char c)
+    {
+        if (*m_at == c) m_at++;
+    }
+    U32 digit()
+    {
+        static const DigitTable table;
+        const int d = table.value[(unsigned char)*m_at];
+        if (d < 0) {   // (a terminating NUL is not consumed)
+            m_bad = true;
+            return 0;
+        }
+        m_at++;
+        return (U32)d;
+    }
+    F32 real()
+    {
+        U32 bits = 0;
+        for (int k = 0; k < 6; k++) bits |= digit() << (6 * k);
+        return bitsToFloat(bits);
+    }
+    Vec3f direction()
+    {
+        const U32 face = digit();
+        const bool axisAligned = (face & 8u) != 0;
+        F32 t[3];   // (major, next, next-next) in cyclic order from the dominant axis
+        t[0] = (face & 4u) ? -1.0f : 1.0f;
+        t[1] = axisAligned ? 0.0f : real();
+        t[2] = axisAligned ? 0.0f : real();
+        const F32 len = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+        const F32 scale = 1.0f / len;   // the reference's normalized(): v * (1 * rcp(length)) (Math.hpp:141)
+        const int d = (face & 3u) < 2u ? (int)(face & 3u) : 2;   // (axis code 3 reads as the z face, as in the reference)
+        F32 out[3];
+        for (int k = 0; k < 3; k++) out[(d + k) % 3] = t[k] * scale;
+        return Vec3f(out[0], out[1], out[2]);
+    }
+    bool atEnd() const { return *m_at == 0; }
+    bool bad() const { return m_bad; }
+
+private:
+    const char* m_at;
+    bool m_bad;
+};
+
+}  // namespace
 
 String CameraControls::encodeSignature(void) const
 {
-    String sig;
-    sig += '"';
-    encodeFloat(sig, m_position.x);
-    encodeFloat(sig, m_position.y);
-    encodeFloat(sig, m_position.z);
-    encodeDirection(sig, m_forward);
-    encodeDirection(sig, m_up);
-    encodeFloat(sig, m_speed);
-    encodeFloat(sig, m_fov);
-    encodeFloat(sig, m_near);
-    encodeFloat(sig, m_far);
-    encodeBits(sig, m_keepAligned ? 1 : 0);
-    sig += "\",";
-    return sig;
+    SignatureWriter w;
+    w.raw("\"");
+    w.real(m_position.x);
+    w.real(m_position.y);
+    w.real(m_position.z);
+    w.direction(m_forward);
+    w.direction(m_up);
+    w.real(m_speed);
+    w.real(m_fov);
+    w.real(m_near);
+    w.real(m_far);
+    w.digit(m_keepAligned ? 1u : 0u);
+    w.raw("\",");
+    return w.text();
 }
 
 void CameraControls::decodeSignature(const String& sig)
 {
-    const char* src = sig.c_str();
-    while (*src == ' ' || *src == '\t' || *src == '\n') src++;
-    if (*src == '"') src++;
-    F32 px = decodeFloat(src), py = decodeFloat(src), pz = decodeFloat(src);
-    Vec3f forward = decodeDirection(src);
-    Vec3f up = decodeDirection(src);
-    F32 speed = decodeFloat(src), fov = decodeFloat(src), znear = decodeFloat(src), zfar = decodeFloat(src);
-    bool keepAligned = (decodeBits(src) != 0);
-    if (*src == '"') src++;
-    if (*src == ',') src++;
-    while (*src == ' ' || *src == '\t' || *src == '\n') src++;
-    if (*src) setError("CameraControls: Invalid signature!");
+    SignatureReader r(sig.c_str());
+    r.skipBlanks();
+    r.skipIf('"');
+    CameraControls parsed(*this);   // nothing of *this changes unless the whole signature parses
+    parsed.m_position.x = r.real();
+    parsed.m_position.y = r.real();
+    parsed.m_position.z = r.real();
+    parsed.m_forward = r.direction();
+    parsed.m_up = r.direction();
+    parsed.m_speed = r.real();
+    parsed.m_fov = r.real();
+    parsed.m_near = r.real();
+    parsed.m_far = r.real();
+    parsed.m_keepAligned = r.digit() != 0;
+    r.skipIf('"');
+    r.skipIf(',');
+    r.skipBlanks();
+    if (r.bad() || !r.atEnd()) {
+        setError("CameraControls: Invalid signature!");
+        return;
+    }
     if (hasError()) return;
-    m_position = Vec3f(px, py, pz);
-    m_forward = forward;
-    m_up = up;
-    m_speed = speed;
-    m_fov = fov;
-    m_near = znear;
-    m_far = zfar;
-    m_keepAligned = keepAligned;
+    *this = parsed;
+}
+
+static Vec3f normalized(const Vec3f& v)
+{
+    const F32 len = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    return v * (1.0f * (1.0f / len));  // VectorBase::normalized (Math.hpp:141)
 }
 
 // ---- matrices ----------------------------------------------------------------------------------------

@@ -63,6 +63,9 @@ EOF
   knob)
     VAR=${ARG%%:*}; VALS=${ARG#*:}
     timeout -k 5 1500 bash scripts/studies/bench_knob.sh $OUT/knob_$VAR.jsonl $VAR ${VALS//:/ } > $OUT/knob_$VAR.txt 2>&1; echo "rc=$?"; cat $OUT/knob_$VAR.txt ;;
+  sh)      # sh:<script>[:args...]  bash scripts/studies/<script>.sh args
+    SCRIPT=${ARG%%:*}; REST=""; [[ "$ARG" == *:* ]] && REST=${ARG#*:}
+    timeout -k 5 1500 bash scripts/studies/$SCRIPT.sh ${REST//:/ } > $OUT/$SCRIPT.out 2>&1; echo "rc=$?"; tail -n 30 $OUT/$SCRIPT.out ;;
   pyexp)   # py: with the experiment build of the library (diagnostic hooks)
     SCRIPT=${ARG%%:*}; REST=""; [[ "$ARG" == *:* ]] && REST=${ARG#*:}
     [ -f scripts/$SCRIPT.py ] || SCRIPT=studies/$SCRIPT; mkdir -p $OUT/studies

@@ -27,11 +27,13 @@ prof_pmc() {  # name, "counters", workload args...
   local tagc=$(echo $ctr | tr ' ' '+' | cut -c1-60)
   timeout -k 5 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/$name/pmc_$tagc -- python3 scripts/workloads.py "$@" > $OUT/$name.pmc_$tagc.log 2>&1
 }
-TRACE_SETS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+# (GRBM_GUI_ACTIVE rides along in every pass but the FETCH_SIZE / WRITE_SIZE ones -- the guide wants those alone --: a share is then a
+# pass's counts over the SAME pass's cycles, scripts/summarize_rocprof.py `@cycles`)
+TRACE_SETS=("FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
   "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES" \
-  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM" \
-  "TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum" "TA_BUFFER_WAVEFRONTS_sum" \
-  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum")
+  "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM" \
+  "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum" \
+  "GRBM_GUI_ACTIVE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum")
 
 trace_all() {  # name, scene, kernel
   prof_trace $1 trace $2 $3 6

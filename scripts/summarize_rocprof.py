@@ -34,14 +34,30 @@ def trace(d):
 
 
 def pmc(dirs):
+    """One rocprofv3 --pmc pass per directory.  Besides every counter's per-dispatch mean, each pass contributes what its OWN launches
+    cost: `<counter>@ns` (mean duration of the same kernel x grid in this pass's kernel trace) and, when the pass also collected
+    GRBM_GUI_ACTIVE, `<counter>@cycles` (GRBM_GUI_ACTIVE / 8 XCDs) -- so that a share is a pass's counts over the same pass's cycles."""
     for d in dirs:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in sorted(glob.glob(d + "/**/*_counter_collection.csv", recursive=True)):
             for r in csv.DictReader(open(f)):
                 agg[(short(r["Kernel_Name"]), r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur = collections.defaultdict(list)
+        for f in sorted(glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)):
+            for r in csv.DictReader(open(f)):
+                dur[(short(r["Kernel_Name"]), r["Grid_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         for k, cs in sorted(agg.items()):
+            gui = cs.get("GRBM_GUI_ACTIVE")
             for c, v in sorted(cs.items()):
                 print("%-72s grid=%10s %-32s n=%4d mean=%.6g" % (k[0], k[1], c, len(v), sum(v) / len(v)))
+                if c == "GRBM_GUI_ACTIVE":
+                    continue
+                if k in dur:
+                    print("%-72s grid=%10s %-32s n=%4d mean=%.6g" % (k[0], k[1], c + "@ns", len(dur[k]), sum(dur[k]) / len(dur[k])))
+                if gui:
+                    print("%-72s grid=%10s %-32s n=%4d mean=%.6g" % (k[0], k[1], c + "@cycles", len(gui), sum(gui) / len(gui) / 8.0))
+            if gui and k in dur:
+                print("%-72s grid=%10s %-32s n=%4d mean=%.6g" % (k[0], k[1], "GRBM_GUI_ACTIVE@ns", len(dur[k]), sum(dur[k]) / len(dur[k])))
 
 
 def to_json(files):

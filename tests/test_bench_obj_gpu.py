@@ -66,3 +66,47 @@ def test_bench_rccl_path_at_world_size_one():
     # the frame-per-rank mode reported beside `value` for N > 1 (here: one rank, one whole frame)
     fpr = out["extras"]["frame_per_rank"]
     assert fpr["ranks"] == 1 and fpr["steps"] == 2 and fpr["mrays"] > 0 and fpr["ms_per_frame"] > 0
+
+
+def _bench_ranks(n, extra, timeout=900):
+    """`python bench.py --gpus n` as a FRESH child process that starts its own ranks (bench.py self-launches before it touches the GPU)
+    with every rank on cuda:0 over gloo: the N > 1 path -- sharded frame, BVH broadcast, per-rank AO from own hits, gather to rank 0,
+    bit-compare against the single-GPU frame -- with real HIP tracing on a one-GPU box."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dist-backend", "gloo", "--one-device", "--steps", "2",
+                        "--warmup", "1", "--no-extras", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("ranks,size,balance", [(2, (1920, 1080), "count"), (3, (1000, 700), "count"), (2, (1000, 700), "predicted")])
+def test_bench_sharded_frame_with_real_kernels_at_world_size_above_one(ranks, size, balance):
+    """nothing above world size 1 had ever traced a ray.  Here N ranks (N processes, one GPU, gloo) each trace
+    their PixelTable range of ONE frame with the HIP kernels, generate AO rays from their own hits, and rank 0 gathers the records and
+    compares the assembled frame bit for bit (primary) / by checksum of checksums (AO) with its own single-GPU trace -- 1080p at two
+    ranks, a 1000 x 700 frame at three (ragged 64-aligned cuts: 700 000 rays do not divide), and cuts of equal predicted cost.  What
+    stays unexecuted without a multi-GPU node: the RCCL transport at N > 1."""
+    w, h = size
+    out = _bench_ranks(ranks, ["--width", str(w), "--height", str(h), "--balance", balance])
+    assert out["n_gpus"] == ranks and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["one_device"] is True and out["config"]["dist_backend"] == "gloo"
+    chk = out["sharded_frame_check"]
+    assert chk and chk["primary_records_equal_single_gpu_frame"] is True and chk["ao_checksum_equal_single_gpu_frame"] is True
+    assert chk["records_compared"] == w * h
+    assert out["gather_ms"] is not None and out["gather_ms"] > 0
+    assert out["extras"]["frame_per_rank"]["ranks"] == ranks and out["extras"]["frame_per_rank"]["mrays"] > 0
+    # every rank traced only its share: rank 0's primary rays are about 1 / ranks of the frame, whole 64-ray tiles
+    own = out["config"]["primary_rays_rank0"]
+    assert 0 < own < w * h and own % 64 == 0
+    if balance == "count":
+        assert abs(own - w * h / ranks) <= 64
+    assert out["config"]["rays_per_step"] > out["config"]["rays_per_step_rank0"]
+
+
+def test_bench_frame_per_rank_mode_at_world_size_two():
+    """--scaling weak (a whole frame of its own camera per rank) at two ranks on one device: the mode in which every launch keeps its
+    single-GPU size; records of both frames are gathered."""
+    out = _bench_ranks(2, ["--width", "640", "--height", "360", "--scaling", "weak"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["rays_per_step"] > 1.5 * out["config"]["rays_per_step_rank0"]
