@@ -157,15 +157,29 @@ NTR_API int ntr_selftest_gather_rate(int64_t tableBytes, int32_t waves, int32_t 
  *   - pool counters of the persistent kernels: 192 captured launches per device;
  *   - dispatch-order prediction scratch (closest-hit per-ray launches of >= 2^20 rays): private to each captured launch
  *     (a replay on any stream never shares it with a live launch); every live launch of a size keeps 4 spares of that size
- *     ready, ntr_trace_graph_reserve(launches, numRays) provisions more (48 entries per process in all);
- *   - the top-of-tree table of a BVH (16 BVHs): trace the BVH once, or call ntr_bvh_validate, before capturing.
+ *     ready, ntr_trace_graph_reserve(launches, numRays) provisions more (48 entries per device in all);
+ *   - the top-of-tree table of a BVH (16 BVHs per device): trace the BVH once, or call ntr_bvh_validate, before capturing.
  * The predicted order is an optimisation: a captured launch that finds no spare scratch is captured in buffer order
- * (no error).  Captured launches never use the tail hand-off's continuation queue either.
+ * (no error).
  * When one of the other stores is exhausted the capture-time call fails with NTR_ERR_NOMEM / NTR_ERR_INVALID and says so.  A host that
  * re-captures graphs (e.g. every frame) calls ntr_trace_graph_release_all() once the graphs holding earlier captures are
  * destroyed: it waits for the device and returns every pinned resource of the current device to its store. */
 NTR_API int ntr_trace_graph_reserve(int32_t launches, int32_t numRays);
 NTR_API int ntr_trace_graph_release_all(void);
+
+/* Scheduling state is kept PER DEVICE (one mutex, 96 automatic hints, 48 prediction scratches, 16 top-of-tree tables each), so the
+ * host threads of a thread-per-GPU driver (ntr_dist_init_all) neither share entries nor contend for one lock.  Within a device an
+ * entry belongs to the stream that created it and is recycled only by that stream (the launch path never synchronises or records an
+ * event).  ntr_stream_release(stream): call before destroying a stream -- waits for it and returns the automatic hints and the
+ * prediction scratch it owns on the current device.  Without it the entries of dead streams stay allocated for the life of the
+ * process; a device whose 96 hint entries all belong to dead streams gives later streams buffer / predicted order only (about
+ * 9 % on re-traced batches), never an error. */
+NTR_API int ntr_stream_release(void* stream);
+
+/* CPU-side self test of the automatic-hint table (no device needed): `devices` simulated devices each trace `keysPerDevice` distinct
+ * batches on a stream of their own, `rounds` times; hintedLastRound[d] = batches of device d that found their hint entry in the
+ * last round (keysPerDevice for every device while keysPerDevice <= 96: no device is starved by the others). */
+NTR_API int ntr_selftest_auto_hint_table(int32_t devices, int32_t keysPerDevice, int32_t rounds, int32_t* hintedLastRound);
 
 /* Re-reads the NTR_* environment tunables.  They are read once, at first use; sweep scripts
  * that change a variable inside one process call this afterwards.  Not needed by applications. */

@@ -98,6 +98,8 @@ SYMBOLS = [
     ("ntr_predict_batch_coherence", C.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
     ("ntr_trace_graph_reserve", C.c_int, [_i32, _i32]),
     ("ntr_trace_graph_release_all", C.c_int, []),
+    ("ntr_stream_release", C.c_int, [_vp]),
+    ("ntr_selftest_auto_hint_table", C.c_int, [_i32, _i32, _i32, C.POINTER(_i32)]),
     ("ntr_lbvh_release_workspace", C.c_int, []),
     ("ntr_sched_hint_create", C.c_int, [C.POINTER(_vp)]),
     ("ntr_sched_hint_destroy", C.c_int, [_vp]),
@@ -335,6 +337,19 @@ def trace_graph_reserve(launches, num_rays):
 def trace_graph_release_all():
     """ntr_trace_graph_release_all: return every resource pinned by captured launches (call when their graphs are destroyed)."""
     _check(lib().ntr_trace_graph_release_all())
+
+
+def stream_release(stream=0):
+    """ntr_stream_release: return the scheduling state (automatic hints, prediction scratch) `stream` owns on the current device; call
+    before destroying the stream."""
+    _check(lib().ntr_stream_release(_vp(stream)))
+
+
+def selftest_auto_hint_table(devices, keys_per_device, rounds=3):
+    """ntr_selftest_auto_hint_table: per simulated device, the batches that found their automatic hint in the last round (CPU only)."""
+    out = (_i32 * devices)()
+    _check(lib().ntr_selftest_auto_hint_table(devices, keys_per_device, rounds, out))
+    return [int(x) for x in out]
 
 
 def lbvh_release_workspace():

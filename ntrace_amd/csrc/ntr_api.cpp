@@ -311,8 +311,6 @@ struct TopTable {
     bool pinned = false;             // referenced by a captured HIP graph: never evicted
 };
 static constexpr int kTopTables = 16;
-static TopTable g_top[kTopTables];
-static unsigned long long g_topClock = 0;
 static constexpr size_t kTopTableBytes = (((size_t)2 << NTR_TOP_DEPTH_MAX) + 16) * 32;  // + padding read by predict_kernel's batches
 
 // Class counters / lists / block order of one prediction.  A live (not captured) launch uses the entry owned by its stream
@@ -335,7 +333,6 @@ struct PredictScratch {
 static constexpr int kScratch = 48;
 static constexpr int kScratchSpares = 4;   // spares a live launch keeps ready (per device, sized for the largest launch seen) for captured launches
 static constexpr int kScratchLive = 16;    // streams with an entry of their own before the least recently used one is recycled
-static PredictScratch g_scratch[kScratch];
 
 #ifdef NTR_AB
 // Continuation queue of the tail hand-off (trace_kernels.hip): one per (device, stream) -- launches on one stream are ordered, two streams
@@ -349,8 +346,77 @@ struct ContScratch {
     bool used = false;
 };
 static constexpr int kContScratch = 16;
-static ContScratch g_cont[kContScratch];
 
+#endif
+
+// Scheduling hint (include/ntrace_amd.h): per-block cost of the previous launch -> block order of the next.
+struct NtrSchedHint {
+    unsigned int* order = nullptr;  // device, numBlocks entries
+    unsigned int* cost = nullptr;   // device, numBlocks entries
+    int numBlocks = 0;              // 0 = unbound
+    int capBlocks = 0;              // blocks the arrays have room for (caller-owned hints grow, never shrink: a frame's short last batch
+                                    // must not cost a hipFree -- a device-wide synchronisation -- and two hipMallocs every frame)
+    int device = -1;
+    int uses = 0;                   // launches since the hint was (re)bound
+    bool valid = false;             // order[] holds a permutation
+    bool predicted = false;         // order[] comes from ntr_sched_hint_predict and has not been used yet
+};
+
+// Automatic scheduling feedback.  The launch time of the per-ray kernel is set by where its long-lived blocks start (DESIGN.md 4.1);
+// what a launch MEASURED about its blocks is the best order for the next launch of the same batch.  The reference's benchmark traces
+// every batch 1 + warm-up + measure times (App.cpp:955-958), a renderer with a parked or slowly moving camera regenerates nearly the
+// same rays into the same buffers frame after frame -- so the library keeps, per (stream, ray buffer, ray count, ray kind, BVH), the
+// scheduling hint a caller could have kept by hand (NtrSchedHint) and uses it without being asked.  Only the dispatch ORDER changes;
+// a stale entry (new rays at the old address) is merely a worse order and adapts within a launch or two.  Entries are per stream
+// (launches on one stream are ordered, so order[] is never rewritten under a launch that reads it); captured launches do not use them.
+struct AutoHint {
+    const void* rays = nullptr;
+    const void* nodes = nullptr;
+    void* stream = nullptr;
+    int numRays = 0, anyHit = 0, device = -1;
+    bool used = false;
+    int sightings = 0;              // launches of this key: storage is allocated at the second one (a batch seen once pays nothing)
+    unsigned long long lastUse = 0;
+    NtrSchedHint hint;              // (its arrays come from the stream-ordered allocator: hipMallocAsync / hipFreeAsync on `stream`)
+};
+static constexpr int kAutoHints = 96;
+
+// Scheduling state of ONE device: top-of-tree tables, prediction scratch, automatic hints (and, in the A/B build, hand-off queues), under
+// the device's own mutex.  Until round 4 these were process-global tables behind one mutex: with one host thread per GPU
+// (ntr_dist_init_all) eight devices x 17 batches are 136 automatic-hint keys for 96 entries, so the devices that came
+// last silently ran in buffer order -- and MAX over ranks is the metric -- while every launch of every device took the same lock.
+struct SchedState {
+    std::mutex mu;
+    unsigned long long clock = 0;   // LRU stamps
+    TopTable top[kTopTables];
+    PredictScratch scratch[kScratch];
+    AutoHint autoHints[kAutoHints];
+#ifdef NTR_AB
+    ContScratch cont[kContScratch];
+#endif
+};
+static SchedState* g_sched[kMaxDevices];   // created on a device's first use, never destroyed (entries hold device memory of a live context)
+
+static int sched_state(int dev, SchedState** out)
+{
+    if (dev < 0 || dev >= kMaxDevices) return set_error(NTR_ERR_INVALID, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_sched[dev]) {
+        g_sched[dev] = new (std::nothrow) SchedState();
+        if (!g_sched[dev]) return set_error(NTR_ERR_NOMEM, "out of host memory (scheduling state of device %d)", dev);
+    }
+    *out = g_sched[dev];
+    return NTR_OK;
+}
+static int sched_state_current(SchedState** out, int* devOut = nullptr)
+{
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    if (devOut) *devOut = dev;
+    return sched_state(dev, out);
+}
+
+#ifdef NTR_AB
 static size_t cont_bytes(int shardSlots)
 {
     return ((size_t)NTR_CONT_SHARDS * NTR_CONT_CTL_WORDS + (size_t)NTR_CONT_SHARDS * shardSlots * NTR_CONT_SLOT_WORDS) * sizeof(unsigned int);
@@ -361,17 +427,19 @@ static int cont_scratch_get(hipStream_t s, int numRays, ContScratch** out)
 {
     *out = nullptr;
     if (stream_is_capturing(s)) return NTR_OK;
+    SchedState* ss = nullptr;
     int dev = 0;
-    NTR_HIP(hipGetDevice(&dev));
+    const int src = sched_state_current(&ss, &dev);
+    if (src != NTR_OK) return src;
     // a quarter of the rays can wait at once (the model's worst case is a third of the rays handed off over a whole launch, K = 1);
     // producers that find their shard full keep their rays
     const int shardSlots = ((numRays / 4 + NTR_CONT_SHARDS - 1) / NTR_CONT_SHARDS + 63) & ~63;
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(ss->mu);
     ContScratch* c = nullptr;
-    for (auto& e : g_cont)
+    for (auto& e : ss->cont)
         if (e.used && e.stream == (void*)s && e.device == dev) { c = &e; break; }
     if (!c)
-        for (auto& e : g_cont)
+        for (auto& e : ss->cont)
             if (!e.used) { c = &e; break; }
     if (!c) return NTR_OK;
     if (c->shardSlots < shardSlots) {
@@ -392,13 +460,15 @@ static int cont_scratch_get(hipStream_t s, int numRays, ContScratch** out)
 
 static int top_table_get(const void* d_nodes, int64_t nodesBytes, hipStream_t s, bool rebuild, TopTable** out)
 {
+    SchedState* ss = nullptr;
     int dev = 0;
-    NTR_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_mu);
+    const int src = sched_state_current(&ss, &dev);
+    if (src != NTR_OK) return src;
+    std::lock_guard<std::mutex> lk(ss->mu);
     const bool capturing = stream_is_capturing(s);
     TopTable* t = nullptr;
     TopTable* lru = nullptr;
-    for (auto& e : g_top) {
+    for (auto& e : ss->top) {
         if (e.nodes == d_nodes && e.bytes == nodesBytes && e.device == dev) { t = &e; break; }
         if (!e.pinned && (!lru || e.lastUse < lru->lastUse)) lru = &e;
     }
@@ -415,7 +485,7 @@ static int top_table_get(const void* d_nodes, int64_t nodesBytes, hipStream_t s,
         t->nodes = d_nodes; t->bytes = nodesBytes; t->device = dev;
         build = true;
     }
-    t->lastUse = ++g_topClock;
+    t->lastUse = ++ss->clock;
     if (capturing) t->pinned = true;
     if (build) {
         const hipError_t e = ntr_launch_top_table(d_nodes, (unsigned int)nodesBytes, tunables().predictDepth, t->table, t->count, s);
@@ -455,21 +525,21 @@ static void scratch_free(PredictScratch* p)
     *p = PredictScratch();
 }
 
-// spares of at least numBlocks on `dev` (g_mu held)
-static int scratch_count_spares(int dev, int numBlocks)
+// spares of at least numBlocks on the state's device (its mutex held)
+static int scratch_count_spares(SchedState* ss, int dev, int numBlocks)
 {
     int n = 0;
-    for (auto& e : g_scratch)
+    for (auto& e : ss->scratch)
         if (e.state == PredictScratch::SPARE && e.device == dev && e.capBlocks >= numBlocks) n++;
     return n;
 }
 
-// makes sure `want` spares of at least numBlocks exist on `dev` (g_mu held, not capturing): smaller spares are regrown first (nothing
+// makes sure `want` spares of at least numBlocks exist on the state's device (its mutex held, not capturing): smaller spares are regrown first (nothing
 // references a spare), then free slots are taken; running out of slots is not an error here
-static int scratch_provision_spares(int dev, int numBlocks, int want)
+static int scratch_provision_spares(SchedState* ss, int dev, int numBlocks, int want)
 {
-    int have = scratch_count_spares(dev, numBlocks);
-    for (auto& e : g_scratch) {
+    int have = scratch_count_spares(ss, dev, numBlocks);
+    for (auto& e : ss->scratch) {
         if (have >= want) break;
         if (e.state == PredictScratch::SPARE && e.device == dev && e.capBlocks < numBlocks) {
             const int rc = scratch_alloc(&e, dev, numBlocks);
@@ -477,7 +547,7 @@ static int scratch_provision_spares(int dev, int numBlocks, int want)
             have++;
         }
     }
-    for (auto& e : g_scratch) {
+    for (auto& e : ss->scratch) {
         if (have >= want) break;
         if (e.state != PredictScratch::FREE) continue;
         const int rc = scratch_alloc(&e, dev, numBlocks);
@@ -490,19 +560,21 @@ static int scratch_provision_spares(int dev, int numBlocks, int want)
 
 static int predict_scratch_get(hipStream_t s, int numBlocks, PredictScratch** out)
 {
+    SchedState* ss = nullptr;
     int dev = 0;
-    NTR_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_mu);
+    const int src = sched_state_current(&ss, &dev);
+    if (src != NTR_OK) return src;
+    std::lock_guard<std::mutex> lk(ss->mu);
     const bool capturing = stream_is_capturing(s);
     if (capturing) {   // a private entry from the spares: the smallest that fits
         PredictScratch* best = nullptr;
-        for (auto& e : g_scratch)
+        for (auto& e : ss->scratch)
             if (e.state == PredictScratch::SPARE && e.device == dev && e.capBlocks >= numBlocks && (!best || e.capBlocks < best->capBlocks)) best = &e;
         // no spare of this size: the launch is captured without a predicted order (an optimisation, not a contract);
         // ntr_trace_graph_reserve provisions spares for graphs that want it
         if (!best) { *out = nullptr; return NTR_OK; }
         best->state = PredictScratch::PINNED;
-        best->lastUse = ++g_topClock;
+        best->lastUse = ++ss->clock;
         *out = best;
         return NTR_OK;
     }
@@ -510,7 +582,7 @@ static int predict_scratch_get(hipStream_t s, int numBlocks, PredictScratch** ou
     PredictScratch* lru = nullptr;
     PredictScratch* empty = nullptr;
     int live = 0;
-    for (auto& e : g_scratch) {
+    for (auto& e : ss->scratch) {
         if (e.state == PredictScratch::LIVE) {
             live++;
             if (e.stream == (void*)s && e.device == dev) { p = &e; break; }
@@ -533,51 +605,40 @@ static int predict_scratch_get(hipStream_t s, int numBlocks, PredictScratch** ou
     if (rc != NTR_OK) return rc;
     p->state = PredictScratch::LIVE;
     p->stream = (void*)s;
-    p->lastUse = ++g_topClock;
-    rc = scratch_provision_spares(dev, numBlocks, kScratchSpares);
+    p->lastUse = ++ss->clock;
+    rc = scratch_provision_spares(ss, dev, numBlocks, kScratchSpares);
     if (rc != NTR_OK) return rc;
     *out = p;
     return NTR_OK;
 }
-
-// Scheduling hint (include/ntrace_amd.h): per-block cost of the previous launch -> block order of the next.
-struct NtrSchedHint {
-    unsigned int* order = nullptr;  // device, numBlocks entries
-    unsigned int* cost = nullptr;   // device, numBlocks entries
-    int numBlocks = 0;              // 0 = unbound
-    int device = -1;
-    int uses = 0;                   // launches since the hint was (re)bound
-    bool valid = false;             // order[] holds a permutation
-    bool predicted = false;         // order[] comes from ntr_sched_hint_predict and has not been used yet
-};
 
 static void sched_hint_release(NtrSchedHint* h)
 {
     if (h->order) (void)hipFree(h->order);
     if (h->cost) (void)hipFree(h->cost);
     h->order = h->cost = nullptr;
-    h->numBlocks = 0; h->uses = 0; h->valid = false; h->predicted = false;
+    h->numBlocks = 0; h->capBlocks = 0; h->uses = 0; h->valid = false; h->predicted = false;
 }
 
-// Automatic scheduling feedback.  The launch time of the per-ray kernel is set by where its long-lived blocks start (DESIGN.md 4.1);
-// what a launch MEASURED about its blocks is the best order for the next launch of the same batch.  The reference's benchmark traces
-// every batch 1 + warm-up + measure times (App.cpp:955-958), a renderer with a parked or slowly moving camera regenerates nearly the
-// same rays into the same buffers frame after frame -- so the library keeps, per (stream, ray buffer, ray count, ray kind, BVH), the
-// scheduling hint a caller could have kept by hand (NtrSchedHint) and uses it without being asked.  Only the dispatch ORDER changes;
-// a stale entry (new rays at the old address) is merely a worse order and adapts within a launch or two.  Entries are per stream
-// (launches on one stream are ordered, so order[] is never rewritten under a launch that reads it); captured launches do not use them.
-struct AutoHint {
-    const void* rays = nullptr;
-    const void* nodes = nullptr;
-    void* stream = nullptr;
-    int numRays = 0, anyHit = 0, device = -1;
-    bool used = false;
-    int sightings = 0;              // launches of this key: storage is allocated at the second one (a batch seen once pays nothing)
-    unsigned long long lastUse = 0;
-    NtrSchedHint hint;              // (its arrays come from the stream-ordered allocator: hipMallocAsync / hipFreeAsync on `stream`)
-};
-static constexpr int kAutoHints = 96;
-static AutoHint g_auto[kAutoHints];
+// Binds a caller-owned hint to a batch of numBlocks blocks on `dev`: the arrays are reallocated only to grow (or on another device); a
+// hint bound to a different block count starts over.
+static int sched_hint_bind(NtrSchedHint* h, int numBlocks, int dev)
+{
+    if (h->device != dev || h->capBlocks < numBlocks || !h->order) {
+        sched_hint_release(h);
+        // order[numBlocks .. numBlocks + 2]: the batch's coherence words, the last one its mini-pool K (0 = not estimated yet, read as 1):
+        // written by the dispatch-order prediction of the batch's first launch, or by the coherence probe of its refresh launches
+        NTR_HIP(hipMalloc((void**)&h->order, ((size_t)numBlocks + 3) * sizeof(unsigned int)));
+        NTR_HIP(hipMalloc((void**)&h->cost, (size_t)numBlocks * sizeof(unsigned int)));
+        h->capBlocks = numBlocks;
+        h->device = dev;
+    }
+    if (h->numBlocks != numBlocks) {
+        h->numBlocks = numBlocks;
+        h->uses = 0; h->valid = false; h->predicted = false;
+    }
+    return NTR_OK;
+}
 
 // returns an automatic hint's arrays in stream order: behind every launch of `s` that reads them (no synchronisation, no event)
 static void auto_hint_release_async(NtrSchedHint* h, hipStream_t s)
@@ -592,38 +653,55 @@ static void auto_hint_release_async(NtrSchedHint* h, hipStream_t s)
 // hint.  Nothing here synchronises, records an event or frees under a launch in flight: an entry is recycled only if it holds no storage
 // or belongs to THIS stream (its arrays are then freed in stream order, behind the launches that read them), and if no entry can be had
 // the launch simply goes without (buffer / predicted order).
+// The table logic alone (no HIP call: ntr_selftest_auto_hint_table drives it on the CPU tier).  Returns the entry of the key on a repeated
+// sighting; on a first sighting registers the key and returns null, *evicted then being an entry whose arrays the caller must return in
+// the order of `stream` (or null).  *noEntry: the table had no entry this launch may take.
+static AutoHint* auto_hint_lookup(SchedState* ss, const void* d_rays, const void* d_nodes, int numRays, int anyHit, void* stream, int dev,
+                                  NtrSchedHint** evicted, bool* noEntry)
+{
+    *evicted = nullptr;
+    *noEntry = false;
+    AutoHint* hit = nullptr;
+    AutoHint* freeE = nullptr;
+    for (auto& e : ss->autoHints) {
+        if (e.used && e.rays == d_rays && e.nodes == d_nodes && e.numRays == numRays && e.anyHit == anyHit && e.stream == stream) { hit = &e; break; }
+        if (!e.used && !freeE) freeE = &e;
+    }
+    if (hit) {
+        hit->lastUse = ++ss->clock;
+        hit->sightings++;
+        return hit;
+    }
+    AutoHint* v = freeE;
+    if (!v) {   // least recently used among the entries this launch may recycle: those without storage, and this stream's own
+        for (auto& e : ss->autoHints) {
+            if (e.hint.order && e.stream != stream) continue;
+            if (!v || e.lastUse < v->lastUse) v = &e;
+        }
+        if (!v) { *noEntry = true; return nullptr; }
+        if (v->hint.order) *evicted = &v->hint;
+    }
+    v->rays = d_rays; v->nodes = d_nodes; v->numRays = numRays; v->anyHit = anyHit; v->stream = stream; v->device = dev;
+    v->used = true;
+    v->sightings = 1;
+    v->lastUse = ++ss->clock;
+    v->hint.uses = 0; v->hint.valid = false;
+    return nullptr;   // first sighting: registered, not hinted
+}
+
 static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, int anyHit, hipStream_t s, int numBlocks, NtrSchedHint** out)
 {
     *out = nullptr;
+    SchedState* ss = nullptr;
     int dev = 0;
-    NTR_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_mu);
-    AutoHint* hit = nullptr;
-    AutoHint* freeE = nullptr;
-    for (auto& e : g_auto) {
-        if (e.used && e.rays == d_rays && e.nodes == d_nodes && e.numRays == numRays && e.anyHit == anyHit && e.stream == (void*)s && e.device == dev) { hit = &e; break; }
-        if (!e.used && !freeE) freeE = &e;
-    }
-    if (!hit) {
-        AutoHint* v = freeE;
-        if (!v) {   // least recently used among the entries this launch may recycle
-            for (auto& e : g_auto) {
-                const bool mine = e.stream == (void*)s && e.device == dev;
-                if (e.hint.order && !mine) continue;
-                if (!v || e.lastUse < v->lastUse) v = &e;
-            }
-            if (!v) return NTR_OK;
-            if (v->hint.order) auto_hint_release_async(&v->hint, s);
-        }
-        v->rays = d_rays; v->nodes = d_nodes; v->numRays = numRays; v->anyHit = anyHit; v->stream = (void*)s; v->device = dev;
-        v->used = true;
-        v->sightings = 1;
-        v->lastUse = ++g_topClock;
-        v->hint.uses = 0; v->hint.valid = false;
-        return NTR_OK;   // first sighting: registered, not hinted
-    }
-    hit->lastUse = ++g_topClock;
-    hit->sightings++;
+    const int src = sched_state_current(&ss, &dev);
+    if (src != NTR_OK) return src;
+    std::lock_guard<std::mutex> lk(ss->mu);
+    NtrSchedHint* evicted = nullptr;
+    bool noEntry = false;
+    AutoHint* hit = auto_hint_lookup(ss, d_rays, d_nodes, numRays, anyHit, (void*)s, dev, &evicted, &noEntry);
+    if (evicted) auto_hint_release_async(evicted, s);
+    if (!hit) return NTR_OK;
     NtrSchedHint* h = &hit->hint;
     if (h->numBlocks != numBlocks || h->device != dev) {   // second sighting: the storage
         if (h->order) auto_hint_release_async(h, s);
@@ -791,13 +869,8 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         int dev = 0;
         NTR_HIP(hipGetDevice(&dev));
         if (hint->numBlocks != numBlocks || hint->device != dev) {
-            sched_hint_release(hint);
-            // order[numBlocks .. numBlocks + 2]: the batch's coherence words, the last one its mini-pool K (0 = not estimated yet, read as 1):
-            // written by the dispatch-order prediction of the batch's first launch, or by the coherence probe of its refresh launches
-            NTR_HIP(hipMalloc((void**)&hint->order, ((size_t)numBlocks + 3) * sizeof(unsigned int)));
-            NTR_HIP(hipMalloc((void**)&hint->cost, (size_t)numBlocks * sizeof(unsigned int)));
-            hint->numBlocks = numBlocks;
-            hint->device = dev;
+            rc = sched_hint_bind(hint, numBlocks, dev);   // (automatic hints arrive bound: auto_hint_get)
+            if (rc != NTR_OK) return rc;
         }
         // costs measured under the natural order differ from those under the derived order, so the first
         // launches all refresh; afterwards every 8th does (slowly drifting rays keep their schedule)
@@ -1015,8 +1088,11 @@ int ntr_trace_handoff_counts(void* stream, uint32_t counts[3])
     unsigned int* mem = nullptr;
     int shardSlots = 0;
     {
-        std::lock_guard<std::mutex> lk(g_mu);
-        for (auto& e : g_cont)
+        SchedState* ss = nullptr;
+        const int rc = sched_state(dev, &ss);
+        if (rc != NTR_OK) return rc;
+        std::lock_guard<std::mutex> lk(ss->mu);
+        for (auto& e : ss->cont)
             if (e.used && e.stream == stream && e.device == dev) { mem = e.mem; shardSlots = e.shardSlots; }
     }
     if (!mem) return NTR_OK;
@@ -1079,11 +1155,14 @@ int ntr_trace_graph_reserve(int32_t launches, int32_t numRays)
     int dev = 0;
     NTR_HIP(hipGetDevice(&dev));
     const int numBlocks = (numRays + 255) / 256;
-    std::lock_guard<std::mutex> lk(g_mu);
+    SchedState* ss = nullptr;
+    rc = sched_state(dev, &ss);
+    if (rc != NTR_OK) return rc;
+    std::lock_guard<std::mutex> lk(ss->mu);
     if (numBlocks > 0 && launches > 0) {
-        rc = scratch_provision_spares(dev, numBlocks, launches);
+        rc = scratch_provision_spares(ss, dev, numBlocks, launches);
         if (rc != NTR_OK) return rc;
-        if (scratch_count_spares(dev, numBlocks) < launches)
+        if (scratch_count_spares(ss, dev, numBlocks) < launches)
             return set_error(NTR_ERR_NOMEM, "ntr_trace_graph_reserve: at most %d prediction scratches exist (ntr_trace_graph_release_all returns the pinned ones)", kScratch);
     }
     return NTR_OK;
@@ -1094,12 +1173,70 @@ int ntr_trace_graph_release_all(void)
     int dev = 0;
     NTR_HIP(hipGetDevice(&dev));
     NTR_HIP(hipDeviceSynchronize());   // replays in flight still read the scratch
+    SchedState* ss = nullptr;
+    const int rc = sched_state(dev, &ss);
+    if (rc != NTR_OK) return rc;
+    {
+        std::lock_guard<std::mutex> lk(ss->mu);
+        for (auto& e : ss->scratch)
+            if (e.state == PredictScratch::PINNED) e.state = PredictScratch::SPARE;   // back to the spares
+        for (auto& t : ss->top) t.pinned = false;
+    }
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& e : g_scratch)
-        if (e.state == PredictScratch::PINNED && e.device == dev) e.state = PredictScratch::SPARE;   // back to the spares
-    for (auto& t : g_top)
-        if (t.device == dev) t.pinned = false;
-    if (dev >= 0 && dev < kMaxDevices) g_dev[dev].nextPinned = 0;
+    g_dev[dev].nextPinned = 0;
+    return NTR_OK;
+}
+
+int ntr_stream_release(void* stream)
+{
+    // The library keeps per-stream scheduling state on the current device -- automatic hints (their arrays come from the stream-ordered
+    // allocator) and the stream's prediction scratch -- and recycles an entry only for the stream that owns it (nothing on the launch path
+    // synchronises).  A host that destroys a stream returns that state here first; otherwise entries of dead streams stay allocated for
+    // the life of the process, and a table full of them (96 hints per device) leaves later streams without the learned dispatch order.
+    SchedState* ss = nullptr;
+    int dev = 0;
+    int rc = sched_state_current(&ss, &dev);
+    if (rc != NTR_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (stream_is_capturing(s)) return set_error(NTR_ERR_INVALID, "ntr_stream_release: the stream is being captured");
+    NTR_HIP(hipStreamSynchronize(s));   // launches in flight still read the arrays
+    std::lock_guard<std::mutex> lk(ss->mu);
+    for (auto& e : ss->autoHints)
+        if (e.used && e.stream == stream) {
+            if (e.hint.order) auto_hint_release_async(&e.hint, s);
+            e = AutoHint();
+        }
+    for (auto& e : ss->scratch)
+        if (e.state == PredictScratch::LIVE && e.stream == stream) scratch_free(&e);
+#ifdef NTR_AB
+    for (auto& e : ss->cont)
+        if (e.used && e.stream == stream) { if (e.mem) (void)hipFree(e.mem); e = ContScratch(); }
+#endif
+    return NTR_OK;
+}
+
+int ntr_selftest_auto_hint_table(int32_t devices, int32_t keysPerDevice, int32_t rounds, int32_t* hintedLastRound)
+{
+    // CPU-side check of the automatic-hint table logic (no device needed): `devices` fake devices, each tracing `keysPerDevice` distinct
+    // batches on one stream of its own, `rounds` times over; hintedLastRound[d] = batches of device d that found their entry in the last
+    // round.  With per-device tables every device is served alike (keysPerDevice each while keysPerDevice <= 96).
+    if (devices < 1 || devices > kMaxDevices || keysPerDevice < 1 || rounds < 1 || !hintedLastRound)
+        return set_error(NTR_ERR_INVALID, "ntr_selftest_auto_hint_table: bad argument");
+    for (int d = 0; d < devices; d++) hintedLastRound[d] = 0;
+    SchedState* fake = new (std::nothrow) SchedState[devices];   // (never touches g_sched: the live tables stay as they are)
+    if (!fake) return set_error(NTR_ERR_NOMEM, "ntr_selftest_auto_hint_table: out of host memory");
+    for (int r = 0; r < rounds; r++)
+        for (int k = 0; k < keysPerDevice; k++)        // batch by batch across the devices, as eight host threads would interleave
+            for (int d = 0; d < devices; d++) {
+                NtrSchedHint* evicted = nullptr;
+                bool noEntry = false;
+                std::lock_guard<std::mutex> lk(fake[d].mu);
+                AutoHint* hit = auto_hint_lookup(&fake[d], (const void*)(uintptr_t)(0x1000 + 64 * k), (const void*)(uintptr_t)0x10, 1 << 20, k & 1,
+                                                 (void*)(uintptr_t)(d + 1), d, &evicted, &noEntry);
+                if (hit) hit->hint.order = (unsigned int*)(uintptr_t)1;   // stands for "storage allocated" (a later eviction must not take it from another stream)
+                if (hit && r == rounds - 1) hintedLastRound[d]++;
+            }
+    delete[] fake;
     return NTR_OK;
 }
 
@@ -1134,11 +1271,8 @@ int ntr_sched_hint_predict(NtrSchedHint* hint, const uint32_t* d_blockCost, int3
     int dev = 0;
     NTR_HIP(hipGetDevice(&dev));
     if (hint->numBlocks != numBlocks || hint->device != dev) {   // (the binding ntr_trace_bvh_hinted would make on first use)
-        sched_hint_release(hint);
-        NTR_HIP(hipMalloc((void**)&hint->order, ((size_t)numBlocks + 3) * sizeof(unsigned int)));
-        NTR_HIP(hipMalloc((void**)&hint->cost, (size_t)numBlocks * sizeof(unsigned int)));
-        hint->numBlocks = numBlocks;
-        hint->device = dev;
+        const int rc = sched_hint_bind(hint, numBlocks, dev);
+        if (rc != NTR_OK) return rc;
     }
     NTR_HIP(hipMemcpyAsync(hint->cost, d_blockCost, (size_t)numBlocks * sizeof(unsigned int), hipMemcpyDeviceToDevice, s));
     hipError_t le = ntr_launch_sched_order(hint->cost, numBlocks, tunables().schedClasses, hint->order, s);

@@ -164,7 +164,7 @@ void Renderer::predictSecondaryOrder(void)
     const int ns = m_params.numSamples;
     const int first = m_shardLo + m_batchStart / ns, count = (int)(m_batchRays->getSize() / ns);
     const int blocks = (int)((m_batchRays->getSize() + 255) / 256);
-    m_blockCost.resizeDiscard((S64)blocks * 4);
+    if (m_blockCost.getSize() < (S64)blocks * 4) m_blockCost.resizeDiscard((S64)blocks * 4);   // grows only: a frame's short last batch reallocates nothing
     int rc = ntr_secondary_block_costs((const NtrRayResult*)m_primaryRays.getResultBuffer().getCudaPtr(), first, count, ns,
                                        (const int32_t*)m_leafDepth.getCudaPtr(), numTris, (uint32_t*)m_blockCost.getMutableCudaPtr(), NULL);
     if (rc == NTR_OK && !m_secondaryHint) rc = ntr_sched_hint_create(&m_secondaryHint);

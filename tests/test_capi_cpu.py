@@ -125,3 +125,18 @@ def test_multi_gpu_partition_and_diagnostics_argument_checks():
     assert L.ntr_dist_broadcast(None, None, 0, 0, None) == -1
     assert L.ntr_dist_gather_records(None, None, 0, 64, None, 0, None) == -1
     assert L.ntr_dist_destroy(None) == 0
+
+
+def test_automatic_hint_table_is_per_device_and_starves_no_one():
+    """the scheduling tables were process-global (96 automatic hints for ALL devices), so eight host threads with 17
+    batches each (a 1080p frame: 1 primary + 16 AO) asked for 136 entries and the devices that came last ran without the learned
+    dispatch order.  The tables are per device now; the table logic itself (no HIP) is driven here for 8 simulated devices x 17 keys:
+    from the second round on every device finds all 17 of its batches.  One device alone holds 96 keys; with more batches than entries
+    cycling through, least-recently-used replacement hints few or none of them -- never an error."""
+    assert nt.selftest_auto_hint_table(8, 17, 3) == [17] * 8
+    assert nt.selftest_auto_hint_table(8, 17, 1) == [0] * 8          # a batch seen once only registers
+    assert nt.selftest_auto_hint_table(64, 96, 2) == [96] * 64
+    got = nt.selftest_auto_hint_table(2, 120, 4)                      # more batches than entries
+    assert len(got) == 2 and all(0 <= g <= 96 for g in got)
+    L = nt.lib()
+    assert L.ntr_selftest_auto_hint_table(0, 1, 1, None) == -1 and L.ntr_selftest_auto_hint_table(1, 1, 1, None) == -1
