@@ -149,8 +149,6 @@ static void tunables_load_locked()
     t.closestWaves = env_int("NTR_TRACE_CLOSEST_WAVES", 1);      // likewise for closest-hit launches: primary +2.1 % with 1
     t.anyHitWaves = env_int("NTR_TRACE_ANYHIT_WAVES", 1);        // waves per workgroup of plain any-hit launches of the per-ray kernel (1, 2, 4): AO +1.7 % with 1
     t.flatFetch = env_int("NTR_TRACE_FLAT_FETCH", 1);             // unified-step loop: one group of global loads per iteration (0 = two masked groups of range-checked buffer loads)
-    t.pair = env_int("NTR_TRACE_PAIR", 0);                        // two rays per lane (trace_bvh_perray_pair): 0 off, 1 any-hit launches, 2 closest-hit launches as well
-    t.pairMinRays = env_int("NTR_TRACE_PAIR_MIN_RAYS", 1 << 19);
     t.minipool = env_int("NTR_TRACE_MINIPOOL", -1);              // closest-hit per-ray launches: rays owned by a wave / 64.  -1: decided per batch on the device (1, or minipoolWide when the prediction finds the batch incoherent); 0: the plain per-ray kernel; 1 ... 16: forced
     t.minipoolWide = env_int("NTR_TRACE_MINIPOOL_WIDE", -1);     // K of an incoherent batch: 2 / 4, or -1 = by tree size (4 from 32 MB of nodes up)
     t.minipoolThreshold = env_int("NTR_TRACE_MINIPOOL_THRESHOLD", 48);   // refill a wave's finished lanes when fewer than this many are live
@@ -970,11 +968,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
             launchBlocks = numBlocks * 4;
             // wave-private mini-pool: a wave owns K x 64 rays and refills its finished lanes from them.  K is decided on the device: the
             // prediction of this launch wrote it (incoherent batch: minipoolWide, else 1), or the batch's hint kept it from its first launch.
-            // two rays per lane (trace_bvh_perray_pair): pair 1 = any-hit launches of at least pairMinRays rays, 2 = closest-hit launches too
-            if (p.flatFetch && tun.pair > 0 && numRays >= tun.pairMinRays && (anyHit || tun.pair >= 2)) {
-                launchVariant = NTR_VARIANT_PERRAY_PAIR;
-                launchBlocks = numBlocks * 2;
-            } else if (p.flatFetch && tun.minipool != 0 && !anyHit) {
+            if (p.flatFetch && tun.minipool != 0 && !anyHit) {
                 launchVariant = NTR_VARIANT_PERRAY_UNIFIED_MINI;
                 p.fetchThreshold = tun.minipoolThreshold;
                 p.poolKConst = tun.minipool > 0 ? tun.minipool : 1;

@@ -24,8 +24,6 @@
 #define NTR_VARIANT_PERRAY_UNIFIED_MINI 7 // the same launch, which runs as the wave-private mini-pool instead when the batch's pool K (TraceParams::poolK,
                                           // decided on the device) is 2 ... 16: a wave owns K x 64 rays and refills its finished lanes from them
 
-#define NTR_VARIANT_PERRAY_PAIR 8         // two rays per lane: a 64-thread workgroup traces 128 consecutive rays (unified-step loop, both fetches in flight)
-
 // bits of the device status word
 #define NTR_STATUS_STACK_OVERFLOW 1u
 

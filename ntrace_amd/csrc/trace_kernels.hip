@@ -469,7 +469,8 @@ __device__ __forceinline__ UnifiedBufs unified_bufs(const TraceParams& p)
 // With FLAT every live lane forms the 64-bit address of its own 64 bytes and ONE group of four global loads serves nodes and triangles
 // alike (64 TA cycles).  Global loads are not range-checked: a lane whose 64 bytes would end beyond its buffer (an empty leaf's
 // terminator in the last 48 bytes of triWoop; a malformed child offset) takes the descriptor path instead, which reads zeros there.
-// One unified step, in two halves so that a wave can have the fetches of two independent rays per lane in flight (traverse_unified_pair).
+// One unified step, in two halves (the two-rays-per-lane experiment of round 5 stepped two rays per iteration with them: 24 % slower --
+// 85 VGPRs, five waves per SIMD; scripts/studies/rejected_patches/two_rays_per_lane.patch, EXPERIMENTS.md).
 // unified_fetch: one 64-byte fetch per lane from its own buffer -- the node of a lane at an inner node, the triangle (48 B + the following
 // word) of a lane at a leaf.  Issues the loads and, apart from the rare end-of-buffer lanes, does not wait for them.
 template <bool FLAT>
@@ -569,87 +570,6 @@ __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs&
         unified_fetch<FLAT>(ub, node, a, b, c, d);
         if (FLAT) { keep(a); keep(b); keep(c); keep(d); }
         unified_advance<FAST, OCT>(a, b, c, d, r, node, st, spill, anyHit, hitAddr, hitU, hitV, status);
-    }
-}
-
-// Two independent rays per lane (round 5): the wave steps ray A and ray B of every lane in one iteration -- both
-// 64-byte fetches are issued before the wave waits for either, then A advances while B's loads are still in flight, then B.  Each
-// ray's own visiting order is traverse_unified's, so every hit record is unchanged.
-// The loads are written out (one asm statement: A's four, B's four, s_waitcnt vmcnt(4)): left to the compiler, loads issued under
-// divergent control flow make it wait with vmcnt(0) before A's arithmetic, and B's fetch would no longer overlap it.  Between that
-// statement and pair_wait_b the B registers hold loads in flight: nothing may read them (they are operands of nothing in between).
-static constexpr int PAIR_LDS_DEPTH = 12;   // LDS stack entries per ray of a pair (12 + 88 in scratch = the CPU tracer's 100): 6 KB per wave
-struct Fetched { u32x4 a, b, c, d; };
-__device__ __forceinline__ void pair_issue(const char* addrA, unsigned long long maskA, const char* addrB, unsigned long long maskB, Fetched& fa, Fetched& fb)
-{
-    unsigned long long sav;
-    asm volatile(
-        "s_mov_b64 %[sav], exec\n\t"
-        "s_and_b64 exec, %[sav], %[ma]\n\t"
-        "global_load_dwordx4 %[a0], %[pa], off\n\t"
-        "global_load_dwordx4 %[b0], %[pa], off offset:16\n\t"
-        "global_load_dwordx4 %[c0], %[pa], off offset:32\n\t"
-        "global_load_dwordx4 %[d0], %[pa], off offset:48\n\t"
-        "s_and_b64 exec, %[sav], %[mb]\n\t"
-        "global_load_dwordx4 %[a1], %[pb], off\n\t"
-        "global_load_dwordx4 %[b1], %[pb], off offset:16\n\t"
-        "global_load_dwordx4 %[c1], %[pb], off offset:32\n\t"
-        "global_load_dwordx4 %[d1], %[pb], off offset:48\n\t"
-        "s_mov_b64 exec, %[sav]\n\t"
-        "s_waitcnt vmcnt(4)"
-        : [a0] "=&v"(fa.a), [b0] "=&v"(fa.b), [c0] "=&v"(fa.c), [d0] "=&v"(fa.d), [a1] "=&v"(fb.a), [b1] "=&v"(fb.b), [c1] "=&v"(fb.c), [d1] "=&v"(fb.d),
-          [sav] "=&s"(sav)
-        : [pa] "v"(addrA), [pb] "v"(addrB), [ma] "s"(maskA), [mb] "s"(maskB)
-        : "memory", "scc");
-}
-__device__ __forceinline__ void pair_wait_b(Fetched& fb)
-{
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(fb.a), "+v"(fb.b), "+v"(fb.c), "+v"(fb.d) : : "memory");
-}
-__device__ __forceinline__ float4 as_f4(const u32x4& v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
-
-// where a lane's next 64 bytes are; ok = the plain global loads may fetch them (not within 64 bytes of the buffer's end: the descriptor form reads zeros there)
-__device__ __forceinline__ const char* unified_addr(const UnifiedBufs& ub, int node, bool& ok)
-{
-    const bool inner = (unsigned)node < (unsigned)kSentinel;
-    const bool atTri = node < 0;
-    const int ofs = inner ? node : (~node) * 16;
-    ok = (inner || atTri) && (unsigned)ofs <= (inner ? ub.nodesBytes : ub.woopBytes) - 64u;
-    return (inner ? ub.nodes : ub.woop) + (unsigned)ofs;
-}
-
-template <bool FAST>
-__device__ __forceinline__ void traverse_unified_pair(const UnifiedBufs& ub, bool anyHit, unsigned int* status,
-                                                      RayRegs& rA, int& nodeA, LaneStack& stA, int (&spillA)[SPILL_DEPTH], int& hitAddrA, float& hitUA, float& hitVA,
-                                                      RayRegs& rB, int& nodeB, LaneStack& stB, int (&spillB)[SPILL_DEPTH], int& hitAddrB, float& hitUB, float& hitVB)
-{
-    for (;;) {
-        const unsigned long long liveA = __ballot(nodeA != kSentinel), liveB = __ballot(nodeB != kSentinel);
-        if ((liveA | liveB) == 0ull) break;
-        bool okA, okB;
-        const char* pa = unified_addr(ub, nodeA, okA);
-        const char* pb = unified_addr(ub, nodeB, okB);
-        Fetched fa, fb;
-        pair_issue(pa, __ballot(okA), pb, __ballot(okB), fa, fb);
-        if (liveA != 0ull) {   // (wave-uniform)
-            float4 a = as_f4(fa.a), b = as_f4(fa.b), c = as_f4(fa.c), d = as_f4(fa.d);
-            const unsigned long long odd = __ballot(nodeA != kSentinel && !okA);
-            if (odd != 0ull) {   // rare: the lanes at the very end of a buffer (this also drains B's loads; harmless)
-                const bool inner = (unsigned)nodeA < (unsigned)kSentinel;
-                fetch64_two_buffers_into(ub.rNodes, ub.rWoop, inner ? nodeA : (~nodeA) * 16, __ballot(inner && !okA), __ballot(nodeA < 0 && !okA), a, b, c, d);
-            }
-            unified_advance<FAST, 8, PAIR_LDS_DEPTH>(a, b, c, d, rA, nodeA, stA, spillA, anyHit, hitAddrA, hitUA, hitVA, status);
-        }
-        pair_wait_b(fb);
-        if (liveB != 0ull) {
-            float4 a = as_f4(fb.a), b = as_f4(fb.b), c = as_f4(fb.c), d = as_f4(fb.d);
-            const unsigned long long odd = __ballot(nodeB != kSentinel && !okB);
-            if (odd != 0ull) {
-                const bool inner = (unsigned)nodeB < (unsigned)kSentinel;
-                fetch64_two_buffers_into(ub.rNodes, ub.rWoop, inner ? nodeB : (~nodeB) * 16, __ballot(inner && !okB), __ballot(nodeB < 0 && !okB), a, b, c, d);
-            }
-            unified_advance<FAST, 8, PAIR_LDS_DEPTH>(a, b, c, d, rB, nodeB, stB, spillB, anyHit, hitAddrB, hitUB, hitVB, status);
-        }
     }
 }
 
@@ -788,49 +708,6 @@ __global__ NTR_PERRAY_BOUNDS(WAVES) void trace_bvh_perray(TraceParams p)
 __global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini(TraceParams p)
 {
     perray_body<1, false, true, true, true>(p);
-}
-
-// ---------------------------------------------------------------------------------
-// Variant 1b: two rays per lane (round 5).  A 64-thread workgroup traces 128 consecutive rays of a 256-ray block: lane l holds ray
-// base + l (slot A) and ray base + 64 + l (slot B), stepped together by traverse_unified_pair.  Half the waves of the per-ray launch,
-// two independent fetch groups in flight per wave.  The 256-ray block stays the unit of the dispatch order and of the cost feedback.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void trace_bvh_perray_pair(TraceParams p)
-{
-    __shared__ int s_stack[2][PAIR_LDS_DEPTH][64];  // [slot][entry][lane]
-    const int lane = threadIdx.x;
-    const unsigned int g = blockIdx.x >> 1, part = blockIdx.x & 1u;
-    const unsigned int block = p.order ? p.order[g] : g;
-    const int rayA = block * 256 + part * 128 + lane, rayB = rayA + 64;
-    const bool validA = rayA < p.numRays, validB = rayB < p.numRays;
-
-    unsigned long long tl0 = 0;
-    if (p.cost) tl0 = __builtin_amdgcn_s_memrealtime();
-
-    RayRegs rA, rB;
-    load_ray(p.rays, validA ? rayA : 0, rA);
-    load_ray(p.rays, validB ? rayB : 0, rB);
-    LaneStack stA, stB;
-    int spillA[SPILL_DEPTH], spillB[SPILL_DEPTH];
-    stA.lds = (lds_int*)&s_stack[0][0][lane];
-    stB.lds = (lds_int*)&s_stack[1][0][lane];
-    NTR_STACK_RESET(stA);
-    NTR_STACK_RESET(stB);
-    int hitAddrA = -1, hitAddrB = -1;
-    float hitUA = 0.0f, hitVA = 0.0f, hitUB = 0.0f, hitVB = 0.0f;
-    // degenerate rays (Util.hpp:65) are misses without traversal
-    int nodeA = (validA && rA.tmin < rA.tmax) ? 0 : kSentinel;
-    int nodeB = (validB && rB.tmin < rB.tmax) ? 0 : kSentinel;
-
-    const bool fastWave = (p.bvhFlags & NTR_BVH_FASTDIV) &&
-                          __ballot((nodeA != kSentinel && !ray_is_nice(rA, p.bvhFlags)) || (nodeB != kSentinel && !ray_is_nice(rB, p.bvhFlags))) == 0ull;
-    const UnifiedBufs ub = unified_bufs(p);
-    if (fastWave) traverse_unified_pair<true>(ub, p.anyHit != 0, p.status, rA, nodeA, stA, spillA, hitAddrA, hitUA, hitVA, rB, nodeB, stB, spillB, hitAddrB, hitUB, hitVB);
-    else traverse_unified_pair<false>(ub, p.anyHit != 0, p.status, rA, nodeA, stA, spillA, hitAddrA, hitUA, hitVA, rB, nodeB, stB, spillB, hitAddrB, hitUB, hitVB);
-
-    if (p.cost && lane == 0) atomicMax(&p.cost[block], (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0));
-    if (validA) store_result(p.results, p.triIndex, rayA, hitAddrA, rA.tmax, hitUA, hitVA);
-    if (validB) store_result(p.results, p.triIndex, rayB, hitAddrB, rB.tmax, hitUB, hitVB);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1207,9 +1084,6 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
         break;
     case NTR_VARIANT_PERRAY_UNIFIED_MINI:   // numBlocks counts waves of 64 rays; needs flatFetch
         hipLaunchKernelGGL(ntr::trace_bvh_perray_mini, dim3(numBlocks), dim3(64), 0, stream, *p);
-        break;
-    case NTR_VARIANT_PERRAY_PAIR:   // numBlocks counts waves of 128 rays; needs flatFetch
-        hipLaunchKernelGGL(ntr::trace_bvh_perray_pair, dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_STATS:
         hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);

@@ -458,56 +458,6 @@ def test_wave_private_mini_pool_changes_no_record(monkeypatch, tree):
             assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), want, "%s mini-pool, batch contents changed (phase %d), launch %d" % (tree, phase, rep))
 
 
-@pytest.mark.parametrize("tree", ["sah leaves of 1", "sah leaves of up to 6", "device lbvh"])
-def test_two_rays_per_lane_changes_no_record(monkeypatch, tree):
-    """trace_bvh_perray_pair (round 5): a wave steps two independent rays per lane -- 128 consecutive rays per 64-thread workgroup, both
-    fetches in flight before the wave waits.  Each ray's own visiting order is untouched, so any-hit and closest-hit records stay the
-    oracle's: ragged counts around the 64 / 128 / 256 boundaries (slot B empty, half empty), degenerate and edge-case rays in either
-    slot, natural and measured (hinted) dispatch orders, deep stacks (a one-triangle-leaf SAH tree is 25 levels deep: 16 LDS entries
-    per slot, the rest in scratch)."""
-    import torch
-    from gpu_util import DeviceBvh, assert_parity, gpu_trace, up
-    tri, pos, cam = scenes.random_soup(6000, seed=33)
-    if tree == "sah leaves of 1":
-        dbvh = DeviceBvh(nt.sah_build(tri, pos, 1, 1))
-    elif tree == "sah leaves of up to 6":
-        dbvh = DeviceBvh(nt.sah_build(tri, pos, 1, 6))
-    else:
-        n = tri.shape[0]
-        capn, capw, capi = nt.lbvh_capacity(n)
-        d_tri, d_pos = up(tri), up(pos)
-        bufs = [torch.zeros(c, dtype=torch.uint8, device="cuda:0") for c in (capn, capw, capi)]
-        mn, mx = oracle.scene_bbox(pos)
-        res = nt.lbvh_build(n, d_tri.data_ptr(), pos.shape[0], d_pos.data_ptr(), mn, mx, 8, 0.001, bufs[0].data_ptr(), capn, bufs[1].data_ptr(), capw,
-                            bufs[2].data_ptr(), capi)
-        torch.cuda.synchronize()
-        dbvh = DeviceBvh(nt.HostBvh(bufs[0].cpu().numpy()[:res.nodesBytes].copy(), bufs[1].cpu().numpy()[:res.triWoopBytes].copy(),
-                                    bufs[2].cpu().numpy()[:res.triIndexBytes].view(np.int32).copy()))
-    allrays = np.concatenate([scenes.primary_rays(cam, 200, 160)[0], edge_rays(), scenes.random_rays(20000, seed=9)])
-    allrays["tmax"][5::7] = -1.0   # degenerate rays (tmax < tmin) sprinkled over both slots, as missed pixels leave them in an AO batch
-    monkeypatch.setenv("NTR_TRACE_PAIR", "2")
-    monkeypatch.setenv("NTR_TRACE_PAIR_MIN_RAYS", "1")
-    monkeypatch.setenv("NTR_TRACE_AUTO_HINT_MIN_RAYS", "1")
-    nt.set_tunables()
-    try:
-        for any_hit in (True, False):
-            ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, allrays, any_hit=any_hit, threads=8)
-            for n in (allrays.shape[0], 1, 63, 64, 65, 127, 128, 129, 255, 257, 4097):
-                got, _ = gpu_trace("fermi_speculative_while_while", dbvh, allrays[:n], any_hit)
-                assert_parity(got, ref[:n], "%s two rays per lane any_hit=%s n=%d" % (tree, any_hit, n))
-            d_rays = up(allrays)
-            d_res = torch.zeros(allrays.shape[0] * 16, dtype=torch.uint8, device="cuda:0")
-            for rep in range(4):   # the same buffers again: the launch runs in the order its predecessor measured
-                d_res.zero_()
-                dbvh.view.trace("fermi_speculative_while_while", allrays.shape[0], any_hit, d_rays.data_ptr(), d_res.data_ptr())
-                torch.cuda.synchronize()
-                assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), ref, "%s two rays per lane, hinted launch %d any_hit=%s" % (tree, rep, any_hit))
-    finally:
-        for k in ("NTR_TRACE_PAIR", "NTR_TRACE_PAIR_MIN_RAYS", "NTR_TRACE_AUTO_HINT_MIN_RAYS"):
-            monkeypatch.delenv(k, raising=False)
-        nt.set_tunables()
-
-
 def test_batch_coherence_estimate_separates_camera_rays_from_scattered_ones(soup, monkeypatch):
     """ntr_predict_batch_coherence (the words the dispatch-order prediction derives on the device): rays from one camera start together
     and point alike -- no incoherent block, K = 1; rays that start anywhere in the scene's box are incoherent in nearly every block --
