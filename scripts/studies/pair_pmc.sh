@@ -1,5 +1,6 @@
 #!/bin/bash
 # pair_pmc.sh <tag>: PMC counters of the bench step's AO launches with one ray per lane (trace_bvh_perray<1, false, true, true>) and with two
+# (The kernel lives in scripts/studies/rejected_patches/two_rays_per_lane.patch: apply it, `make -C ntrace_amd/csrc`, then run this.)
 # (trace_bvh_perray_pair, NTR_TRACE_PAIR=1) -- wait share, VALU / TA load, waves -- for the record of the two-rays-per-lane experiment
 # (VERDICT r04 item 1).  Separate --pmc passes, kernel trace only beside them.
 TAG=${1:-r05}
