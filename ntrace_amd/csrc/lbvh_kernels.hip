@@ -52,7 +52,6 @@ struct LbvhState {
     unsigned int topLvlOfs[34];  // per-level offsets into the top pass's node list
     unsigned int topTrieLevels;  // cell-table top: deepest trie level holding a top node, plus one
     unsigned int rootSplit;      // bottom-up path: split position of the root (its node gets index 0)
-    unsigned int holes;          // bottom-up path: node indices (= leaf terminators) set aside inside leaves the depth rule made larger
 };
 
 // ---- Morton codes ------------------------------------------------------------------------------
@@ -281,8 +280,6 @@ struct AggCtx {
     AggSlotG* slotG;             // [n + 1][2] meeting slots in memory
     const unsigned int* abortFlag;     // non-zero: the sort gave up (a look-back timed out) -- the keys are not sorted, and the meeting
                                        // protocol (exactly two arrivals per boundary) only terminates on sorted keys: emit nothing
-    unsigned long long* holeNodeBits;  // bit i: node index i was set aside inside a leaf the depth rule enlarged and stays unused (zeroed per build)
-    unsigned long long* holeSlotBits;  // bit o: triWoop / triIndex slot o likewise (the terminator slots of the leaves that were merged)
 };
 
 // exclusive rank of position p (set bits before p) = count before its 1024-block + count inside the block before its 256-tile
@@ -736,11 +733,10 @@ __global__ __launch_bounds__(256) void lbvh_agglomerate_top_kernel(AggCtx c, int
 // Runs of more than leafSize equal keys: the reference splits them at the median (emitTreeKernel.cu:282) until a part holds at
 // most leafSize triangles or the level bit reaches 0 (:289-292), so the subtree depends on the run's depth -- the number of its
 // ancestors, found by walking the parent positions.  One wave per run writes the median nodes (named by their split position, which
-// lies strictly inside the run; lbvh_leafmark_kernel has marked the leaf starts of the run's subtree as it is WITHOUT the depth rule,
+// lies strictly inside the run; lbvh_leafmark_kernel has marked the leaf starts of the run's subtree exactly, depth rule included,
 // so indices and storage are ranks like everywhere else) and patches the reference its parent holds.  Boxes are folded per child range.
 // Where the depth rule cuts the subtree short (a node at depth 29 only has leaf children; a run at depth 30 is a leaf whatever its
-// size) the leaf is larger than the marks assume: its triangles are written again, contiguously, at the leaf's storage, and the
-// storage and node indices the marks had set aside inside it stay unused (zero-filled).
+// size) the leaf is larger than leafSize; its rows were written by the agglomerate kernel like any leaf's.
 // box of the sorted positions [a, b) by a whole wave: lanes stride over the range, min / max across the lanes by shuffles
 __device__ __forceinline__ void agg_fold_box_wave(const AggCtx& c, int a, int b, float (&box)[6])
 {
@@ -766,36 +762,15 @@ __device__ __forceinline__ void agg_fold_box_wave(const AggCtx& c, int a, int b,
     }
 }
 
-// a leaf [a, b) of more than leafSize equal keys (depth rule): rows, indices, terminator; zeroes what the marks had set aside
-__device__ __forceinline__ void agg_rewrite_big_leaf(const AggCtx& c, int rootSplit, int a, int b)
+// A leaf [a, b) the depth rule made larger than leafSize: lbvh_leafmark_kernel marked it as ONE leaf (it counts the run's depth itself),
+// so the agglomerate kernel has written its rows, indices and terminator like any other leaf's.  Checked here: a mark inside such a
+// leaf would mean the two depth computations disagree -- the build then fails loudly (overflow bit 4) instead of returning a wrong tree.
+__device__ __forceinline__ void agg_check_big_leaf(const AggCtx& c, int a, int b)
 {
     const int lane = threadIdx.x & 63;
-    const int base = agg_leaf_storage(c, a);
-    for (int j = a + lane; j < b; j += 64) {
-        const int t = c.triSorted[j];
-        const TriVerts tv = c.triVerts[t];
-        float4 r0, r1, r2;
-        woop_rows_verts(tv.v[0].x, tv.v[0].y, tv.v[0].z, tv.v[1].x, tv.v[1].y, tv.v[1].z, tv.v[2].x, tv.v[2].y, tv.v[2].z, r0, r1, r2);
-        const int o = base + 3 * (j - a);
-        c.outWoop[o + 0] = r0; c.outWoop[o + 1] = r1; c.outWoop[o + 2] = r2;
-        c.outIdx[o + 0] = t; c.outIdx[o + 1] = 0; c.outIdx[o + 2] = 0;
-        const bool reserved = j > a && ((c.sBits[j >> 6] >> (j & 63)) & 1ull);   // a node index the marks set aside inside the leaf
-        if (reserved) {
-            const int idx = agg_node_index(c, j, rootSplit);
-            int4* nd = reinterpret_cast<int4*>(c.nodes + (size_t)idx * 16);
-            nd[0] = nd[1] = nd[2] = nd[3] = make_int4(0, 0, 0, 0);
-            atomicOr(&c.holeNodeBits[idx >> 6], 1ull << (idx & 63));
-        }
-        const unsigned long long rm = __ballot(reserved);
-        if (lane == 0 && rm) atomicAdd(&c.st->holes, (unsigned int)__popcll(rm));
-    }
-    const int term = base + 3 * (b - a), endAll = agg_leaf_storage(c, b);   // b is a marked leaf start (or n)
-    const float nz = __uint_as_float(0x80000000u);
-    for (int o = term + lane; o < endAll; o += 64) {
-        c.outWoop[o] = o == term ? make_float4(nz, nz, nz, nz) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        c.outIdx[o] = 0;
-        if (o != term) atomicOr(&c.holeSlotBits[o >> 6], 1ull << (o & 63));
-    }
+    bool bad = false;
+    for (int j = a + 1 + lane; j < b; j += 64) bad = bad || ((c.sBits[j >> 6] >> (j & 63)) & 1ull);
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(&c.st->overflow, 4u);
 }
 
 __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
@@ -820,7 +795,7 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
         int* parentLink = q.x >= 0 ? c.nodes + (size_t)q.x * 16 + 12 + q.y : nullptr;
         if (depth >= 30) {                              // the parent's level bit is 0: a leaf whatever its size
             if (lane == 0) *parentLink = ~agg_leaf_storage(c, q.z);
-            agg_rewrite_big_leaf(c, rootSplit, q.z, q.w);
+            agg_check_big_leaf(c, q.z, q.w);
             continue;
         }
         // a run of at most 64 triangles (the common case) is gathered ONCE, one triangle per lane; the child boxes of its median nodes
@@ -867,7 +842,7 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
             for (int k = 0; k < 2; k++) {
                 if ((ce[k] - cs[k]) <= c.leafSize || d == 29) {
                     link[k] = ~agg_leaf_storage(c, cs[k]);
-                    if ((ce[k] - cs[k]) > c.leafSize) agg_rewrite_big_leaf(c, rootSplit, cs[k], ce[k]);
+                    if ((ce[k] - cs[k]) > c.leafSize) agg_check_big_leaf(c, cs[k], ce[k]);
                 } else {
                     const int cm = (cs[k] + ce[k]) >> 1;
                     link[k] = agg_node_index(c, cm, rootSplit) * 64;
@@ -887,7 +862,9 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
 // Leaf starts of every sorted position, from the keys alone -- BEFORE the tree is formed, so that the bottom-up pass can write nodes,
 // Woop rows and indices straight to their final places (indices and storage are ranks of these marks).  Distinct-enough keys: the
 // start of agg_leaf_of's leaf.  Inside a run of more than leafSize equal keys: the leaves of the reference's median splits
-// (emitTreeKernel.cu:282) taken until a part holds at most leafSize triangles.  Also finds the root's split position, the one boundary
+// (emitTreeKernel.cu:282) taken until a part holds at most leafSize triangles or the depth rule ends the subtree (round 5: the marks
+// are EXACT -- until round 4 they ignored the depth rule, and the slots set aside inside leaves it enlarged were squeezed out by a
+// relocation pass of five kernels, which the bench scene paid on every build).  Also finds the root's split position, the one boundary
 // where the highest bit in which the first and the last key differ flips.  One workgroup per RANK_BLOCK positions: bit masks, the
 // block's count and the counts before each 256 positions inside it.
 constexpr int MARK_THREADS = 256;              // one workgroup marks one prefix-count block, four positions per thread
@@ -976,8 +953,11 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
     for (int r = 0; r < MARK_SUBS; r++) {
         const int i = beg + r * MARK_THREADS + tid;
         bool mark = false, isRun = false;
+        int s0 = 0, e0 = 0;               // the run of equal keys position i lies in (isRun)
+        bool deepRun = false;             // ... and the depth rule could cut its subtree short: its depth is needed
+        unsigned int myKey = 0;
         if (i < n) {
-            const unsigned int myKey = sKeys[AGG_HALO + r * MARK_THREADS + tid];
+            myKey = sKeys[AGG_HALO + r * MARK_THREADS + tid];
             int ls = 0, le = 0;
             agg_leaf_of(i, leafSize, dAt, isRun, ls, le);
             if (!isRun) {
@@ -986,7 +966,7 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
                 // the run [s, e) of myKey: the boundary bits held in LDS first; when the run reaches beyond them, gallop over the
                 // sorted keys in memory (doubling steps, then a binary search inside the last step)
                 const int loEdge = max(beg - AGG_HALO + 1, 0), hiEdge = min(beg + RANK_BLOCK + AGG_HALO, n);   // d valid on [loEdge, hiEdge)
-                int s0 = i, e0 = i + 1;
+                s0 = i; e0 = i + 1;
                 while (s0 > loEdge && dAt(s0) == -1) s0--;
                 if (s0 > 0 && s0 == loEdge && dAt(s0) == -1) {
                     int hi = s0, stepw = 64, lo = max(hi - stepw, 0);        // key[hi] == myKey; find the first position holding myKey
@@ -1006,14 +986,46 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
                         e0 = hi;
                     }
                 }
-                int a = s0, b = e0;
-                while (b - a > leafSize) {
-                    const int m = (a + b) >> 1;
-                    if (i < m) b = m; else a = m;
-                }
-                mark = i == a;
+                // The run's parent splits at the lower of the two bits in which the run's key differs from its neighbours'; every
+                // ancestor splits at a bit of its own in [parentBit, 29], so the run's first median node lies at depth <= 30 - parentBit,
+                // and with no more median levels than parentBit the depth rule (below) cannot bite.  Otherwise the depth is counted.
+                const int dS = s0 > 0 ? hbit(keys[s0 - 1] ^ myKey) : 64, dE = e0 < n ? hbit(keys[e0] ^ myKey) : 64;
+                const int parentBit = min(dS, dE);
+                deepRun = parentBit != 64 && agg_run_height(e0 - s0, leafSize) > parentBit;
             }
             if (i > 0 && topBit >= 0 && dAt(i) == topBit) st->rootSplit = (unsigned int)i;
+        }
+        // Depth of a run = number of its ancestors = bits b at which the keys that share the run key's bits above b hold both values
+        // of bit b (that prefix group is split there).  One lane per bit: a lower bound over the sorted keys for the first key of the
+        // group's OTHER half, which exists iff the key found still lies in that half.  Wave-uniform; rare (runs long enough to matter).
+        int depth = 0;
+        for (unsigned long long todo = __ballot(deepRun); todo != 0ull;) {
+            const int leader = (int)__builtin_ctzll(todo);
+            const unsigned int k = (unsigned int)__shfl((int)myKey, leader);
+            const int sLead = __shfl(s0, leader);
+            bool split = false;
+            if (lane < 30) {
+                const unsigned int bit = 1u << lane, group = k & ~(2u * bit - 1u);
+                const unsigned int want = (k & bit) ? group : (group | bit);      // first key value of the other half
+                int lo = 0, hi = n;                                               // lower bound of `want`
+                while (lo < hi) { const int m = (lo + hi) >> 1; if (keys[m] < want) lo = m + 1; else hi = m; }
+                split = lo < n && keys[lo] < want + bit;
+            }
+            const int d = __popcll(__ballot(split));
+            const bool same = deepRun && s0 == sLead;
+            if (same) depth = d;
+            todo &= ~__ballot(same);
+        }
+        if (isRun) {
+            // the leaves of the reference's median splits (emitTreeKernel.cu:282) of the run, WITH its depth rule (:289-292, oldLevel == 0):
+            // a node at depth 29 only has leaf children, a run whose first node would lie at depth 30 is one leaf -- whatever the sizes
+            int a = s0, b = e0, level = depth;
+            while (b - a > leafSize && level < 30) {
+                const int m = (a + b) >> 1;
+                if (i < m) b = m; else a = m;
+                level++;
+            }
+            mark = i == a;
         }
         const unsigned long long mb = __ballot(mark), rb = __ballot(isRun);
         if (lane == 0) {
@@ -1038,7 +1050,6 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
 using namespace ntr;
 
 #include "lbvh_workspace.h"   // PhaseEvents, the per-device workspace, Carver
-#include "lbvh_compact.h"     // hole compaction (rare)
 #ifdef NTR_EXPERIMENTS
 #define NTR_LBVH_EXP_SECTION 6
 #include "lbvh_kernels_exp.h"
@@ -1126,10 +1137,6 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oArrive = takeIf(bottomUp, ((size_t)n + 1) * 4);
     const size_t oExportCount = takeIf(bottomUp, (size_t)aggTiles * 4);
     const size_t oAggMisc = takeIf(bottomUp, 64);           // [0] number of runs of more than leafSize equal keys
-    // hole bitmasks (node indices / storage slots left unused inside leaves the depth rule enlarged), in whole 512-bit chunks
-    const size_t holeNodeWords = ((((size_t)n + 2 + 63) / 64 + HOLE_CHUNK_WORDS - 1) / HOLE_CHUNK_WORDS) * HOLE_CHUNK_WORDS;
-    const size_t holeSlotWords = ((((size_t)n * 4 + 4 + 63) / 64 + HOLE_CHUNK_WORDS - 1) / HOLE_CHUNK_WORDS) * HOLE_CHUNK_WORDS;
-    const size_t oHoleNodeBits = takeIf(bottomUp, holeNodeWords * 8), oHoleSlotBits = takeIf(bottomUp, holeSlotWords * 8);
     const int cntTiles = (n + 1 + RANK_BLOCK - 1) / RANK_BLOCK;    // prefix-count blocks
     const size_t oAggZeroEnd = cv.off;
     const size_t oOsState = cv.take((size_t)osTiles * 256 * 4);
@@ -1280,7 +1287,6 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             a.runs = (int4*)(ws + oRuns); a.runCount = aggMisc; a.st = state; a.useLds = tun.lbvhAggLds;
             a.exports = (AggExport*)(ws + oExports); a.exportCount = (unsigned int*)(ws + oExportCount); a.slotG = (AggSlotG*)(ws + oSlot);
             a.abortFlag = osMisc + 4;
-            a.holeNodeBits = (unsigned long long*)(ws + oHoleNodeBits); a.holeSlotBits = (unsigned long long*)(ws + oHoleSlotBits);
             // leaf starts and their prefix counts first: everything after it writes to final places
             hipLaunchKernelGGL(lbvh_leafmark_kernel, dim3(cntTiles), dim3(MARK_THREADS), 0, s, n, leafSize, keys, (unsigned long long*)(ws + oLeafBits),
                                (unsigned long long*)(ws + oRunBits), (unsigned int*)(ws + oTileCount), (unsigned int*)(ws + oSubBase), state);
@@ -1357,6 +1363,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     result->emitMs = pe.ms(3, 4);
     result->refitMs = pe.ms(4, 6);
     result->seconds = pe.ms(0, 6) * 1e-3f;
+    if (h.overflow & 4u) return set_error(NTR_ERR_HIP, "ntr_lbvh_build: the leaf marks disagree with the depth of a run of equal Morton codes (internal error)");
     if (h.overflow) return set_error(NTR_ERR_OVERFLOW, "ntr_lbvh_build: node buffer overflow");
     if (sortErr) return set_error(NTR_ERR_HIP, "ntr_lbvh_build: a chained scan timed out waiting for a predecessor tile (status %u)", sortErr);
     int numLevels = 0;
@@ -1373,21 +1380,9 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     // cannot be expressed (the buffers were sized for it, so nothing was written out of bounds; the references are what overflowed)
     if ((unsigned long long)numNodes * 64ull > 0x76543200ull)
         return set_error(NTR_ERR_OVERFLOW, "ntr_lbvh_build: %u nodes exceed what BVHLayout_Compact's 32-bit child offsets address", numNodes);
-    // Bottom-up path: where the depth rule (level bit 0) made a leaf of more than leafSize equal keys, the node indices and terminator
-    // slots the leaf marks had set aside inside it stay unused (zero-filled).  They are squeezed out here (rare; NTR_LBVH_COMPACT=0 keeps
-    // them: the buffers' extents then include them, the counts do not), so that the extents equal the reference's exact sizes.
-    unsigned int leafs = (unsigned int)(h.leafPtr & 0xFFFFFFFFull);
-    unsigned int holesLeft = h.holes;
-    if (bottomUp && h.holes > 0 && tun.lbvhCompact != 0) {
-        const int rc = lbvh_compact_holes(s, n, numNodes, leafs, h.holes, (const unsigned long long*)(ws + oHoleNodeBits), holeNodeWords,
-                                          (const unsigned long long*)(ws + oHoleSlotBits), holeSlotWords, d_nodes, d_triWoop, d_triIndex);
-        if (rc != NTR_OK) return rc;
-        numNodes -= h.holes;
-        leafs -= h.holes;
-        holesLeft = 0;
-    }
-    result->numNodes = (int32_t)(numNodes - holesLeft);
-    result->numLeaves = (int32_t)(leafs - holesLeft);
+    const unsigned int leafs = (unsigned int)(h.leafPtr & 0xFFFFFFFFull);
+    result->numNodes = (int32_t)numNodes;
+    result->numLeaves = (int32_t)leafs;
     result->numLevels = numLevels;
     result->nodesBytes = (int64_t)numNodes * 64;                // HLBVHBuilder.cpp:382-386
     result->triWoopBytes = ((int64_t)n * 3 + leafs) * 16;

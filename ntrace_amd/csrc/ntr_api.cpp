@@ -179,7 +179,6 @@ static void tunables_load_locked()
     t.lbvhEmit = env_int("NTR_LBVH_EMIT", 0);          // 0: bottom-up emit with scanned indices; 1: cell-table top + subtree workgroups
     t.lbvhAggLds = env_int("NTR_LBVH_AGG_LDS", 1);     // bottom-up emit: meetings inside a tile through LDS
     t.lbvhAggStaged = env_int("NTR_LBVH_AGG_STAGED", -1);  // bottom-up emit in two launches: -1 = from 2^20 triangles, 0 / 1 = never / always
-    t.lbvhCompact = env_int("NTR_LBVH_COMPACT", 1);    // squeeze out the unused node / terminator slots of leaves the depth rule enlarged (extents = the reference's exact sizes)
     if (t.chunk < 1) t.chunk = 1;
     g_tun = t;
     g_tunLoaded = true;

@@ -16,7 +16,7 @@ struct Tunables {
 #endif
     int autoHint, autoHintMinRays, predict, predictPersistent, predictDepth, predictMinRays, predictMinNodes;
     int schedRefreshEvery, schedClasses;
-    int lbvhLevelSync, lbvhSplit, lbvhSubThreads, lbvhLegacyTop, lbvhLegacySort, lbvhEmit, lbvhAggLds, lbvhAggStaged, lbvhCompact;
+    int lbvhLevelSync, lbvhSplit, lbvhSubThreads, lbvhLegacyTop, lbvhLegacySort, lbvhEmit, lbvhAggLds, lbvhAggStaged;
 };
 Tunables tunables();
 

@@ -12,6 +12,8 @@
 #include <vector>
 
 #include "DistGroup.hpp"
+#include <thread>
+#include <string>
 #include "HLBVHBuilder.hpp"
 #include "Random.hpp"
 #include "Renderer.hpp"
@@ -464,6 +466,61 @@ static void gpuTests()
         for (int i = 0; i < W * H; i++) written += tilesAO[(size_t)i] != 0u;
         CHECK(written == W * H);   // the ranks' AO tiles cover the image exactly once
         CHECK(std::memcmp(assembled.data(), primPixels.getPtr(), (size_t)W * H * 4) == 0);
+    }
+
+    // Thread-per-GPU mode on ONE device: N host threads, each with its own sharded Renderer tracing its range of the
+    // same frame CONCURRENTLY through the one library (per-thread error state, per-device scheduling state under its own mutex), the
+    // gather stubbed by a device copy of every rank's slice of hit records into the assembled frame -- which must equal the unsharded
+    // frame bit for bit.  (The RCCL transport needs one GPU per rank and stays unexecuted at N > 1 on this box.)
+    {
+        const int N = 3;
+        Renderer whole("SAHBVH");
+        whole.setScene(&scene);
+        Renderer::Params p;
+        p.kernelName = "fermi_speculative_while_while";
+        p.rayType = Renderer::RayType_AO;
+        p.numSamples = 8;
+        p.aoRadius = 2.0f;
+        whole.setParams(p);
+        whole.beginFrame(cam);
+        const int totalAO = whole.getTotalNumRays();
+        while (whole.nextBatch()) whole.traceBatch();
+        Buffer assembled;
+        assembled.resizeDiscard((S64)W * H * 16);
+        assembled.clear(0xEE);
+        void* d_assembled = (void*)assembled.getMutableCudaPtr();
+        std::vector<int> rangeLo(N), rangeHi(N), aoRays(N), ok(N, 0);
+        std::vector<std::string> errors(N);
+        std::vector<std::thread> threads;
+        for (int r = 0; r < N; r++)
+            threads.emplace_back([&, r]() {
+                try {
+                    Renderer part("SAHBVH");
+                    part.setScene(&scene);
+                    part.setShard(r, N);
+                    part.setParams(p);
+                    for (int frame = 0; frame < 3; frame++) {   // re-traced frames: the automatic scheduling feedback of every thread's batches is live
+                        part.beginFrame(cam);
+                        while (part.nextBatch()) part.traceBatch();
+                    }
+                    rangeLo[r] = part.getShardLo(); rangeHi[r] = part.getShardHi(); aoRays[r] = part.getTotalNumRays();
+                    // the gather, stubbed: this rank's slice of records -> its place in the assembled frame (device to device)
+                    const char* own = (const char*)part.getPrimaryRays().getResultBuffer().getCudaPtr() + (S64)rangeLo[r] * 16;
+                    if (ntr_memcpy_d2d((char*)d_assembled + (S64)rangeLo[r] * 16, own, (size_t)(rangeHi[r] - rangeLo[r]) * 16, NULL) != NTR_OK ||
+                        ntr_stream_synchronize(NULL) != NTR_OK) throw FatalError{ntr_last_error()};
+                    ok[r] = 1;
+                } catch (const FatalError& e) { errors[r] = e.message; }
+            });
+        for (auto& t : threads) t.join();
+        int covered = 0, sumAO = 0;
+        for (int r = 0; r < N; r++) {
+            if (!ok[r]) std::printf("thread %d: %s\n", r, errors[r].c_str());
+            CHECK(ok[r] == 1 && rangeLo[r] == covered && rangeLo[r] % 64 == 0);
+            covered = rangeHi[r];
+            sumAO += aoRays[r];
+        }
+        CHECK(covered == W * H && sumAO == totalAO);
+        CHECK(std::memcmp(assembled.getPtr(), whole.getPrimaryRays().getResultBuffer().getPtr(), (size_t)W * H * 16) == 0);
     }
 
     // layout mismatch is fatal (CudaBVHTracer.cpp:99-100)

@@ -86,19 +86,13 @@ def gpu_lbvh(tri, pos, leaf_size=8, epsilon=0.001):
     return nodes, woop, idx, res, (d_nodes, d_woop, d_idx)
 
 
-def check_against_oracle(tri, pos, leaf_size=8, epsilon=0.001, allow_holes=False):
-    """allow_holes: with NTR_LBVH_COMPACT=0 the bottom-up path leaves the slots it had set aside inside leaves the depth rule enlarged; by
-    default they are squeezed out and every extent equals the oracle's (the reference's exact sizes, HLBVHBuilder.cpp:382-386)."""
+def check_against_oracle(tri, pos, leaf_size=8, epsilon=0.001):
+    """Counts, exact extents (the reference's sizes, HLBVHBuilder.cpp:382-386: the leaf marks follow the depth rule too, so no slot is
+    ever set aside and left unused) and the canonical tree."""
     nodes, woop, idx, res, keep = gpu_lbvh(tri, pos, leaf_size, epsilon)
     ref = oracle.lbvh_build(tri, pos, leaf_size, epsilon)
     assert res.numNodes == ref["num_inner"] and res.numLeaves == ref["num_leaves"] and res.numLevels == ref["num_levels"]
-    # extents: equal to the oracle's, except where the depth rule made a leaf of more than leaf_size equal codes -- the bottom-up path
-    # leaves the node indices / terminator slots it had set aside inside such a leaf unused (one of each per hole, zero-filled)
-    holes = (nodes.nbytes - ref["nodes"].nbytes) // 64
-    assert holes >= 0 and nodes.nbytes == ref["nodes"].nbytes + 64 * holes
-    assert woop.nbytes == ref["woop"].nbytes + 16 * holes and idx.nbytes == ref["tri_index"].nbytes + 4 * holes
-    if not allow_holes:
-        assert holes == 0
+    assert nodes.nbytes == ref["nodes"].nbytes and woop.nbytes == ref["woop"].nbytes and idx.nbytes == ref["tri_index"].nbytes
     assert oracle.bvh_canonical_hash(nodes, woop, idx) == oracle.bvh_canonical_hash(ref["nodes"], ref["woop"], ref["tri_index"])
     return nodes, woop, idx, res, ref, keep
 
@@ -162,13 +156,6 @@ def test_lbvh_depth_limit_forces_oversized_leaves():
     assert res.numLevels == 30
     # the bvhcache file written from this tree has the reference's size: S32 layout + 3 x (S64 size + bytes), exact extents
     assert 4 + 3 * 8 + nodes.nbytes + woop.nbytes + idx.nbytes == 4 + 3 * 8 + ref["nodes"].nbytes + ref["woop"].nbytes + ref["tri_index"].nbytes
-    # the uncompacted form (NTR_LBVH_COMPACT=0): one unused node index and one unused terminator slot per hole, same canonical tree
-    nt.set_tunables(NTR_LBVH_COMPACT=0)
-    try:
-        n2, w2, i2, res2, _, _ = check_against_oracle(tri, pos, leaf_size=2, allow_holes=True)
-        assert n2.nbytes >= nodes.nbytes and (n2.nbytes - nodes.nbytes) // 64 == (w2.nbytes - woop.nbytes) // 16
-    finally:
-        nt.set_tunables(NTR_LBVH_COMPACT=None)
     w = woop.view(np.uint32).reshape(-1, 4)
     sizes, a, cur = [], 0, 0
     while a < w.shape[0]:
@@ -177,6 +164,47 @@ def test_lbvh_depth_limit_forces_oversized_leaves():
         else:
             cur += 1; a += 3
     assert max(sizes) >= 10
+
+
+def _cell_triangles(cells):
+    ctr = (np.array(cells, dtype=np.float64) + 0.5)
+    d = 0.05
+    p = np.stack([ctr + [-d, -d, 0], ctr + [d, -d, 0], ctr + [0, d, 0]], axis=1).reshape(-1, 3)
+    corner = np.array([[0, 0, 0], [0.01, 0, 0], [0, 0.01, 0], [1024, 1024, 1024], [1023.99, 1024, 1024], [1024, 1023.99, 1024]])
+    pos = np.concatenate([p, corner]).astype(np.float32)
+    nt_ = len(cells)
+    tri = np.concatenate([np.arange(nt_ * 3).reshape(-1, 3), [[nt_ * 3, nt_ * 3 + 1, nt_ * 3 + 2], [nt_ * 3 + 3, nt_ * 3 + 4, nt_ * 3 + 5]]]).astype(np.int32)
+    return tri, pos
+
+
+@pytest.mark.parametrize("depth,dups,leaf", [(30, 10, 2), (30, 700, 8), (29, 37, 2), (29, 1500, 8), (28, 200, 2), (27, 70, 4), (26, 3000, 8), (12, 5000, 2)])
+def test_lbvh_depth_rule_at_every_depth_with_exact_extents(depth, dups, leaf):
+    """The leaf marks follow the depth rule themselves (round 5: no relocation pass).  `dups` triangles in Morton cell 0 below a chain of
+    `depth` ancestors (one code 2^b per ancestor, the highest bits): the run's median subtree may use the levels depth ... 29 only
+    (emitTreeKernel.cu:289-292) -- a run at depth 30 is ONE leaf, at depth 29 two leaves, and so on, whatever leafSize says.  Runs
+    longer than a wave, than a 512-key tile and than a 1024-key mark block; counts, exact extents and the canonical tree equal the
+    oracle's on every build path."""
+    cells = [(0, 0, 0)] * dups
+    for k in range(30 - depth, 30):
+        c = [0, 0, 0]
+        c[k % 3] = 1 << (k // 3)
+        cells.append(tuple(c))
+    # a second, shallower run elsewhere (its subtree is not cut short), and a few loose triangles
+    far = [0, 0, 0]
+    far[29 % 3] = (1 << (29 // 3)) | 3
+    cells += [tuple(far)] * (3 * leaf + 1)
+    tri, pos = _cell_triangles(cells)
+    nodes, woop, idx, res, ref, _ = check_against_oracle(tri, pos, leaf_size=leaf)
+    w = woop.view(np.uint32).reshape(-1, 4)
+    sizes, a, cur = [], 0, 0
+    while a < w.shape[0]:
+        if w[a, 0] == 0x80000000:
+            sizes.append(cur); cur = 0; a += 1
+        else:
+            cur += 1; a += 3
+    levels_left = 30 - depth
+    want_big = dups > leaf * (1 << levels_left)          # the run cannot be cut down to leafSize in the levels it has left
+    assert (max(sizes) > leaf) == want_big
 
 
 def test_trace_on_gpu_built_lbvh_matches_oracle_trace():
