@@ -270,7 +270,8 @@ struct AggCtx {
     float4* outWoop;             // output: Woop rows + terminators
     int* outIdx;                 // output: triangle indices, parallel to outWoop
     unsigned int* arrive;        // [n + 1] meeting counters (memory protocol), zeroed
-    int* parentPos;              // [nodes] index of a node's parent (the root is node 0)
+    const unsigned char* runDepth;   // [n] depth (number of ancestors) of the run of equal keys that STARTS at a position, written by
+                                     // lbvh_leafmark_kernel for the runs long enough for the depth rule to matter (others: not written, not read)
     int4* runs;                  // (parent node or -1, side, start, end) of the runs of more than leafSize equal keys
     unsigned int* runCount;
     LbvhState* st;
@@ -423,7 +424,6 @@ __device__ __forceinline__ bool agg_form_parent(const AggCtx& c, int rootSplit, 
             link[k] = ~(int)(3u * (unsigned int)cs[k] + clb[k]);
         } else if (ck[k] == 1) {
             link[k] = cr[k] * 64;
-            c.parentPos[cr[k]] = idx;
         } else {
             link[k] = AGG_REF_RUN;
             const unsigned int g = atomicAdd(c.runCount, 1u);
@@ -784,14 +784,11 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
         const int parentBit = q.y >> 1;                 // split bit of the run's parent: the parent has at most 29 - parentBit ancestors
         q.y &= 1;
         // The depth rule can only bite when the run's subtree could reach level 30: its root lies at depth <= 30 - parentBit, so with
-        // no more median levels than parentBit it cannot, and the walk up the parent indices (a chain of dependent loads) is skipped;
-        // the tree's level count does not need it either -- a run cluster carries its height to the root.
+        // no more median levels than parentBit it cannot, and the depth is not needed (the tree's level count does not need it either --
+        // a run cluster carries its height to the root).  Otherwise lbvh_leafmark_kernel has counted it (the same test, the same run)
+        // and left it at the run's first position: one load instead of a walk up to thirty parents.
         const bool walk = q.x >= 0 && agg_run_height(q.w - q.z, c.leafSize) > parentBit;
-        int depth = 0;
-        if (walk) {
-            depth = 1;
-            for (int p = q.x; p != 0; p = c.parentPos[p]) depth++;
-        }
+        const int depth = walk ? (int)c.runDepth[q.z] : 0;
         int* parentLink = q.x >= 0 ? c.nodes + (size_t)q.x * 16 + 12 + q.y : nullptr;
         if (depth >= 30) {                              // the parent's level bit is 0: a leaf whatever its size
             if (lane == 0) *parentLink = ~agg_leaf_storage(c, q.z);
@@ -927,7 +924,7 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_markscan_kernel(int n, int 
 __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int leafSize, const unsigned int* __restrict__ keys,
                                                                      unsigned long long* __restrict__ sBits, unsigned long long* __restrict__ rBits,
                                                                      unsigned int* __restrict__ blockCount, unsigned int* __restrict__ subBase,
-                                                                     LbvhState* st)
+                                                                     unsigned char* __restrict__ runDepth, LbvhState* st)
 {
     constexpr int SPAN = RANK_BLOCK + 2 * AGG_HALO;
     __shared__ unsigned int sKeys[SPAN];
@@ -1014,6 +1011,7 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
             const int d = __popcll(__ballot(split));
             const bool same = deepRun && s0 == sLead;
             if (same) depth = d;
+            if (same && i == s0) runDepth[s0] = (unsigned char)d;   // for lbvh_runs_kernel (a depth is at most 30)
             todo &= ~__ballot(same);
         }
         if (isRun) {
@@ -1150,7 +1148,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oSlot = takeIf(bottomUp, ((size_t)n + 1) * 96);
     const size_t oExports = takeIf(bottomUp, (size_t)aggTiles * AGG_EXPORT_CAP * sizeof(AggExport));
     const size_t oTriVerts = takeIf(bottomUp, (size_t)n * 36);
-    const size_t oParentPos = takeIf(bottomUp, ((size_t)n + 1) * 4);
+    const size_t oRunDepth = takeIf(bottomUp, (size_t)n + 1);
     const size_t oRuns = takeIf(bottomUp, ((size_t)n / 2 + 2) * 16);
     const size_t oLeafBits = takeIf(bottomUp, (size_t)cntTiles * (RANK_BLOCK / 8)), oRunBits = takeIf(bottomUp, (size_t)cntTiles * (RANK_BLOCK / 8));
     const size_t oTileCount = takeIf(bottomUp, (size_t)cntTiles * 4), oTileBase = takeIf(bottomUp, (size_t)cntTiles * 4);
@@ -1283,13 +1281,13 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             a.numBitWords = cntTiles * (RANK_BLOCK / 64); a.blockBase = (const unsigned int*)(ws + oTileBase);
             a.subBase = (const unsigned int*)(ws + oSubBase);
             a.nodes = (int*)d_nodes; a.outWoop = (float4*)d_triWoop; a.outIdx = d_triIndex;
-            a.arrive = (unsigned int*)(ws + oArrive); a.parentPos = (int*)(ws + oParentPos);
+            a.arrive = (unsigned int*)(ws + oArrive); a.runDepth = (const unsigned char*)(ws + oRunDepth);
             a.runs = (int4*)(ws + oRuns); a.runCount = aggMisc; a.st = state; a.useLds = tun.lbvhAggLds;
             a.exports = (AggExport*)(ws + oExports); a.exportCount = (unsigned int*)(ws + oExportCount); a.slotG = (AggSlotG*)(ws + oSlot);
             a.abortFlag = osMisc + 4;
             // leaf starts and their prefix counts first: everything after it writes to final places
             hipLaunchKernelGGL(lbvh_leafmark_kernel, dim3(cntTiles), dim3(MARK_THREADS), 0, s, n, leafSize, keys, (unsigned long long*)(ws + oLeafBits),
-                               (unsigned long long*)(ws + oRunBits), (unsigned int*)(ws + oTileCount), (unsigned int*)(ws + oSubBase), state);
+                               (unsigned long long*)(ws + oRunBits), (unsigned int*)(ws + oTileCount), (unsigned int*)(ws + oSubBase), (unsigned char*)(ws + oRunDepth), state);
             hipLaunchKernelGGL(lbvh_markscan_kernel, dim3(1), dim3(MARK_THREADS), 0, s, n, cntTiles, (const unsigned int*)(ws + oTileCount),
                                (unsigned int*)(ws + oTileBase), state);
             pe.mark(4);
