@@ -9,10 +9,10 @@ surface (the likelier entered by an arbitrary ray).  Layouts measured on the sam
   pc_pairs   aligned (parent, preferred child) pairs as above; a head without an inner child leaves the other half of its line empty
   dfs        depth-first preorder (node, then its first inner child's subtree): the cheap numbering that puts a node next to a child
              about half of the time, aligned or not
-With `sah` appended to a scene name (e.g. courtyard:sah) the tree is the host SAH build instead of the device LBVH (item 4c: what the
+With `@sah` appended to a scene name (e.g. courtyard@sah) the tree is the host SAH build instead of the device LBVH (item 4c: what the
 longest chain of dependent steps is on a better tree).
 
-usage: parent_child_line_study.py <scene>[:sah][,<scene>...] [batches=incoherent,primary,diffuse]"""
+usage: parent_child_line_study.py <scene>[@sah][,<scene>...] [batches=incoherent,primary,diffuse]"""
 import json
 import os
 import sys
@@ -121,7 +121,7 @@ def relocate(nodes_u8, mode):
 def main():
     want = sys.argv[2].split(",") if len(sys.argv) > 2 else ["incoherent", "primary", "diffuse"]
     for spec in sys.argv[1].split(","):
-        scene, _, builder = spec.partition(":")
+        scene, _, builder = spec.partition("@")
         tri, pos, cam = scene_of(scene)
         t0 = time.time()
         if builder == "sah" or scene in ("atrium", "conference"):
