@@ -410,7 +410,10 @@ NTR_API int ntr_dist_broadcast_bvh(NtrDist* dist, void* d_nodes, int64_t nodesBy
  * d_fullRecords + lo_r on the root (numPrimary records; ignored elsewhere).  _pixels: rank r's pixels -- the tiles of
  * its range inside its own W*H framebuffer d_ownPixels, as ntr_reconstruct wrote them -- land in the root's framebuffer
  * d_fullPixels; d_slotToPixel is the PixelTable's index-to-pixel map (ntr_pixel_table), d_scratch numPrimary words on
- * every rank.  Asynchronous on `stream`. */
+ * every rank.  Asynchronous on `stream`.  As with any collective, every rank of the group makes the matching call: a rank that
+ * returns an argument error has posted nothing and its peers wait for it (argument errors must be uniform across ranks; the ranges
+ * are, by construction).  Executed so far at world size 1 only (one-GPU test boxes); the N-rank flow around it runs at N = 2-3
+ * with host-staged collectives (bench.py --dist-backend gloo --one-device). */
 NTR_API int ntr_dist_gather_records(NtrDist* dist, const NtrRayResult* d_ownRecords, int32_t numPrimary, int32_t align,
                                     NtrRayResult* d_fullRecords, int32_t root, void* stream);
 NTR_API int ntr_dist_gather_pixels(NtrDist* dist, const uint32_t* d_ownPixels, const int32_t* d_slotToPixel, int32_t numPrimary,

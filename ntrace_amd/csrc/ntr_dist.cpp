@@ -152,7 +152,10 @@ extern "C" int ntr_dist_init_all(int32_t numDevices, const int32_t* devices, Ntr
     ncclComm_t comms[64];
     int devs[64];
     for (int i = 0; i < numDevices; i++) devs[i] = devices ? devices[i] : i;
-    NTR_RCCL(g_rccl.commInitAll(comms, numDevices, devs));   // one process: a communicator per device, used by one host thread each
+    {   // one process: a communicator per device, used by one host thread each (ncclCommInitAll visits the devices: put the caller's back either way)
+        const ncclResult_t ie = g_rccl.commInitAll(comms, numDevices, devs);
+        if (ie != ncclSuccess) { (void)hipSetDevice(prev); return rccl_fail(ie, "ncclCommInitAll"); }
+    }
     for (int i = 0; i < numDevices; i++) {
         NtrDist* d = new (std::nothrow) NtrDist();
         if (!d) {   // give everything back: the groups made so far (with their communicators) and the communicators not yet wrapped
@@ -203,7 +206,10 @@ extern "C" int ntr_dist_broadcast_bvh(NtrDist* d, void* d_nodes, int64_t nodesBy
     return rc;
 }
 
-// every rank's slice [lo_r, hi_r) x elemBytes of a frame-sized array -> the root's full array, at the slices' own offsets
+// every rank's slice [lo_r, hi_r) x elemBytes of a frame-sized array -> the root's full array, at the slices' own offsets.
+// Like every collective: ALL ranks of the group must make the matching call.  A rank that returns an argument error here (a null slice,
+// a null destination on the root) has posted nothing, and its peers wait in ncclSend / ncclRecv for it: argument errors are programming
+// errors that must be uniform across the ranks (the sizes and offsets are, by construction: ntr_frame_shard of the same numPrimary).
 static int gather_slices(NtrDist* d, const void* d_own, int32_t numPrimary, int32_t align, int32_t elemBytes, void* d_full, int32_t root, void* stream,
                          const char* who)
 {
