@@ -248,8 +248,9 @@ class Frame:
         i32 = torch.int32
         n = w * h
         self.n_primary = n
-        d_tab = torch.zeros(n, dtype=i32, device=dev)
+        d_tab = self.d_tab = torch.zeros(n, dtype=i32, device=dev)
         nt.pixel_table(w, h, d_tab.data_ptr(), 0, stream)
+        self.w, self.h, self.scenes, self.view, self.args, self.tri_normals = w, h, scenes, view, args, tri_normals
         self.d_rays = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
         self.d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
         self.d_i2s = torch.zeros(n, dtype=i32, device=dev)
@@ -276,7 +277,7 @@ class Frame:
             live = nt.count_hits(self.d_res.data_ptr() + first * 16, cnt, stream) * ns
             self.keep.append((b_rays, b_res, b_a))
             self.batches.append(dict(name="ao", n=cnt * ns, any_hit=True, rays=b_rays.data_ptr(), res=b_res.data_ptr(), live=live,
-                                     res_t=b_res, rays_t=b_rays, first=first, count=cnt))
+                                     res_t=b_res, rays_t=b_rays, slots_t=b_a, first=first, count=cnt))
         # Dispatch hints of the secondary batches, made beside ray generation (untimed like it): a block's cost class from the depth in the
         # tree of the leaves its pixels' primary rays hit (ntr_bvh_leaf_depths once per BVH, ntr_secondary_block_costs per batch).
         self.nt, self.stream, self.ns = nt, stream, ns
@@ -290,6 +291,20 @@ class Frame:
                 b["hint"] = nt.SchedHint()
             self.predict_hints()
         torch.cuda.synchronize()
+
+    def regenerate_primary(self, cam):
+        """A new camera position: the frame's primary rays again, into the SAME buffers (what a renderer with a moving camera does)."""
+        self.nt.raygen_primary(self.d_rays.data_ptr(), self.d_i2s.data_ptr(), self.d_s2i.data_ptr(), self.d_tab.data_ptr(), cam["eye"],
+                               self.scenes.nscreen_to_world(cam, self.w, self.h), self.w, self.h, cam["far"], 0, self.stream)
+
+    def regenerate_ao(self):
+        """The AO batches again from the primary hit records as they are now, into the same buffers; the batches' live counts follow."""
+        for b in self.batches[1:]:
+            a = b["slots_t"]
+            self.nt.raygen_ao(b["rays"], a.data_ptr(), a.data_ptr(), self.d_rays.data_ptr(), self.d_res.data_ptr(), self.tri_normals.data_ptr(),
+                              b["first"], b["count"], self.ns, self.args.ao_radius, 0xFFF2D5E4, self.stream)
+            b["live"] = self.nt.count_hits(self.d_res.data_ptr() + b["first"] * 16, b["count"], self.stream) * self.ns
+        self.batches[0]["live"] = self.plan.hi - self.plan.lo
 
     def predict_hints(self):
         """(Re)starts every secondary batch's hint from its predicted block costs -- what a renderer does when it generates the batch."""
@@ -565,7 +580,7 @@ def main():
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
         try:
-            extras = run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, HBM_PEAK_GBS)
+            extras = run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, HBM_PEAK_GBS, cam)
         except Exception as e:  # extras never invalidate the headline
             extras = {"error": repr(e)}
 
@@ -767,7 +782,7 @@ def overlapped_frame(args, nt, torch, view, frame, dev, stream, try_graph=True):
     return ov / steps, note, steps
 
 
-def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, hbm_peak):
+def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, hbm_peak, frame_cam):
     """Measured outside the timed region, one GPU only: the frame overlapped on streams and replayed as a HIP graph, the
     opt-in scheduling hints, the device-to-device copy ceiling, the on-device LBVH build of the bench scene, the ray sort
     and the HBM-resident roofline point (10 M-triangle BVH)."""
@@ -832,6 +847,53 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         "primary_ms": float(hms[:, 0].mean()), "steps": hsteps}
     for hnt in hints:
         hnt.close()
+
+    # (2b) a moving camera: every step the eye moves on (0.25 units of a 3 600-unit hall: ~1 pixel at the far wall), the primary rays are
+    # generated again into the same buffers and the AO batches again from the new hits -- every batch holds NEW rays, but the library's
+    # automatic feedback (keyed by buffer) dispatches it in the order the PREVIOUS frame's launch of that buffer measured.  What a renderer
+    # in motion gets: between `value` (the same rays again) and cold_dispatch_order (nothing known).  Ray generation untimed, as everywhere.
+    try:
+        msteps = max(3, min(args.steps, 10))
+        cam0 = dict(frame_cam)
+        mev = [[(E(enable_timing=True), E(enable_timing=True)) for _ in batches] for _ in range(msteps)]
+        mrays = 0
+        for s_ in range(-2, msteps):      # two untimed frames first: the hints of the moving sequence form
+            camm = dict(cam0)
+            eye = np.array(camm["eye"], dtype=np.float64)
+            eye[2] += 0.25 * (s_ + 3)
+            camm["eye"] = tuple(eye)
+            frame.regenerate_primary(camm)
+            b0_ = batches[0]
+            if s_ >= 0:
+                mev[s_][0][0].record()
+            view.trace(args.kernel, b0_["n"], False, b0_["rays"], b0_["res"], stream, False)
+            if s_ >= 0:
+                mev[s_][0][1].record()
+            frame.regenerate_ao()
+            for bi, b in enumerate(batches[1:], start=1):
+                if s_ >= 0:
+                    mev[s_][bi][0].record()
+                view.trace(args.kernel, b["n"], True, b["rays"], b["res"], stream, False, hint=b.get("hint"))
+                if s_ >= 0:
+                    mev[s_][bi][1].record()
+            if s_ >= 0:
+                mrays += frame.rays_per_step
+        torch.cuda.synchronize()
+        mms = np.array([[e0.elapsed_time(e1) for (e0, e1) in st_] for st_ in mev])
+        extras["moving_camera"] = {
+            "what": "the eye moves 0.25 units per step; primary rays and AO batches regenerated into the same buffers every step (untimed), traced in the "
+                    "order the previous frame's launches measured (the library's automatic feedback / the batch's hint): new rays every launch",
+            "mrays": mrays / (float(mms.sum()) * 1e-3) / 1e6, "primary_ms": float(mms[:, 0].mean()),
+            "ao_total_ms": float(mms[:, 1:].sum(axis=1).mean()) if len(batches) > 1 else 0.0, "steps": msteps}
+        # back to the bench camera (the extras below and the cpu_baseline leg compare against these buffers)
+        frame.regenerate_primary(cam0)
+        view.trace(args.kernel, batches[0]["n"], False, batches[0]["rays"], batches[0]["res"], stream, False)
+        frame.regenerate_ao()
+        for b in batches[1:]:
+            view.trace(args.kernel, b["n"], True, b["rays"], b["res"], stream, False)
+        torch.cuda.synchronize()
+    except Exception as e:
+        extras["moving_camera"] = {"error": repr(e)}
 
     # (3) practical HBM ceiling: device-to-device copy of a buffer larger than the Infinity Cache
     cp_src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)

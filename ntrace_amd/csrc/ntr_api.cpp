@@ -149,6 +149,7 @@ static void tunables_load_locked()
     t.closestWaves = env_int("NTR_TRACE_CLOSEST_WAVES", 1);      // likewise for closest-hit launches: primary +2.1 % with 1
     t.anyHitWaves = env_int("NTR_TRACE_ANYHIT_WAVES", 1);        // waves per workgroup of plain any-hit launches of the per-ray kernel (1, 2, 4): AO +1.7 % with 1
     t.flatFetch = env_int("NTR_TRACE_FLAT_FETCH", 1);             // unified-step loop: one group of global loads per iteration (0 = two masked groups of range-checked buffer loads)
+    t.uniformPrologue = env_int("NTR_TRACE_UNIFORM_PROLOGUE", 1);  // per-ray kernels: scalar node fetches while the lanes of a fresh wave all hold the same inner node
     t.minipool = env_int("NTR_TRACE_MINIPOOL", -1);              // closest-hit per-ray launches: rays owned by a wave / 64.  -1: decided per batch on the device (1, or minipoolWide when the prediction finds the batch incoherent); 0: the plain per-ray kernel; 1 ... 16: forced
     t.minipoolWide = env_int("NTR_TRACE_MINIPOOL_WIDE", -1);     // K of an incoherent batch: 2 / 4, or -1 = by tree size (4 from 32 MB of nodes up)
     t.minipoolThreshold = env_int("NTR_TRACE_MINIPOOL_THRESHOLD", 48);   // refill a wave's finished lanes when fewer than this many are live
@@ -784,6 +785,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.fetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (dynamicFetch ? (unified ? 48 : 24) : 0);
     p.bvhFlags = bvhFlags;
     p.flatFetch = (tun.flatFetch != 0 && nodesBytes >= 64 && triWoopBytes >= 64) ? 1 : 0;
+    p.uniformPrologue = tun.uniformPrologue != 0 ? 1 : 0;
     p.leafSwitchBelow = tun.leafSwitchBelow >= 0 ? tun.leafSwitchBelow : (anyHit ? 24 : 32);
     p.octant = tun.octant;
     p.stats = ds->stats;

@@ -454,6 +454,7 @@ struct UnifiedBufs {
     const char* nodes; const char* woop;
     unsigned int nodesBytes, woopBytes;
     u32x4 rNodes, rWoop;
+    bool uniformPrologue;   // per-ray kernels: scalar fetches while the wave's lanes all hold the same inner node (TraceParams::uniformPrologue)
 };
 __device__ __forceinline__ UnifiedBufs unified_bufs(const TraceParams& p)
 {
@@ -461,6 +462,7 @@ __device__ __forceinline__ UnifiedBufs unified_bufs(const TraceParams& p)
     u.nodes = (const char*)p.nodes; u.woop = (const char*)p.woop;
     u.nodesBytes = p.nodesBytes; u.woopBytes = p.woopBytes;
     u.rNodes = rsrc_words(p.nodes, p.nodesBytes); u.rWoop = rsrc_words(p.woop, p.woopBytes);
+    u.uniformPrologue = p.uniformPrologue != 0;
     return u;
 }
 
@@ -498,6 +500,22 @@ __device__ __forceinline__ void unified_fetch(const UnifiedBufs& ub, int node, f
 
 // unified_advance: the lane's ray takes the step its 64 bytes allow -- one inner node (trace<BVHLayout_Compact>, CudaBVH.cpp:721-775) or one
 // triangle (intersectTriangles + updateHit, CudaBVH.cpp:1084-1126, 1183-1225).
+// one inner node of trace<BVHLayout_Compact> (CudaBVH.cpp:721-775): both child boxes, nearer child first (ties -> child 0), the other pushed
+template <bool FAST, int OCT, int LD = LDS_DEPTH>
+__device__ __forceinline__ void inner_advance(const float4& a, const float4& b, const float4& c, const float4& d, const RayRegs& r, int& node,
+                                              LaneStack& st, int (&spill)[SPILL_DEPTH], unsigned int* status)
+{
+    float mn0, mx0, mn1, mx1;
+    ray_box2<FAST, OCT>(r, a, b, c, mn0, mx0, mn1, mx1);
+    const bool i0 = (mn0 <= mx0) && (mx0 >= r.tmin) && (mn0 <= r.tmax);
+    const bool i1 = (mn1 <= mx1) && (mx1 >= r.tmin) && (mn1 <= r.tmax);
+    const int c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
+    const bool swp = i1 && (!i0 || mn0 > mn1);
+    const int nearC = swp ? c1 : c0, farC = swp ? c0 : c1;
+    if (i0 && i1) stack_push<LD>(st, spill, farC, status);
+    node = (i0 || i1) ? nearC : stack_pop<LD>(st, spill);
+}
+
 template <bool FAST, int OCT, int LD = LDS_DEPTH>
 __device__ __forceinline__ void unified_advance(const float4& a, const float4& b, const float4& c, const float4& d, RayRegs& r, int& node,
                                                 LaneStack& st, int (&spill)[SPILL_DEPTH], bool anyHit, int& hitAddr, float& hitU, float& hitV,
@@ -506,15 +524,7 @@ __device__ __forceinline__ void unified_advance(const float4& a, const float4& b
     const bool inner = (unsigned)node < (unsigned)kSentinel;
     const bool atTri = node < 0;
     if (inner) {
-        float mn0, mx0, mn1, mx1;
-        ray_box2<FAST, OCT>(r, a, b, c, mn0, mx0, mn1, mx1);
-        const bool i0 = (mn0 <= mx0) && (mx0 >= r.tmin) && (mn0 <= r.tmax);
-        const bool i1 = (mn1 <= mx1) && (mx1 >= r.tmin) && (mn1 <= r.tmax);
-        const int c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
-        const bool swp = i1 && (!i0 || mn0 > mn1);
-        const int nearC = swp ? c1 : c0, farC = swp ? c0 : c1;
-        if (i0 && i1) stack_push<LD>(st, spill, farC, status);
-        node = (i0 || i1) ? nearC : stack_pop<LD>(st, spill);
+        inner_advance<FAST, OCT, LD>(a, b, c, d, r, node, st, spill, status);
     } else if (atTri) {
         bool leafDone = __float_as_uint(a.x) == 0x80000000u;   // terminator: an empty leaf
         if (!leafDone) {
@@ -545,11 +555,42 @@ __device__ __forceinline__ void unified_advance(const float4& a, const float4& b
     }
 }
 
-template <bool FAST, bool FLAT, int OCT = 8>
+// Wave-uniform prologue (round 5).  The rays of a fresh wave all start at the root, and the rays of one wave -- an 8 x 8 pixel tile, or
+// the AO samples of eight neighbouring pixels -- take the same way down the top of the tree: while every live lane holds the SAME inner
+// node, that node is fetched ONCE through the scalar cache (s_load, no texture-path cycles: the per-lane fetch costs the TA 64 cycles per
+// wave and iteration whatever the lanes hold) and the planes are scalar operands of the same arithmetic.  The loop ends for good at the
+// first iteration in which the lanes disagree, or hold a leaf: the test (one v_readlane, one compare) is paid only while it succeeds --
+// run on EVERY iteration it cost more than the fetches it saved (round 2, EXPERIMENTS.md).  Per-ray arithmetic, visiting order and
+// stack are untouched: hit records cannot change.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) f32x4* const_f32x4_ptr;   // constant address space: a wave-uniform load becomes s_load
+
+template <bool FAST, int OCT>
+__device__ __forceinline__ void uniform_prologue(const UnifiedBufs& ub, const RayRegs& r, int& node, LaneStack& st, int (&spill)[SPILL_DEPTH],
+                                                 unsigned int* status)
+{
+    if ((reinterpret_cast<unsigned long long>(ub.nodes) & 63ull) != 0ull) return;   // (s_load_dwordx16 wants the record 64-byte aligned)
+    for (;;) {
+        const bool live = node != kSentinel;
+        const unsigned long long liveMask = __ballot(live);
+        if (liveMask == 0ull) return;
+        const int unode = __builtin_amdgcn_readlane(node, (int)__builtin_ctzll(liveMask));   // the first live lane's node: a scalar
+        if (__ballot(live && node != unode) != 0ull) return;                                  // the lanes disagree: the general loop from here on
+        if ((unsigned)unode >= (unsigned)kSentinel || (unsigned)unode > ub.nodesBytes - 64u) return;   // a leaf (or a malformed offset): likewise
+        const const_f32x4_ptr q = (const_f32x4_ptr)(ub.nodes + (unsigned)unode);
+        const f32x4 A = q[0], B = q[1], C = q[2], D = q[3];
+        if (live)
+            inner_advance<FAST, OCT>(make_float4(A.x, A.y, A.z, A.w), make_float4(B.x, B.y, B.z, B.w), make_float4(C.x, C.y, C.z, C.w),
+                                     make_float4(D.x, D.y, D.z, D.w), r, node, st, spill, status);
+    }
+}
+
+template <bool FAST, bool FLAT, int OCT = 8, bool PROLOGUE = false>
 __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs& r, int& node, LaneStack& st,
                                                  int (&spill)[SPILL_DEPTH], bool anyHit, int& hitAddr, float& hitU, float& hitV,
                                                  unsigned int* status, bool poolEmpty, int fetchThreshold)
 {
+    if (PROLOGUE && ub.uniformPrologue) uniform_prologue<FAST, OCT>(ub, r, node, st, spill, status);
 #if defined(NTR_AB) && defined(NTR_AGE_SHIFT)
     unsigned int ageIt = 0;   // A/B experiment: waves that have been stepping for long (they hold the long rays: the launch's critical path) get issue priority
 #endif
@@ -642,7 +683,7 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
     }
     if (UNIFIED) {
         const UnifiedBufs ub = unified_bufs(p);
-#define NTR_UNIFIED_OCT(O) traverse_unified<true, FLATF, O>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0)
+#define NTR_UNIFIED_OCT(O) traverse_unified<true, FLATF, O, true>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0)
         if (oct < 8) {
             switch (oct) {
                 case 0: NTR_UNIFIED_OCT(0); break;
@@ -656,8 +697,8 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
             }
         }
 #undef NTR_UNIFIED_OCT
-        else if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
-        else traverse_unified<false, FLATF>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
+        else if (fastWave) traverse_unified<true, FLATF, 8, true>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
+        else traverse_unified<false, FLATF, 8, true>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
     } else
 #define NTR_TRAVERSE_OCT(O) traverse<true, STATS, false, O>(nodes, woop, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow)
     if (!STATS && oct < 8) {

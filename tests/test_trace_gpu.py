@@ -458,6 +458,97 @@ def test_wave_private_mini_pool_changes_no_record(monkeypatch, tree):
             assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), want, "%s mini-pool, batch contents changed (phase %d), launch %d" % (tree, phase, rep))
 
 
+@pytest.mark.parametrize("tree", ["sah leaves of 1", "device lbvh"])
+def test_uniform_prologue_changes_no_record(monkeypatch, tree):
+    """Wave-uniform prologue of the per-ray kernels (round 5): while every live lane of a fresh wave holds the same inner node the node
+    is fetched once through the scalar cache.  Same arithmetic, same visiting order: records equal the oracle's with the prologue on
+    and off -- camera tiles (uniform for many levels), bundles of rays from ONE origin (uniform until the directions part), waves that
+    are half degenerate (the first live lane is not lane 0), edge-case rays (non-finite values take the generic slab path through the
+    prologue too), any hit and closest hit, and a node buffer that is only 16-byte aligned (the prologue then stands down)."""
+    import torch
+    from gpu_util import DeviceBvh, assert_parity, gpu_trace, up
+    tri, pos, cam = scenes.random_soup(6000, seed=41)
+    if tree == "sah leaves of 1":
+        host = nt.sah_build(tri, pos, 1, 1)
+    else:
+        n = tri.shape[0]
+        capn, capw, capi = nt.lbvh_capacity(n)
+        d_tri, d_pos = up(tri), up(pos)
+        bufs = [torch.zeros(c, dtype=torch.uint8, device="cuda:0") for c in (capn, capw, capi)]
+        mn, mx = oracle.scene_bbox(pos)
+        res = nt.lbvh_build(n, d_tri.data_ptr(), pos.shape[0], d_pos.data_ptr(), mn, mx, 8, 0.001, bufs[0].data_ptr(), capn, bufs[1].data_ptr(), capw,
+                            bufs[2].data_ptr(), capi)
+        torch.cuda.synchronize()
+        host = nt.HostBvh(bufs[0].cpu().numpy()[:res.nodesBytes].copy(), bufs[1].cpu().numpy()[:res.triWoopBytes].copy(),
+                          bufs[2].cpu().numpy()[:res.triIndexBytes].view(np.int32).copy())
+    dbvh = DeviceBvh(host)
+    prim = scenes.primary_rays(cam, 256, 192)[0]
+    bundle = scenes.random_rays(64 * 300, seed=3)
+    for k in ("ox", "oy", "oz"):                       # 300 bundles of 64 rays from one origin each
+        bundle[k] = np.repeat(bundle[k][::64], 64)
+    allrays = np.concatenate([prim, bundle, edge_rays(), scenes.random_rays(5000, seed=4)])
+    allrays["tmax"][0:6400:2] = -1.0                   # every other ray of the first hundred waves degenerate
+    allrays["tmax"][64 * 200:64 * 200 + 37] = -1.0     # a wave whose first 37 lanes are dead
+    # the same BVH behind a node pointer that is 16-byte but not 64-byte aligned
+    raw = torch.zeros(host.nodes.nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    raw[16:16 + host.nodes.nbytes] = up(host.nodes)
+    off_view = nt.BvhView(raw.data_ptr() + 16, host.nodes.nbytes, dbvh.woop.data_ptr(), host.woop.nbytes, dbvh.idx.data_ptr())
+    off_view.validate()
+    try:
+        for any_hit in (False, True):
+            ref, _ = oracle.trace(host.nodes, host.woop, host.tri_index, allrays, any_hit=any_hit, threads=8)
+            for knob in ("1", "0"):
+                monkeypatch.setenv("NTR_TRACE_UNIFORM_PROLOGUE", knob)
+                nt.set_tunables()
+                for n in (allrays.shape[0], 64, 65, 4097):
+                    got, _ = gpu_trace("fermi_speculative_while_while", dbvh, allrays[:n], any_hit)
+                    assert_parity(got, ref[:n], "%s prologue=%s any_hit=%s n=%d" % (tree, knob, any_hit, n))
+                d_rays = up(allrays)
+                d_res = torch.full((allrays.shape[0] * 16,), 0xCD, dtype=torch.uint8, device="cuda:0")
+                off_view.trace("fermi_speculative_while_while", allrays.shape[0], any_hit, d_rays.data_ptr(), d_res.data_ptr())
+                torch.cuda.synchronize()
+                assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), ref, "%s prologue=%s any_hit=%s, node buffer at +16 bytes" % (tree, knob, any_hit))
+    finally:
+        monkeypatch.delenv("NTR_TRACE_UNIFORM_PROLOGUE", raising=False)
+        nt.set_tunables()
+
+
+def test_stream_release_returns_a_streams_scheduling_state(monkeypatch):
+    """ntr_stream_release: a stream's automatic hints and prediction scratch go back before the host destroys the stream; tracing on the
+    stream afterwards simply starts over (first sighting, second sighting, hint), and other streams' entries are untouched."""
+    import torch
+    from gpu_util import DeviceBvh, assert_parity, up
+    tri, pos, cam = scenes.random_soup(4000, seed=43)
+    dbvh = DeviceBvh(nt.sah_build(tri, pos, 1, 1))
+    rays = scenes.primary_rays(cam, 320, 240)[0]
+    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
+    monkeypatch.setenv("NTR_TRACE_AUTO_HINT_MIN_RAYS", "1")
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
+    nt.set_tunables()
+    try:
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        d_rays = up(rays)
+        outs = [torch.zeros(rays.shape[0] * 16, dtype=torch.uint8, device="cuda:0") for _ in streams]
+        torch.cuda.synchronize()
+        for cycle in range(3):
+            for rep in range(4):
+                for s_, o in zip(streams, outs):
+                    o.zero_()
+                    torch.cuda.synchronize()
+                    dbvh.view.trace("fermi_speculative_while_while", rays.shape[0], False, d_rays.data_ptr(), o.data_ptr(), s_.cuda_stream, False)
+                torch.cuda.synchronize()
+                for o in outs:
+                    assert_parity(o.cpu().numpy().view(nt.RESULT_DTYPE), ref, "cycle %d launch %d" % (cycle, rep))
+            nt.stream_release(streams[0].cuda_stream)       # stream 0 starts over in the next cycle, stream 1 keeps its hint
+        nt.stream_release(streams[1].cuda_stream)
+        nt.stream_release(streams[1].cuda_stream)           # releasing a stream that owns nothing is fine
+    finally:
+        for k in ("NTR_TRACE_AUTO_HINT_MIN_RAYS", "NTR_TRACE_PREDICT_MIN_RAYS", "NTR_TRACE_PREDICT_MIN_NODES"):
+            monkeypatch.delenv(k, raising=False)
+        nt.set_tunables()
+
+
 def test_batch_coherence_estimate_separates_camera_rays_from_scattered_ones(soup, monkeypatch):
     """ntr_predict_batch_coherence (the words the dispatch-order prediction derives on the device): rays from one camera start together
     and point alike -- no incoherent block, K = 1; rays that start anywhere in the scene's box are incoherent in nearly every block --
