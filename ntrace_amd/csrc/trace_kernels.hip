@@ -561,7 +561,9 @@ __device__ __forceinline__ void unified_advance(const float4& a, const float4& b
 // wave and iteration whatever the lanes hold) and the planes are scalar operands of the same arithmetic.  The loop ends for good at the
 // first iteration in which the lanes disagree, or hold a leaf: the test (one v_readlane, one compare) is paid only while it succeeds --
 // run on EVERY iteration it cost more than the fetches it saved (round 2), and looking again every 2 / 4 / 8 / 16 iterations of the
-// general loop loses 1-4 % too (profiles/r05_uniform_recheck_knob.txt): once apart, the lanes of a wave rarely all meet again.  Per-ray arithmetic, visiting order and
+// general loop loses 1-4 % (profiles/r05_uniform_recheck_knob.txt): once apart, the lanes of a wave rarely all meet again.  Measured
+// and left out as well: the same for a triangle every lane stands at (no gain, and 2.5 % lost to the larger loop:
+// profiles/r05_uniform_prologue_levels_knob.txt), and the prologue after a persistent wave's refill (nothing).  Per-ray arithmetic, visiting order and
 // stack are untouched: hit records cannot change.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) f32x4* const_f32x4_ptr;   // constant address space: a wave-uniform load becomes s_load
@@ -909,14 +911,8 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
         if (timeline) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tlRefill += __builtin_amdgcn_s_memtime() - tlA; }
         // ---- while-while traversal ------------------------------------------------
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
-        const UnifiedBufs ub = unified_bufs(p);
-        // a wave that has just taken a whole chunk holds 64 fresh rays at the root: the wave-uniform prologue (scalar fetches while the lanes
-        // agree) applies exactly as in the per-ray kernel; after a partial refill the lanes differ and the first comparison ends it
-        if (ub.uniformPrologue) {
-            if (fastWave) uniform_prologue<true, 8>(ub, r, node, st, spill, p.status);
-            else uniform_prologue<false, 8>(ub, r, node, st, spill, p.status);
-        }
         if (UNIFIED) {
+            const UnifiedBufs ub = unified_bufs(p);
             if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
             else traverse_unified<false, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
         } else if (fastWave) traverse<true, false, true>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
