@@ -163,7 +163,6 @@ static void tunables_load_locked()
     t.unified = env_int("NTR_TRACE_UNIFIED", 1);                  // kepler_dynamic_fetch: unified-step loop (0 = while-while loop + dynamic fetch)
     t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", 1);     // per-ray kernel with the unified-step loop: 1 = always (the default since the one-correction divide: AO batches on one-triangle-leaf trees -4 %), 0 = never, -1 = closest-hit launches always, any-hit launches only on trees flagged NTR_BVH_WIDE_LEAVES (the rule of round 3)
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/studies/persist_diag.py)
-    t.persistentWaves = env_int("NTR_TRACE_PERSISTENT_WAVES", 4);  // waves per workgroup of the persistent kernels: 4, or 1 (experiment)
     t.autoHint = env_int("NTR_TRACE_AUTO_HINT", 1);               // dispatch order learned from the previous launch of the same batch (stream, rays, count, BVH)
     t.autoHintMinRays = env_int("NTR_TRACE_AUTO_HINT_MIN_RAYS", 1 << 17);
     t.predict = env_int("NTR_TRACE_PREDICT", 1);
@@ -776,7 +775,6 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.numHeads = 8;
     p.numBlocks = 0;
     p.numBlocksIncoherent = 0;
-    p.persistentWaves = NTR_TRACE_WAVES_PER_BLOCK;
     p.orderBlocks = 0;
     // persistent kernels (scripts/studies/persist_sweep.py): 64-ray chunks, 6 workgroups per CU; dynamic fetch only for the kernel
     // named after it (it costs about 10 % here: refilled lanes de-cohere a wave's node fetches)
@@ -822,13 +820,9 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     if (variant == NTR_VARIANT_PERSISTENT) {
         // Persistent grid: CUs x resident blocks per CU (the reference hard-codes
         // 720 warps for GT200/Fermi, CudaBVHTracer.cpp:155-159).
-        // Workgroups of four waves (the default) or of one (NTR_TRACE_PERSISTENT_WAVES=1: the same waves per CU, retired and
-        // refilled wave by wave as the per-ray kernel's are)
-        const int pWaves = tun.persistentWaves == 1 ? 1 : NTR_TRACE_WAVES_PER_BLOCK;
-        p.persistentWaves = pWaves;
-        const int blocksPerCU = tun.blocksPerCU * (NTR_TRACE_WAVES_PER_BLOCK / pWaves);
+        const int blocksPerCU = tun.blocksPerCU;
         numBlocks = ds->numCUs * blocksPerCU;
-        const int needed = (numRays + pWaves * 64 - 1) / (pWaves * 64);
+        const int needed = (numRays + blockThreads - 1) / blockThreads;
         if (numBlocks > needed) numBlocks = needed;
         {
             // a launch that is being captured into a HIP graph keeps its pool heads for the graph's lifetime
@@ -853,8 +847,8 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         p.numBlocks = numBlocks;
         // (only the dynamic-fetch kernel: its waves stay full from the pool; the while-while persistent kernel refills a wave only when it is
         // empty and loses with fewer waves -- hairball box rays 9.3 -> 14.7 ms)
-        if (dynamicFetch && tun.blocksPerCUIncoherent > 0 && tun.blocksPerCUIncoherent < tun.blocksPerCU) {
-            p.numBlocksIncoherent = ds->numCUs * tun.blocksPerCUIncoherent * (NTR_TRACE_WAVES_PER_BLOCK / pWaves);
+        if (dynamicFetch && tun.blocksPerCUIncoherent > 0 && tun.blocksPerCUIncoherent < blocksPerCU) {
+            p.numBlocksIncoherent = ds->numCUs * tun.blocksPerCUIncoherent;
             if (p.numBlocksIncoherent > numBlocks) p.numBlocksIncoherent = numBlocks;
         }
         p.shardRays = ((chunksTotal + heads - 1) / heads) * p.chunk;

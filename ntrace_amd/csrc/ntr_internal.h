@@ -10,7 +10,7 @@ int hip_fail(hipError_t e, const char* what);
 
 // Tunables (environment overrides for sweeps), read once at first use -- see ntr_api.cpp.
 struct Tunables {
-    int chunk, fetchThreshold, leafSwitchBelow, blocksPerCU, blocksPerCUIncoherent, poolHeads, persistentWaves, octant, anyHitWaves, closestWaves, unified, perrayUnified, flatFetch, uniformPrologue, minipool, minipoolThreshold, minipoolWide;
+    int chunk, fetchThreshold, leafSwitchBelow, blocksPerCU, blocksPerCUIncoherent, poolHeads, octant, anyHitWaves, closestWaves, unified, perrayUnified, flatFetch, uniformPrologue, minipool, minipoolThreshold, minipoolWide;
 #ifdef NTR_AB
     int handoff, handoffBelow, handoffMinQueue, handoffKeepWaves, handoffFlags;   // tail hand-off (A/B build only)
 #endif

@@ -55,7 +55,6 @@ struct TraceParams {
     int32_t shardRays;       // persistent: rays per pool shard (numHeads shards, a multiple of chunk)
     int32_t numHeads;        // persistent: pool heads, a multiple of 8 (one group per XCD), <= 1024
     int32_t numBlocks;       // persistent: grid size (the statically assigned first chunks are counted from it)
-    int32_t persistentWaves; // persistent: waves per workgroup (4, or 1)
     int32_t numBlocksIncoherent;   // persistent: the grid that works on a batch whose pool word (poolK) says incoherent (0 = the whole grid)
     int32_t orderBlocks;     // persistent, with `order`: number of 256-ray blocks in order[]
     int32_t fetchThreshold;  // persistent: refill when fewer lanes are live

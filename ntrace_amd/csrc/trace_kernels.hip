@@ -1133,19 +1133,11 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
         hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERSISTENT_UNIFIED:
-        if (p->persistentWaves == 1 && !p->timeline && p->flatFetch) {
-            hipLaunchKernelGGL((ntr::trace_bvh_persistent<1, false, true, true>), dim3(numBlocks), dim3(64), 0, stream, *p);
-            break;
-        }
         if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         else if (p->flatFetch) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERSISTENT:
-        if (p->persistentWaves == 1 && !p->timeline) {
-            hipLaunchKernelGGL((ntr::trace_bvh_persistent<1, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
-            break;
-        }
         if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
