@@ -598,7 +598,9 @@ def main():
     symbol = launched_symbol(args.kernel, wide)
     pmc, pmc_src = load_pmc(symbol, launched_grid(args.kernel, b0["n"]))
     visits = st.numInnerVisits + st.numTriTests   # lane steps of the unified-step loop (a terminator arrives with its triangle)
-    binding = profiled_shares(pmc, pmc_src, visits)
+    # (lanes per wave-iteration is only reported for the persistent kernels: the per-ray kernels' uniform prologue fetches through the
+    # scalar cache, so their vector-load count no longer counts iterations)
+    binding = profiled_shares(pmc, pmc_src, visits if "persistent" in symbol else None)
     traffic = binding.get("hbm_traffic_bytes") if binding else None
     par = ("one frame sharded by screen tile over %d ranks (PixelTable ranges), BVH built on rank 0 and broadcast, %s gather of hit records"
            % (world, "RCCL" if args.dist_backend == "nccl" else "gloo (host-staged)")
@@ -669,7 +671,7 @@ def main():
         ao_sym = launched_symbol(args.kernel, wide, any_hit=True)
         ao_roof = l1_roofline(ao_alg, ao_ms * 1e-3, cus)
         ao_pmc, ao_src = load_pmc(ao_sym, launched_grid(args.kernel, batches[1]["n"]))
-        ao_bind = profiled_shares(ao_pmc, ao_src, ao_visits // max(len(batches) - 1, 1)) if ao_pmc else None
+        ao_bind = profiled_shares(ao_pmc, ao_src, (ao_visits // max(len(batches) - 1, 1)) if "persistent" in ao_sym else None) if ao_pmc else None
         ao_roof.update({"kernel": "%s (%s), the %d AO batches of rank 0 (any hit)" % (ao_sym, args.kernel, len(batches) - 1),
                         "share_of_step": ao_ms / (ao_ms + prim_ms),
                         "hbm_algorithmic": {"achieved": ao_alg / (ao_ms * 1e-3) / 1e9, "frac": ao_alg / (ao_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "cache_served": True},
@@ -1004,7 +1006,7 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         r_inc = roof(sr, secr)
         sym = launched_symbol(best_kn, wide10)
         pmc_i, src_i = load_pmc(sym, launched_grid(best_kn, nr), tag="courtyard")
-        bind_i = profiled_shares(pmc_i, src_i, sr.numInnerVisits + sr.numTriTests) if pmc_i else None
+        bind_i = profiled_shares(pmc_i, src_i, (sr.numInnerVisits + sr.numTriTests) if "persistent" in sym else None) if pmc_i else None
         gr = extras.get("gather_roof", {})
         steps_i = sr.numInnerVisits + sr.numTriTests
         r_inc.update({"kernel": "%s (%s)" % (sym, best_kn), "launch_ms": secr * 1e3,

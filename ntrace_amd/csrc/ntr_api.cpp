@@ -159,6 +159,8 @@ static void tunables_load_locked()
     t.handoffMinQueue = env_int("NTR_TRACE_HANDOFF_MIN_QUEUE", 64);   // M: waiting continuations needed to fill up rather than hand off (capped by the wave's free lanes)
     t.handoffKeepWaves = env_int("NTR_TRACE_HANDOFF_KEEP_WAVES", 1024);   // A: with no more waves than this left in the launch nobody hands off
     t.handoffFlags = env_int("NTR_TRACE_HANDOFF_FLAGS", 0);       // 1: raised priority for waves that took continuations; 2: batches with pool K = 1 run as one-chunk pools and hand their tails off too
+#else
+    t.handoff = t.handoffBelow = t.handoffMinQueue = t.handoffKeepWaves = t.handoffFlags = 0;
 #endif
     t.unified = env_int("NTR_TRACE_UNIFIED", 1);                  // kepler_dynamic_fetch: unified-step loop (0 = while-while loop + dynamic fetch)
     t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", 1);     // per-ray kernel with the unified-step loop: 1 = always (the default since the one-correction divide: AO batches on one-triangle-leaf trees -4 %), 0 = never, -1 = closest-hit launches always, any-hit launches only on trees flagged NTR_BVH_WIDE_LEAVES (the rule of round 3)
