@@ -786,7 +786,14 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     const bool unified = dynamicFetch && tun.unified != 0;
     p.fetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (dynamicFetch ? (unified ? 48 : 24) : 0);
     p.bvhFlags = bvhFlags;
-    p.flatFetch = (tun.flatFetch != 0 && nodesBytes >= 64 && triWoopBytes >= 64) ? 1 : 0;
+    {   // the flat fetch addresses both buffers from one scalar base with 32-bit lane offsets: they must lie inside one 4 GiB window
+        // (two allocations of one heap practically always do; otherwise the two-descriptor fetch, which has no such condition)
+        const unsigned long long an = (unsigned long long)d_nodes, aw = (unsigned long long)d_triWoop;
+        const unsigned long long lo = an < aw ? an : aw;
+        const unsigned long long hiN = an + (unsigned long long)nodesBytes, hiW = aw + (unsigned long long)triWoopBytes;
+        const bool oneWindow = ((hiN > hiW ? hiN : hiW) - lo) <= 0xFFFFFFFFull;
+        p.flatFetch = (tun.flatFetch != 0 && nodesBytes >= 64 && triWoopBytes >= 64 && oneWindow) ? 1 : 0;
+    }
     p.uniformPrologue = tun.uniformPrologue != 0 ? 1 : 0;
     p.leafSwitchBelow = tun.leafSwitchBelow >= 0 ? tun.leafSwitchBelow : (anyHit ? 24 : 32);
     p.octant = tun.octant;

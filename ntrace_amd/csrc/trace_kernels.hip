@@ -455,6 +455,13 @@ struct UnifiedBufs {
     unsigned int nodesBytes, woopBytes;
     u32x4 rNodes, rWoop;
     bool uniformPrologue;   // per-ray kernels: scalar fetches while the wave's lanes all hold the same inner node (TraceParams::uniformPrologue)
+    // FLAT fetch: both buffers lie inside one 4 GiB window (the host checks it before it selects the flat fetch), so a lane's 64 bytes
+    // are base + a 32-bit offset -- the global load takes the scalar base and the lane's offset as they are, where two unrelated 64-bit
+    // pointers cost every iteration a per-lane 64-bit select and add (round 5)
+    const char* base;       // the lower of the two buffers
+    unsigned int dN, dW;    // nodes - base, woop - base
+    unsigned int limNode;   // largest inner-node offset whose 64 bytes lie inside the node buffer (below the sentinel: `node <= limNode` implies inner)
+    int limTri;             // smallest (most negative) triangle cursor ~index whose 64 bytes lie inside triWoop
 };
 __device__ __forceinline__ UnifiedBufs unified_bufs(const TraceParams& p)
 {
@@ -463,6 +470,12 @@ __device__ __forceinline__ UnifiedBufs unified_bufs(const TraceParams& p)
     u.nodesBytes = p.nodesBytes; u.woopBytes = p.woopBytes;
     u.rNodes = rsrc_words(p.nodes, p.nodesBytes); u.rWoop = rsrc_words(p.woop, p.woopBytes);
     u.uniformPrologue = p.uniformPrologue != 0;
+    const unsigned long long an = (unsigned long long)p.nodes, aw = (unsigned long long)p.woop;
+    const unsigned long long lo = an < aw ? an : aw;
+    u.base = (const char*)lo;
+    u.dN = (unsigned int)(an - lo); u.dW = (unsigned int)(aw - lo);
+    u.limNode = p.nodesBytes - 64u;
+    u.limTri = ~(int)((p.woopBytes - 64u) >> 4);
     return u;
 }
 
@@ -481,19 +494,26 @@ __device__ __forceinline__ void unified_fetch(const UnifiedBufs& ub, int node, f
     const bool inner = (unsigned)node < (unsigned)kSentinel;
     const bool atTri = node < 0;
     // (Written as `inner ? ld4(nodes, ..) : ld4(woop, ..)` hipcc selects the descriptor per lane and wraps every load in a waterfall loop.)
-    const int ofs = inner ? node : (~node) * 16;
     if (FLAT) {
-        const bool flatOk = (inner || atTri) && (unsigned)ofs <= (inner ? ub.nodesBytes : ub.woopBytes) - 64u;   // (extents are >= 64 here)
         asm volatile("" : "=v"(a.x), "=v"(a.y), "=v"(a.z), "=v"(a.w), "=v"(b.x), "=v"(b.y), "=v"(b.z), "=v"(b.w));   // defined, whatever the lane
         asm volatile("" : "=v"(c.x), "=v"(c.y), "=v"(c.z), "=v"(c.w), "=v"(d.x), "=v"(d.y), "=v"(d.z), "=v"(d.w));
-        if (flatOk) {
-            const float4* q = reinterpret_cast<const float4*>((inner ? ub.nodes : ub.woop) + (unsigned)ofs);
-            a = q[0]; b = q[1]; c = q[2]; d = q[3];
+        const bool okNode = (unsigned)node <= ub.limNode, okTri = atTri && node >= ub.limTri;   // (extents are >= 64 here)
+        const bool flatOk = okNode || okTri;
+        const unsigned int cofs = okNode ? ub.dN + (unsigned)node : ub.dW + ((unsigned)(~node) << 4);   // from the scalar base: a 32-bit offset
+        if (flatOk) {   // (global address space spelled out: the base comes out of integer arithmetic, and a generic pointer would be a flat_load)
+            typedef const __attribute__((address_space(1))) u32x4* global_u4_ptr;
+            const global_u4_ptr q = (global_u4_ptr)((const __attribute__((address_space(1))) char*)ub.base + cofs);
+            const u32x4 qa = q[0], qb = q[1], qc = q[2], qd = q[3];
+            a = make_float4(__uint_as_float(qa.x), __uint_as_float(qa.y), __uint_as_float(qa.z), __uint_as_float(qa.w));
+            b = make_float4(__uint_as_float(qb.x), __uint_as_float(qb.y), __uint_as_float(qb.z), __uint_as_float(qb.w));
+            c = make_float4(__uint_as_float(qc.x), __uint_as_float(qc.y), __uint_as_float(qc.z), __uint_as_float(qc.w));
+            d = make_float4(__uint_as_float(qd.x), __uint_as_float(qd.y), __uint_as_float(qd.z), __uint_as_float(qd.w));
         }
         const unsigned long long odd = __ballot((inner || atTri) && !flatOk);
         if (odd != 0ull)   // rare: range-checked descriptor loads, into the same registers, for the lanes at the very end of a buffer
-            fetch64_two_buffers_into(ub.rNodes, ub.rWoop, ofs, __ballot(inner && !flatOk), __ballot(atTri && !flatOk), a, b, c, d);
-    } else {   // four loads under the inner lanes' mask and four under the triangle lanes' mask into the SAME registers, one wait
+            fetch64_two_buffers_into(ub.rNodes, ub.rWoop, inner ? node : (~node) * 16, __ballot(inner && !flatOk), __ballot(atTri && !flatOk), a, b, c, d);
+    } else {
+        const int ofs = inner ? node : (~node) * 16;   // four loads under the inner lanes' mask and four under the triangle lanes' mask into the SAME registers, one wait
         fetch64_two_buffers(ub.rNodes, ub.rWoop, ofs, __ballot(inner), __ballot(atTri), a, b, c, d);
     }
 }

@@ -513,6 +513,33 @@ def test_uniform_prologue_changes_no_record(monkeypatch, tree):
         nt.set_tunables()
 
 
+def test_buffers_more_than_4_gib_apart_take_the_descriptor_fetch():
+    """The flat fetch of the unified-step loop addresses node and triangle buffers from ONE scalar base with 32-bit lane offsets (round 5),
+    so the library uses it only when both buffers lie inside one 4 GiB window; buffers further apart get the two-descriptor fetch.
+    Here 5 GiB of other allocations sit between the two: records equal the oracle's for every kernel name, closest hit and any hit."""
+    import torch
+    from gpu_util import assert_parity, up
+    tri, pos, cam = scenes.random_soup(5000, seed=47)
+    host = nt.sah_build(tri, pos, 1, 4)
+    rays = np.concatenate([scenes.primary_rays(cam, 160, 120)[0], edge_rays(), scenes.random_rays(8000, seed=6)])
+    d_nodes = up(host.nodes)
+    spacer = torch.empty(5 << 30, dtype=torch.uint8, device="cuda:0")     # keeps the next allocation far away
+    d_woop, d_idx = up(host.woop), up(host.tri_index)
+    if abs(d_woop.data_ptr() - d_nodes.data_ptr()) < (4 << 30):
+        pytest.skip("the allocator placed the two buffers within 4 GiB of each other")
+    view = nt.BvhView(d_nodes.data_ptr(), host.nodes.nbytes, d_woop.data_ptr(), host.woop.nbytes, d_idx.data_ptr())
+    view.validate()
+    d_rays = up(rays)
+    for any_hit in (False, True):
+        ref, _ = oracle.trace(host.nodes, host.woop, host.tri_index, rays, any_hit=any_hit, threads=8)
+        for kernel in KERNELS:
+            d_res = torch.full((rays.shape[0] * 16,), 0xCD, dtype=torch.uint8, device="cuda:0")
+            view.trace(kernel, rays.shape[0], any_hit, d_rays.data_ptr(), d_res.data_ptr())
+            torch.cuda.synchronize()
+            assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), ref, "%s any_hit=%s, buffers %d MiB apart" % (kernel, any_hit, abs(d_woop.data_ptr() - d_nodes.data_ptr()) >> 20))
+    del spacer
+
+
 def test_stream_release_returns_a_streams_scheduling_state(monkeypatch):
     """ntr_stream_release: a stream's automatic hints and prediction scratch go back before the host destroys the stream; tracing on the
     stream afterwards simply starts over (first sighting, second sighting, hint), and other streams' entries are untouched."""
