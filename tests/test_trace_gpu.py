@@ -523,10 +523,18 @@ def test_buffers_more_than_4_gib_apart_take_the_descriptor_fetch():
     host = nt.sah_build(tri, pos, 1, 4)
     rays = np.concatenate([scenes.primary_rays(cam, 160, 120)[0], edge_rays(), scenes.random_rays(8000, seed=6)])
     d_nodes = up(host.nodes)
-    spacer = torch.empty(5 << 30, dtype=torch.uint8, device="cuda:0")     # keeps the next allocation far away
-    d_woop, d_idx = up(host.woop), up(host.tri_index)
-    if abs(d_woop.data_ptr() - d_nodes.data_ptr()) < (4 << 30):
-        pytest.skip("the allocator placed the two buffers within 4 GiB of each other")
+    # the allocator decides where things go: interleave spacers and copies of the triangle buffer until one copy lies > 4 GiB from the nodes
+    spacer, d_woop = [], None
+    for _ in range(6):
+        spacer.append(torch.empty(3 << 30, dtype=torch.uint8, device="cuda:0"))
+        cand = up(host.woop)
+        if abs(cand.data_ptr() - d_nodes.data_ptr()) > (4 << 30) + host.woop.nbytes + host.nodes.nbytes:
+            d_woop = cand
+            break
+        spacer.append(cand)
+    if d_woop is None:
+        pytest.skip("the allocator kept every copy within 4 GiB of the node buffer")
+    d_idx = up(host.tri_index)
     view = nt.BvhView(d_nodes.data_ptr(), host.nodes.nbytes, d_woop.data_ptr(), host.woop.nbytes, d_idx.data_ptr())
     view.validate()
     d_rays = up(rays)
