@@ -297,12 +297,18 @@ class Frame:
         self.nt.raygen_primary(self.d_rays.data_ptr(), self.d_i2s.data_ptr(), self.d_s2i.data_ptr(), self.d_tab.data_ptr(), cam["eye"],
                                self.scenes.nscreen_to_world(cam, self.w, self.h), self.w, self.h, cam["far"], 0, self.stream)
 
-    def regenerate_ao(self):
-        """The AO batches again from the primary hit records as they are now, into the same buffers; the batches' live counts follow."""
+    def regenerate_ao(self, count=True):
+        """The AO batches again from the primary hit records as they are now, into the same buffers (asynchronous); with `count` the batches'
+        live counts follow (a read-back per batch: a host synchronisation -- recount() does it after the frame's launches instead)."""
         for b in self.batches[1:]:
             a = b["slots_t"]
             self.nt.raygen_ao(b["rays"], a.data_ptr(), a.data_ptr(), self.d_rays.data_ptr(), self.d_res.data_ptr(), self.tri_normals.data_ptr(),
                               b["first"], b["count"], self.ns, self.args.ao_radius, 0xFFF2D5E4, self.stream)
+        if count:
+            self.recount()
+
+    def recount(self):
+        for b in self.batches[1:]:
             b["live"] = self.nt.count_hits(self.d_res.data_ptr() + b["first"] * 16, b["count"], self.stream) * self.ns
         self.batches[0]["live"] = self.plan.hi - self.plan.lo
 
@@ -871,13 +877,14 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
             view.trace(args.kernel, b0_["n"], False, b0_["rays"], b0_["res"], stream, False)
             if s_ >= 0:
                 mev[s_][0][1].record()
-            frame.regenerate_ao()
+            frame.regenerate_ao(count=False)      # (no read-back between ray generation and the launches: the GPU stays fed, as in the timed region of `value`)
             for bi, b in enumerate(batches[1:], start=1):
                 if s_ >= 0:
                     mev[s_][bi][0].record()
                 view.trace(args.kernel, b["n"], True, b["rays"], b["res"], stream, False, hint=b.get("hint"))
                 if s_ >= 0:
                     mev[s_][bi][1].record()
+            frame.recount()                       # the frame's non-degenerate ray count, after its launches
             if s_ >= 0:
                 mrays += frame.rays_per_step
         torch.cuda.synchronize()
