@@ -868,7 +868,7 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         for s_ in range(-2, msteps):      # two untimed frames first: the hints of the moving sequence form
             camm = dict(cam0)
             eye = np.array(camm["eye"], dtype=np.float64)
-            eye[2] += 0.25 * (s_ + 3)
+            eye[2] += float(os.environ.get("NTR_BENCH_MOVE_STEP", "0.25")) * (s_ + 3)
             camm["eye"] = tuple(eye)
             frame.regenerate_primary(camm)
             b0_ = batches[0]
