@@ -642,7 +642,8 @@ def main():
                                         "refined by every launch's measurement (ntr_trace_bvh_hinted)") if frame.d_depth is not None else "none (library's automatic feedback)"},
         "primary_mrays": prim_live_total * args.steps / prim_kernel_max / 1e6,
         "ao_mrays": (ao_live_total * args.steps / ao_kernel_max / 1e6) if ao_kernel_max > 0 else None,
-        "kernel_ms": {"primary": prim_ms, "ao_total": ao_ms, "per_step_rank0": float(kern_ms.sum(axis=1).mean())},
+        "kernel_ms": {"primary": prim_ms, "ao_total": ao_ms, "per_step_rank0": float(kern_ms.sum(axis=1).mean()),
+                      "per_batch": [round(float(x), 4) for x in kern_ms.mean(axis=0)]},
         "gather_ms": gather_ms,
         "gather_native": native_gather,
         "sharded_frame_check": frame_check,
@@ -864,6 +865,7 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         msteps = max(3, min(args.steps, 10))
         cam0 = dict(frame_cam)
         mev = [[(E(enable_timing=True), E(enable_timing=True)) for _ in batches] for _ in range(msteps)]
+        lib_ms = np.zeros((msteps, len(batches)))
         mrays = 0
         for s_ in range(-2, msteps):      # two untimed frames first: the hints of the moving sequence form
             camm = dict(cam0)
@@ -872,28 +874,36 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
             camm["eye"] = tuple(eye)
             frame.regenerate_primary(camm)
             b0_ = batches[0]
+            lib_timed = os.environ.get("NTR_BENCH_MOVE_TIMED") == "1"   # diagnostic: the library's own per-launch seconds (its events exclude the feedback kernels)
             if s_ >= 0:
                 mev[s_][0][0].record()
-            view.trace(args.kernel, b0_["n"], False, b0_["rays"], b0_["res"], stream, False)
+            t_ = view.trace(args.kernel, b0_["n"], False, b0_["rays"], b0_["res"], stream, lib_timed)
             if s_ >= 0:
                 mev[s_][0][1].record()
+                if lib_timed:
+                    lib_ms[s_][0] = t_ * 1e3
             frame.regenerate_ao(count=False)      # (no read-back between ray generation and the launches: the GPU stays fed, as in the timed region of `value`)
             for bi, b in enumerate(batches[1:], start=1):
                 if s_ >= 0:
                     mev[s_][bi][0].record()
-                view.trace(args.kernel, b["n"], True, b["rays"], b["res"], stream, False, hint=b.get("hint"))
+                t_ = view.trace(args.kernel, b["n"], True, b["rays"], b["res"], stream, lib_timed, hint=b.get("hint"))
                 if s_ >= 0:
                     mev[s_][bi][1].record()
+                    if lib_timed:
+                        lib_ms[s_][bi] = t_ * 1e3
             frame.recount()                       # the frame's non-degenerate ray count, after its launches
             if s_ >= 0:
                 mrays += frame.rays_per_step
         torch.cuda.synchronize()
         mms = np.array([[e0.elapsed_time(e1) for (e0, e1) in st_] for st_ in mev])
+        if os.environ.get("NTR_BENCH_MOVE_TIMED") == "1":
+            mms = lib_ms
         extras["moving_camera"] = {
             "what": "the eye moves 0.25 units per step; primary rays and AO batches regenerated into the same buffers every step (untimed), traced in the "
                     "order the previous frame's launches measured (the library's automatic feedback / the batch's hint): new rays every launch",
             "mrays": mrays / (float(mms.sum()) * 1e-3) / 1e6, "primary_ms": float(mms[:, 0].mean()),
-            "ao_total_ms": float(mms[:, 1:].sum(axis=1).mean()) if len(batches) > 1 else 0.0, "steps": msteps}
+            "ao_total_ms": float(mms[:, 1:].sum(axis=1).mean()) if len(batches) > 1 else 0.0, "steps": msteps,
+            "per_batch_ms": [round(float(x), 4) for x in mms.mean(axis=0)]}
         # back to the bench camera (the extras below and the cpu_baseline leg compare against these buffers)
         frame.regenerate_primary(cam0)
         view.trace(args.kernel, batches[0]["n"], False, batches[0]["rays"], batches[0]["res"], stream, False)
