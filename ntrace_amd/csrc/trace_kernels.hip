@@ -608,10 +608,12 @@ __device__ __forceinline__ void uniform_prologue(const UnifiedBufs& ub, const Ra
     }
 }
 
-template <bool FAST, bool FLAT, int OCT = 8, bool PROLOGUE = false>
+// SLICED: the loop also ends after `slice` iterations (the drain phase of the persistent kernels looks at the wave's lanes again:
+// split_settle / split_donate, trace_split.h).
+template <bool FAST, bool FLAT, int OCT = 8, bool PROLOGUE = false, bool SLICED = false>
 __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs& r, int& node, LaneStack& st,
                                                  int (&spill)[SPILL_DEPTH], bool anyHit, int& hitAddr, float& hitU, float& hitV,
-                                                 unsigned int* status, bool poolEmpty, int fetchThreshold)
+                                                 unsigned int* status, bool poolEmpty, int fetchThreshold, int slice = 0)
 {
     if (PROLOGUE && ub.uniformPrologue) uniform_prologue<FAST, OCT>(ub, r, node, st, spill, status);
 #if defined(NTR_AB) && defined(NTR_AGE_SHIFT)
@@ -622,6 +624,7 @@ __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs&
         if (live == 0ull) break;
         // dynamic fetch (kepler_dynamic_fetch.cu:310): too few live lanes while rays remain in the pool -> refill
         if (!poolEmpty && __popcll(live) < fetchThreshold) break;
+        if (SLICED && --slice < 0) break;
 #if defined(NTR_AB) && defined(NTR_AGE_SHIFT)
         if ((++ageIt & ((1u << NTR_AGE_SHIFT) - 1u)) == 0u) {
             const unsigned int a = ageIt >> NTR_AGE_SHIFT;
@@ -637,12 +640,16 @@ __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs&
     }
 }
 
+}  // namespace ntr
+#include "trace_split.h"   // drain phase of the persistent waves: idle lanes take over parts of the wave's long rays
+namespace ntr {
+
 // ---------------------------------------------------------------------------------
 // Variant 1: one ray per lane, while-while ("fermi_speculative_while_while" slot).
 // ---------------------------------------------------------------------------------
 // UNIFIED: the unified-step loop (traverse_unified) -- for trees whose leaves hold several triangles (the device LBVH).
 // MINI: the launch may run as the wave-private mini-pool instead (minipool_body below), decided on the device per batch.
-template <bool FLATF>
+template <bool FLATF, bool SPLIT>
 __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int K, lds_int* stackBase);
 
 #if defined(NTR_AB) && defined(NTR_OCC8)
@@ -650,9 +657,11 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
 #else
 #define NTR_PERRAY_BOUNDS(W) __launch_bounds__((W) * 64, NTR_TRACE_MIN_WAVES_PER_SIMD)
 #endif
-template <int WAVES, bool STATS, bool UNIFIED = false, bool FLATF = true, bool MINI = false>
+// SPLIT (MINI only): closest-hit launches let the lanes that are done take over parts of the wave's live rays (trace_split.h).
+template <int WAVES, bool STATS, bool UNIFIED = false, bool FLATF = true, bool MINI = false, bool SPLIT = false>
 __device__ __forceinline__ void perray_body(const TraceParams& p)
 {
+    static_assert(!SPLIT || MINI, "ray splitting is compiled into the mini-pool launch only");
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     if constexpr (MINI) {
         static_assert(WAVES == 1 && UNIFIED && !STATS, "the mini-pool shares the one-wave unified-step launch");
@@ -663,7 +672,7 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
         pooled = pooled || (K == 1u && p.cont && (p.contFlags & NTR_CONT_FLAG_K1));   // (hand-off experiment: one-chunk pools hand their tails off too)
 #endif
         if (pooled) {
-            minipool_body<FLATF>(p, K, (lds_int*)&s_stack[0][0][threadIdx.x]);
+            minipool_body<FLATF, SPLIT>(p, K, (lds_int*)&s_stack[0][0][threadIdx.x]);
             return;
         }
     }
@@ -704,9 +713,22 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
         if ((sx == 0ull || sx == liveMask) && (sy == 0ull || sy == liveMask) && (sz == 0ull || sz == liveMask))
             oct = (sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0);
     }
+    bool recordsOut = false;   // SPLIT: every ray's record was written when the ray was complete
     if (UNIFIED) {
         const UnifiedBufs ub = unified_bufs(p);
-#define NTR_UNIFIED_OCT(O) traverse_unified<true, FLATF, O, true>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0)
+        // SPLIT: the traversal runs in slices; between them helpers report, finished rays leave and the lanes they free take over the
+        // bottom stack entries of the rays still on their way (any-hit launches: one slice, nothing else)
+        SplitState split;
+        split_reset(split);
+        const int splitSlice = (SPLIT && p.anyHit == 0) ? p.splitSlice : 0;
+        int myRay = valid ? rayIdx : -1;
+        bool niceLane = true;   // (the wave runs FAST or not as a whole: a helper's ray is a copy of a ray of this wave)
+        for (;;) {
+        const int slice = splitSlice > 0 ? splitSlice : 0x7FFFFFFF;
+        if (SPLIT && splitSlice > 0) {
+            split_donate(split, r, node, st, myRay, hitAddr, hitU, hitV, niceLane);
+        }
+#define NTR_UNIFIED_OCT(O) traverse_unified<true, FLATF, O, true, SPLIT>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0, slice)
         if (oct < 8) {
             switch (oct) {
                 case 0: NTR_UNIFIED_OCT(0); break;
@@ -720,8 +742,17 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
             }
         }
 #undef NTR_UNIFIED_OCT
-        else if (fastWave) traverse_unified<true, FLATF, 8, true>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
-        else traverse_unified<false, FLATF, 8, true>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
+        else if (fastWave) traverse_unified<true, FLATF, 8, true, SPLIT>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0, slice);
+        else traverse_unified<false, FLATF, 8, true, SPLIT>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0, slice);
+        if (!SPLIT || splitSlice <= 0) break;
+        split_settle(split, r, node, st, hitAddr, hitU, hitV);
+        if (myRay >= 0 && node == kSentinel && split.base == 0) {   // the ray's record goes out as soon as all of it is known: its lane is free
+            store_result(p.results, p.triIndex, myRay, hitAddr, r.tmax, hitU, hitV);
+            myRay = -1;
+        }
+        if (__ballot(myRay >= 0) == 0ull) break;
+        }
+        recordsOut = SPLIT && splitSlice > 0;
     } else
 #define NTR_TRAVERSE_OCT(O) traverse<true, STATS, false, O>(nodes, woop, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow)
     if (!STATS && oct < 8) {
@@ -748,7 +779,7 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
     }
     if (p.cost && lane == 0)  // scheduling feedback: a block's cost is the lifetime of its longest wave
         atomicMax(&p.cost[block], (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0));
-    if (!valid) return;
+    if (!valid || recordsOut) return;
     store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
     if (STATS) {  // diagnostics variant only: plain per-lane atomics
         atomicAdd(&p.stats[0], (unsigned long long)ls.inner);
@@ -771,8 +802,14 @@ __global__ NTR_PERRAY_BOUNDS(WAVES) void trace_bvh_perray(TraceParams p)
 #endif
 __global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini(TraceParams p)
 {
-    perray_body<1, false, true, true, true>(p);
+    perray_body<1, false, true, true, true, false>(p);
 }
+#ifdef NTR_AB   // the same launch with ray splitting compiled in (A/B build only: measured, it does not pay here -- EXPERIMENTS.md round 5)
+__global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini_split(TraceParams p)
+{
+    perray_body<1, false, true, true, true, true>(p);
+}
+#endif
 
 // ---------------------------------------------------------------------------------
 // Variant 2: persistent waves.  Each wave owns a chunk [next,end) of the ray index
@@ -836,6 +873,11 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     // chunks of head h handed out statically: one per wave of every block with blockIdx % numHeads == h
     auto static_rays = [&](int h) { return ((numBlocksEff - h + numHeads - 1) / numHeads) * WAVES * p.chunk; };
     LaneStats ls = {0u, 0u, 0u};
+    // drain phase (unified-step loop, closest hit): once the pool is dry, idle lanes take over parts of the wave's rays (trace_split.h)
+    SplitState split;
+    split_reset(split);
+    bool splitOn = false;             // wave-uniform
+    const int splitSlice = (UNIFIED && !anyHit) ? p.splitSlice : 0;
 
     // diagnostic stamps (NTR_TRACE_TIMELINE): wave start, end, cycles spent refilling, refill count
     unsigned long long tlStart = 0, tlRefill = 0, tlCount = 0, tlRays = 0;
@@ -930,16 +972,22 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
 
         if (timeline) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tlRefill += __builtin_amdgcn_s_memtime() - tlA; }
         // ---- while-while traversal ------------------------------------------------
+        if (UNIFIED && poolEmpty && splitSlice > 0) {
+            if (!splitOn) { splitOn = true; split_reset(split); }
+            split_donate(split, r, node, st, rayIdx, hitAddr, hitU, hitV, nice);
+        }
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
         if (UNIFIED) {
             const UnifiedBufs ub = unified_bufs(p);
-            if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
-            else traverse_unified<false, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
+            const int slice = splitOn ? splitSlice : 0x7FFFFFFF;   // drain phase with splitting: the lanes are looked at again every `slice` steps
+            if (fastWave) traverse_unified<true, FLATF, 8, false, true>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold, slice);
+            else traverse_unified<false, FLATF, 8, false, true>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold, slice);
+            if (splitOn) split_settle(split, r, node, st, hitAddr, hitU, hitV);
         } else if (fastWave) traverse<true, false, true>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
         else traverse<false, false, true>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
 
-        // ---- retire finished rays ---------------------------------------------------
-        if (rayIdx >= 0 && node == kSentinel) {
+        // ---- retire finished rays (an owner whose helpers are still out waits for their reports) ------
+        if (rayIdx >= 0 && node == kSentinel && (!splitOn || split.base == 0)) {
             store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
             rayIdx = -1;
         }
@@ -971,7 +1019,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
 // Unified-step loop, flat fetch; 256-ray blocks keep their role as the unit of the dispatch order and of the cost feedback.
 // A/B build only (-DNTR_AB): with a continuation queue (p.cont, round 4) the tail of a pool is handed off, trace_handoff_ab.h.
 // ---------------------------------------------------------------------------------
-template <bool FLATF>
+template <bool FLATF, bool SPLIT>
 __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int K, lds_int* stackBase)
 {
     // The launch has one wave per 64-ray chunk (the per-ray kernel's grid); K consecutive chunks of the dispatch order form a pool, and one
@@ -1024,6 +1072,11 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
     int node = kSentinel, rayIdx = -1, hitAddr = -1;
     float hitU = 0.0f, hitV = 0.0f;
     bool nice = true;
+    // once the wave's own rays are all started, lanes that are done take over parts of the rays still on their way (trace_split.h)
+    SplitState split;
+    split_reset(split);
+    bool splitOn = false;                  // wave-uniform
+    const int splitSlice = (SPLIT && !anyHit) ? p.splitSlice : 0;
 
     for (;;) {
         // ---- start the wave's next rays on its empty lanes (from the current chunk; what it cannot fill is filled next time round) --
@@ -1089,11 +1142,17 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
         }
 #endif
         // ---- unified-step traversal until every lane is done, or until enough lanes are free to be worth a refill -------------
+        if (SPLIT && poolEmpty && splitSlice > 0) {
+            if (!splitOn) { splitOn = true; split_reset(split); }
+            split_donate(split, r, node, st, rayIdx, hitAddr, hitU, hitV, nice);
+        }
+        const int slice = splitOn ? splitSlice : 0x7FFFFFFF;
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
-        if (fastWave) traverse_unified<true, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, !stopEarly, stopBelow);
-        else traverse_unified<false, FLATF>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, !stopEarly, stopBelow);
-        // ---- retire finished rays ---------------------------------------------------------------------------------------------
-        if (rayIdx >= 0 && node == kSentinel) {
+        if (fastWave) traverse_unified<true, FLATF, 8, false, SPLIT>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, !stopEarly, stopBelow, slice);
+        else traverse_unified<false, FLATF, 8, false, SPLIT>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, !stopEarly, stopBelow, slice);
+        if (SPLIT && splitOn) split_settle(split, r, node, st, hitAddr, hitU, hitV);
+        // ---- retire finished rays (an owner whose helpers are still out waits for their reports) ------------------------------
+        if (rayIdx >= 0 && node == kSentinel && (!SPLIT || !splitOn || split.base == 0)) {
             store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
             rayIdx = -1;
         }
@@ -1147,6 +1206,12 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
         else hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, true, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_UNIFIED_MINI:   // numBlocks counts waves of 64 rays; needs flatFetch
+#ifdef NTR_AB   // A/B build: the per-ray launch with ray splitting (measured: it loses where other waves still have bulk work, EXPERIMENTS.md round 5)
+        if (p->splitSlice > 0 && p->splitPerRay && !p->anyHit) {
+            hipLaunchKernelGGL(ntr::trace_bvh_perray_mini_split, dim3(numBlocks), dim3(64), 0, stream, *p);
+            break;
+        }
+#endif
         hipLaunchKernelGGL(ntr::trace_bvh_perray_mini, dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_STATS:
