@@ -111,3 +111,29 @@ def test_tail_handoff_on_two_streams_and_repeated_launches(monkeypatch):
             pushed, popped, _ = nt.trace_handoff_counts(streams[i].cuda_stream)
             assert pushed == popped and pushed > 0, (i, rep, pushed, popped)
     assert nt.trace_status() == 0
+
+
+@pytest.mark.parametrize("tree", ["sah leaves of 1", "device lbvh"])
+def test_per_ray_launch_with_ray_splitting_changes_no_record(monkeypatch, tree):
+    """The A/B build's per-ray / mini-pool launch with ray splitting compiled in (NTR_TRACE_SPLIT_PERRAY=1; trace_split.h -- measured, it
+    only pays in the drain phase of the persistent kernels, which is where the product has it): every lane of a wave that is done takes
+    over stack entries of the lanes still on their way, with and without the wave-private pool.  Records stay the oracle's."""
+    from gpu_util import DeviceBvh, assert_parity, gpu_trace
+    tri, pos, cam = scenes.random_soup(30000, seed=37)
+    dbvh = DeviceBvh(nt.sah_build(tri, pos, 1, 1)) if tree == "sah leaves of 1" else _lbvh_device_bvh(tri, pos)
+    rays = np.concatenate([scenes.box_rays(pos, 200000, seed=6), edge_rays(), scenes.primary_rays(cam, 320, 200)[0]])
+    ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=False, threads=8)
+    try:
+        monkeypatch.setenv("NTR_TRACE_SPLIT_PERRAY", "1")
+        for pool in ("1", "4", "-1"):
+            for slice_ in ("1", "8", "32"):
+                monkeypatch.setenv("NTR_TRACE_MINIPOOL", pool)
+                monkeypatch.setenv("NTR_TRACE_SPLIT_SLICE", slice_)
+                nt.set_tunables()
+                for n in (rays.shape[0], 63, 4097):
+                    got, _ = gpu_trace(K, dbvh, rays[:n], False)
+                    assert_parity(got, ref[:n], "%s per-ray split, pool %s slice %s n=%d" % (tree, pool, slice_, n))
+    finally:
+        for k in ("NTR_TRACE_SPLIT_PERRAY", "NTR_TRACE_MINIPOOL", "NTR_TRACE_SPLIT_SLICE"):
+            monkeypatch.delenv(k, raising=False)
+        nt.set_tunables()

@@ -513,6 +513,50 @@ def test_uniform_prologue_changes_no_record(monkeypatch, tree):
         nt.set_tunables()
 
 
+@pytest.mark.parametrize("tree", ["atrium, sah leaves of 1", "soup, device lbvh"])
+def test_ray_splitting_changes_no_record(monkeypatch, tree):
+    """Ray splitting in the drain phase of the persistent kernels (trace_split.h, round 5): once the pool is dry, lanes without a ray
+    traverse the bottom stack entries of the wave's live rays.  The reference's record depends on the traversal's history (a triangle a
+    few ulp closer than the record can sit in a node the lone ray skips), so a helper's hit counts only under the bound the lone ray
+    would bring along -- merging parts by t differs from the reference on ~5 of every 10^6 box rays of the atrium tree, which is why
+    that tree is here at 2^20 rays.  Records must be the oracle's with the lanes looked at after every step, every 3 / 8 / 64 steps and
+    never; ragged counts (waves that start with most lanes idle), edge-case rays (non-finite values: the helpers copy the generic slab
+    path's ray too), closest hit (splits) and any hit (must not), unified-step and while-while persistent kernels."""
+    from gpu_util import DeviceBvh, assert_parity, gpu_trace
+    if tree.startswith("atrium"):
+        tri, pos, cam = scenes.atrium()
+        dbvh = DeviceBvh(nt.sah_build(tri, pos, 1, 1))
+        rays = np.concatenate([scenes.box_rays(pos, 1 << 20, seed=21), edge_rays()])
+    else:
+        import torch
+        from gpu_util import up
+        tri, pos, cam = scenes.random_soup(40000, seed=53)
+        n = tri.shape[0]
+        capn, capw, capi = nt.lbvh_capacity(n)
+        d_tri, d_pos = up(tri), up(pos)
+        bufs = [torch.zeros(c, dtype=torch.uint8, device="cuda:0") for c in (capn, capw, capi)]
+        mn, mx = oracle.scene_bbox(pos)
+        res = nt.lbvh_build(n, d_tri.data_ptr(), pos.shape[0], d_pos.data_ptr(), mn, mx, 8, 0.001, bufs[0].data_ptr(), capn, bufs[1].data_ptr(), capw,
+                            bufs[2].data_ptr(), capi)
+        torch.cuda.synchronize()
+        dbvh = DeviceBvh(nt.HostBvh(bufs[0].cpu().numpy()[:res.nodesBytes].copy(), bufs[1].cpu().numpy()[:res.triWoopBytes].copy(),
+                                    bufs[2].cpu().numpy()[:res.triIndexBytes].view(np.int32).copy()))
+        rays = np.concatenate([scenes.box_rays(pos, 300000, seed=22), edge_rays(), scenes.primary_rays(cam, 320, 200)[0], scenes.random_rays(50000, seed=9)])
+    try:
+        for any_hit in (False, True):
+            ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit, threads=8)
+            for slice_ in (("1", "3", "8", "64", "0") if not any_hit else ("8",)):
+                monkeypatch.setenv("NTR_TRACE_SPLIT_SLICE", slice_)
+                nt.set_tunables()
+                for kernel in ("kepler_dynamic_fetch", "tesla_persistent_while_while"):
+                    for n in ((rays.shape[0], 65, 4097) if kernel == "kepler_dynamic_fetch" else (rays.shape[0],)):
+                        got, _ = gpu_trace(kernel, dbvh, rays[:n], any_hit)
+                        assert_parity(got, ref[:n], "%s %s split slice %s any_hit=%s n=%d" % (tree, kernel, slice_, any_hit, n))
+    finally:
+        monkeypatch.delenv("NTR_TRACE_SPLIT_SLICE", raising=False)
+        nt.set_tunables()
+
+
 def test_buffers_more_than_4_gib_apart_take_the_descriptor_fetch():
     """The flat fetch of the unified-step loop addresses node and triangle buffers from ONE scalar base with 32-bit lane offsets (round 5),
     so the library uses it only when both buffers lie inside one 4 GiB window; buffers further apart get the two-descriptor fetch.
