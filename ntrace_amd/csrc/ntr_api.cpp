@@ -935,7 +935,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
 
     // A hinted batch is predicted once (its hint then holds a measured order); its coherence words -- the mini-pool K -- are estimated again
     // on the hint's refresh launches by a probe of their own (three small launches, every 16th launch): rays drift.
-    const bool probeCoherence = !predScratch && hint && refresh && variant == NTR_VARIANT_PERRAY && !anyHit && tun.minipool < 0 && p.flatFetch &&
+    const bool probeCoherence = !predScratch && hint && refresh && variant == NTR_VARIANT_PERRAY && !anyHit && tun.minipool < 0 &&
                                 tun.predict != 0 && numRays >= tun.predictMinRays && nodesBytes >= (int64_t)tun.predictMinNodes * 64;
     if (probeCoherence) {
         rc = top_table_get(d_nodes, nodesBytes, s, false, &predTable);
@@ -982,7 +982,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
             launchBlocks = numBlocks * 4;
             // wave-private mini-pool: a wave owns K x 64 rays and refills its finished lanes from them.  K is decided on the device: the
             // prediction of this launch wrote it (incoherent batch: minipoolWide, else 1), or the batch's hint kept it from its first launch.
-            if (p.flatFetch && tun.minipool != 0 && !anyHit) {
+            if (tun.minipool != 0 && !anyHit) {
                 launchVariant = NTR_VARIANT_PERRAY_UNIFIED_MINI;
                 p.fetchThreshold = tun.minipoolThreshold;
                 p.poolKConst = tun.minipool > 0 ? tun.minipool : 1;

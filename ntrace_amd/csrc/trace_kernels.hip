@@ -804,6 +804,12 @@ __global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini(TraceParams p)
 {
     perray_body<1, false, true, true, true, false>(p);
 }
+// ... with the two-descriptor fetch, for a BVH whose node and triangle buffers do not lie inside one 4 GiB window (the flat fetch's
+// condition): such a batch keeps its ray pools -- without them an incoherent batch is 60 % slower (hairball box rays 3.6 -> 5.8 ms)
+__global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini_desc(TraceParams p)
+{
+    perray_body<1, false, true, false, true, false>(p);
+}
 #ifdef NTR_AB   // the same launch with ray splitting compiled in (A/B build only: measured, it does not pay here -- EXPERIMENTS.md round 5)
 __global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini_split(TraceParams p)
 {
@@ -1205,14 +1211,15 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
         if (p->flatFetch) hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, true, true>), dim3(numBlocks), dim3(64), 0, stream, *p);
         else hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, true, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
-    case NTR_VARIANT_PERRAY_UNIFIED_MINI:   // numBlocks counts waves of 64 rays; needs flatFetch
+    case NTR_VARIANT_PERRAY_UNIFIED_MINI:   // numBlocks counts waves of 64 rays
 #ifdef NTR_AB   // A/B build: the per-ray launch with ray splitting (measured: it loses where other waves still have bulk work, EXPERIMENTS.md round 5)
-        if (p->splitSlice > 0 && p->splitPerRay && !p->anyHit) {
+        if (p->splitSlice > 0 && p->splitPerRay && !p->anyHit && p->flatFetch) {
             hipLaunchKernelGGL(ntr::trace_bvh_perray_mini_split, dim3(numBlocks), dim3(64), 0, stream, *p);
             break;
         }
 #endif
-        hipLaunchKernelGGL(ntr::trace_bvh_perray_mini, dim3(numBlocks), dim3(64), 0, stream, *p);
+        if (p->flatFetch) hipLaunchKernelGGL(ntr::trace_bvh_perray_mini, dim3(numBlocks), dim3(64), 0, stream, *p);
+        else hipLaunchKernelGGL(ntr::trace_bvh_perray_mini_desc, dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_STATS:
         hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);

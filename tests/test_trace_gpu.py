@@ -411,8 +411,10 @@ def test_wave_private_mini_pool_changes_no_record(monkeypatch, tree):
                     {"NTR_TRACE_MINIPOOL": "5"}, {"NTR_TRACE_MINIPOOL": "7", "NTR_TRACE_MINIPOOL_THRESHOLD": "33"}, {"NTR_TRACE_MINIPOOL": "16"},
                     {"NTR_TRACE_MINIPOOL": "4", "NTR_TRACE_MINIPOOL_THRESHOLD": "1"}, {"NTR_TRACE_MINIPOOL": "2", "NTR_TRACE_MINIPOOL_THRESHOLD": "64"},
                     {"NTR_TRACE_MINIPOOL": "-1", "NTR_TRACE_MINIPOOL_WIDE": "4"}, {"NTR_TRACE_MINIPOOL": "-1", "NTR_TRACE_MINIPOOL_WIDE": "2"},
+                    # the pools with the two-descriptor fetch (what a BVH whose buffers lie more than 4 GiB apart gets)
+                    {"NTR_TRACE_MINIPOOL": "4", "NTR_TRACE_FLAT_FETCH": "0"}, {"NTR_TRACE_MINIPOOL": "-1", "NTR_TRACE_FLAT_FETCH": "0"},
                     {"NTR_TRACE_MINIPOOL": "0"}):
-            for k in ("NTR_TRACE_MINIPOOL", "NTR_TRACE_MINIPOOL_THRESHOLD", "NTR_TRACE_MINIPOOL_WIDE"):
+            for k in ("NTR_TRACE_MINIPOOL", "NTR_TRACE_MINIPOOL_THRESHOLD", "NTR_TRACE_MINIPOOL_WIDE", "NTR_TRACE_FLAT_FETCH"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
