@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ray splitting (trace_split.h): launch times of closest-hit batches with NTR_TRACE_SPLIT_SLICE off / on, every record compared with the
 first setting's (split off).  Batches: 2^21 box rays, 1080p primary, one 2^20-ray diffuse batch; device LBVH (SAH tree for atrium).
-usage: split_study.py <scene> [settings, comma separated: slice[/blocksPerCUIncoherent]] [kernels, comma separated]"""
+usage: split_study.py <scene> [settings, comma separated: slice[/blocksPerCUIncoherent][+NTR_NAME=value...]] [kernels, comma separated] [batches]"""
 import json
 import os
 import sys
@@ -20,6 +20,7 @@ dev = torch.device("cuda:0")
 scene = sys.argv[1] if len(sys.argv) > 1 else "courtyard"
 settings = (sys.argv[2] if len(sys.argv) > 2 else "0,8,16,32,0").split(",")
 kernels = (sys.argv[3] if len(sys.argv) > 3 else "kepler_dynamic_fetch").split(",")
+only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
 tri, pos, cam = scene_of(scene)
 if scene in ("atrium", "conference"):
     bvh = nt.sah_build(tri, pos, 1, 1)
@@ -47,15 +48,20 @@ nt.raygen_ao(b_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(
 batches["diffuse_2^20"] = (b_rays, cnt * ns)
 for kernel in kernels:
     for name, (d_r, n) in batches.items():
+        if only and not any(name.startswith(o) for o in only):
+            continue
         ref = None
         for sl in settings:
-            f = (sl.split("/") + ["3"])[:2]
-            nt.set_tunables(NTR_TRACE_SPLIT_SLICE=f[0], NTR_TRACE_BLOCKS_PER_CU_INCOHERENT=f[1])
+            # a setting: slice[/blocksPerCUIncoherent][+NTR_NAME=value...]
+            extra = dict(kv.split("=") for kv in sl.split("+")[1:])
+            f = (sl.split("+")[0].split("/") + ["3"])[:2]
+            nt.set_tunables(NTR_TRACE_SPLIT_SLICE=f[0], NTR_TRACE_BLOCKS_PER_CU_INCOHERENT=f[1], **extra)
             d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
             view.trace(kernel, n, False, d_r.data_ptr(), d_res.data_ptr())
             ts = [view.trace(kernel, n, False, d_r.data_ptr(), d_res.data_ptr()) for _ in range(5)]
             torch.cuda.synchronize()
             out = d_res.cpu().numpy().view(np.int32).reshape(-1, 4)
+            nt.set_tunables(**{k: None for k in extra})
             if ref is None:
                 ref = out.copy()
             diff = int((out != ref).any(axis=1).sum())
