@@ -129,6 +129,7 @@ def main(argv=None):
     ap.add_argument("--progress", default=None, help="file that receives the running totals about once a minute (survives a killed run)")
     args = ap.parse_args(argv)
     rng = np.random.default_rng(args.seed)
+    env_at_start = {k: v for k, v in os.environ.items() if k.startswith("NTR_")}
     cores = os.cpu_count() or 1
     t_end = time.time() + args.seconds
     tot = dict(rounds=0, sah_rounds=0, lbvh_rounds=0, lbvh_tree_mismatch=0, rays_compared=0, record_mismatches=0, counter_mismatches=0,
@@ -245,6 +246,9 @@ def main(argv=None):
         tot["triangles"] += int(tri.shape[0])
         del keep
         os.environ.pop("NTR_TRACE_PREDICT_MIN_RAYS", None)
+    # leave no tunable of the last round behind: run in-process (tests/test_fuzz_gpu.py) the draws would otherwise steer the tests that
+    # follow -- e.g. NTR_TRACE_PERRAY_UNIFIED=0 takes the per-ray launch off its pools, and the hand-off tests then hand nothing off
+    nt.set_tunables(**{k: env_at_start.get(k) for k in set(list(os.environ) + list(env_at_start)) if k.startswith("NTR_TRACE_") or k.startswith("NTR_LBVH_")})
     tot["failures"] = [f for f in failures if f["kind"] != "trace"][:20] + [f for f in failures if f["kind"] == "trace"][:6]
     tot["seed"] = args.seed
     tot["seconds"] = args.seconds
