@@ -599,14 +599,22 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
         }
     }
 
+    // the key differences at the cluster's two ends: from the keys (LDS near the tile), or -- after a meeting through memory -- carried
+    // along like the second stage does: the sibling's slot holds the difference at ITS far end, which is the parent's (one round trip
+    // per level of the border chain less than reading four keys from memory)
+    unsigned int dl = 0u, dr = 0u;
+    bool carried = false;
     for (;;) {
         if (l == 0 && r == n) {                       // only a single run can get here unmerged: all keys equal
             const unsigned int g = atomicAdd(c.runCount, 1u);
             c.runs[g] = make_int4(-1, 0, 0, n);
             break;
         }
-        const unsigned int dl = l > 0 ? (key(l - 1) ^ key(l)) : 0xFFFFFFFFu;
-        const unsigned int dr = r < n ? (key(r - 1) ^ key(r)) : 0xFFFFFFFFu;
+        if (!carried) {
+            dl = l > 0 ? (key(l - 1) ^ key(l)) : 0xFFFFFFFFu;
+            dr = r < n ? (key(r - 1) ^ key(r)) : 0xFFFFFFFFu;
+        }
+        carried = false;
         const bool sibRight = dr < dl;                // the sibling lies beyond r: this cluster is the left child
         const int B = sibRight ? r : l;
         const int hb = 31 - __clz((int)(sibRight ? dr : dl));
@@ -666,7 +674,7 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
                 AggSlotG mine;
 #pragma unroll
                 for (int k = 0; k < 6; k++) mine.b[k] = box[k];
-                mine.farKind = farKind; mine.refH = refH; mine.dFar = 0; mine.lbFar = sibRight ? lbL : lbR;
+                mine.farKind = farKind; mine.refH = refH; mine.dFar = sibRight ? dl : dr; mine.lbFar = sibRight ? lbL : lbR;
                 mine.pad[0] = mine.pad[1] = 0;
                 agg_store_slot(&c.slotG[2 * (size_t)B + side], mine);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slot has reached memory before the arrival is announced
@@ -678,6 +686,8 @@ __global__ __launch_bounds__(AGG_TILE) void lbvh_agglomerate_kernel(AggCtx c)
 #pragma unroll
             for (int k = 0; k < 6; k++) sibBox[k] = sib.b[k];
             sFarKind = sib.farKind; sRefH = sib.refH; sLbFar = sib.lbFar;
+            if (sibRight) dr = sib.dFar; else dl = sib.dFar;   // the parent's far end is the sibling's
+            carried = true;
         }
         // ---- second to arrive: form the parent ------------------------------------------------------------------------------
         if (agg_form_parent(c, rootSplit, sibRight, B, hb, l, r, kind, ref, h, lbL, lbR, box, (int)(sFarKind & 0x0FFFFFFFu), (int)(sFarKind >> 28),
@@ -1305,7 +1315,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
                 hipLaunchKernelGGL(lbvh_agglomerate_kernel<false>, dim3(aggTiles), dim3(AGG_TILE), 0, s, a);
             }
             pe.mark(5);
-            hipLaunchKernelGGL(lbvh_runs_kernel, dim3(2048), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(lbvh_runs_kernel, dim3(512), dim3(64), 0, s, a);
             pe.mark(6);
         } else {
         if (topMode == 0) {

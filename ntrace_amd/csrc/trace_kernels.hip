@@ -1213,7 +1213,7 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
         break;
     case NTR_VARIANT_PERRAY_UNIFIED_MINI:   // numBlocks counts waves of 64 rays
 #ifdef NTR_AB   // A/B build: the per-ray launch with ray splitting (measured: it loses where other waves still have bulk work, EXPERIMENTS.md round 5)
-        if (p->splitSlice > 0 && p->splitPerRay && !p->anyHit && p->flatFetch) {
+        if (p->splitSlice > 0 && p->splitPerRay && !p->anyHit && p->flatFetch && !p->cont) {   // (one experiment at a time: not with the tail hand-off's queue)
             hipLaunchKernelGGL(ntr::trace_bvh_perray_mini_split, dim3(numBlocks), dim3(64), 0, stream, *p);
             break;
         }

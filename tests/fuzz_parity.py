@@ -202,7 +202,10 @@ def main(argv=None):
                         # library ignores these): every threshold drawn at random, pools of one chunk included
                         NTR_TRACE_HANDOFF=int(rng.choice([0, 1, 1])) if HAS_HANDOFF else 0, NTR_TRACE_HANDOFF_BELOW=int(rng.integers(1, 65)),
                         NTR_TRACE_HANDOFF_MIN_QUEUE=int(rng.choice([1, 4, 16, 64])), NTR_TRACE_HANDOFF_KEEP_WAVES=int(rng.choice([0, 0, 64, 1024, 100000])),
-                        NTR_TRACE_HANDOFF_FLAGS=int(rng.integers(0, 4)))
+                        NTR_TRACE_HANDOFF_FLAGS=int(rng.integers(0, 4)),
+                        # ray splitting in the drain phase of the persistent kernels (trace_split.h): how often the lanes are looked at; in the
+                        # A/B build the per-ray / mini-pool launch may split too
+                        NTR_TRACE_SPLIT_SLICE=int(rng.choice([8, 8, 1, 2, 5, 32, 0])), NTR_TRACE_SPLIT_PERRAY=int(rng.choice([0, 1])) if HAS_HANDOFF else 0)
             nt.set_tunables(**loop)
             tot["handoff_rounds"] = tot.get("handoff_rounds", 0) + loop["NTR_TRACE_HANDOFF"]
             hint = nt.SchedHint() if sched >= 2 else None
