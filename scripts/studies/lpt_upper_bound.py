@@ -34,18 +34,35 @@ steps = per_ray_steps(host, rays)
 rng = np.random.default_rng(5)
 orders = {"buffer order": np.arange(nr)}
 orders["longest first (true steps)"] = np.argsort(-steps, kind="stable")
-for sg in (0.5, 1.0):
+for sg in (1.0,):
     orders["longest first, steps known to a factor e^+-%.1f" % sg] = np.argsort(-(steps * np.exp(rng.normal(0.0, sg, nr))), kind="stable")
 top = np.argsort(-steps, kind="stable")[: nr // 10]
 rest = np.setdiff1d(np.arange(nr), top, assume_unique=True)
 orders["longest tenth first, the rest in buffer order"] = np.concatenate([top, rest])
+# the same costs DEALT over the persistent kernel's 128 pool heads (buffer-order pool: head h owns the contiguous range
+# ((h & 7) * 16 + (h >> 3)) of nr / 128 rays and hands it out front to back in chunks of 64): sorted chunk c goes to head c % 128
+if nr % (128 * 64) == 0:
+    heads, shard = 128, nr // 128
+    for label, key in (("true steps", steps.astype(np.float64)), ("steps known to a factor e^+-1.0", steps * np.exp(rng.normal(0.0, 1.0, nr)))):
+        srt = np.argsort(-key, kind="stable")
+        p_ = np.arange(nr)
+        c = p_ // 64
+        h = c % heads
+        pos = ((h & 7) * (heads >> 3) + (h >> 3)) * shard + (c // heads) * 64 + (p_ % 64)
+        perm = np.empty(nr, dtype=np.int64)
+        perm[pos] = srt
+        orders["longest first DEALT over the pool heads (%s; prediction off, 3 workgroups per CU)" % label] = perm
+    orders["buffer order (prediction off, 3 workgroups per CU)"] = np.arange(nr)
 ref = None
 for name, perm in orders.items():
     d_r = up(rays[perm])
     out = {}
     for kernel in ("kepler_dynamic_fetch", "fermi_speculative_while_while"):
         res = torch.zeros(nr * 16, dtype=torch.uint8, device=dev)
-        nt.set_tunables()
+        if "prediction off" in name:
+            nt.set_tunables(NTR_TRACE_PREDICT_PERSISTENT=0, NTR_TRACE_BLOCKS_PER_CU=3)
+        else:
+            nt.set_tunables(NTR_TRACE_PREDICT_PERSISTENT=None, NTR_TRACE_BLOCKS_PER_CU=None)
         view.trace(kernel, nr, False, d_r.data_ptr(), res.data_ptr())
         ts = [view.trace(kernel, nr, False, d_r.data_ptr(), res.data_ptr()) for _ in range(5)]
         out[kernel.split("_")[0] + "_ms_min"] = round(min(ts) * 1e3, 3)
