@@ -126,7 +126,11 @@ NTR_API int ntr_query_config(const char* kernelName, NtrKernelConfig* config);
  *
  * Closest-hit launches of the per-ray kernel with at least 2^20 rays dispatch their 256-ray blocks in
  * predicted-cost order (two small launches in front of the trace kernel, inside the timed bracket; the
- * order never changes a result; NTR_TRACE_PREDICT=0 disables it).  An asynchronous call can be captured
+ * order never changes a result; NTR_TRACE_PREDICT=0 disables it).  Closest-hit launches of
+ * "kepler_dynamic_fetch" end with ray splitting: once the ray pool is dry, lanes without a ray traverse
+ * stack entries of the wave's live rays, and a helper's result counts only where it provably is the
+ * result the ray alone would have computed (csrc/trace_split.h; NTR_TRACE_SPLIT_SLICE=0 disables it) --
+ * records are the reference CPU tracer's either way.  An asynchronous call can be captured
  * into a HIP graph and replayed once a first call on that stream has allocated its scratch buffers. */
 NTR_API int ntr_trace_bvh(const char* kernelName, int32_t numRays, int32_t anyHit,
                           const NtrRay* d_rays, NtrRayResult* d_results,
