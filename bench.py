@@ -1013,6 +1013,11 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
             lview.trace(kn, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream)
             tr = [lview.trace(kn, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream) for _ in range(5)]
             per_kernel[kn] = float(np.mean(tr))
+        # the same launch without ray splitting in the drain phase (csrc/trace_split.h), for the record
+        nt.set_tunables(NTR_TRACE_SPLIT_SLICE=0)
+        lview.trace("kepler_dynamic_fetch", nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream)
+        split_off = float(np.mean([lview.trace("kepler_dynamic_fetch", nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream) for _ in range(3)]))
+        nt.set_tunables(NTR_TRACE_SPLIT_SLICE=None)
         sr = lview.trace_stats(args.kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream)
         best_kn = min(per_kernel, key=per_kernel.get)
         secr = per_kernel[best_kn]
@@ -1039,6 +1044,7 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
             "primary": {"rays": w * h, "ms": sec * 1e3, "mrays": w * h / sec / 1e6, "trace_stats": s10.as_dict(), "roofline": roof(s10, sec)},
             "incoherent": {"rays": nr, "what": "2^21 closest-hit rays, origins uniform in the bounding box, directions uniform on the sphere",
                            "ms_by_kernel": {k: v * 1e3 for k, v in per_kernel.items()}, "kernel": best_kn,
+                           "kepler_dynamic_fetch_without_ray_splitting_ms": split_off * 1e3,
                            "ms": secr * 1e3, "mrays": nr / secr / 1e6, "trace_stats": sr.as_dict(), "roofline": r_inc},
             "note": "HBM-side bytes (FETCH_SIZE / WRITE_SIZE / L2 hit rate) of these launches: profiles/*_trace_courtyard_* summaries",
             "lbvh_build": info10}
