@@ -207,6 +207,55 @@ def test_lbvh_depth_rule_at_every_depth_with_exact_extents(depth, dups, leaf):
     assert (max(sizes) > leaf) == want_big
 
 
+def test_ray_splitting_on_coincident_triangles_in_a_deep_tree(monkeypatch):
+    """The hardest case for the persistent kernels' ray splitting (csrc/trace_split.h): 3 000 IDENTICAL triangles in one Morton cell
+    below a chain of 18 ancestors.  Every ray that hits one of them hits all of them at the same t -- the record is the first one in
+    visiting order, nothing else distinguishes them --, every box of the run's median subtree is the same box, so both children are
+    entered at every level and the stacks run 12 entries deep over the chain.  Helpers' hits can only ever be valid under the exact
+    bound of the lone ray here; records must be the oracle's with the lanes looked at after every step, every 3 / 8 steps and never."""
+    import torch
+    from gpu_util import assert_parity, up
+    depth, dups, leaf = 18, 3000, 2
+    cells = [(0, 0, 0)] * dups
+    for k in range(30 - depth, 30):
+        c = [0, 0, 0]
+        c[k % 3] = 1 << (k // 3)
+        cells.append(tuple(c))
+    tri, pos = _cell_triangles(cells)
+    nodes, woop, idx, res, ref, (d_nodes, d_woop, d_idx) = check_against_oracle(tri, pos, leaf_size=leaf)
+    view = nt.BvhView(d_nodes.data_ptr(), res.nodesBytes, d_woop.data_ptr(), res.triWoopBytes, d_idx.data_ptr())
+    view.validate()
+    rng = np.random.default_rng(77)
+    n = 24000
+    rays = np.zeros(n, dtype=nt.RAY_DTYPE)
+    target = np.array([0.5, 0.5, 0.5]) + rng.uniform(-0.06, 0.06, size=(n, 3)) * [1, 1, 0]     # points on and just around the triangles
+    origin = target + rng.normal(size=(n, 3)) * rng.choice([0.3, 5.0, 300.0], size=(n, 1))
+    d = target - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for k, a in zip(("ox", "oy", "oz"), origin.T):
+        rays[k] = a.astype(np.float32)
+    for k, a in zip(("dx", "dy", "dz"), d.T):
+        rays[k] = a.astype(np.float32)
+    rays["tmin"] = 0.0
+    rays["tmax"] = 4000.0
+    exp, _ = oracle.trace(nodes, woop, idx, rays, any_hit=False, threads=8)
+    assert (exp["id"] >= 0).sum() > n // 8
+    d_rays = up(rays)
+    try:
+        for slice_ in ("1", "3", "8", "0"):
+            monkeypatch.setenv("NTR_TRACE_SPLIT_SLICE", slice_)
+            nt.set_tunables()
+            for m in (n, 4097, 65):
+                d_res = torch.zeros(m * 16, dtype=torch.uint8, device="cuda:0")
+                view.trace("kepler_dynamic_fetch", m, False, d_rays.data_ptr(), d_res.data_ptr())
+                torch.cuda.synchronize()
+                assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE), exp[:m], "coincident triangles, split slice %s, n=%d" % (slice_, m))
+        assert nt.trace_status() == 0
+    finally:
+        monkeypatch.delenv("NTR_TRACE_SPLIT_SLICE", raising=False)
+        nt.set_tunables()
+
+
 def test_trace_on_gpu_built_lbvh_matches_oracle_trace():
     """Parity hazard 8: Woop data from the GPU builder differs from the host
     woopifyTri, so parity is defined on the downloaded GPU-built buffers fed to both tracers."""
