@@ -1014,10 +1014,11 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
             tr = [lview.trace(kn, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream) for _ in range(5)]
             per_kernel[kn] = float(np.mean(tr))
         # the same launch without ray splitting in the drain phase (csrc/trace_split.h), for the record
+        split_env = os.environ.get("NTR_TRACE_SPLIT_SLICE")
         nt.set_tunables(NTR_TRACE_SPLIT_SLICE=0)
         lview.trace("kepler_dynamic_fetch", nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream)
         split_off = float(np.mean([lview.trace("kepler_dynamic_fetch", nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream) for _ in range(3)]))
-        nt.set_tunables(NTR_TRACE_SPLIT_SLICE=None)
+        nt.set_tunables(NTR_TRACE_SPLIT_SLICE=split_env)   # (back to what the run was started with)
         sr = lview.trace_stats(args.kernel, nr, False, d_rr.data_ptr(), d_ro.data_ptr(), stream)
         best_kn = min(per_kernel, key=per_kernel.get)
         secr = per_kernel[best_kn]
