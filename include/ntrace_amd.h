@@ -126,7 +126,7 @@ NTR_API int ntr_query_config(const char* kernelName, NtrKernelConfig* config);
  *
  * Closest-hit launches of the per-ray kernel with at least 2^20 rays dispatch their 256-ray blocks in
  * predicted-cost order (two small launches in front of the trace kernel, inside the timed bracket; the
- * order never changes a result; NTR_TRACE_PREDICT=0 disables it).  Closest-hit launches of
+ * order never changes a result; NTR_TRACE_PREDICT=0 disables it).  Launches of
  * "kepler_dynamic_fetch" end with ray splitting: once the ray pool is dry, lanes without a ray traverse
  * stack entries of the wave's live rays, and a helper's result counts only where it provably is the
  * result the ray alone would have computed (csrc/trace_split.h; NTR_TRACE_SPLIT_SLICE=0 disables it) --

@@ -150,7 +150,7 @@ static void tunables_load_locked()
     t.anyHitWaves = env_int("NTR_TRACE_ANYHIT_WAVES", 1);        // waves per workgroup of plain any-hit launches of the per-ray kernel (1, 2, 4): AO +1.7 % with 1
     t.flatFetch = env_int("NTR_TRACE_FLAT_FETCH", 1);             // unified-step loop: one group of global loads per iteration (0 = two masked groups of range-checked buffer loads)
     t.uniformPrologue = env_int("NTR_TRACE_UNIFORM_PROLOGUE", 1);  // per-ray kernels: scalar node fetches while the lanes of a fresh wave all hold the same inner node
-    t.splitSlice = env_int("NTR_TRACE_SPLIT_SLICE", 8);   // persistent kernels, unified-step loop, closest hit: once the pool is dry, lanes without a ray take over stack entries of the wave's live rays; looked at every N steps (0 = off)
+    t.splitSlice = env_int("NTR_TRACE_SPLIT_SLICE", 8);   // persistent kernels, unified-step loop: once the pool is dry, lanes without a ray take over stack entries of the wave's live rays; looked at every N steps (0 = off)
     t.splitPerRay = env_int("NTR_TRACE_SPLIT_PERRAY", 0); // A/B build only: the per-ray / mini-pool launch splits too
     t.minipool = env_int("NTR_TRACE_MINIPOOL", -1);              // closest-hit per-ray launches: rays owned by a wave / 64.  -1: decided per batch on the device (1, or minipoolWide when the prediction finds the batch incoherent); 0: the plain per-ray kernel; 1 ... 16: forced
     t.minipoolWide = env_int("NTR_TRACE_MINIPOOL_WIDE", -1);     // K of an incoherent batch: 2 / 4, or -1 = by tree size (4 from 32 MB of nodes up)

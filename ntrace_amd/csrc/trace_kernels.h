@@ -63,7 +63,7 @@ struct TraceParams {
     int32_t octant;          // per-ray kernel: specialise the slab test for waves whose rays share their direction signs
     int32_t flatFetch;       // unified-step loop: one group of global loads for nodes and triangles (needs both extents >= 64 bytes)
     int32_t uniformPrologue; // per-ray kernels, unified-step loop: scalar node fetches while every live lane of the wave holds the same inner node
-    int32_t splitSlice;      // persistent kernels, unified-step loop, closest hit: once the pool is dry, idle lanes take over stack entries of the wave's
+    int32_t splitSlice;      // persistent kernels, unified-step loop: once the pool is dry, idle lanes take over stack entries of the wave's
                              // live rays; the lanes are looked at every splitSlice steps (trace_split.h); 0 = off
     int32_t splitPerRay;     // A/B build only: the per-ray / mini-pool launch splits too
     unsigned long long* timeline;  // diagnostic: per-wave realtime stamps (scripts/timeline*.py), or null

@@ -745,7 +745,7 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
         else if (fastWave) traverse_unified<true, FLATF, 8, true, SPLIT>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0, slice);
         else traverse_unified<false, FLATF, 8, true, SPLIT>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0, slice);
         if (!SPLIT || splitSlice <= 0) break;
-        split_settle(split, r, node, st, hitAddr, hitU, hitV);
+        split_settle(split, r, node, st, hitAddr, hitU, hitV, false);
         if (myRay >= 0 && node == kSentinel && split.base == 0) {   // the ray's record goes out as soon as all of it is known: its lane is free
             store_result(p.results, p.triIndex, myRay, hitAddr, r.tmax, hitU, hitV);
             myRay = -1;
@@ -879,11 +879,11 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     // chunks of head h handed out statically: one per wave of every block with blockIdx % numHeads == h
     auto static_rays = [&](int h) { return ((numBlocksEff - h + numHeads - 1) / numHeads) * WAVES * p.chunk; };
     LaneStats ls = {0u, 0u, 0u};
-    // drain phase (unified-step loop, closest hit): once the pool is dry, idle lanes take over parts of the wave's rays (trace_split.h)
+    // drain phase (unified-step loop): once the pool is dry, idle lanes take over parts of the wave's rays (trace_split.h)
     SplitState split;
     split_reset(split);
     bool splitOn = false;             // wave-uniform
-    const int splitSlice = (UNIFIED && !anyHit) ? p.splitSlice : 0;
+    const int splitSlice = UNIFIED ? p.splitSlice : 0;
 
     // diagnostic stamps (NTR_TRACE_TIMELINE): wave start, end, cycles spent refilling, refill count
     unsigned long long tlStart = 0, tlRefill = 0, tlCount = 0, tlRays = 0;
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
             const int slice = splitOn ? splitSlice : 0x7FFFFFFF;   // drain phase with splitting: the lanes are looked at again every `slice` steps
             if (fastWave) traverse_unified<true, FLATF, 8, false, true>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold, slice);
             else traverse_unified<false, FLATF, 8, false, true>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold, slice);
-            if (splitOn) split_settle(split, r, node, st, hitAddr, hitU, hitV);
+            if (splitOn) split_settle(split, r, node, st, hitAddr, hitU, hitV, anyHit);
         } else if (fastWave) traverse<true, false, true>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
         else traverse<false, false, true>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
 
@@ -1156,7 +1156,7 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
         if (fastWave) traverse_unified<true, FLATF, 8, false, SPLIT>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, !stopEarly, stopBelow, slice);
         else traverse_unified<false, FLATF, 8, false, SPLIT>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, !stopEarly, stopBelow, slice);
-        if (SPLIT && splitOn) split_settle(split, r, node, st, hitAddr, hitU, hitV);
+        if (SPLIT && splitOn) split_settle(split, r, node, st, hitAddr, hitU, hitV, anyHit);
         // ---- retire finished rays (an owner whose helpers are still out waits for their reports) ------------------------------
         if (rayIdx >= 0 && node == kSentinel && (!SPLIT || !splitOn || split.base == 0)) {
             store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);

@@ -9,7 +9,7 @@
 // stack, the entry at the BOTTOM is the subtree the ray would visit last (usually the largest: the far child of a node near the
 // root), and an idle lane can traverse it at once.
 //
-// Exactness (closest hit only; any-hit launches are left alone).  The reference's record is NOT the smallest t over all triangles: a
+// Exactness.  The reference's closest-hit record is NOT the smallest t over all triangles: a
 // node is skipped when its box lies beyond the closest hit so far, boxes and triangle tests round differently, and a triangle a few ulp
 // closer than the record can sit in a skipped node (ten of 2^21 box rays on the atrium tree differ when parts are merged by t).  The
 // record is a function of the traversal's HISTORY, so a helper's hit counts only where the history is provably the lone ray's:
@@ -26,6 +26,10 @@
 // and follow), the slot is marked, and the donor traverses that entry itself when its turn comes, with the true bound (a closer hit
 // exists by then, so that is usually over at the entry's root).  By induction over the helpers of helpers every lane ends with the
 // lone ray's result for its part, and the ray's owner writes the record.
+// Any-hit launches (the record is the FIRST hit in visiting order, and the ray ends there) follow the same rules: no lane holds a hit
+// while it is on its way, so every bound is the ray's own tmax; a helper's hit is the ray's record exactly when everything before its
+// entry has finished without one -- the acceptance rule above --, and a lane that has a hit, its own or one it took over, drops the
+// slots it still has out instead of settling them: the lone ray would never have got there.
 #pragma once
 
 namespace ntr {
@@ -63,7 +67,8 @@ __device__ __forceinline__ void split_drop_top(SplitState& s, LaneStack& st)
 enum { SPLIT_NONE = 0, SPLIT_NOHIT = 1, SPLIT_GIVEUP = 2, SPLIT_ACCEPT = 3 };
 
 // What the helpers have to say, and what the lanes that have finished their own part do about their dead zone.
-__device__ __forceinline__ void split_settle(SplitState& s, RayRegs& r, int& node, LaneStack& st, int& hitAddr, float& hitU, float& hitV)
+__device__ __forceinline__ void split_settle(SplitState& s, RayRegs& r, int& node, LaneStack& st, int& hitAddr, float& hitU, float& hitV,
+                                             bool anyHit)
 {
     const int lane = threadIdx.x & 63;
     if (__ballot(s.parent >= 0 || s.base > 0) == 0ull) return;
@@ -106,6 +111,11 @@ __device__ __forceinline__ void split_settle(SplitState& s, RayRegs& r, int& nod
     }
     // ---- lanes that have finished what they kept settle their dead zone from the top: the lone ray's order -----------------------
     while (node == kSentinel && s.base > 0) {
+        if (anyHit && hitAddr >= 0) {             // any hit: the ray has ended; what is still out is of no interest (its helpers become orphans)
+            s.epoch++;
+            s.base = 0; s.masks = 0u; s.topEntry = kSentinel;
+            break;
+        }
         const unsigned int out = 1u << s.base, redo = 1u << (16 + s.base);
         if (s.masks & out) break;                 // its helper is still out
         if (s.masks & redo) {                     // came back unsettled: traversed here, now, with the true bound

@@ -46,6 +46,9 @@ b_a = torch.zeros(cnt * ns, dtype=torch.int32, device=dev)
 nt.raygen_ao(b_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(), d_res0.data_ptr(), d_nrm.data_ptr(), min(900000, npr - cnt), cnt, ns,
              cam["far"], 0xFFF2D5E4)
 batches["diffuse_2^20"] = (b_rays, cnt * ns)
+# the same rays as an any-hit batch (shadow-ray like: long any-hit rays), and the box rays as any-hit
+batches["anyhit_diffuse_2^20"] = (b_rays, cnt * ns)
+batches["anyhit_box_rays_2^21"] = batches["box_rays_2^21"]
 for kernel in kernels:
     for name, (d_r, n) in batches.items():
         if only and not any(name.startswith(o) for o in only):
@@ -57,8 +60,9 @@ for kernel in kernels:
             f = (sl.split("+")[0].split("/") + ["3"])[:2]
             nt.set_tunables(NTR_TRACE_SPLIT_SLICE=f[0], NTR_TRACE_BLOCKS_PER_CU_INCOHERENT=f[1], **extra)
             d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
-            view.trace(kernel, n, False, d_r.data_ptr(), d_res.data_ptr())
-            ts = [view.trace(kernel, n, False, d_r.data_ptr(), d_res.data_ptr()) for _ in range(5)]
+            anyh = name.startswith("anyhit")
+            view.trace(kernel, n, anyh, d_r.data_ptr(), d_res.data_ptr())
+            ts = [view.trace(kernel, n, anyh, d_r.data_ptr(), d_res.data_ptr()) for _ in range(5)]
             torch.cuda.synchronize()
             out = d_res.cpu().numpy().view(np.int32).reshape(-1, 4)
             nt.set_tunables(**{k: None for k in extra})

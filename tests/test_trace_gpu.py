@@ -523,7 +523,8 @@ def test_ray_splitting_changes_no_record(monkeypatch, tree):
     would bring along -- merging parts by t differs from the reference on ~5 of every 10^6 box rays of the atrium tree, which is why
     that tree is here at 2^20 rays.  Records must be the oracle's with the lanes looked at after every step, every 3 / 8 / 64 steps and
     never; ragged counts (waves that start with most lanes idle), edge-case rays (non-finite values: the helpers copy the generic slab
-    path's ray too), closest hit (splits) and any hit (must not), unified-step and while-while persistent kernels."""
+    path's ray too), closest hit and any hit (the record is then the FIRST hit in visiting order: a helper's hit counts only when
+    everything before its entry ended without one), unified-step and while-while persistent kernels."""
     from gpu_util import DeviceBvh, assert_parity, gpu_trace
     if tree.startswith("atrium"):
         tri, pos, cam = scenes.atrium()
@@ -547,7 +548,7 @@ def test_ray_splitting_changes_no_record(monkeypatch, tree):
     try:
         for any_hit in (False, True):
             ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit, threads=8)
-            for slice_ in (("1", "3", "8", "64", "0") if not any_hit else ("8",)):
+            for slice_ in (("1", "3", "8", "64", "0") if not any_hit else ("1", "8", "0")):
                 monkeypatch.setenv("NTR_TRACE_SPLIT_SLICE", slice_)
                 nt.set_tunables()
                 for kernel in ("kepler_dynamic_fetch", "tesla_persistent_while_while"):
