@@ -49,6 +49,12 @@ batches["diffuse_2^20"] = (b_rays, cnt * ns)
 # the same rays as an any-hit batch (shadow-ray like: long any-hit rays), and the box rays as any-hit
 batches["anyhit_diffuse_2^20"] = (b_rays, cnt * ns)
 batches["anyhit_box_rays_2^21"] = batches["box_rays_2^21"]
+# ... and a short-ray AO batch (radius as in scripts/workloads.py)
+diag = float(np.linalg.norm(pos.max(0).astype(np.float64) - pos.min(0)))
+a_rays = torch.zeros(cnt * ns * 32, dtype=torch.uint8, device=dev)
+nt.raygen_ao(a_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(), d_res0.data_ptr(), d_nrm.data_ptr(), min(900000, npr - cnt), cnt, ns,
+             5.0 if scene == "atrium" else 5.0 * diag / 4300.0, 0xFFF2D5E4)
+batches["anyhit_ao_2^20"] = (a_rays, cnt * ns)
 for kernel in kernels:
     for name, (d_r, n) in batches.items():
         if only and not any(name.startswith(o) for o in only):
