@@ -54,12 +54,12 @@ class _HostBvhInfo(C.Structure):
 
 
 def lib_path():
-    # NTR_LIB_OVERRIDE: A/B experiments with alternative builds (scripts/ only)
+    # NTR_LIB_OVERRIDE: another build of the library (scripts/ only: a patched build for an A/B run, scripts/studies/rejected_patches/)
     return os.environ.get("NTR_LIB_OVERRIDE") or os.path.join(_HERE, "libntrace_amd.so")
 
 
 _lib = None
-_libs = {}   # path -> loaded CDLL (use_library switches between the product library and the experiment build inside one process)
+_libs = {}   # path -> loaded CDLL (use_library switches between two builds of the library inside one process: scripts/studies/lib_ab.py)
 
 # every symbol include/ntrace_amd.h declares: (name, restype, argtypes)
 _vp, _i32, _i64, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
@@ -135,8 +135,6 @@ SYMBOLS = [
     ("ntr_host_bvh_wrap", C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, C.POINTER(_vp)]),
     ("ntr_host_bvh_trace", C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, C.POINTER(TraceStats)]),
 ]
-# entry points that exist only in the A/B build (libntrace_amd_ab.so; ntrace_amd/csrc/ntr_ab.h)
-AB_SYMBOLS = [("ntr_trace_handoff_counts", C.c_int, [_vp, C.POINTER(_u32 * 3)])]
 
 
 def _load(path):
@@ -156,11 +154,6 @@ def _load(path):
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        for name, res, args in AB_SYMBOLS:   # entry points of the A/B build only (ntrace_amd/csrc/ntr_ab.h)
-            fn = getattr(L, name, None)
-            if fn is not None:
-                fn.restype = res
-                fn.argtypes = args
         _libs[path] = L
     return _libs[path]
 
@@ -173,19 +166,9 @@ def lib():
     return _lib
 
 
-def exp_lib_path():
-    return os.path.join(_HERE, "libntrace_amd_exp.so")
-
-
-def ab_lib_path():
-    """The A/B build (`make -C ntrace_amd/csrc ab`, -DNTR_AB): the product plus measured-and-rejected experiments (the tail hand-off)."""
-    return os.path.join(_HERE, "libntrace_amd_ab.so")
-
-
 def use_library(path=None):
-    """Tests / scripts only: make `path` (default: the product library, or NTR_LIB_OVERRIDE) the library every wrapper of this
-    module calls.  The experiment build (exp_lib_path(): diagnostic hooks + the superseded LBVH build paths kept for A/B runs) and
-    the product library can both be loaded in one process; each has its own tunables and workspaces."""
+    """Scripts only: make `path` (default: the product library, or NTR_LIB_OVERRIDE) the library every wrapper of this module calls.
+    Two builds of the library can be loaded in one process (an A/B run of a patched build); each has its own tunables and workspaces."""
     global _lib
     _lib = _load(path or lib_path())
     return _lib
@@ -249,16 +232,6 @@ def trace_status(stream=0):
     bits = _u32(0)
     _check(lib().ntr_trace_status(_vp(stream), C.byref(bits)))
     return int(bits.value)
-
-
-def trace_handoff_counts(stream=0):
-    """ntr_trace_handoff_counts (A/B build only: use_library(ab_lib_path())): (continuations appended, continuations taken up, queue
-    capacity) of the stream's last pooled launch."""
-    if not hasattr(lib(), "ntr_trace_handoff_counts"):
-        raise NtrError(-1, "the tail hand-off lives in the A/B build only (make -C ntrace_amd/csrc ab; use_library(ab_lib_path()))")
-    c = (_u32 * 3)()
-    _check(lib().ntr_trace_handoff_counts(_vp(stream), C.byref(c)))
-    return int(c[0]), int(c[1]), int(c[2])
 
 
 def selftest_gather_rate(table_bytes, waves, lanes_per_wave=64, steps=256, stream=0):
@@ -364,17 +337,6 @@ def set_tunables(**kv):
         else:
             os.environ[k] = str(v)
     _check(lib().ntr_tunables_reload())
-
-
-def experiment_hooks(timeline=0, order=0):
-    """Diagnostic hooks (per-wave timeline buffer, explicit block order) -- only in builds made with
-    `make -C ntrace_amd/csrc exp`; the shipped library does not export them."""
-    L = lib()
-    if not hasattr(L, "ntr_experiment_hooks"):
-        raise NtrError(-1, "this libntrace_amd.so was built without -DNTR_EXPERIMENTS (build `make -C ntrace_amd/csrc exp`, run with NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_exp.so)")
-    L.ntr_experiment_hooks.restype = C.c_int
-    L.ntr_experiment_hooks.argtypes = [_vp, _vp]
-    _check(L.ntr_experiment_hooks(_vp(timeline), _vp(order)))
 
 
 def bvh_leaf_depths(d_nodes, nodes_bytes, d_woop, woop_bytes, d_tri_index, num_tris, d_depth_by_tri, stream=0):

@@ -17,8 +17,8 @@
 //   lbvh_gather_box_kernel (box terms in sorted order), lbvh_top_kernel (one workgroup splits ranges larger than the split size level
 //   by level), lbvh_subtree_kernel (one workgroup per smaller range: topology in an LDS entry list, one pair of global atomics, bottom-up
 //   refit), lbvh_top_refit_kernel, lbvh_place_kernel (Woop rows straight into the slots the leaves reserved).
-// The round-1 / round-2 A/B paths (one launch per level, three-kernel sort passes, cell-table top pass) live in lbvh_kernels_exp.h and are
-// compiled only with -DNTR_EXPERIMENTS into libntrace_amd_exp.so (`make exp`); tests/test_lbvh_gpu.py runs them against that library.
+// The round-1 / round-2 paths (one launch per level, three-kernel sort passes, cell-table top pass) are kept as a patch:
+// scripts/studies/rejected_patches/lbvh_superseded_paths.patch.
 // This file is the shipped bottom-up pipeline and the build driver (ntr_lbvh_build); lbvh_workspace.h holds the driver's host helpers.
 //
 // The tree is the reference's tree: same split rule (highest differing Morton bit at or below the
@@ -70,11 +70,6 @@ struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
 struct __attribute__((packed, aligned(4))) TriVerts { V3 v[3]; };
 static_assert(sizeof(TriVerts) == 36, "TriVerts must be 36 bytes");
 
-#ifdef NTR_EXPERIMENTS
-#define NTR_LBVH_EXP_SECTION 1
-#include "lbvh_kernels_exp.h"
-#undef NTR_LBVH_EXP_SECTION
-#endif
 // Morton codes as lbvh_morton_kernel, fused with everything else that one pass over the mesh can produce:
 //   * the digit histograms of all four radix passes (LDS, then one global add per non-empty bin and workgroup), so
 //     that the sort is four one-sweep launches and nothing else;
@@ -85,10 +80,6 @@ static_assert(sizeof(TriVerts) == 36, "TriVerts must be 36 bytes");
 // Grid-stride over a bounded number of workgroups, so that the histogram flush stays at <= 2048 x 1024 atomics.
 constexpr int MORTON_THREADS = 256;
 constexpr int MORTON_MAX_BLOCKS = 2048;
-#ifdef NTR_EXPERIMENTS
-constexpr int TOP_CELL_BITS = 14;                      // cell-table top pass: the top of the tree is derived from the keys' upper 14 bits
-constexpr int TOP_CELLS = 1 << TOP_CELL_BITS;
-#endif
 
 __global__ __launch_bounds__(MORTON_THREADS) void lbvh_morton_hist_kernel(int n, const int* __restrict__ tri, const float* __restrict__ pos,
                                                                           F3 lo, F3 step, float eps, unsigned int* __restrict__ keys,
@@ -165,34 +156,7 @@ __device__ __forceinline__ void woop_rows(const int* __restrict__ tri, const flo
                     pos[3 * i2 + 1], pos[3 * i2 + 2], r0, r1, r2);
 }
 
-#ifdef NTR_EXPERIMENTS
-#define NTR_LBVH_EXP_SECTION 2
-#include "lbvh_kernels_exp.h"
-#undef NTR_LBVH_EXP_SECTION
-#endif
-
-#ifdef NTR_EXPERIMENTS
-#define NTR_LBVH_EXP_SECTION 3
-#include "lbvh_kernels_exp.h"
-#undef NTR_LBVH_EXP_SECTION
-#endif
-#define NTR_LBVH_TOPDOWN_PART 1
 #include "lbvh_topdown.h"   // the top-down fallback (small scenes, oversize leaves)
-#undef NTR_LBVH_TOPDOWN_PART
-#ifdef NTR_EXPERIMENTS
-#define NTR_LBVH_EXP_SECTION 4
-#include "lbvh_kernels_exp.h"
-#undef NTR_LBVH_EXP_SECTION
-#endif
-
-#define NTR_LBVH_TOPDOWN_PART 2
-#include "lbvh_topdown.h"   // the top-down fallback (small scenes, oversize leaves)
-#undef NTR_LBVH_TOPDOWN_PART
-#ifdef NTR_EXPERIMENTS
-#define NTR_LBVH_EXP_SECTION 5
-#include "lbvh_kernels_exp.h"
-#undef NTR_LBVH_EXP_SECTION
-#endif
 
 // =====================================================================================================================
 // Bottom-up ("agglomerative") emit + refit in one pass, indices by prefix counts.
@@ -1058,11 +1022,6 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
 using namespace ntr;
 
 #include "lbvh_workspace.h"   // PhaseEvents, the per-device workspace, Carver
-#ifdef NTR_EXPERIMENTS
-#define NTR_LBVH_EXP_SECTION 6
-#include "lbvh_kernels_exp.h"
-#undef NTR_LBVH_EXP_SECTION
-#endif
 
 extern "C" {
 
@@ -1095,22 +1054,11 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     hipStream_t s = (hipStream_t)stream;
     const int n = numTris;
     if (n >= (1 << 28)) return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: at most 2^28 - 1 triangles");
-#ifdef NTR_EXPERIMENTS
-    const int nb = (n + SORT_TILE - 1) / SORT_TILE;
-#endif
     // one-sweep tiles: 2048 keys while the launch is latency-bound; 6144 / 8192 for large inputs (fewer tiles to look back over, longer
     // runs per digit in the scatter: 10 M keys 80 -> 71 us per pass, scripts/jobs/gpu_job_r02sort.sh)
     const int osItems = n >= (1 << 23) ? 32 : (n >= (1 << 21) ? 24 : 8);
     const int osTiles = (n + OS_THREADS * osItems - 1) / (OS_THREADS * osItems);
     const Tunables tun = tunables();
-#ifdef NTR_EXPERIMENTS   // A/B scaffolding of rounds 1-2, compiled into libntrace_amd_exp.so only (tests/test_lbvh_gpu.py runs them against it)
-    const bool levelSync = tun.lbvhLevelSync != 0;
-    const bool legacySort = levelSync || tun.lbvhLegacySort != 0;
-    const bool cellsTop = tun.lbvhEmit == 1;
-    const bool legacyTop = tun.lbvhLegacyTop != 0;
-#else
-    constexpr bool levelSync = false, legacySort = false, cellsTop = false, legacyTop = false;
-#endif
     if (n >= (1 << 27)) return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: at most 2^27 - 1 triangles");
 
     int spillSize = tun.lbvhSplit;
@@ -1119,21 +1067,18 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     // 0: the whole tree is one hand-over root (scenes of at most `spill` triangles: one subtree workgroup);
     // 2: level-by-level top pass with key probes + subtree workgroups (n <= leafSize: a root over two leaves; leaves of more than
     //    AGG_HALO triangles: the bottom-up path keeps that many neighbours of a tile in LDS);
-    // 3: bottom-up emit with ranked indices -- the default; [experiments: 1 = cell-table top + subtree workgroups]
-    const int topMode = n <= spillSize ? 0 : ((legacyTop || n <= leafSize || leafSize > AGG_HALO) ? 2 : (cellsTop ? 1 : 3));
-    const bool bottomUp = !levelSync && topMode == 3;
-    const bool topDown = !levelSync && topMode != 3;
+    // 3: bottom-up emit with ranked indices -- the default
+    const int topMode = n <= spillSize ? 0 : ((n <= leafSize || leafSize > AGG_HALO) ? 2 : 3);
+    const bool bottomUp = topMode == 3;
+    const bool topDown = topMode != 3;
 
     // workspace: only the slices of the path that runs are reserved (bottom-up: about 175 B per triangle, top-down: about 100 B)
     Carver cv;
     auto takeIf = [&](bool cond, size_t bytes) { return cv.take(cond ? bytes : 0); };
     const size_t oKeysA = cv.take((size_t)n * 4), oKeysB = cv.take((size_t)n * 4);
     const size_t oIdxA = cv.take((size_t)n * 4), oIdxB = cv.take((size_t)n * 4);
-    const size_t oWoop = takeIf(levelSync || topDown, (size_t)n * (levelSync ? 48 : 24));  // per-level path: Woop rows in mesh order; top-down path: box terms in mesh order
-    const size_t oQ0 = takeIf(levelSync || topDown, ((size_t)n + 2) * 16), oQ1 = takeIf(levelSync || topDown, ((size_t)n + 2) * 16);
-#ifdef NTR_EXPERIMENTS
-    const size_t oHist = takeIf(legacySort, ((size_t)nb * 256 + 256) * 4);
-#endif
+    const size_t oWoop = takeIf(topDown, (size_t)n * 24);  // top-down path: box terms in mesh order
+    const size_t oQ0 = takeIf(topDown, ((size_t)n + 2) * 16), oQ1 = takeIf(topDown, ((size_t)n + 2) * 16);
     // cleared by ONE memset per build: builder state, one-sweep digit histograms, error flag and tickets
     const size_t oState = cv.take(sizeof(LbvhState));
     const size_t oOsHist = cv.take(4 * 256 * 4);
@@ -1151,9 +1096,6 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oSubList = takeIf(topDown, ((size_t)n / 2 + 2) * 16);
     const size_t oTopLst = takeIf(topDown, ((size_t)n + 2) * 4);
     const size_t oTriBox = takeIf(topDown, (size_t)n * 24), oTriOut = takeIf(topDown, (size_t)n * 4);
-#ifdef NTR_EXPERIMENTS
-    const size_t oCell = takeIf(topMode == 1, ((size_t)TOP_CELLS + 1) * 4), oTopIdx = takeIf(topMode == 1, (size_t)TOP_HEAP * 4);
-#endif
     // bottom-up emit: slots of the border meetings, exported roots, vertex records, parent indices, runs, leaf / run marks and their counts
     const size_t oSlot = takeIf(bottomUp, ((size_t)n + 1) * 96);
     const size_t oExports = takeIf(bottomUp, (size_t)aggTiles * AGG_EXPORT_CAP * sizeof(AggExport));
@@ -1183,32 +1125,18 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     F3 step = {(sceneMax[0] - sceneMin[0]) / 1024.0f, (sceneMax[1] - sceneMin[1]) / 1024.0f, (sceneMax[2] - sceneMin[2]) / 1024.0f};
     unsigned int *kIn = (unsigned int*)(ws + oKeysA), *kOut = (unsigned int*)(ws + oKeysB);
     int *vIn = (int*)(ws + oIdxA), *vOut = (int*)(ws + oIdxB);
-#ifdef NTR_EXPERIMENTS
-    if (levelSync) {
-        hipLaunchKernelGGL(lbvh_morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, lo, step, kIn, vIn);
-    } else
-#endif
     {
         int mb = (n + MORTON_THREADS * 4 - 1) / (MORTON_THREADS * 4);
         if (mb > MORTON_MAX_BLOCKS) mb = MORTON_MAX_BLOCKS;
         hipLaunchKernelGGL(lbvh_morton_hist_kernel, dim3(mb), dim3(MORTON_THREADS), 0, s, n, d_triVtxIndex, d_vtxPos, lo, step, epsilon, kIn, vIn,
                            bottomUp ? (float2*)nullptr : (float2*)(ws + oWoop), bottomUp ? (TriVerts*)(ws + oTriVerts) : (TriVerts*)nullptr, osHist,
-                           (unsigned int*)(ws + oOsState), legacySort ? 0 : osTiles * 256);
+                           (unsigned int*)(ws + oOsState), osTiles * 256);
     }
     pe.mark(1);
 
     // L2: stable radix sort by key, 4 passes of 8 bits (the 30-bit code fits)
     for (int pass = 0; pass < 4; pass++) {
         const int shift = pass * 8;
-#ifdef NTR_EXPERIMENTS
-        if (legacySort) {
-            unsigned int* hist = (unsigned int*)(ws + oHist);
-            hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, 1, shift, hist, nb);
-            hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(256), dim3(256), 0, s, hist, nb, hist + (size_t)nb * 256);
-            hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nb), dim3(SORT_THREADS), 0, s, n, kIn, (const int*)vIn, kOut, vOut, 1,
-                               shift, (const unsigned int*)hist, (const unsigned int*)hist + (size_t)nb * 256, nb);
-        } else
-#endif
         {
             if (osItems == 32)
                 hipLaunchKernelGGL((onesweep_pass_kernel<32, 0>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
@@ -1230,31 +1158,15 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const unsigned int* keys = kIn;  // after 4 passes the sorted data is back in the A buffers
     const int* triSorted = vIn;
 
-    // L4: Woop rows in original triangle order (per-level path), or the per-triangle box terms in sorted order plus the
-    // cell table of the top pass (subtree path; its Woop rows are produced by lbvh_place_kernel once the leaves have their slots)
-#ifdef NTR_EXPERIMENTS
-    if (levelSync)
-        hipLaunchKernelGGL(lbvh_woop_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_triVtxIndex, d_vtxPos, (float4*)(ws + oWoop));
-    else if (topMode != 3)
-        hipLaunchKernelGGL(lbvh_gather_box_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, keys, triSorted, (const float2*)(ws + oWoop),
-                           (float2*)(ws + oTriBox), topMode == 1 ? (unsigned int*)(ws + oCell) : (unsigned int*)nullptr);
-#else
+    // L4 (top-down path only): the per-triangle box terms in sorted order; its Woop rows are produced by lbvh_place_kernel once the leaves
+    // have their slots.  The bottom-up path writes Woop rows inside the agglomerate kernel.
     if (topMode != 3)
-        hipLaunchKernelGGL(lbvh_gather_box_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, keys, triSorted, (const float2*)(ws + oWoop),
-                           (float2*)(ws + oTriBox), (unsigned int*)nullptr);
-#endif
+        hipLaunchKernelGGL(lbvh_gather_box_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, triSorted, (const float2*)(ws + oWoop), (float2*)(ws + oTriBox));
     pe.mark(3);
 
     // L3 + L5: emit and refit
     const unsigned int nodeCap = (unsigned int)(nodesCapacity / 64);
     LbvhState h;
-#ifdef NTR_EXPERIMENTS
-    if (levelSync) {
-        const int rc = lbvh_levelsync_emit_refit(s, n, leafSize, epsilon, state, h, keys, triSorted, ws, oWoop, oQ0, oQ1, d_nodes, nodeCap, d_triWoop, d_triIndex,
-                                                 d_triVtxIndex, d_vtxPos, pe);
-        if (rc != NTR_OK) return rc;
-    } else
-#endif
     {
         EmitCtx c;
         c.st = state; c.keys = keys; c.triBox = (const float2*)(ws + oTriBox); c.triOut = (int*)(ws + oTriOut);
@@ -1327,12 +1239,6 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             NTR_HIP(hipMemcpyAsync(state, &init, sizeof(init), hipMemcpyHostToDevice, s));
             const int root[4] = {0, 0, n, 0};
             NTR_HIP(hipMemcpyAsync(c.subList, root, 16, hipMemcpyHostToDevice, s));
-#ifdef NTR_EXPERIMENTS
-        } else if (topMode == 1) {
-            NTR_HIP(hipFuncSetAttribute((const void*)lbvh_top_cells_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TopLds)));
-            hipLaunchKernelGGL(lbvh_top_cells_kernel, dim3(1), dim3(TOP_THREADS), sizeof(TopLds), s, c, n, (const unsigned int*)(ws + oCell),
-                               (int*)(ws + oTopIdx), q0, q1, (int*)(ws + oTopLst));
-#endif
         } else {
             hipLaunchKernelGGL(lbvh_top_kernel, dim3(1), dim3(TOP_THREADS), 0, s, c, n, q0, q1, (int*)(ws + oTopLst));
         }
@@ -1346,12 +1252,6 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             if (rc != NTR_OK) return rc;
         }
         pe.mark(5);
-#ifdef NTR_EXPERIMENTS
-        if (topMode == 1)
-            hipLaunchKernelGGL(lbvh_top_cells_refit_kernel, dim3(1), dim3(TOP_THREADS), 0, s, (const LbvhState*)state, (const int*)(ws + oTopLst),
-                               (const int*)(ws + oTopIdx), (int*)d_nodes);
-        else
-#endif
         if (topMode == 2)
             hipLaunchKernelGGL(lbvh_top_refit_kernel, dim3(1), dim3(TOP_THREADS), 0, s, (const LbvhState*)state, (const int*)(ws + oTopLst),
                                (int*)d_nodes);
@@ -1374,15 +1274,8 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     if (h.overflow & 4u) return set_error(NTR_ERR_HIP, "ntr_lbvh_build: the leaf marks disagree with the depth of a run of equal Morton codes (internal error)");
     if (h.overflow) return set_error(NTR_ERR_OVERFLOW, "ntr_lbvh_build: node buffer overflow");
     if (sortErr) return set_error(NTR_ERR_HIP, "ntr_lbvh_build: a chained scan timed out waiting for a predecessor tile (status %u)", sortErr);
-    int numLevels = 0;
-    unsigned int numNodes = 0;
-    if (levelSync) {
-        while (numLevels < 31 && h.lvlNodes[numLevels] > 0) { numNodes += h.lvlNodes[numLevels]; numLevels++; }
-    } else {
-        numNodes = h.nodeCount;
-        numLevels = (int)h.maxLevel;
-    }
-    (void)legacySort; (void)cellsTop;
+    const unsigned int numNodes = h.nodeCount;
+    const int numLevels = (int)h.maxLevel;
 
     // Compact child references are S32 byte offsets below the sentinel 0x76543210 (CudaBVH.hpp:42-46): a tree with more nodes than that
     // cannot be expressed (the buffers were sized for it, so nothing was written out of bounds; the references are what overflowed)

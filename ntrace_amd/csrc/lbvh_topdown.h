@@ -2,30 +2,17 @@
 // the whole tree in LDS), n <= leafSize, and leaves of more than 32 triangles, which the bottom-up path of lbvh_kernels.hip does not
 // take.  A level-by-level top pass with key probes (lbvh_top_kernel) hands ranges of at most `spill` triangles to subtree workgroups
 // (lbvh_subtree_kernel: emit + refit with workgroup barriers only).  Same split and leaf rules as the reference
-// (emitTreeKernel.cu:233-381).  Included by lbvh_kernels.hip in two parts (NTR_LBVH_TOPDOWN_PART), around the experiment build's
-// cell-table top pass, which uses part 1.
+// (emitTreeKernel.cu:233-381).  Included by lbvh_kernels.hip.
 
-#if NTR_LBVH_TOPDOWN_PART == 1
-// After the sort: box terms in sorted order (one 24-byte gather per triangle) and the cell table of the top pass:
-// cellStart[c] = first sorted position whose key's upper TOP_CELL_BITS bits are >= c (cellStart[TOP_CELLS] = n).
-__global__ __launch_bounds__(256) void lbvh_gather_box_kernel(int n, const unsigned int* __restrict__ keys, const int* __restrict__ triSorted,
-                                                              const float2* __restrict__ boxMesh, float2* __restrict__ triBox,
-                                                              unsigned int* __restrict__ cellStart)
+// After the sort: box terms in sorted order (one 24-byte gather per triangle).
+__global__ __launch_bounds__(256) void lbvh_gather_box_kernel(int n, const int* __restrict__ triSorted, const float2* __restrict__ boxMesh,
+                                                              float2* __restrict__ triBox)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int t = triSorted[j];
     const float2 a = boxMesh[3 * (size_t)t], b = boxMesh[3 * (size_t)t + 1], c = boxMesh[3 * (size_t)t + 2];
     triBox[3 * (size_t)j] = a; triBox[3 * (size_t)j + 1] = b; triBox[3 * (size_t)j + 2] = c;
-#ifdef NTR_EXPERIMENTS
-    if (cellStart) {
-        const int c1 = (int)(keys[j] >> (30 - TOP_CELL_BITS));
-        const int c0 = j ? (int)(keys[j - 1] >> (30 - TOP_CELL_BITS)) : -1;
-        for (int cc = c0 + 1; cc <= c1; cc++) cellStart[cc] = (unsigned int)j;
-        if (j == n - 1)
-            for (int cc = c1 + 1; cc <= TOP_CELLS; cc++) cellStart[cc] = (unsigned int)n;
-    }
-#endif
 }
 
 // Subtree path, after the emit: Woop rows and original index of every triangle, written straight to the
@@ -255,9 +242,7 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_kernel(EmitCtx c, int n,
     }
 }
 
-#endif  // part 1
 
-#if NTR_LBVH_TOPDOWN_PART == 2
 // Split position as find_split, for ranges of fewer than 2^16 keys held in LDS: 32-bit probe arithmetic.
 template <int LOGK>
 __device__ __forceinline__ int find_split_small(const unsigned int* keys, int nStart, int nEnd, int level, unsigned int startBit)
@@ -428,4 +413,3 @@ __global__ __launch_bounds__(TOP_THREADS) void lbvh_top_refit_kernel(const LbvhS
     refit_levels<TOP_THREADS>(ofs, lv, topLst, nodes);
 }
 
-#endif  // part 2

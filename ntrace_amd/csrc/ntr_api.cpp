@@ -16,9 +16,6 @@
 #include "ntrace_amd.h"
 #include "ntr_internal.h"
 #include "trace_kernels.h"
-#ifdef NTR_AB
-#include "ntr_ab.h"
-#endif
 
 namespace {
 
@@ -151,19 +148,9 @@ static void tunables_load_locked()
     t.flatFetch = env_int("NTR_TRACE_FLAT_FETCH", 1);             // unified-step loop: one group of global loads per iteration (0 = two masked groups of range-checked buffer loads)
     t.uniformPrologue = env_int("NTR_TRACE_UNIFORM_PROLOGUE", 1);  // per-ray kernels: scalar node fetches while the lanes of a fresh wave all hold the same inner node
     t.splitSlice = env_int("NTR_TRACE_SPLIT_SLICE", 8);   // persistent kernels, unified-step loop: once the pool is dry, lanes without a ray take over stack entries of the wave's live rays; looked at every N steps (0 = off)
-    t.splitPerRay = env_int("NTR_TRACE_SPLIT_PERRAY", 0); // A/B build only: the per-ray / mini-pool launch splits too
     t.minipool = env_int("NTR_TRACE_MINIPOOL", -1);              // closest-hit per-ray launches: rays owned by a wave / 64.  -1: decided per batch on the device (1, or minipoolWide when the prediction finds the batch incoherent); 0: the plain per-ray kernel; 1 ... 16: forced
     t.minipoolWide = env_int("NTR_TRACE_MINIPOOL_WIDE", -1);     // K of an incoherent batch: 2 / 4, or -1 = by tree size (4 from 32 MB of nodes up)
     t.minipoolThreshold = env_int("NTR_TRACE_MINIPOOL_THRESHOLD", 48);   // refill a wave's finished lanes when fewer than this many are live
-#ifdef NTR_AB
-    t.handoff = env_int("NTR_TRACE_HANDOFF", 0);                  // mini-pool launches: tail hand-off through the continuation queue.  OFF: it cuts the wave-iterations 3x and the VALU work 2.2x as modelled, and the launch gets 5-10 % slower (profiles/r04_handoff_*; EXPERIMENTS.md)
-    t.handoffBelow = env_int("NTR_TRACE_HANDOFF_BELOW", 16);      // T: a pool wave with fewer live lanes (own rays all started) fills up from the queue or hands its rays off
-    t.handoffMinQueue = env_int("NTR_TRACE_HANDOFF_MIN_QUEUE", 64);   // M: waiting continuations needed to fill up rather than hand off (capped by the wave's free lanes)
-    t.handoffKeepWaves = env_int("NTR_TRACE_HANDOFF_KEEP_WAVES", 1024);   // A: with no more waves than this left in the launch nobody hands off
-    t.handoffFlags = env_int("NTR_TRACE_HANDOFF_FLAGS", 0);       // 1: raised priority for waves that took continuations; 2: batches with pool K = 1 run as one-chunk pools and hand their tails off too
-#else
-    t.handoff = t.handoffBelow = t.handoffMinQueue = t.handoffKeepWaves = t.handoffFlags = 0;
-#endif
     t.unified = env_int("NTR_TRACE_UNIFIED", 1);                  // kepler_dynamic_fetch: unified-step loop (0 = while-while loop + dynamic fetch)
     t.perrayUnified = env_int("NTR_TRACE_PERRAY_UNIFIED", 1);     // per-ray kernel with the unified-step loop: 1 = always (the default since the one-correction divide: AO batches on one-triangle-leaf trees -4 %), 0 = never, -1 = closest-hit launches always, any-hit launches only on trees flagged NTR_BVH_WIDE_LEAVES (the rule of round 3)
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/studies/persist_diag.py)
@@ -176,12 +163,8 @@ static void tunables_load_locked()
     t.predictMinNodes = env_int("NTR_TRACE_PREDICT_MIN_NODES", 4096);
     t.schedRefreshEvery = env_int("NTR_SCHED_REFRESH_EVERY", 16);
     t.schedClasses = env_int("NTR_SCHED_CLASSES", 32);
-    t.lbvhLevelSync = env_int("NTR_LBVH_LEVELSYNC", 0);
     t.lbvhSplit = env_int("NTR_LBVH_SPLIT", 3072);
     t.lbvhSubThreads = env_int("NTR_LBVH_SUB_THREADS", 128);
-    t.lbvhLegacyTop = env_int("NTR_LBVH_LEGACY_TOP", 0);
-    t.lbvhLegacySort = env_int("NTR_LBVH_LEGACY_SORT", 0);
-    t.lbvhEmit = env_int("NTR_LBVH_EMIT", 0);          // 0: bottom-up emit with scanned indices; 1: cell-table top + subtree workgroups
     t.lbvhAggLds = env_int("NTR_LBVH_AGG_LDS", 1);     // bottom-up emit: meetings inside a tile through LDS
     t.lbvhAggStaged = env_int("NTR_LBVH_AGG_STAGED", -1);  // bottom-up emit in two launches: -1 = from 2^20 triangles, 0 / 1 = never / always
     if (t.chunk < 1) t.chunk = 1;
@@ -204,18 +187,6 @@ extern "C" int ntr_tunables_reload(void)
     return NTR_OK;
 }
 
-#ifdef NTR_EXPERIMENTS
-// Diagnostic hooks of scripts/timeline*.py and scripts/studies/order_experiment.py; compiled only into experiment builds
-// (`make exp` -> libntrace_amd_exp.so).  The shipped library has no way to inject a device pointer into a launch.
-static unsigned long long* g_expTimeline = nullptr;
-static const unsigned int* g_expOrder = nullptr;
-extern "C" NTR_API int ntr_experiment_hooks(void* d_timeline, const void* d_order)
-{
-    g_expTimeline = (unsigned long long*)d_timeline;
-    g_expOrder = (const unsigned int*)d_order;
-    return NTR_OK;
-}
-#endif
 
 using namespace ntr;
 
@@ -336,20 +307,6 @@ static constexpr int kScratch = 48;
 static constexpr int kScratchSpares = 4;   // spares a live launch keeps ready (per device, sized for the largest launch seen) for captured launches
 static constexpr int kScratchLive = 16;    // streams with an entry of their own before the least recently used one is recycled
 
-#ifdef NTR_AB
-// Continuation queue of the tail hand-off (trace_kernels.hip): one per (device, stream) -- launches on one stream are ordered, two streams
-// must not share a queue.  A fixed number of entries, never evicted and never touched during a capture: a launch that finds none runs
-// without the hand-off (it is an optimisation, not a contract).
-struct ContScratch {
-    void* stream = nullptr;
-    int device = -1;
-    unsigned int* mem = nullptr;   // NTR_CONT_SHARDS control lines, then NTR_CONT_SHARDS x shardSlots slots
-    int shardSlots = 0;
-    bool used = false;
-};
-static constexpr int kContScratch = 16;
-
-#endif
 
 // Scheduling hint (include/ntrace_amd.h): per-block cost of the previous launch -> block order of the next.
 struct NtrSchedHint {
@@ -393,9 +350,6 @@ struct SchedState {
     TopTable top[kTopTables];
     PredictScratch scratch[kScratch];
     AutoHint autoHints[kAutoHints];
-#ifdef NTR_AB
-    ContScratch cont[kContScratch];
-#endif
 };
 static SchedState* g_sched[kMaxDevices];   // created on a device's first use, never destroyed (entries hold device memory of a live context)
 
@@ -418,47 +372,6 @@ static int sched_state_current(SchedState** out, int* devOut = nullptr)
     return sched_state(dev, out);
 }
 
-#ifdef NTR_AB
-static size_t cont_bytes(int shardSlots)
-{
-    return ((size_t)NTR_CONT_SHARDS * NTR_CONT_CTL_WORDS + (size_t)NTR_CONT_SHARDS * shardSlots * NTR_CONT_SLOT_WORDS) * sizeof(unsigned int);
-}
-
-// the queue of stream `s` with room for a launch of numRays rays, or null (no entry free, or the stream is being captured)
-static int cont_scratch_get(hipStream_t s, int numRays, ContScratch** out)
-{
-    *out = nullptr;
-    if (stream_is_capturing(s)) return NTR_OK;
-    SchedState* ss = nullptr;
-    int dev = 0;
-    const int src = sched_state_current(&ss, &dev);
-    if (src != NTR_OK) return src;
-    // a quarter of the rays can wait at once (the model's worst case is a third of the rays handed off over a whole launch, K = 1);
-    // producers that find their shard full keep their rays
-    const int shardSlots = ((numRays / 4 + NTR_CONT_SHARDS - 1) / NTR_CONT_SHARDS + 63) & ~63;
-    std::lock_guard<std::mutex> lk(ss->mu);
-    ContScratch* c = nullptr;
-    for (auto& e : ss->cont)
-        if (e.used && e.stream == (void*)s && e.device == dev) { c = &e; break; }
-    if (!c)
-        for (auto& e : ss->cont)
-            if (!e.used) { c = &e; break; }
-    if (!c) return NTR_OK;
-    if (c->shardSlots < shardSlots) {
-        if (c->mem) {
-            NTR_HIP(hipStreamSynchronize(s));   // the stream's previous launch may still use the smaller queue
-            (void)hipFree(c->mem);
-            c->mem = nullptr; c->shardSlots = 0;
-        }
-        NTR_HIP(hipMalloc((void**)&c->mem, cont_bytes(shardSlots)));
-        NTR_HIP(hipMemsetAsync(c->mem, 0xFF, cont_bytes(shardSlots), s));   // every slot's flag word: -1 = empty (consumers put it back)
-        c->shardSlots = shardSlots;
-    }
-    c->used = true; c->stream = (void*)s; c->device = dev;
-    *out = c;
-    return NTR_OK;
-}
-#endif
 
 static int top_table_get(const void* d_nodes, int64_t nodesBytes, hipStream_t s, bool rebuild, TopTable** out)
 {
@@ -798,27 +711,13 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     }
     p.uniformPrologue = tun.uniformPrologue != 0 ? 1 : 0;
     p.splitSlice = tun.splitSlice > 0 ? tun.splitSlice : 0;
-    p.splitPerRay = tun.splitPerRay;
     p.leafSwitchBelow = tun.leafSwitchBelow >= 0 ? tun.leafSwitchBelow : (anyHit ? 24 : 32);
     p.octant = tun.octant;
     p.stats = ds->stats;
-    p.timeline = nullptr;
     p.order = nullptr;
     p.cost = nullptr;
     p.poolK = nullptr;
     p.poolKConst = 1;
-#ifdef NTR_AB
-    p.cont = nullptr;
-    p.contShardSlots = 0;
-    p.contBelow = tun.handoffBelow < 1 ? 1 : (tun.handoffBelow > 64 ? 64 : tun.handoffBelow);
-    p.contMinQueue = tun.handoffMinQueue < 1 ? 1 : tun.handoffMinQueue;
-    p.contKeepWaves = tun.handoffKeepWaves < 0 ? 0 : tun.handoffKeepWaves;
-    p.contFlags = tun.handoffFlags;
-#endif
-#ifdef NTR_EXPERIMENTS
-    p.timeline = g_expTimeline;
-    p.order = g_expOrder;
-#endif
     int variant = k->variant;
     if (stats) {
         // RayStats counters (src/rt/bvh/BVH.hpp:44-, filled at CudaBVH.cpp:746-757,1107-1111) are
@@ -990,20 +889,6 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
                     if (predScratch) p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 2;
                     else if (hint && hint->numBlocks == numBlocks && hint->order) p.poolK = hint->order + numBlocks + 2;
                 }
-#ifdef NTR_AB
-                // tail hand-off: the pool waves' continuation queue (used only if the launch runs as pools)
-                if (tun.handoff != 0 && (p.poolK || p.poolKConst >= 2 || (p.contFlags & NTR_CONT_FLAG_K1))) {
-                    ContScratch* cq = nullptr;
-                    rc = cont_scratch_get(s, numRays, &cq);
-                    if (rc != NTR_OK) return rc;   // (events not created yet: see below)
-                    if (cq) {
-                        const hipError_t ze = ntr_launch_zero_words(cq->mem, NTR_CONT_SHARDS * NTR_CONT_CTL_WORDS, s);
-                        if (ze != hipSuccess) return hip_fail(ze, "zero_words launch");
-                        p.cont = cq->mem;
-                        p.contShardSlots = cq->shardSlots;
-                    }
-                }
-#endif
             }
         }
     }
@@ -1027,9 +912,6 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         NTR_HIP(hipMemcpyAsync(&st, ds->status + 8, sizeof(st), hipMemcpyDeviceToHost, s));
         NTR_HIP(hipStreamSynchronize(s));
         if (st & NTR_STATUS_STACK_OVERFLOW) return set_error(NTR_ERR_OVERFLOW, "trace_bvh: traversal stack overflow");
-#ifdef NTR_AB
-        if (st & NTR_STATUS_HANDOFF_TIMEOUT) return set_error(NTR_ERR_HIP, "trace_bvh: a handed-off ray never arrived (continuation queue)");
-#endif
     }
     if (stats) {
         unsigned long long h[4];
@@ -1079,43 +961,9 @@ int ntr_trace_status(void* stream, uint32_t* statusBits)
     if (statusBits) *statusBits = st;
     if (st & NTR_STATUS_STACK_OVERFLOW)
         return set_error(NTR_ERR_OVERFLOW, "trace_bvh: traversal stack overflow in a launch since the last status check");
-#ifdef NTR_AB
-    if (st & NTR_STATUS_HANDOFF_TIMEOUT)
-        return set_error(NTR_ERR_HIP, "trace_bvh: a handed-off ray never arrived (continuation queue) in a launch since the last status check");
-#endif
     return NTR_OK;
 }
 
-#ifdef NTR_AB
-int ntr_trace_handoff_counts(void* stream, uint32_t counts[3])
-{
-    if (!counts) return set_error(NTR_ERR_INVALID, "ntr_trace_handoff_counts: null argument");
-    counts[0] = counts[1] = counts[2] = 0;
-    int dev = 0;
-    NTR_HIP(hipGetDevice(&dev));
-    unsigned int* mem = nullptr;
-    int shardSlots = 0;
-    {
-        SchedState* ss = nullptr;
-        const int rc = sched_state(dev, &ss);
-        if (rc != NTR_OK) return rc;
-        std::lock_guard<std::mutex> lk(ss->mu);
-        for (auto& e : ss->cont)
-            if (e.used && e.stream == stream && e.device == dev) { mem = e.mem; shardSlots = e.shardSlots; }
-    }
-    if (!mem) return NTR_OK;
-    static thread_local unsigned int ctl[NTR_CONT_SHARDS * NTR_CONT_CTL_WORDS];
-    NTR_HIP(hipMemcpyAsync(ctl, mem, sizeof(ctl), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    NTR_HIP(hipStreamSynchronize((hipStream_t)stream));
-    for (int sh = 0; sh < NTR_CONT_SHARDS; sh++) {
-        const unsigned int reserved = ctl[sh * NTR_CONT_CTL_WORDS + 0], popped = ctl[sh * NTR_CONT_CTL_WORDS + 1];
-        counts[0] += reserved < (unsigned int)shardSlots ? reserved : (unsigned int)shardSlots;   // (reservations beyond the capacity are void)
-        counts[1] += popped < (unsigned int)shardSlots ? popped : (unsigned int)shardSlots;
-    }
-    counts[2] = (uint32_t)shardSlots * NTR_CONT_SHARDS;
-    return NTR_OK;
-}
-#endif
 
 int ntr_predict_block_costs(int32_t numRays, const NtrRay* d_rays, const void* d_nodes, int64_t nodesBytes, uint32_t* d_blockCost, void* stream)
 {
@@ -1216,10 +1064,6 @@ int ntr_stream_release(void* stream)
         }
     for (auto& e : ss->scratch)
         if (e.state == PredictScratch::LIVE && e.stream == stream) scratch_free(&e);
-#ifdef NTR_AB
-    for (auto& e : ss->cont)
-        if (e.used && e.stream == stream) { if (e.mem) (void)hipFree(e.mem); e = ContScratch(); }
-#endif
     return NTR_OK;
 }
 

@@ -10,13 +10,10 @@ int hip_fail(hipError_t e, const char* what);
 
 // Tunables (environment overrides for sweeps), read once at first use -- see ntr_api.cpp.
 struct Tunables {
-    int chunk, fetchThreshold, leafSwitchBelow, blocksPerCU, blocksPerCUIncoherent, poolHeads, octant, anyHitWaves, closestWaves, unified, perrayUnified, flatFetch, uniformPrologue, splitSlice, splitPerRay, minipool, minipoolThreshold, minipoolWide;
-    // tail hand-off: read from the environment by the A/B build only (zero in the product).  Declared unconditionally: only ntr_api.cpp and
-    // trace_kernels.hip are compiled with -DNTR_AB for the A/B library, and every other translation unit must see the same struct.
-    int handoff, handoffBelow, handoffMinQueue, handoffKeepWaves, handoffFlags;
+    int chunk, fetchThreshold, leafSwitchBelow, blocksPerCU, blocksPerCUIncoherent, poolHeads, octant, anyHitWaves, closestWaves, unified, perrayUnified, flatFetch, uniformPrologue, splitSlice, minipool, minipoolThreshold, minipoolWide;
     int autoHint, autoHintMinRays, predict, predictPersistent, predictDepth, predictMinRays, predictMinNodes;
     int schedRefreshEvery, schedClasses;
-    int lbvhLevelSync, lbvhSplit, lbvhSubThreads, lbvhLegacyTop, lbvhLegacySort, lbvhEmit, lbvhAggLds, lbvhAggStaged;
+    int lbvhSplit, lbvhSubThreads, lbvhAggLds, lbvhAggStaged;
 };
 Tunables tunables();
 

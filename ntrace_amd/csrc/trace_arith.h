@@ -12,25 +12,13 @@ namespace ntr {
 // pair (all D, both quotient binades, |numerator| <= 8: 46.5 M pairs) in exact integer arithmetic: none differs; with a reciprocal one ulp
 // off 14 % of them do (which is why the hardware divide's own chain -- v_rcp refined once, NOT always correctly rounded -- needs the two
 // corrections this path used until round 4).  ntr_selftest_division() checks FAST == GENERIC on the device, those pairs included.
-#if defined(NTR_AB) && defined(NTR_DIV_TWO_CORRECTIONS)   // A/B build: the chain of rounds 1-3 (v_rcp refined once, two corrections)
-__device__ __forceinline__ float exact_rcp(float d)
-{
-    const float r0 = __builtin_amdgcn_rcpf(d);
-    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
-}
-#else
 __device__ __forceinline__ float exact_rcp(float d) { return 1.0f / d; }
-#endif
 __device__ __forceinline__ float fast_div(float x, float d, float r)
 {
     const float q0 = x * r;
     const float e1 = __builtin_fmaf(-d, q0, x);
     const float q1 = __builtin_fmaf(e1, r, q0);
-#if defined(NTR_AB) && defined(NTR_DIV_TWO_CORRECTIONS)
-    return __builtin_fmaf(__builtin_fmaf(-d, q1, x), r, q1);
-#else
     return q1;
-#endif
 }
 
 }  // namespace ntr

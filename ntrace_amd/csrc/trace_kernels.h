@@ -27,15 +27,6 @@
 // bits of the device status word
 #define NTR_STATUS_STACK_OVERFLOW 1u
 
-#ifdef NTR_AB
-#define NTR_STATUS_HANDOFF_TIMEOUT 2u     // a continuation slot never arrived (cannot happen: its producer reserved it before the claim)
-// tail hand-off of the mini-pool waves (A/B build only): continuation queue (trace_handoff_ab.h)
-#define NTR_CONT_SHARDS 64                // independent queues (power of two), a wave uses shard = its ordinal % shards
-#define NTR_CONT_CTL_WORDS 32             // a shard's control line: 128 bytes
-#define NTR_CONT_SLOT_WORDS 32            // a continuation: 8 words of ray state + up to 24 stack entries
-#define NTR_CONT_FLAG_PRIO 1              // waves that took continuations run at raised priority
-#define NTR_CONT_FLAG_K1 2                // a batch whose pool K is 1 runs as pools of one chunk too (so that its tails are handed off)
-#endif
 
 namespace ntr {
 
@@ -65,8 +56,6 @@ struct TraceParams {
     int32_t uniformPrologue; // per-ray kernels, unified-step loop: scalar node fetches while every live lane of the wave holds the same inner node
     int32_t splitSlice;      // persistent kernels, unified-step loop: once the pool is dry, idle lanes take over stack entries of the wave's
                              // live rays; the lanes are looked at every splitSlice steps (trace_split.h); 0 = off
-    int32_t splitPerRay;     // A/B build only: the per-ray / mini-pool launch splits too
-    unsigned long long* timeline;  // diagnostic: per-wave realtime stamps (scripts/timeline*.py), or null
     const unsigned int* order;     // per-ray kernel: workgroup i traces ray block order[i] (null = identity); persistent kernels: the pool
                                    // hands the 256-ray blocks out in this order
     unsigned int* cost;            // per-ray kernel: cost[block] = max wave lifetime in 10 ns ticks (null = off)
@@ -74,15 +63,6 @@ struct TraceParams {
     const unsigned int* poolK;  // mini-pool kernel: device word holding the rays a wave owns / 64 (1 .. NTR_MINIPOOL_MAX_K; anything else reads as 1),
                                 // written by the dispatch-order prediction of this launch or kept in the launch's hint; null = poolKConst
     int32_t poolKConst;
-#ifdef NTR_AB
-    unsigned int* cont;         // mini-pool kernel: continuation queue of the tail hand-off (NTR_CONT_SHARDS control lines, cleared before the launch, then
-                                // NTR_CONT_SHARDS x contShardSlots slots whose first word is -1); null = no hand-off
-    int32_t contShardSlots;     // slots per shard
-    int32_t contBelow;          // T: a pool wave with fewer live lanes than this (its own rays all started) fills up from the queue or hands its rays off
-    int32_t contMinQueue;       // M: continuations that must be waiting for a wave to fill up rather than hand off (capped by its free lanes)
-    int32_t contKeepWaves;      // A: while no more than this many waves of the launch are left nobody hands off (the last rays run sparse: a lone lane steps fastest)
-    int32_t contFlags;          // NTR_CONT_FLAG_*
-#endif
 };
 
 }  // namespace ntr

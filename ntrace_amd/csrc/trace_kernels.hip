@@ -67,11 +67,7 @@ namespace ntr {
 
 static constexpr int kSentinel = 0x76543210;  // CudaTracerKernels.hpp:38 (EntrypointSentinel)
 static constexpr int LDS_DEPTH = 16;
-#ifdef NTR_EXPERIMENT_NO_SPILL
-static constexpr int SPILL_DEPTH = 1;
-#else
 static constexpr int SPILL_DEPTH = 88;        // 16 + 88 >= the reference CPU stack of 100 (CudaBVH.cpp:701)
-#endif
 
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -146,12 +142,6 @@ __device__ __forceinline__ void ray_box2(const RayRegs& r, const float4& n0, con
         for (int k = 0; k < 12; k++) e[k] = __builtin_fmaf(-d[(k % 6) >> 1], q[k], x[k]);
 #pragma unroll
         for (int k = 0; k < 12; k++) q[k] = __builtin_fmaf(e[k], rc[(k % 6) >> 1], q[k]);
-#if defined(NTR_AB) && defined(NTR_DIV_TWO_CORRECTIONS)
-#pragma unroll
-        for (int k = 0; k < 12; k++) e[k] = __builtin_fmaf(-d[(k % 6) >> 1], q[k], x[k]);
-#pragma unroll
-        for (int k = 0; k < 12; k++) q[k] = __builtin_fmaf(e[k], rc[(k % 6) >> 1], q[k]);
-#endif
         if (OCT < 8) {
             constexpr int sx = OCT & 1, sy = (OCT >> 1) & 1, sz = (OCT >> 2) & 1;   // 1: the hi plane is the near one
             mn0 = fmaxf(fmaxf(q[0 + sx], q[2 + sy]), q[4 + sz]);
@@ -616,23 +606,12 @@ __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs&
                                                  unsigned int* status, bool poolEmpty, int fetchThreshold, int slice = 0)
 {
     if (PROLOGUE && ub.uniformPrologue) uniform_prologue<FAST, OCT>(ub, r, node, st, spill, status);
-#if defined(NTR_AB) && defined(NTR_AGE_SHIFT)
-    unsigned int ageIt = 0;   // A/B experiment: waves that have been stepping for long (they hold the long rays: the launch's critical path) get issue priority
-#endif
     for (;;) {
         const unsigned long long live = __ballot(node != kSentinel);
         if (live == 0ull) break;
         // dynamic fetch (kepler_dynamic_fetch.cu:310): too few live lanes while rays remain in the pool -> refill
         if (!poolEmpty && __popcll(live) < fetchThreshold) break;
         if (SLICED && --slice < 0) break;
-#if defined(NTR_AB) && defined(NTR_AGE_SHIFT)
-        if ((++ageIt & ((1u << NTR_AGE_SHIFT) - 1u)) == 0u) {
-            const unsigned int a = ageIt >> NTR_AGE_SHIFT;
-            if (a == 1u) __builtin_amdgcn_s_setprio(1);
-            else if (a == 2u) __builtin_amdgcn_s_setprio(2);
-            else if (a == 3u) __builtin_amdgcn_s_setprio(3);
-        }
-#endif
         float4 a, b, c, d;
         unified_fetch<FLAT>(ub, node, a, b, c, d);
         if (FLAT) { keep(a); keep(b); keep(c); keep(d); }
@@ -649,30 +628,21 @@ namespace ntr {
 // ---------------------------------------------------------------------------------
 // UNIFIED: the unified-step loop (traverse_unified) -- for trees whose leaves hold several triangles (the device LBVH).
 // MINI: the launch may run as the wave-private mini-pool instead (minipool_body below), decided on the device per batch.
-template <bool FLATF, bool SPLIT>
+template <bool FLATF>
 __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int K, lds_int* stackBase);
 
-#if defined(NTR_AB) && defined(NTR_OCC8)
-#define NTR_PERRAY_BOUNDS(W) __launch_bounds__((W) * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
-#else
 #define NTR_PERRAY_BOUNDS(W) __launch_bounds__((W) * 64, NTR_TRACE_MIN_WAVES_PER_SIMD)
-#endif
-// SPLIT (MINI only): closest-hit launches let the lanes that are done take over parts of the wave's live rays (trace_split.h).
-template <int WAVES, bool STATS, bool UNIFIED = false, bool FLATF = true, bool MINI = false, bool SPLIT = false>
+template <int WAVES, bool STATS, bool UNIFIED = false, bool FLATF = true, bool MINI = false>
 __device__ __forceinline__ void perray_body(const TraceParams& p)
 {
-    static_assert(!SPLIT || MINI, "ray splitting is compiled into the mini-pool launch only");
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     if constexpr (MINI) {
         static_assert(WAVES == 1 && UNIFIED && !STATS, "the mini-pool shares the one-wave unified-step launch");
         unsigned int K = (unsigned int)p.poolKConst;
         if (p.poolK) K = *p.poolK;   // wave-uniform (scalar load)
         bool pooled = K >= 2u && K <= (unsigned int)NTR_MINIPOOL_MAX_K;
-#ifdef NTR_AB
-        pooled = pooled || (K == 1u && p.cont && (p.contFlags & NTR_CONT_FLAG_K1));   // (hand-off experiment: one-chunk pools hand their tails off too)
-#endif
         if (pooled) {
-            minipool_body<FLATF, SPLIT>(p, K, (lds_int*)&s_stack[0][0][threadIdx.x]);
+            minipool_body<FLATF>(p, K, (lds_int*)&s_stack[0][0][threadIdx.x]);
             return;
         }
     }
@@ -687,7 +657,7 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
     const Rsrc nodes = make_rsrc(p.nodes, p.nodesBytes), woop = make_rsrc(p.woop, p.woopBytes);
 
     unsigned long long tl0 = 0;
-    if (p.timeline || p.cost) tl0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz; scheduling feedback / diagnostics
+    if (p.cost) tl0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz; scheduling feedback
 
     RayRegs r;
     load_ray(p.rays, valid ? rayIdx : 0, r);
@@ -713,22 +683,9 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
         if ((sx == 0ull || sx == liveMask) && (sy == 0ull || sy == liveMask) && (sz == 0ull || sz == liveMask))
             oct = (sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0);
     }
-    bool recordsOut = false;   // SPLIT: every ray's record was written when the ray was complete
     if (UNIFIED) {
         const UnifiedBufs ub = unified_bufs(p);
-        // SPLIT: the traversal runs in slices; between them helpers report, finished rays leave and the lanes they free take over the
-        // bottom stack entries of the rays still on their way (any-hit launches: one slice, nothing else)
-        SplitState split;
-        split_reset(split);
-        const int splitSlice = (SPLIT && p.anyHit == 0) ? p.splitSlice : 0;
-        int myRay = valid ? rayIdx : -1;
-        bool niceLane = true;   // (the wave runs FAST or not as a whole: a helper's ray is a copy of a ray of this wave)
-        for (;;) {
-        const int slice = splitSlice > 0 ? splitSlice : 0x7FFFFFFF;
-        if (SPLIT && splitSlice > 0) {
-            split_donate(split, r, node, st, myRay, hitAddr, hitU, hitV, niceLane);
-        }
-#define NTR_UNIFIED_OCT(O) traverse_unified<true, FLATF, O, true, SPLIT>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0, slice)
+#define NTR_UNIFIED_OCT(O) traverse_unified<true, FLATF, O, true>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0)
         if (oct < 8) {
             switch (oct) {
                 case 0: NTR_UNIFIED_OCT(0); break;
@@ -742,17 +699,8 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
             }
         }
 #undef NTR_UNIFIED_OCT
-        else if (fastWave) traverse_unified<true, FLATF, 8, true, SPLIT>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0, slice);
-        else traverse_unified<false, FLATF, 8, true, SPLIT>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0, slice);
-        if (!SPLIT || splitSlice <= 0) break;
-        split_settle(split, r, node, st, hitAddr, hitU, hitV, false);
-        if (myRay >= 0 && node == kSentinel && split.base == 0) {   // the ray's record goes out as soon as all of it is known: its lane is free
-            store_result(p.results, p.triIndex, myRay, hitAddr, r.tmax, hitU, hitV);
-            myRay = -1;
-        }
-        if (__ballot(myRay >= 0) == 0ull) break;
-        }
-        recordsOut = SPLIT && splitSlice > 0;
+        else if (fastWave) traverse_unified<true, FLATF, 8, true>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
+        else traverse_unified<false, FLATF, 8, true>(ub, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, p.status, true, 0);
     } else
 #define NTR_TRAVERSE_OCT(O) traverse<true, STATS, false, O>(nodes, woop, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow)
     if (!STATS && oct < 8) {
@@ -771,15 +719,9 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
     else if (fastWave) traverse<true, STATS, false>(nodes, woop, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
     else traverse<false, STATS, false>(nodes, woop, r, node, st, spill, p.anyHit != 0, hitAddr, hitU, hitV, ls, p.status, true, 0, p.leafSwitchBelow);
 
-    if (p.timeline && lane == 0) {
-        const unsigned int w = block * 4 + part * WAVES + wave;
-        p.timeline[3 * w + 0] = tl0;
-        p.timeline[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
-        p.timeline[3 * w + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
-    }
     if (p.cost && lane == 0)  // scheduling feedback: a block's cost is the lifetime of its longest wave
         atomicMax(&p.cost[block], (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0));
-    if (!valid || recordsOut) return;
+    if (!valid) return;
     store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
     if (STATS) {  // diagnostics variant only: plain per-lane atomics
         atomicAdd(&p.stats[0], (unsigned long long)ls.inner);
@@ -795,27 +737,17 @@ __global__ NTR_PERRAY_BOUNDS(WAVES) void trace_bvh_perray(TraceParams p)
     perray_body<WAVES, STATS, UNIFIED, FLATF, false>(p);
 }
 // The one-wave unified-step launch that may run as mini-pools (K decided on the device).
-#ifdef NTR_AB   // with the out-of-line hand-off calls, whose calling convention would push it to 74 registers: held to the 72 of seven waves per SIMD
-#define NTR_MINI_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7)))
-#else
 #define NTR_MINI_BOUNDS __launch_bounds__(64)
-#endif
 __global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini(TraceParams p)
 {
-    perray_body<1, false, true, true, true, false>(p);
+    perray_body<1, false, true, true, true>(p);
 }
 // ... with the two-descriptor fetch, for a BVH whose node and triangle buffers do not lie inside one 4 GiB window (the flat fetch's
 // condition): such a batch keeps its ray pools -- without them an incoherent batch is 60 % slower (hairball box rays 3.6 -> 5.8 ms)
 __global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini_desc(TraceParams p)
 {
-    perray_body<1, false, true, false, true, false>(p);
+    perray_body<1, false, true, false, true>(p);
 }
-#ifdef NTR_AB   // the same launch with ray splitting compiled in (A/B build only: measured, it does not pay here -- EXPERIMENTS.md round 5)
-__global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini_split(TraceParams p)
-{
-    perray_body<1, false, true, true, true, true>(p);
-}
-#endif
 
 // ---------------------------------------------------------------------------------
 // Variant 2: persistent waves.  Each wave owns a chunk [next,end) of the ray index
@@ -831,13 +763,10 @@ __global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini_split(TraceParams p)
 // head ran dry reads all heads with one 64-lane load and moves to the next one that still has rays, instead of
 // paying an atomic round trip per dry head.
 // ---------------------------------------------------------------------------------
-// TL: the diagnostic stamps of NTR_TRACE_TIMELINE are compiled into their own instantiation -- they cost 18 VGPRs,
-// i.e. two waves of occupancy per SIMD, which the production kernel must not pay.
 // UNIFIED: the unified-step loop (traverse_unified) instead of the while-while loop -- what kepler_dynamic_fetch launches.
-template <int WAVES, bool TL, bool UNIFIED = false, bool FLATF = true>
+template <int WAVES, bool UNIFIED = false, bool FLATF = true>
 __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_persistent(TraceParams p)
 {
-    unsigned long long* const timeline = TL ? p.timeline : nullptr;
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Rsrc nodes = make_rsrc(p.nodes, p.nodesBytes), woop = make_rsrc(p.woop, p.woopBytes);
@@ -885,17 +814,11 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     bool splitOn = false;             // wave-uniform
     const int splitSlice = UNIFIED ? p.splitSlice : 0;
 
-    // diagnostic stamps (NTR_TRACE_TIMELINE): wave start, end, cycles spent refilling, refill count
-    unsigned long long tlStart = 0, tlRefill = 0, tlCount = 0, tlRays = 0;
-    if (timeline) tlStart = __builtin_amdgcn_s_memrealtime();
-
     // Invariant at the top of the loop: a lane either holds a live ray
     // (rayIdx >= 0, node != sentinel) or is empty (rayIdx < 0, node == sentinel).
     for (;;) {
         // ---- refill empty lanes from the wave's chunk ----------------------------
         unsigned long long empty = __ballot(rayIdx < 0);
-        unsigned long long tlA = 0;
-        if (timeline) { tlA = __builtin_amdgcn_s_memtime(); tlCount++; tlRays += __popcll(empty); }
         while (empty != 0ull && !poolEmpty) {
             if (chunkNext >= chunkEnd) {  // wave-uniform: grab the next chunk
                 // The ray index space is cut into 8 contiguous ranges with one pool head each
@@ -976,7 +899,6 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
             empty = __ballot(rayIdx < 0);
         }
 
-        if (timeline) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tlRefill += __builtin_amdgcn_s_memtime() - tlA; }
         // ---- while-while traversal ------------------------------------------------
         if (UNIFIED && poolEmpty && splitSlice > 0) {
             if (!splitOn) { splitOn = true; split_reset(split); }
@@ -999,20 +921,8 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
         }
         if (poolEmpty && __ballot(rayIdx >= 0) == 0ull) break;
     }
-    if (timeline && lane == 0) {
-        const unsigned int w = blockIdx.x * WAVES + wave;
-        timeline[6 * w + 0] = tlStart;
-        timeline[6 * w + 1] = __builtin_amdgcn_s_memrealtime();
-        timeline[6 * w + 2] = tlRefill;
-        timeline[6 * w + 3] = tlCount;
-        timeline[6 * w + 4] = tlRays;
-        timeline[6 * w + 5] = __builtin_amdgcn_s_memtime();
-    }
 }
 
-#ifdef NTR_AB
-#include "trace_handoff_ab.h"   // continuation queue of the opt-in tail hand-off: A/B build only
-#endif
 
 // ---------------------------------------------------------------------------------
 // Variant 3: per-ray kernel with a wave-private mini-pool (round 3).  A hardware-scheduled 64-thread workgroup owns K x 64 consecutive
@@ -1023,9 +933,8 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
 // path per wave -- which is why the pool stays small and private: the global pool of the persistent kernels keeps every lane busy
 // until it runs dry, and then 6 144 waves each hold a few long rays (a tail of 60-70 % of their launch, profiles/r03_divergence_timelines.jsonl).
 // Unified-step loop, flat fetch; 256-ray blocks keep their role as the unit of the dispatch order and of the cost feedback.
-// A/B build only (-DNTR_AB): with a continuation queue (p.cont, round 4) the tail of a pool is handed off, trace_handoff_ab.h.
 // ---------------------------------------------------------------------------------
-template <bool FLATF, bool SPLIT>
+template <bool FLATF>
 __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int K, lds_int* stackBase)
 {
     // The launch has one wave per 64-ray chunk (the per-ray kernel's grid); K consecutive chunks of the dispatch order form a pool, and one
@@ -1050,25 +959,6 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
 
     unsigned long long tl0 = 0;
     if (p.cost) tl0 = __builtin_amdgcn_s_memrealtime();
-    unsigned int life = 0;                 // scheduling feedback: the wave's lifetime (A/B build: up to the hand-off of its tail)
-
-#ifdef NTR_AB
-    // tail hand-off: this wave's shard of the continuation queue
-    ContShard cs = {nullptr, nullptr, 0, 0};
-    bool final = true;                     // wave-uniform: no (more) hand-off, the wave runs what it holds to completion
-    bool shardLast = false;                // wave-uniform: every other wave of the shard is gone; this one drains the shard
-    int keepWaves = 0;
-    if (p.cont) {
-        const unsigned int numWaves = (numChunks + K - 1u) / K;
-        const unsigned int shard = q & (unsigned int)(NTR_CONT_SHARDS - 1);
-        cs.ctl = p.cont + shard * NTR_CONT_CTL_WORDS;
-        cs.capacity = p.contShardSlots;
-        cs.slots = reinterpret_cast<unsigned long long*>(p.cont + NTR_CONT_SHARDS * NTR_CONT_CTL_WORDS) + (size_t)shard * cs.capacity * (NTR_CONT_SLOT_WORDS / 2);
-        cs.waves = (int)((numWaves - shard + (unsigned int)NTR_CONT_SHARDS - 1u) / (unsigned int)NTR_CONT_SHARDS);
-        keepWaves = max(p.contKeepWaves / NTR_CONT_SHARDS, 1);
-        final = false;
-    }
-#endif
 
     LaneStack st;
     int spill[SPILL_DEPTH];
@@ -1078,11 +968,6 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
     int node = kSentinel, rayIdx = -1, hitAddr = -1;
     float hitU = 0.0f, hitV = 0.0f;
     bool nice = true;
-    // once the wave's own rays are all started, lanes that are done take over parts of the rays still on their way (trace_split.h)
-    SplitState split;
-    split_reset(split);
-    bool splitOn = false;                  // wave-uniform
-    const int splitSlice = (SPLIT && !anyHit) ? p.splitSlice : 0;
 
     for (;;) {
         // ---- start the wave's next rays on its empty lanes (from the current chunk; what it cannot fill is filled next time round) --
@@ -1108,85 +993,19 @@ __device__ __forceinline__ void minipool_body(const TraceParams& p, unsigned int
             poolNext += min(__popcll(empty), avail);
         }
         const bool poolEmpty = poolNext >= poolEnd && chunk + 1u >= chunkEnd;
-        // ---- tail: the wave's own rays are all started.  Below T live lanes: fill up from the queue, or hand the rays off ----------
-        bool stopEarly = !poolEmpty;               // leave the traversal when fewer than `stopBelow` lanes are live
-        int stopBelow = p.fetchThreshold;
-#ifdef NTR_AB
-        if (poolEmpty && !final) {
-            int nlive = __popcll(__ballot(node != kSentinel));
-            if (nlive < p.contBelow) {
-                if (rayIdx >= 0 && node == kSentinel) {   // (rays that ended, degenerate ones just started: their lanes are free)
-                    store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
-                    rayIdx = -1;
-                }
-                if (p.cost && life == 0u) life = (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0);
-                unsigned int rr = 0, pp = 0, ex = 0;
-                if (lane == 0) { pp = cont_ld(cs.ctl + 1); rr = cont_ld(cs.ctl + 0); ex = cont_ld(cs.ctl + 2); }
-                const int queued = (int)(__builtin_amdgcn_readfirstlane(rr) - __builtin_amdgcn_readfirstlane(pp));
-                const int remaining = cs.waves - (int)__builtin_amdgcn_readfirstlane(ex);   // waves of the shard not yet gone, this one included
-                const int freeLanes = 64 - nlive;
-                const int need = min(freeLanes, p.contMinQueue);
-                if (shardLast || remaining <= keepWaves) {            // end game: nobody hands off any more; take what is left, then run to the end
-                    if (queued > 0 && freeLanes > 0) {
-                        LaneState ls; NTR_LANE_PACK(ls);
-                        cont_consume(cs.ctl, cs.slots, cs.capacity, p.rays, p.bvhFlags, p.status, min(queued, freeLanes), ls, st.lds, spill);
-                        NTR_LANE_UNPACK(ls);
-                    } else final = true;
-                } else if (queued >= need && queued > 0) {            // consumer
-                    LaneState ls; NTR_LANE_PACK(ls);
-                    const int got = cont_consume(cs.ctl, cs.slots, cs.capacity, p.rays, p.bvhFlags, p.status, min(queued, freeLanes), ls, st.lds, spill);
-                    NTR_LANE_UNPACK(ls);
-                    if (got > 0 && (p.contFlags & NTR_CONT_FLAG_PRIO)) __builtin_amdgcn_s_setprio(2);
-                } else if (nlive > 0) {                               // producer: the rays go on in another wave
-                    LaneState ls; NTR_LANE_PACK(ls);
-                    cont_produce(cs.ctl, cs.slots, cs.capacity, __ballot(node != kSentinel && st.sp <= CONT_STACK), ls, st.lds, spill);
-                    NTR_LANE_UNPACK(ls);
-                }
-                nlive = __popcll(__ballot(node != kSentinel));
-            }
-            if (!final) { stopEarly = true; stopBelow = min(p.contBelow, nlive); }   // look again as soon as a ray ends below T
-        }
-#endif
-        // ---- unified-step traversal until every lane is done, or until enough lanes are free to be worth a refill -------------
-        if (SPLIT && poolEmpty && splitSlice > 0) {
-            if (!splitOn) { splitOn = true; split_reset(split); }
-            split_donate(split, r, node, st, rayIdx, hitAddr, hitU, hitV, nice);
-        }
-        const int slice = splitOn ? splitSlice : 0x7FFFFFFF;
+        // ---- unified-step traversal until every lane is done, or (rays left in the pool) until enough lanes are free to be worth a refill --
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
-        if (fastWave) traverse_unified<true, FLATF, 8, false, SPLIT>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, !stopEarly, stopBelow, slice);
-        else traverse_unified<false, FLATF, 8, false, SPLIT>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, !stopEarly, stopBelow, slice);
-        if (SPLIT && splitOn) split_settle(split, r, node, st, hitAddr, hitU, hitV, anyHit);
-        // ---- retire finished rays (an owner whose helpers are still out waits for their reports) ------------------------------
-        if (rayIdx >= 0 && node == kSentinel && (!SPLIT || !splitOn || split.base == 0)) {
+        if (fastWave) traverse_unified<true, FLATF, 8, false>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
+        else traverse_unified<false, FLATF, 8, false>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold);
+        // ---- retire finished rays -------------------------------------------------------------------------------------------------
+        if (rayIdx >= 0 && node == kSentinel) {
             store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
             rayIdx = -1;
         }
-        if (poolEmpty && __ballot(rayIdx >= 0) == 0ull) {
-#ifndef NTR_AB
-            break;
-#else
-            if (!p.cont) break;
-            // ---- leaving: a wave that holds nothing.  The one that completes its shard drains what nobody claimed ----------------------
-            if (!shardLast) {
-                unsigned int old = 0;
-                if (lane == 0) old = __hip_atomic_fetch_add(cs.ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)__builtin_amdgcn_readfirstlane(old) + 1 < cs.waves) break;
-                shardLast = true;
-            }
-            unsigned int rr = 0, pp = 0;
-            if (lane == 0) { pp = cont_ld(cs.ctl + 1); rr = cont_ld(cs.ctl + 0); }
-            const int queued = (int)(__builtin_amdgcn_readfirstlane(rr) - __builtin_amdgcn_readfirstlane(pp));
-            if (queued <= 0) break;
-            final = false;   // (looks at the queue again whenever it runs empty)
-            LaneState ls; NTR_LANE_PACK(ls);
-            cont_consume(cs.ctl, cs.slots, cs.capacity, p.rays, p.bvhFlags, p.status, min(queued, 64), ls, st.lds, spill);
-            NTR_LANE_UNPACK(ls);
-#endif
-        }
+        if (poolEmpty && __ballot(rayIdx >= 0) == 0ull) break;
     }
     if (p.cost && lane == 0) {  // scheduling feedback: a block's cost is the lifetime of the longest wave that traced a part of it
-        if (life == 0u) life = (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0);
+        const unsigned int life = (unsigned int)(__builtin_amdgcn_s_memrealtime() - tl0);
         for (unsigned int c = q * K; c < chunkEnd; c += 4u - (c & 3u)) atomicMax(&p.cost[p.order ? p.order[c >> 2] : (c >> 2)], life);
     }
 }
@@ -1212,12 +1031,6 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
         else hipLaunchKernelGGL((ntr::trace_bvh_perray<1, false, true, false>), dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERRAY_UNIFIED_MINI:   // numBlocks counts waves of 64 rays
-#ifdef NTR_AB   // A/B build: the per-ray launch with ray splitting (measured: it loses where other waves still have bulk work, EXPERIMENTS.md round 5)
-        if (p->splitSlice > 0 && p->splitPerRay && !p->anyHit && p->flatFetch && !p->cont) {   // (one experiment at a time: not with the tail hand-off's queue)
-            hipLaunchKernelGGL(ntr::trace_bvh_perray_mini_split, dim3(numBlocks), dim3(64), 0, stream, *p);
-            break;
-        }
-#endif
         if (p->flatFetch) hipLaunchKernelGGL(ntr::trace_bvh_perray_mini, dim3(numBlocks), dim3(64), 0, stream, *p);
         else hipLaunchKernelGGL(ntr::trace_bvh_perray_mini_desc, dim3(numBlocks), dim3(64), 0, stream, *p);
         break;
@@ -1225,13 +1038,11 @@ extern "C" hipError_t ntr_launch_trace(int variant, const ntr::TraceParams* p, i
         hipLaunchKernelGGL((ntr::trace_bvh_perray<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERSISTENT_UNIFIED:
-        if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
-        else if (p->flatFetch) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
-        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        if (p->flatFetch) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     case NTR_VARIANT_PERSISTENT:
-        if (p->timeline) hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, true>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
-        else hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
+        hipLaunchKernelGGL((ntr::trace_bvh_persistent<WAVES, false>), dim3(numBlocks), dim3(WAVES * 64), 0, stream, *p);
         break;
     default:
         return hipErrorInvalidValue;

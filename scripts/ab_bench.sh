@@ -1,13 +1,14 @@
 #!/bin/bash
 # Interleaved A/B of two builds of the library on ONE GPU box (boxes differ by +-1.5 %, so only same-box alternation ranks variants):
-#   scripts/ab_bench.sh <reps> [bench.py args...]      A = libntrace_amd.so, B = libntrace_amd_ab.so (make -C ntrace_amd/csrc ab)
+#   scripts/ab_bench.sh <reps> [bench.py args...]      A = libntrace_amd.so, B = $AB_LIB (default ntrace_amd/libntrace_amd_b.so: build the
+#   variant, copy the library there, rebuild the product)
 # Prints value / primary / AO Mrays/s per run and the means.
 REPS=${1:-3}; shift || true
 OUT=${AB_OUT:-gpurun_out/ab}; mkdir -p $OUT
 : > $OUT/ab.jsonl
 for i in $(seq 1 $REPS); do
   for V in A B; do
-    LIB=ntrace_amd/libntrace_amd.so; [ $V = B ] && LIB=ntrace_amd/libntrace_amd_ab.so
+    LIB=ntrace_amd/libntrace_amd.so; [ $V = B ] && LIB=${AB_LIB:-ntrace_amd/libntrace_amd_b.so}
     NTR_LIB_OVERRIDE=$LIB timeout -k 5 300 python3 bench.py --no-extras --no-cpu-baseline "$@" 2> $OUT/ab_$V.err | tail -n 1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())

@@ -14,9 +14,9 @@
 #   shard            scripts/studies/shard_balance_study.py
 #   lbvh             scripts/studies/lbvh_sweep3.py
 #   fuzz:<seconds>   tests/fuzz_parity.py for that long
-#   ab:<reps>        scripts/ab_bench.sh: bench.py alternately against libntrace_amd.so and libntrace_amd_ab.so
+#   ab:<reps>        scripts/ab_bench.sh: bench.py alternately against libntrace_amd.so and a second build (AB_LIB, default ntrace_amd/libntrace_amd_b.so)
 #   knob:<VAR>:<v1>:<v2>...   scripts/studies/bench_knob.sh: the bench step under each value of one run-time tunable ("-" = unset), interleaved
-#   py:<script>[:args...]   python3 scripts/<script>.py (or scripts/studies/<script>.py) args (':' separated); pyexp: the same with libntrace_amd_exp.so
+#   py:<script>[:args...]   python3 scripts/<script>.py (or scripts/studies/<script>.py) args (':' separated); pyexp: the same with a build that has scripts/studies/rejected_patches/experiment_builds_trace.patch applied (ntrace_amd/libntrace_amd_diag.so)
 set -u
 TAG=${1:?tag}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
@@ -58,7 +58,7 @@ EOF
     timeout -k 5 900 python3 scripts/studies/lbvh_sweep3.py ${ARG//:/ } > $OUT/lbvh_sweep.jsonl 2> $OUT/lbvh_sweep.err; echo "rc=$?"; cat $OUT/lbvh_sweep.jsonl; tail -n 3 $OUT/lbvh_sweep.err ;;
   fuzz)
     timeout -k 5 $((ARG + 120)) python3 tests/fuzz_parity.py --seconds $ARG --seed ${FUZZ_SEED:-41} --progress $OUT/fuzz_progress.json > $OUT/fuzz.json 2> $OUT/fuzz.err; echo "rc=$?"; tail -c 1500 $OUT/fuzz.json; tail -n 3 $OUT/fuzz.err ;;
-  ab)      # interleaved A/B of libntrace_amd.so and libntrace_amd_ab.so: ab:<reps>
+  ab)      # interleaved A/B of libntrace_amd.so and a second build of the library: ab:<reps>
     AB_OUT=$OUT bash scripts/ab_bench.sh ${ARG:-3} 2>&1 | tail -n 4 ;;
   knob)
     VAR=${ARG%%:*}; VALS=${ARG#*:}
@@ -66,10 +66,10 @@ EOF
   sh)      # sh:<script>[:args...]  bash scripts/studies/<script>.sh args
     SCRIPT=${ARG%%:*}; REST=""; [[ "$ARG" == *:* ]] && REST=${ARG#*:}
     timeout -k 5 1500 bash scripts/studies/$SCRIPT.sh ${REST//:/ } > $OUT/$SCRIPT.out 2>&1; echo "rc=$?"; tail -n 30 $OUT/$SCRIPT.out ;;
-  pyexp)   # py: with the experiment build of the library (diagnostic hooks)
+  pyexp)   # py: with a diagnostic build of the library (per-wave timeline hooks: a patch, see scripts/studies/INDEX.md)
     SCRIPT=${ARG%%:*}; REST=""; [[ "$ARG" == *:* ]] && REST=${ARG#*:}
     [ -f scripts/$SCRIPT.py ] || SCRIPT=studies/$SCRIPT; mkdir -p $OUT/studies
-    NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_exp.so timeout -k 5 1500 python3 scripts/$SCRIPT.py ${REST//:/ } > $OUT/$SCRIPT.out 2> $OUT/$SCRIPT.err; echo "rc=$?"; tail -n 40 $OUT/$SCRIPT.out | cut -c1-1500; tail -n 5 $OUT/$SCRIPT.err ;;
+    NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_diag.so timeout -k 5 1500 python3 scripts/$SCRIPT.py ${REST//:/ } > $OUT/$SCRIPT.out 2> $OUT/$SCRIPT.err; echo "rc=$?"; tail -n 40 $OUT/$SCRIPT.out | cut -c1-1500; tail -n 5 $OUT/$SCRIPT.err ;;
   py)
     SCRIPT=${ARG%%:*}; REST=""; [[ "$ARG" == *:* ]] && REST=${ARG#*:}
     [ -f scripts/$SCRIPT.py ] || SCRIPT=studies/$SCRIPT; mkdir -p $OUT/studies

@@ -3,9 +3,11 @@
 # them for gfx950 with the product's flags (no GPU needed) -- the numbers DESIGN.md quotes (waves per SIMD = min(8, 512 / ceil8(VGPRs))).
 cd "$(dirname "$0")/../ntrace_amd/csrc" || exit 1
 FILES=${@:-trace_kernels.hip lbvh_kernels.hip sched_kernels.hip}
+TMP=$(mktemp -d)
+# the Makefile's own CXXFLAGS / KERNELFLAGS (target `resources`), so the numbers cannot drift from the build
+make -s resources RES_DIR="$TMP" RES_FILES="$FILES" || exit 1
 for F in $FILES; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt \
-    -fno-slp-vectorize -I../../include -I. -I../host --cuda-device-only -S -o /tmp/kr_$$.s $F 2>/dev/null
+  cp "$TMP/kr_$F.s" /tmp/kr_$$.s
   echo "== $F"
   grep -E "^\s+\.(vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size|name|vgpr_spill_count):" /tmp/kr_$$.s | paste - - - - - - |
     sed 's/ \+/ /g;s/_segment_fixed_size//g;s/_count//g' | while read -r L; do
@@ -18,3 +20,4 @@ for F in $FILES; do
     done
   rm -f /tmp/kr_$$.s
 done
+rm -rf "$TMP"

@@ -28,7 +28,6 @@ from oracle import oracle  # noqa: E402
 
 KERNELS = ["fermi_speculative_while_while", "kepler_dynamic_fetch", "tesla_persistent_while_while"]
 DEV = "cuda:0"
-HAS_HANDOFF = hasattr(nt.lib(), "ntr_trace_handoff_counts")   # the A/B build of the library (NTR_LIB_OVERRIDE)
 
 
 def up(a):
@@ -198,16 +197,9 @@ def main(argv=None):
                         NTR_TRACE_FETCH_THRESHOLD=int(rng.choice([-1, -1, 1, 16, 33, 64])), NTR_TRACE_FLAT_FETCH=int(rng.choice([1, 1, 0])),
                         # wave-private mini-pool of the closest-hit per-ray launches: by the device's coherence estimate, off, or forced
                         NTR_TRACE_MINIPOOL=int(rng.choice([-1, -1, 0, 1, 2, 3, 4, 5, 8, 16])), NTR_TRACE_MINIPOOL_THRESHOLD=int(rng.choice([48, 48, 1, 33, 64])),
-                        # tail hand-off of the pool waves (A/B build only: run with NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_ab.so; the product
-                        # library ignores these): every threshold drawn at random, pools of one chunk included
-                        NTR_TRACE_HANDOFF=int(rng.choice([0, 1, 1])) if HAS_HANDOFF else 0, NTR_TRACE_HANDOFF_BELOW=int(rng.integers(1, 65)),
-                        NTR_TRACE_HANDOFF_MIN_QUEUE=int(rng.choice([1, 4, 16, 64])), NTR_TRACE_HANDOFF_KEEP_WAVES=int(rng.choice([0, 0, 64, 1024, 100000])),
-                        NTR_TRACE_HANDOFF_FLAGS=int(rng.integers(0, 4)),
-                        # ray splitting in the drain phase of the persistent kernels (trace_split.h): how often the lanes are looked at; in the
-                        # A/B build the per-ray / mini-pool launch may split too
-                        NTR_TRACE_SPLIT_SLICE=int(rng.choice([8, 8, 1, 2, 5, 32, 0])), NTR_TRACE_SPLIT_PERRAY=int(rng.choice([0, 1])) if HAS_HANDOFF else 0)
+                        # ray splitting in the drain phase of the persistent kernels (trace_split.h): how often the lanes are looked at
+                        NTR_TRACE_SPLIT_SLICE=int(rng.choice([8, 8, 1, 2, 5, 32, 0])))
             nt.set_tunables(**loop)
-            tot["handoff_rounds"] = tot.get("handoff_rounds", 0) + loop["NTR_TRACE_HANDOFF"]
             hint = nt.SchedHint() if sched >= 2 else None
             if sched == 3:
                 nbk = (n + 255) // 256
@@ -230,10 +222,6 @@ def main(argv=None):
                         view.trace(kernel, n, any_hit, d_rays.data_ptr(), d_res.data_ptr(), hint=hint)
                         torch.cuda.synchronize()
                         got2 = d_res.cpu().numpy().view(nt.RESULT_DTYPE)
-                        if loop["NTR_TRACE_HANDOFF"] and kernel == KERNELS[0] and not any_hit:
-                            pushed, popped, _ = nt.trace_handoff_counts(0)
-                            tot["rays_handed_off"] = tot.get("rays_handed_off", 0) + pushed
-                            bad += int(pushed != popped)
                         bad += int(((got2["id"] != exp["id"]) | (got2["t"].view(np.uint32) != exp["t"].view(np.uint32))).sum())
                         tot["rays_compared"] += n
                     tot["rays_compared"] += n

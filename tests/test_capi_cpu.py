@@ -105,7 +105,7 @@ def test_multi_gpu_partition_and_diagnostics_argument_checks():
     assert L.ntr_frame_ao_batches(0, 1000, 8, 1 << 20, None, None, 4, C.byref(n)) == -1                     # capacity without arrays
     assert nt.frame_ao_batches(64, 1064, 8, 4096) == [(64, 512), (576, 488)]
     # diagnostics
-    assert not hasattr(L, "ntr_trace_handoff_counts")   # the rejected tail hand-off lives in the A/B build only (ntrace_amd/csrc/ntr_ab.h)
+    assert not hasattr(L, "ntr_trace_handoff_counts") and not hasattr(L, "ntr_experiment_hooks")   # rejected experiments / diagnostic hooks are patches (scripts/studies/rejected_patches/), never in the library
     sec = C.c_float(0.0)
     assert L.ntr_selftest_gather_rate(16, 1, 64, 1, None, C.byref(sec)) == -1          # table too small
     assert L.ntr_selftest_gather_rate(1 << 20, 1, 65, 1, None, C.byref(sec)) == -1     # more lanes than a wave has

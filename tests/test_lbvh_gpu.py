@@ -13,23 +13,17 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "split16-64t", "split40-256t", "bottom-up-no-lds", "bottom-up-no-lds-split16", "bottom-up-staged", "bottom-up-staged-split16", "bottom-up-one-launch", "bottom-up-one-launch-split16", "cells-top", "cells-top-split16",
-                                       "legacy-top-and-sort", "legacy-top-split16", "levelsync"])
+@pytest.fixture(autouse=True, params=["default", "split16-64t", "split40-256t", "bottom-up-no-lds", "bottom-up-no-lds-split16", "bottom-up-staged", "bottom-up-staged-split16", "bottom-up-one-launch", "bottom-up-one-launch-split16"])
 def build_path(request, monkeypatch):
     """Every test runs on the default path (one-sweep sort, bottom-up emit with scanned indices; scenes of at most `split`
     triangles are one subtree workgroup), on the same path with a tiny `split` (so that small scenes take the bottom-up emit, and
-    runs of equal keys its slow path with hand-over roots and the oversize fallback), with every meeting through memory, on the
-    cell-table top pass + subtree workgroups, on the round-1 sort / top pass, and on the per-level kernels."""
-    # the round-1 / round-2 paths (per-level kernels, three-kernel sort, cell-table top, forced legacy top) are A/B scaffolding compiled
-    # only into the experiment build of the library: those parameters run against libntrace_amd_exp.so
-    exp_only = request.param in ("cells-top", "cells-top-split16", "legacy-top-and-sort", "legacy-top-split16", "levelsync")
-    nt.use_library(nt.exp_lib_path() if exp_only else None)
-    request.addfinalizer(lambda: (nt.use_library(None), nt.set_tunables()))
-    for k in ("NTR_LBVH_LEVELSYNC", "NTR_LBVH_SPLIT", "NTR_LBVH_SUB_THREADS", "NTR_LBVH_LEGACY_TOP", "NTR_LBVH_LEGACY_SORT", "NTR_LBVH_EMIT", "NTR_LBVH_AGG_LDS", "NTR_LBVH_AGG_STAGED"):
+    runs of equal keys its slow path with hand-over roots and the oversize fallback), with every meeting through memory, and with
+    the border chains in one launch / two launches.  (The superseded round-1 / round-2 paths are a patch under
+    scripts/studies/rejected_patches/ and no longer part of any build.)"""
+    request.addfinalizer(lambda: nt.set_tunables())
+    for k in ("NTR_LBVH_SPLIT", "NTR_LBVH_SUB_THREADS", "NTR_LBVH_AGG_LDS", "NTR_LBVH_AGG_STAGED"):
         monkeypatch.delenv(k, raising=False)
-    if request.param == "levelsync":
-        monkeypatch.setenv("NTR_LBVH_LEVELSYNC", "1")
-    elif request.param == "bottom-up-no-lds":  # every meeting of the bottom-up emit through memory
+    if request.param == "bottom-up-no-lds":  # every meeting of the bottom-up emit through memory
         monkeypatch.setenv("NTR_LBVH_AGG_LDS", "0")
     elif request.param == "bottom-up-no-lds-split16":
         monkeypatch.setenv("NTR_LBVH_AGG_LDS", "0")
@@ -44,20 +38,9 @@ def build_path(request, monkeypatch):
     elif request.param == "bottom-up-staged-split16":
         monkeypatch.setenv("NTR_LBVH_AGG_STAGED", "1")
         monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
-    elif request.param == "cells-top":  # cell-table top pass + one workgroup per subtree
-        monkeypatch.setenv("NTR_LBVH_EMIT", "1")
-    elif request.param == "cells-top-split16":
-        monkeypatch.setenv("NTR_LBVH_EMIT", "1")
-        monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
     elif request.param == "split16-64t":
         monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
         monkeypatch.setenv("NTR_LBVH_SUB_THREADS", "64")
-    elif request.param == "legacy-top-and-sort":  # round-1 pipeline: 12-launch sort, level-by-level top pass with key probes
-        monkeypatch.setenv("NTR_LBVH_LEGACY_TOP", "1")
-        monkeypatch.setenv("NTR_LBVH_LEGACY_SORT", "1")
-    elif request.param == "legacy-top-split16":
-        monkeypatch.setenv("NTR_LBVH_LEGACY_TOP", "1")
-        monkeypatch.setenv("NTR_LBVH_SPLIT", "16")
     elif request.param == "split40-256t":
         monkeypatch.setenv("NTR_LBVH_SPLIT", "40")
         monkeypatch.setenv("NTR_LBVH_SUB_THREADS", "256")
