@@ -185,6 +185,41 @@ NTR_API int ntr_stream_release(void* stream);
  * last round (keysPerDevice for every device while keysPerDevice <= 96: no device is starved by the others). */
 NTR_API int ntr_selftest_auto_hint_table(int32_t devices, int32_t keysPerDevice, int32_t rounds, int32_t* hintedLastRound);
 
+/* The PLAN of a trace launch (diagnostic; no device needed): everything ntr_trace_bvh decides from the tunables, the kernel name and the
+ * batch's sizes and flags alone -- which kernel variant, how many workgroups, which loop, pool geometry, and which scheduling aids
+ * (automatic hint, dispatch-order prediction, pool depth decided on the device) the launch will ask for.  ntr_trace_bvh computes exactly
+ * this (csrc/trace_plan.h) before it touches the device; what depends on run-time state (which hint entry, which prediction scratch)
+ * is not part of it.  No counterpart in the reference (CudaBVHTracer::traceBatch sizes its grid inline, CudaBVHTracer.cpp:152-160). */
+typedef struct NtrTracePlan {
+    int32_t variant;            /* NTR_VARIANT_* after the stats override (csrc/trace_kernels.h) */
+    int32_t launchVariant;      /* the kernel that is launched */
+    int32_t launchBlocks;       /* its workgroups */
+    int32_t numBlocks;          /* per-ray kernels: 256-ray blocks (unit of dispatch order and cost feedback); persistent: the grid */
+    int32_t orderBlocks;        /* 256-ray blocks of the batch */
+    int32_t chunk, fetchThreshold, leafSwitchBelow, octant, flatFetch, uniformPrologue, splitSlice;
+    int32_t numHeads, shardRays, numBlocksIncoherent;   /* persistent kernels: pool heads, rays per head, grid of an incoherent batch */
+    int32_t unified;            /* persistent: unified-step loop (kepler_dynamic_fetch) */
+    int32_t minipool;           /* closest-hit per-ray launch that may run as wave-private ray pools */
+    int32_t poolKConst;         /* pool depth when it is not decided on the device */
+    int32_t poolKFromDevice;    /* it is: the prediction of this launch, or the batch's hint, holds K */
+    int32_t minipoolWide;       /* K of a batch the device finds incoherent */
+    int32_t hintable;           /* the variant honours a scheduling hint */
+    int32_t useAutoHint;        /* the batch is looked up in the library's own hint table */
+    int32_t predictable;        /* dispatch-order prediction applies when no measured order is at hand */
+    int32_t persistentOrder;    /* ... for a persistent launch: the pool is handed out in predicted order */
+    int32_t probeOnRefresh;     /* a hinted batch's pool depth is estimated again on the hint's refresh launches */
+    int32_t coherentRoute;      /* persistent names: a batch the device finds coherent is traced by the per-ray body (see ntr_query_config) */
+} NtrTracePlan;
+#define NTR_PLAN_FLAG_STATS 1        /* ntr_trace_bvh_stats */
+#define NTR_PLAN_FLAG_CAPTURING 2    /* the stream is being captured into a HIP graph */
+#define NTR_PLAN_FLAG_CALLER_HINT 4  /* the caller passes an NtrSchedHint */
+NTR_API int ntr_trace_plan(const char* kernelName, int32_t numRays, int32_t anyHit, uint64_t nodesAddr, int64_t nodesBytes,
+                           uint64_t triWoopAddr, int64_t triWoopBytes, uint32_t bvhFlags, int32_t numCUs, int32_t flags,
+                           NtrTracePlan* plan);
+/* One launch in the life of a scheduling hint: out[0] = the hint's pool-depth words are cleared, out[1] = the launch records per-block
+ * costs (refresh), out[2] = the launch is dispatched in the hint's order. */
+NTR_API int ntr_trace_plan_hint_step(int32_t valid, int32_t predicted, int32_t uses, int32_t out[3]);
+
 /* Re-reads the NTR_* environment tunables.  They are read once, at first use; sweep scripts
  * that change a variable inside one process call this afterwards.  Not needed by applications. */
 NTR_API int ntr_tunables_reload(void);

@@ -11,7 +11,7 @@ from ._capi import (BvhView, RAY_DTYPE, RESULT_DTYPE, HostBvh, KernelConfig, Ntr
                     lib_path, query_config, sah_build, trace_bvh, trace_bvh_stats, pixel_table,
                     raygen_primary, raygen_ao, count_hits, selftest_division, selftest_division_hard, bvh_leaf_depths, secondary_block_costs, lbvh_capacity,
                     lbvh_build, LbvhResult, reconstruct, ray_morton_sort, camera_decode, camera_reencode,
-                    camera_nscreen_to_world, obj_load, SchedHint, trace_status, set_tunables, host_bvh_wrap, use_library, trace_graph_reserve, trace_graph_release_all, stream_release, selftest_auto_hint_table, selftest_gather_rate, frame_shard, frame_ao_batches, DistGroup,
+                    camera_nscreen_to_world, obj_load, SchedHint, trace_status, trace_plan, trace_plan_hint_step, TracePlan, set_tunables, host_bvh_wrap, use_library, trace_graph_reserve, trace_graph_release_all, stream_release, selftest_auto_hint_table, selftest_gather_rate, frame_shard, frame_ao_batches, DistGroup,
                     lbvh_release_workspace, predict_block_costs, predict_batch_coherence)
 
 BVHLayout_Compact = 4

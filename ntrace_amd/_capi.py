@@ -81,6 +81,8 @@ SYMBOLS = [
     ("ntr_trace_bvh_hinted", C.c_int, [C.c_char_p, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _u32, _vp,
                                        C.POINTER(C.c_float), _vp]),
     ("ntr_trace_status", C.c_int, [_vp, C.POINTER(_u32)]),
+    ("ntr_trace_plan", C.c_int, [C.c_char_p, _i32, _i32, C.c_uint64, _i64, C.c_uint64, _i64, _u32, _i32, _i32, _vp]),
+    ("ntr_trace_plan_hint_step", C.c_int, [_i32, _i32, _i32, C.POINTER(_i32 * 3)]),
     ("ntr_selftest_gather_rate", C.c_int, [_i64, _i32, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     ("ntr_frame_shard", C.c_int, [_i32, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     ("ntr_frame_ao_batches", C.c_int, [_i32, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), _i32, C.POINTER(_i32)]),
@@ -224,6 +226,36 @@ def trace_bvh(kernel, num_rays, any_hit, d_rays, d_results, d_nodes, nodes_bytes
     else:
         _check(lib().ntr_trace_bvh_hinted(*args, hint._h))
     return float(sec.value) if timed else None
+
+
+class TracePlan(C.Structure):
+    """NtrTracePlan (include/ntrace_amd.h): what ntr_trace_bvh decides before it touches the device."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "variant", "launchVariant", "launchBlocks", "numBlocks", "orderBlocks", "chunk", "fetchThreshold", "leafSwitchBelow", "octant",
+        "flatFetch", "uniformPrologue", "splitSlice", "numHeads", "shardRays", "numBlocksIncoherent", "unified", "minipool", "poolKConst",
+        "poolKFromDevice", "minipoolWide", "hintable", "useAutoHint", "predictable", "persistentOrder", "probeOnRefresh", "coherentRoute")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+PLAN_FLAG_STATS, PLAN_FLAG_CAPTURING, PLAN_FLAG_CALLER_HINT = 1, 2, 4
+
+
+def trace_plan(kernel, num_rays, any_hit, nodes_bytes, woop_bytes, nodes_addr=1 << 32, woop_addr=None, bvh_flags=0, num_cus=256, flags=0):
+    """ntr_trace_plan: the launch plan of such a batch (no device needed)."""
+    if woop_addr is None:
+        woop_addr = nodes_addr + nodes_bytes
+    pl = TracePlan()
+    _check(lib().ntr_trace_plan(kernel.encode(), int(num_rays), int(bool(any_hit)), int(nodes_addr), int(nodes_bytes), int(woop_addr),
+                                int(woop_bytes), int(bvh_flags), int(num_cus), int(flags), C.byref(pl)))
+    return pl
+
+
+def trace_plan_hint_step(valid, predicted, uses):
+    out = (_i32 * 3)()
+    _check(lib().ntr_trace_plan_hint_step(int(bool(valid)), int(bool(predicted)), int(uses), C.byref(out)))
+    return dict(zeroK=bool(out[0]), refresh=bool(out[1]), useOrder=bool(out[2]))
 
 
 def trace_status(stream=0):

@@ -16,6 +16,7 @@
 #include "ntrace_amd.h"
 #include "ntr_internal.h"
 #include "trace_kernels.h"
+#include "trace_plan.h"
 
 namespace {
 
@@ -51,7 +52,6 @@ struct DeviceState {
     int nextPinned = 0;
     int numCUs = 0;
 };
-static constexpr int kPoolHeadsMax = 1024;
 static constexpr int kNumCounters = 64;  // ring of counter sets (kPoolHeadsMax heads x 64 B each)
 static constexpr int kPinnedCounters = 192;  // counter sets handed to launches captured into HIP graphs: never reused
 static constexpr int kMaxDevices = 64;
@@ -634,18 +634,6 @@ static int auto_hint_get(const void* d_rays, const void* d_nodes, int numRays, i
     return NTR_OK;
 }
 
-// Pool K of an incoherent batch.  Long rays (big trees) amortise a deeper private pool, and the batch must oversubscribe the machine
-// (rays / 64 / K waves against 7 168 wave slots): below that a launch is bound by its longest rays, and fewer, longer-lived waves only
-// lengthen that path.  Box rays, K = 1 / 2 / 4 (scripts/studies/small_batch_minipool.py, profiles/r03_minipool_batch_sizes.jsonl), ms:
-//   courtyard-10M  2^19: 2.81 / 3.12 / 3.52   2^20: 3.74 / 3.33 / 3.55   1.5 M: 5.23 / 4.36 / 3.84   2^21: 6.79 / 5.38 / 4.73   2^22: 12.8 / 9.9 / 7.8
-//   hairball-2.8M  2^19: 1.76 / 1.50 / 1.69   2^20: 2.79 / 2.38 / 2.39   1.5 M: 3.92 / 3.10 / 3.28   2^21: 5.04 / 3.77 / 3.80   2^22: 9.5 / 6.6 / 6.4
-//   atrium-262k    2^19: .230 / .217 / .276   2^20: .374 / .375 / .349   1.5 M: .520 / .483 / .520   2^21: .670 / .598 / .627   2^22: 1.24 / 1.04 / 1.03
-static int minipool_wide(const Tunables& tun, int64_t nodesBytes, int numRays)
-{
-    if (tun.minipoolWide >= 2 && tun.minipoolWide <= NTR_MINIPOOL_MAX_K) return tun.minipoolWide;
-    return (nodesBytes >= (int64_t)32 << 20 && numRays >= (3 << 19)) ? 4 : 2;
-}
-
 static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, const NtrRay* d_rays,
                       NtrRayResult* d_results, const void* d_nodes, int64_t nodesBytes, const void* d_triWoop,
                       int64_t triWoopBytes, const int32_t* d_triIndex, int32_t layout, uint32_t bvhFlags,
@@ -676,6 +664,24 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     if (rc != NTR_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
 
+    // ---- plan: a pure function of the tunables and the batch (trace_plan.h; ntr_trace_plan exposes it to the CPU test tier) ----------
+    const Tunables tun = tunables();
+    TraceBatchDesc bd;
+    bd.variant = k->variant;
+    bd.dynamicFetch = strcmp(k->name, "kepler_dynamic_fetch") == 0;
+    bd.numRays = numRays;
+    bd.anyHit = anyHit != 0;
+    bd.nodesBytes = nodesBytes; bd.triWoopBytes = triWoopBytes;
+    bd.nodesAddr = (uint64_t)d_nodes; bd.woopAddr = (uint64_t)d_triWoop;
+    bd.bvhFlags = bvhFlags;
+    bd.wantStats = stats != nullptr;
+    bd.capturing = stream_is_capturing(s);
+    bd.callerHint = hint != nullptr;
+    bd.numCUs = ds->numCUs;
+    const TracePlan pl = plan_trace(tun, bd);
+    const int variant = pl.variant, numBlocks = pl.numBlocks, orderBlocks = pl.orderBlocks;
+
+    // ---- launch: bind the run-time state the plan asks for (counters, hints, prediction scratch), then the kernels ------------------
     TraceParams p;
     p.numRays = numRays;
     p.anyHit = anyHit ? 1 : 0;
@@ -688,59 +694,31 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.triIndex = d_triIndex;
     p.status = ds->status;
     p.counter = nullptr;
-    p.shardRays = 0;
-    p.numHeads = 8;
-    p.numBlocks = 0;
-    p.numBlocksIncoherent = 0;
+    p.shardRays = pl.shardRays;
+    p.numHeads = pl.numHeads;
+    p.numBlocks = variant == NTR_VARIANT_PERSISTENT ? pl.numBlocks : 0;
+    p.numBlocksIncoherent = pl.numBlocksIncoherent;
     p.orderBlocks = 0;
-    // persistent kernels (scripts/studies/persist_sweep.py): 64-ray chunks, 6 workgroups per CU; dynamic fetch only for the kernel
-    // named after it (it costs about 10 % here: refilled lanes de-cohere a wave's node fetches)
-    const Tunables tun = tunables();
-    p.chunk = tun.chunk;
-    const bool dynamicFetch = strcmp(k->name, "kepler_dynamic_fetch") == 0;
-    const bool unified = dynamicFetch && tun.unified != 0;
-    p.fetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (dynamicFetch ? (unified ? 48 : 24) : 0);
+    p.chunk = pl.chunk;
+    p.fetchThreshold = pl.fetchThreshold;
     p.bvhFlags = bvhFlags;
-    {   // the flat fetch addresses both buffers from one scalar base with 32-bit lane offsets: they must lie inside one 4 GiB window
-        // (two allocations of one heap practically always do; otherwise the two-descriptor fetch, which has no such condition)
-        const unsigned long long an = (unsigned long long)d_nodes, aw = (unsigned long long)d_triWoop;
-        const unsigned long long lo = an < aw ? an : aw;
-        const unsigned long long hiN = an + (unsigned long long)nodesBytes, hiW = aw + (unsigned long long)triWoopBytes;
-        const bool oneWindow = ((hiN > hiW ? hiN : hiW) - lo) <= 0xFFFFFFFFull;
-        p.flatFetch = (tun.flatFetch != 0 && nodesBytes >= 64 && triWoopBytes >= 64 && oneWindow) ? 1 : 0;
-    }
-    p.uniformPrologue = tun.uniformPrologue != 0 ? 1 : 0;
-    p.splitSlice = tun.splitSlice > 0 ? tun.splitSlice : 0;
-    p.leafSwitchBelow = tun.leafSwitchBelow >= 0 ? tun.leafSwitchBelow : (anyHit ? 24 : 32);
-    p.octant = tun.octant;
+    p.flatFetch = pl.flatFetch;
+    p.uniformPrologue = pl.uniformPrologue;
+    p.splitSlice = pl.splitSlice;
+    p.leafSwitchBelow = pl.leafSwitchBelow;
+    p.octant = pl.octant;
     p.stats = ds->stats;
     p.order = nullptr;
     p.cost = nullptr;
     p.poolK = nullptr;
-    p.poolKConst = 1;
-    int variant = k->variant;
-    if (stats) {
-        // RayStats counters (src/rt/bvh/BVH.hpp:44-, filled at CudaBVH.cpp:746-757,1107-1111) are
-        // produced by the instrumented per-ray kernel; every variant visits nodes in the same
-        // per-ray order, so the counts do not depend on the variant.
-        variant = NTR_VARIANT_PERRAY_STATS;
-        NTR_HIP(hipMemsetAsync(ds->stats, 0, 4 * sizeof(unsigned long long), s));
-    }
+    p.poolKConst = pl.poolKConst;
+    if (stats) NTR_HIP(hipMemsetAsync(ds->stats, 0, 4 * sizeof(unsigned long long), s));
 
-    constexpr int blockThreads = NTR_TRACE_WAVES_PER_BLOCK * 64;
-    int numBlocks;
     if (variant == NTR_VARIANT_PERSISTENT) {
-        // Persistent grid: CUs x resident blocks per CU (the reference hard-codes
-        // 720 warps for GT200/Fermi, CudaBVHTracer.cpp:155-159).
-        const int blocksPerCU = tun.blocksPerCU;
-        numBlocks = ds->numCUs * blocksPerCU;
-        const int needed = (numRays + blockThreads - 1) / blockThreads;
-        if (numBlocks > needed) numBlocks = needed;
         {
             // a launch that is being captured into a HIP graph keeps its pool heads for the graph's lifetime
-            const bool capturing = stream_is_capturing(s);
             std::lock_guard<std::mutex> lk(g_mu);
-            if (capturing) {
+            if (bd.capturing) {
                 if (ds->nextPinned >= kPinnedCounters)
                     return set_error(NTR_ERR_NOMEM, "ntr_trace_bvh: more than %d persistent launches captured into HIP graphs", kPinnedCounters);
                 p.counter = ds->counters + kPoolHeadsMax * 16 * (kNumCounters + ds->nextPinned++);
@@ -749,53 +727,35 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
                 ds->next = (ds->next + 1) % kNumCounters;
             }
         }
-        {   // cleared by a kernel: memset nodes do not survive HIP graph replays (see sched_kernels.hip)
-            const hipError_t ze = ntr_launch_zero_words(p.counter, kPoolHeadsMax * 16, s);
-            if (ze != hipSuccess) return hip_fail(ze, "zero_words launch");
-        }
-        const int chunksTotal = (numRays + p.chunk - 1) / p.chunk;
-        int heads = tun.poolHeads < 8 ? 8 : (tun.poolHeads > kPoolHeadsMax ? kPoolHeadsMax : tun.poolHeads & ~7);
-        p.numHeads = heads;
-        p.numBlocks = numBlocks;
-        // (only the dynamic-fetch kernel: its waves stay full from the pool; the while-while persistent kernel refills a wave only when it is
-        // empty and loses with fewer waves -- hairball box rays 9.3 -> 14.7 ms)
-        if (dynamicFetch && tun.blocksPerCUIncoherent > 0 && tun.blocksPerCUIncoherent < blocksPerCU) {
-            p.numBlocksIncoherent = ds->numCUs * tun.blocksPerCUIncoherent;
-            if (p.numBlocksIncoherent > numBlocks) p.numBlocksIncoherent = numBlocks;
-        }
-        p.shardRays = ((chunksTotal + heads - 1) / heads) * p.chunk;
-    } else {
-        numBlocks = (numRays + blockThreads - 1) / blockThreads;
+        // cleared by a kernel: memset nodes do not survive HIP graph replays (see sched_kernels.hip)
+        const hipError_t ze = ntr_launch_zero_words(p.counter, kPoolHeadsMax * 16, s);
+        if (ze != hipSuccess) return hip_fail(ze, "zero_words launch");
     }
 
     // no hint from the caller: the library's own, keyed by (stream, batch, BVH)
-    if (!hint && !stats && tun.autoHint != 0 && variant == NTR_VARIANT_PERRAY && numRays >= tun.autoHintMinRays && !stream_is_capturing(s)) {
+    if (pl.useAutoHint) {
         rc = auto_hint_get(d_rays, d_nodes, numRays, anyHit ? 1 : 0, s, numBlocks, &hint);
         if (rc != NTR_OK) return rc;
     }
     // Scheduling hint: the per-ray kernel dispatches blocks in the hint's order; on refresh launches it
     // also records per-block costs, from which the next order is derived right after the launch.
     bool refresh = false;
-    if (hint && variant == NTR_VARIANT_PERRAY) {
+    if (hint && pl.hintable) {
         int dev = 0;
         NTR_HIP(hipGetDevice(&dev));
         if (hint->numBlocks != numBlocks || hint->device != dev) {
             rc = sched_hint_bind(hint, numBlocks, dev);   // (automatic hints arrive bound: auto_hint_get)
             if (rc != NTR_OK) return rc;
         }
-        // costs measured under the natural order differ from those under the derived order, so the first
-        // launches all refresh; afterwards every 8th does (slowly drifting rays keep their schedule)
-        const bool firstOfPrediction = hint->predicted && hint->valid;   // (ntr_sched_hint_predict cleared the K words itself)
-        if (hint->uses == 0 && !firstOfPrediction) {   // a hint that starts over (new, or an automatic one recycled for another batch) forgets its K
+        const HintStep hs = plan_hint_step(tun, hint->valid, hint->predicted, hint->uses);
+        if (hs.zeroK) {
             const hipError_t zk = ntr_launch_zero_words(hint->order + numBlocks, 3, s);
             if (zk != hipSuccess) return hip_fail(zk, "zero_words launch");
         }
-        const int every = tun.schedRefreshEvery;
-        refresh = hint->uses < 3 || every <= 1 || (hint->uses % every) == 0;
-        if (firstOfPrediction) refresh = false;   // the first launch of a predicted order just runs it (a batch traced once pays nothing for feedback)
+        refresh = hs.refresh;
         hint->predicted = false;
         hint->uses++;
-        if (hint->valid) p.order = hint->order;
+        if (hs.useOrder) p.order = hint->order;
         if (refresh) {
             const hipError_t ze = ntr_launch_zero_words(hint->cost, numBlocks, s);
             if (ze != hipSuccess) return hip_fail(ze, "zero_words launch");
@@ -803,19 +763,11 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         }
     }
 
-    // Dispatch-order prediction (sched_kernels.hip): closest-hit launches of the per-ray kernel that are large
-    // enough for the tail to outweigh the two small launches (about 30 us; break-even near 1 M rays).  Any-hit
-    // batches measured no net gain.
+    // Dispatch-order prediction (plan_trace: which launches qualify).  A launch whose hint holds no measured order yet -- the first one
+    // of a batch -- is predicted like an unhinted one.
     TopTable* predTable = nullptr;
     PredictScratch* predScratch = nullptr;
-    // (a tree of a few hundred nodes is traced faster than it is predicted: Cornell-box class scenes are left alone)
-    // The persistent kernels hand their pool out in the same predicted order (the heavy blocks' long rays start first instead of being
-    // the chunks fetched last): there the prediction covers batches of all 256-ray blocks and needs pool chunks that divide 256.
-    const bool persistentOrder = variant == NTR_VARIANT_PERSISTENT && tun.predictPersistent != 0 && (256 % p.chunk) == 0;
-    const int orderBlocks = (numRays + 255) / 256;
-    // (a launch whose hint holds no measured order yet -- the first one of a batch -- is predicted like an unhinted one)
-    if (!(hint && hint->valid) && !p.order && (variant == NTR_VARIANT_PERRAY || persistentOrder) && !anyHit && numRays >= tun.predictMinRays &&
-        nodesBytes >= (int64_t)tun.predictMinNodes * 64 && tun.predict != 0) {
+    if (pl.predictable && !(hint && hint->valid) && !p.order) {
         rc = top_table_get(d_nodes, nodesBytes, s, false, &predTable);
         if (rc != NTR_OK) return rc;
         rc = predict_scratch_get(s, orderBlocks, &predScratch);
@@ -834,11 +786,15 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
 
     // A hinted batch is predicted once (its hint then holds a measured order); its coherence words -- the mini-pool K -- are estimated again
     // on the hint's refresh launches by a probe of their own (three small launches, every 16th launch): rays drift.
-    const bool probeCoherence = !predScratch && hint && refresh && variant == NTR_VARIANT_PERRAY && !anyHit && tun.minipool < 0 &&
-                                tun.predict != 0 && numRays >= tun.predictMinRays && nodesBytes >= (int64_t)tun.predictMinNodes * 64;
+    const bool probeCoherence = !predScratch && hint && refresh && pl.probeOnRefresh;
     if (probeCoherence) {
         rc = top_table_get(d_nodes, nodesBytes, s, false, &predTable);
         if (rc != NTR_OK) return rc;
+    }
+    // pool depth K of a mini-pool launch: the prediction of this launch wrote it, or the batch's hint kept it from its first launch
+    if (pl.minipool && pl.poolKFromDevice) {
+        if (predScratch) p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 2;
+        else if (hint && hint->numBlocks == numBlocks && hint->order) p.poolK = hint->order + numBlocks + 2;
     }
 
     struct EventPair {   // destroyed on every return path of the timed bracket
@@ -856,43 +812,14 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     if (predScratch) {  // inside the timed bracket: the prediction is part of what the launch costs
         const hipError_t pe = ntr_launch_predict(d_rays, numRays, orderBlocks, predTable->table, predTable->count, predScratch->classCount,
                                                  predScratch->classList, predScratch->order,
-                                                 (hint && variant == NTR_VARIANT_PERRAY) ? hint->order + numBlocks + 2 : nullptr, minipool_wide(tun, nodesBytes, numRays), s);
+                                                 (hint && pl.hintable) ? hint->order + numBlocks + 2 : nullptr, pl.minipoolWide, s);
         if (pe != hipSuccess) return hip_fail(pe, "predict launch");
     } else if (probeCoherence) {   // (also inside the bracket)
         const hipError_t ce = ntr_launch_coherence(d_rays, numRays, orderBlocks, predTable->table, predTable->count, hint->order + numBlocks,
-                                                  minipool_wide(tun, nodesBytes, numRays), s);
+                                                  pl.minipoolWide, s);
         if (ce != hipSuccess) return hip_fail(ce, "coherence launch");
     }
-    // Workgroup size of the per-ray kernel: smaller workgroups retire (and are replaced) sooner.  The dispatch order and the cost
-    // feedback stay in units of 256 rays: numBlocks counts those, the launch has 4 / waves workgroups per unit.
-    int launchVariant = variant, launchBlocks = numBlocks;
-    if (variant == NTR_VARIANT_PERSISTENT && unified) launchVariant = NTR_VARIANT_PERSISTENT_UNIFIED;
-    const int wantWaves = anyHit ? tun.anyHitWaves : tun.closestWaves;
-    if (variant == NTR_VARIANT_PERRAY && wantWaves < NTR_TRACE_WAVES_PER_BLOCK) {
-        const int waves = wantWaves <= 1 ? 1 : 2;
-        launchVariant = waves == 1 ? NTR_VARIANT_PERRAY_W1 : NTR_VARIANT_PERRAY_W2;
-        launchBlocks = numBlocks * (4 / waves);
-        // unified-step loop (one node OR one triangle per lane and iteration, one group of loads): closest-hit launches on any tree
-        // (atrium primary +5 %, conference +21 %, LBVH trees +50 %) and any-hit launches (multi-triangle leaves: always ahead; short AO
-        // rays in one-triangle-leaf trees: the while-while loop was 2-3 % ahead while a step cost ~100 vector instructions, the unified
-        // loop is 4 % ahead since the one-correction divide -- profiles/r04_perray_unified_anyhit_knob.txt)
-        if (tun.perrayUnified > 0 || (tun.perrayUnified < 0 && (!anyHit || (bvhFlags & NTR_BVH_WIDE_LEAVES)))) {
-            launchVariant = NTR_VARIANT_PERRAY_UNIFIED_W1;
-            launchBlocks = numBlocks * 4;
-            // wave-private mini-pool: a wave owns K x 64 rays and refills its finished lanes from them.  K is decided on the device: the
-            // prediction of this launch wrote it (incoherent batch: minipoolWide, else 1), or the batch's hint kept it from its first launch.
-            if (tun.minipool != 0 && !anyHit) {
-                launchVariant = NTR_VARIANT_PERRAY_UNIFIED_MINI;
-                p.fetchThreshold = tun.minipoolThreshold;
-                p.poolKConst = tun.minipool > 0 ? tun.minipool : 1;
-                if (tun.minipool < 0) {
-                    if (predScratch) p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 2;
-                    else if (hint && hint->numBlocks == numBlocks && hint->order) p.poolK = hint->order + numBlocks + 2;
-                }
-            }
-        }
-    }
-    hipError_t le = ntr_launch_trace(launchVariant, &p, launchBlocks, s);
+    hipError_t le = ntr_launch_trace(pl.launchVariant, &p, pl.launchBlocks, s);
     if (le != hipSuccess) return hip_fail(le, "trace_bvh launch");
     if (seconds) NTR_HIP(hipEventRecord(ev1, s));
     if (refresh) {
@@ -942,6 +869,38 @@ int ntr_trace_bvh_hinted(const char* kernelName, int32_t numRays, int32_t anyHit
 {
     return trace_impl(kernelName, numRays, anyHit, d_rays, d_results, d_nodes, nodesBytes, d_triWoop, triWoopBytes,
                       d_triIndex, layout, bvhFlags, stream, seconds, nullptr, hint);
+}
+
+int ntr_trace_plan(const char* kernelName, int32_t numRays, int32_t anyHit, uint64_t nodesAddr, int64_t nodesBytes, uint64_t triWoopAddr,
+                   int64_t triWoopBytes, uint32_t bvhFlags, int32_t numCUs, int32_t flags, NtrTracePlan* plan)
+{
+    if (!plan) return set_error(NTR_ERR_INVALID, "ntr_trace_plan: null plan");
+    memset(plan, 0, sizeof(*plan));
+    const KernelInfo* k = find_kernel(kernelName);
+    if (!k) return set_error(NTR_ERR_UNKNOWN_KERNEL, "unknown kernel '%s'", kernelName ? kernelName : "(null)");
+    if (numRays < 0 || numCUs < 1 || nodesBytes < 0 || triWoopBytes < 0) return set_error(NTR_ERR_INVALID, "ntr_trace_plan: bad argument");
+    TraceBatchDesc bd;
+    bd.variant = k->variant;
+    bd.dynamicFetch = strcmp(k->name, "kepler_dynamic_fetch") == 0;
+    bd.numRays = numRays;
+    bd.anyHit = anyHit != 0;
+    bd.nodesBytes = nodesBytes; bd.triWoopBytes = triWoopBytes;
+    bd.nodesAddr = nodesAddr; bd.woopAddr = triWoopAddr;
+    bd.bvhFlags = bvhFlags;
+    bd.wantStats = (flags & NTR_PLAN_FLAG_STATS) != 0;
+    bd.capturing = (flags & NTR_PLAN_FLAG_CAPTURING) != 0;
+    bd.callerHint = (flags & NTR_PLAN_FLAG_CALLER_HINT) != 0;
+    bd.numCUs = numCUs;
+    *plan = plan_trace(tunables(), bd);
+    return NTR_OK;
+}
+
+int ntr_trace_plan_hint_step(int32_t valid, int32_t predicted, int32_t uses, int32_t out[3])
+{
+    if (!out || uses < 0) return set_error(NTR_ERR_INVALID, "ntr_trace_plan_hint_step: bad argument");
+    const HintStep h = plan_hint_step(tunables(), valid != 0, predicted != 0, uses);
+    out[0] = h.zeroK; out[1] = h.refresh; out[2] = h.useOrder;
+    return NTR_OK;
 }
 
 int ntr_trace_status(void* stream, uint32_t* statusBits)

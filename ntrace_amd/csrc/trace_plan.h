@@ -1,0 +1,159 @@
+// trace_plan.h -- the PLAN of a trace launch: everything ntr_trace_bvh decides from the tunables, the kernel name and the batch's
+// sizes and flags alone, as a pure function (no HIP call, no global state).  ntr_api.cpp's trace_impl validates, plans, then launches;
+// ntr_trace_plan() exposes the plan through the C-ABI so that the CPU test tier can check it without a device
+// (tests/test_trace_plan_cpu.py).  What depends on run-time state -- which hint / prediction scratch / counters a launch gets -- stays
+// in the launch half.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "ntrace_amd.h"
+#include "ntr_internal.h"
+#include "trace_kernels.h"
+
+namespace ntr {
+
+static constexpr int kPoolHeadsMax = 1024;
+
+struct TraceBatchDesc {
+    int variant;            // the kernel name's variant (NTR_VARIANT_PERRAY / NTR_VARIANT_PERSISTENT)
+    bool dynamicFetch;      // the name is kepler_dynamic_fetch
+    int32_t numRays;
+    bool anyHit;
+    int64_t nodesBytes, triWoopBytes;
+    uint64_t nodesAddr, woopAddr;
+    uint32_t bvhFlags;
+    bool wantStats;         // ntr_trace_bvh_stats: the instrumented per-ray kernel, whatever the name
+    bool capturing;         // the stream is being captured into a HIP graph
+    bool callerHint;        // the caller passed an NtrSchedHint
+    int numCUs;
+};
+
+typedef NtrTracePlan TracePlan;   // include/ntrace_amd.h: plain int32 fields, so that ntr_trace_plan can hand it out as it is
+
+// Pool K of an incoherent batch.  Long rays (big trees) amortise a deeper private pool, and the batch must oversubscribe the machine
+// (rays / 64 / K waves against 7 168 wave slots): below that a launch is bound by its longest rays, and fewer, longer-lived waves only
+// lengthen that path.  Box rays, K = 1 / 2 / 4 (scripts/studies/small_batch_minipool.py, profiles/r03_minipool_batch_sizes.jsonl), ms:
+//   courtyard-10M  2^19: 2.81 / 3.12 / 3.52   2^20: 3.74 / 3.33 / 3.55   1.5 M: 5.23 / 4.36 / 3.84   2^21: 6.79 / 5.38 / 4.73   2^22: 12.8 / 9.9 / 7.8
+//   hairball-2.8M  2^19: 1.76 / 1.50 / 1.69   2^20: 2.79 / 2.38 / 2.39   1.5 M: 3.92 / 3.10 / 3.28   2^21: 5.04 / 3.77 / 3.80   2^22: 9.5 / 6.6 / 6.4
+//   atrium-262k    2^19: .230 / .217 / .276   2^20: .374 / .375 / .349   1.5 M: .520 / .483 / .520   2^21: .670 / .598 / .627   2^22: 1.24 / 1.04 / 1.03
+inline int minipool_wide(const Tunables& tun, int64_t nodesBytes, int numRays)
+{
+    if (tun.minipoolWide >= 2 && tun.minipoolWide <= NTR_MINIPOOL_MAX_K) return tun.minipoolWide;
+    return (nodesBytes >= (int64_t)32 << 20 && numRays >= (3 << 19)) ? 4 : 2;
+}
+
+inline TracePlan plan_trace(const Tunables& tun, const TraceBatchDesc& b)
+{
+    TracePlan pl;
+    memset(&pl, 0, sizeof(pl));
+    const bool dynamicFetch = b.dynamicFetch;
+    pl.unified = dynamicFetch && tun.unified != 0;
+    pl.chunk = tun.chunk;
+    // persistent kernels (scripts/studies/persist_sweep.py): 64-ray chunks, 6 workgroups per CU; dynamic fetch only for the kernel
+    // named after it (it costs about 10 % on coherent batches: refilled lanes de-cohere a wave's node fetches)
+    pl.fetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (dynamicFetch ? (pl.unified ? 48 : 24) : 0);
+    {   // the flat fetch addresses both buffers from one scalar base with 32-bit lane offsets: they must lie inside one 4 GiB window
+        // (two allocations of one heap practically always do; otherwise the two-descriptor fetch, which has no such condition)
+        const uint64_t an = b.nodesAddr, aw = b.woopAddr;
+        const uint64_t lo = an < aw ? an : aw;
+        const uint64_t hiN = an + (uint64_t)b.nodesBytes, hiW = aw + (uint64_t)b.triWoopBytes;
+        const bool oneWindow = ((hiN > hiW ? hiN : hiW) - lo) <= 0xFFFFFFFFull;
+        pl.flatFetch = (tun.flatFetch != 0 && b.nodesBytes >= 64 && b.triWoopBytes >= 64 && oneWindow) ? 1 : 0;
+    }
+    pl.uniformPrologue = tun.uniformPrologue != 0 ? 1 : 0;
+    pl.splitSlice = tun.splitSlice > 0 ? tun.splitSlice : 0;
+    pl.leafSwitchBelow = tun.leafSwitchBelow >= 0 ? tun.leafSwitchBelow : (b.anyHit ? 24 : 32);
+    pl.octant = tun.octant;
+    pl.numHeads = 8;
+    pl.poolKConst = 1;
+    pl.minipoolWide = minipool_wide(tun, b.nodesBytes, b.numRays);
+
+    // RayStats counters (src/rt/bvh/BVH.hpp:44-, filled at CudaBVH.cpp:746-757,1107-1111) are produced by the instrumented per-ray
+    // kernel; every variant visits nodes in the same per-ray order, so the counts do not depend on the variant.
+    pl.variant = b.wantStats ? NTR_VARIANT_PERRAY_STATS : b.variant;
+    constexpr int blockThreads = NTR_TRACE_WAVES_PER_BLOCK * 64;
+    pl.orderBlocks = (b.numRays + 255) / 256;
+    if (pl.variant == NTR_VARIANT_PERSISTENT) {
+        // Persistent grid: CUs x resident blocks per CU (the reference hard-codes 720 warps for GT200/Fermi, CudaBVHTracer.cpp:155-159).
+        const int blocksPerCU = tun.blocksPerCU;
+        pl.numBlocks = b.numCUs * blocksPerCU;
+        const int needed = (b.numRays + blockThreads - 1) / blockThreads;
+        if (pl.numBlocks > needed) pl.numBlocks = needed;
+        const int chunksTotal = (b.numRays + pl.chunk - 1) / pl.chunk;
+        pl.numHeads = tun.poolHeads < 8 ? 8 : (tun.poolHeads > kPoolHeadsMax ? kPoolHeadsMax : tun.poolHeads & ~7);
+        // (only the dynamic-fetch kernel: its waves stay full from the pool; the while-while persistent kernel refills a wave only when it is
+        // empty and loses with fewer waves -- hairball box rays 9.3 -> 14.7 ms)
+        if (dynamicFetch && tun.blocksPerCUIncoherent > 0 && tun.blocksPerCUIncoherent < blocksPerCU) {
+            pl.numBlocksIncoherent = b.numCUs * tun.blocksPerCUIncoherent;
+            if (pl.numBlocksIncoherent > pl.numBlocks) pl.numBlocksIncoherent = pl.numBlocks;
+        }
+        pl.shardRays = ((chunksTotal + pl.numHeads - 1) / pl.numHeads) * pl.chunk;
+    } else {
+        pl.numBlocks = (b.numRays + blockThreads - 1) / blockThreads;
+    }
+    pl.hintable = pl.variant == NTR_VARIANT_PERRAY;
+    pl.useAutoHint = !b.callerHint && !b.wantStats && tun.autoHint != 0 && pl.hintable && b.numRays >= tun.autoHintMinRays && !b.capturing;
+
+    // Dispatch-order prediction (sched_kernels.hip): closest-hit launches of the per-ray kernel that are large enough for the tail to
+    // outweigh the two small launches (about 30 us; break-even near 1 M rays).  Any-hit batches measured no net gain.  A tree of a few
+    // hundred nodes is traced faster than it is predicted: Cornell-box class scenes are left alone.  The persistent kernels hand their
+    // pool out in the same predicted order (the heavy blocks' long rays start first instead of being the chunks fetched last): there the
+    // prediction covers batches of all 256-ray blocks and needs pool chunks that divide 256.
+    pl.persistentOrder = pl.variant == NTR_VARIANT_PERSISTENT && tun.predictPersistent != 0 && (256 % pl.chunk) == 0;
+    const bool bigEnough = b.numRays >= tun.predictMinRays && b.nodesBytes >= (int64_t)tun.predictMinNodes * 64 && tun.predict != 0;
+    pl.predictable = (pl.variant == NTR_VARIANT_PERRAY || pl.persistentOrder) && !b.anyHit && bigEnough;
+    pl.probeOnRefresh = pl.variant == NTR_VARIANT_PERRAY && !b.anyHit && tun.minipool < 0 && bigEnough;
+
+    // Workgroup size of the per-ray kernel: smaller workgroups retire (and are replaced) sooner.  The dispatch order and the cost
+    // feedback stay in units of 256 rays: numBlocks counts those, the launch has 4 / waves workgroups per unit.
+    pl.launchVariant = pl.variant;
+    pl.launchBlocks = pl.numBlocks;
+    if (pl.variant == NTR_VARIANT_PERSISTENT && pl.unified) pl.launchVariant = NTR_VARIANT_PERSISTENT_UNIFIED;
+    const int wantWaves = b.anyHit ? tun.anyHitWaves : tun.closestWaves;
+    if (pl.variant == NTR_VARIANT_PERRAY && wantWaves < NTR_TRACE_WAVES_PER_BLOCK) {
+        const int waves = wantWaves <= 1 ? 1 : 2;
+        pl.launchVariant = waves == 1 ? NTR_VARIANT_PERRAY_W1 : NTR_VARIANT_PERRAY_W2;
+        pl.launchBlocks = pl.numBlocks * (4 / waves);
+        // unified-step loop (one node OR one triangle per lane and iteration, one group of loads): closest-hit launches on any tree
+        // (atrium primary +5 %, conference +21 %, LBVH trees +50 %) and any-hit launches (multi-triangle leaves: always ahead; short AO
+        // rays in one-triangle-leaf trees: the while-while loop was 2-3 % ahead while a step cost ~100 vector instructions, the unified
+        // loop is 4 % ahead since the one-correction divide -- profiles/r04_perray_unified_anyhit_knob.txt)
+        if (tun.perrayUnified > 0 || (tun.perrayUnified < 0 && (!b.anyHit || (b.bvhFlags & NTR_BVH_WIDE_LEAVES)))) {
+            pl.launchVariant = NTR_VARIANT_PERRAY_UNIFIED_W1;
+            pl.launchBlocks = pl.numBlocks * 4;
+            // wave-private mini-pool: a wave owns K x 64 rays and refills its finished lanes from them.  K is decided on the device: the
+            // prediction of this launch wrote it (incoherent batch: minipoolWide, else 1), or the batch's hint kept it from its first launch.
+            if (tun.minipool != 0 && !b.anyHit) {
+                pl.launchVariant = NTR_VARIANT_PERRAY_UNIFIED_MINI;
+                pl.minipool = true;
+                pl.fetchThreshold = tun.minipoolThreshold;
+                pl.poolKConst = tun.minipool > 0 ? tun.minipool : 1;
+                pl.poolKFromDevice = tun.minipool < 0;
+            }
+        }
+    }
+    return pl;
+}
+
+// One launch in the life of a scheduling hint (pure: the caller applies `uses++`, `predicted = false` afterwards).
+struct HintStep {
+    bool zeroK;      // a hint that starts over (new, or an automatic one recycled for another batch) forgets its pool K
+    bool refresh;    // this launch records per-block costs and the next order is derived from them
+    bool useOrder;   // the launch is dispatched in the hint's order
+};
+inline HintStep plan_hint_step(const Tunables& tun, bool valid, bool predicted, int uses)
+{
+    HintStep h;
+    // costs measured under the natural order differ from those under the derived order, so the first launches all refresh; afterwards
+    // every `schedRefreshEvery`-th does (slowly drifting rays keep their schedule)
+    const bool firstOfPrediction = predicted && valid;   // (ntr_sched_hint_predict cleared the K words itself)
+    h.zeroK = uses == 0 && !firstOfPrediction;
+    const int every = tun.schedRefreshEvery;
+    h.refresh = uses < 3 || every <= 1 || (uses % every) == 0;
+    if (firstOfPrediction) h.refresh = false;   // the first launch of a predicted order just runs it (a batch traced once pays nothing for feedback)
+    h.useOrder = valid;
+    return h;
+}
+
+}  // namespace ntr
