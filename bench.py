@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achi
 # MI355X_MICROARCH.md, 'Indexed rows: gather' table: chip-wide rate of row gathers served by the XCD L2s
 # (16.8-18.8 TB/s) and by the Infinity Cache (8.6 TB/s) -- the practical ceilings of a cache-resident BVH.
 L2_GATHER_PEAK_GBS = 18800.0
+L2_STREAM_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md, L2 section: ~34.5 TB/s aggregate over the eight XCD L2s
 MALL_GATHER_PEAK_GBS = 8600.0
 NUM_SIMDS = 1024           # 256 CUs x 4 SIMD-32
 NUM_TAS = 256              # one texture-address unit per CU
@@ -164,7 +165,9 @@ def profiled_shares(pmc, pmc_src, visits=None):
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=250,
+                    help="timed steps (frames); the default keeps the timed region above 0.25 s -- a step is ~1.2 ms on one MI355X -- so that "
+                         "utilisation samplers see the GPU busy")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong (default): ONE frame sharded by screen tile over the ranks; weak: a full frame per rank")
@@ -196,6 +199,7 @@ def parse(argv=None):
     ap.add_argument("--no-ao-prediction", action="store_true",
                     help="trace the AO batches without the leaf-depth dispatch hint made beside ray generation (buffer order until a launch has measured)")
     ap.add_argument("--no-hbm-point", action="store_true", help="skip the 10 M-triangle HBM-resident roofline point (extras)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs 3-5 table (extras.configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold-order", action="store_true", help="skip the extra K steps with the scheduling feedback off")
     ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
@@ -369,6 +373,15 @@ def main():
             dist.init_process_group("gloo")
     nt.lib()
     stream = torch.cuda.current_stream().cuda_stream
+    # The library's OWN multi-GPU entry points (ntr_dist_*, csrc/ntr_dist.cpp: RCCL bound by the C-ABI -- what a C++ host of the reference's
+    # shape uses) carry the BVH broadcast and the frame's one collective whenever the ranks run on RCCL; torch.distributed
+    # then only hands out the 128-byte group id, the barriers and the scalar reductions of the report.  gloo runs (CPU tier, --one-device)
+    # keep the host-staged torch.distributed path: RCCL refuses two ranks on one GPU.
+    grp = None
+    if use_dist and args.dist_backend == "nccl" and os.environ.get("NTR_BENCH_TORCH_GATHER") != "1":
+        uid = torch.frombuffer(bytearray(nt.DistGroup.unique_id() if rank == 0 else bytes(128)), dtype=torch.uint8).to(dev)
+        ntd.broadcast_(uid, 0)
+        grp = nt.DistGroup(bytes(uid.cpu().numpy().tobytes()), rank, world)
 
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
@@ -388,7 +401,14 @@ def main():
         sah_seconds = time.time() - t0
     parts = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()) if bvh is not None else None
              for a in ((bvh.nodes, bvh.woop, bvh.tri_index) if bvh is not None else (None, None, None))]
-    d_nodes, d_woop, d_idx = [ntd.broadcast_bytes(p, 0, dev) for p in parts]
+    if grp is not None:   # ntr_dist_broadcast_bvh: the three Compact buffers from the root, sizes first (24 bytes over torch.distributed)
+        sizes = torch.tensor([p_.numel() for p_ in parts] if rank == 0 else [0, 0, 0], dtype=torch.int64, device=dev)
+        ntd.broadcast_(sizes, 0)
+        d_nodes, d_woop, d_idx = [parts[i].to(dev) if rank == 0 else torch.empty(int(sizes[i].item()), dtype=torch.uint8, device=dev) for i in range(3)]
+        grp.broadcast_bvh(d_nodes.data_ptr(), d_nodes.numel(), d_woop.data_ptr(), d_woop.numel(), d_idx.data_ptr(), d_idx.numel(), 0, stream)
+        torch.cuda.synchronize()
+    else:
+        d_nodes, d_woop, d_idx = [ntd.broadcast_bytes(p, 0, dev) for p in parts]
     view = nt.BvhView(d_nodes.data_ptr(), d_nodes.numel(), d_woop.data_ptr(), d_woop.numel(), d_idx.data_ptr())
     view.validate(stream)
     d_nrm = up(scenes.tri_normals(tri, pos))
@@ -486,9 +506,20 @@ def main():
     gather_ms, frame_check, native_gather = None, None, None
     sharded = use_dist and not (args.scaling == "weak" and world > 1)
     if use_dist:
+        full = torch.zeros(n_primary * 16, dtype=torch.uint8, device=dev) if (sharded and grp is not None and rank == 0) else None
         barrier()
         g0 = time.perf_counter()
-        if sharded:
+        if sharded and grp is not None:
+            # the frame's ONE collective through the library: grouped ncclSend / ncclRecv of the ranks' 16-byte hit records to rank 0, at the
+            # ranges' own offsets (equal ranges: ntr_dist_gather_records; ranges of equal predicted cost: the cut table)
+            own = frame.own_primary_records()
+            if plan.cuts is not None:
+                grp.gather_records_cuts(own.data_ptr(), plan.cuts, full.data_ptr() if rank == 0 else 0, 0, stream)
+            else:
+                grp.gather_records(own.data_ptr(), n_primary, full.data_ptr() if rank == 0 else 0, 0, stream)
+            native_gather = {"how": "ntr_dist_gather_records%s (csrc/ntr_dist.cpp): grouped ncclSend / ncclRecv of the ranks' 16-byte hit records to rank 0"
+                                    % ("_cuts" if plan.cuts is not None else ""), "bvh_broadcast": "ntr_dist_broadcast_bvh"}
+        elif sharded:
             full = ntd.gather_hit_records(frame.own_primary_records(), n_primary, cuts=plan.cuts)
         else:
             outs = [torch.empty_like(frame.d_res) for _ in range(world)] if rank == 0 else None
@@ -496,20 +527,8 @@ def main():
             full = None
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        # the same gather through the library's own multi-GPU entry points (ntr_dist_*: RCCL bound by the C-ABI, what a C++ host of the
-        # reference's shape uses -- INTEGRATION.md), opt-in: NTR_BENCH_NATIVE_GATHER=1.  The 128-byte group id travels over torch.distributed.
-        if sharded and os.environ.get("NTR_BENCH_NATIVE_GATHER") == "1" and plan.cuts is None and not (args.one_device and world > 1):
-            uid = torch.frombuffer(bytearray(nt.DistGroup.unique_id() if rank == 0 else bytes(128)), dtype=torch.uint8).to(dev)
-            ntd.broadcast_(uid, 0)
-            grp = nt.DistGroup(bytes(uid.cpu().numpy().tobytes()), rank, world)
-            full_n = torch.zeros(n_primary * 16, dtype=torch.uint8, device=dev) if rank == 0 else None
-            barrier()
-            n0 = time.perf_counter()
-            grp.gather_records(frame.own_primary_records().data_ptr(), n_primary, full_n.data_ptr() if rank == 0 else 0, 0, stream)
-            barrier()
-            native_gather = {"ms": (time.perf_counter() - n0) * 1e3, "equal_torch_gather": bool(torch.equal(full_n, full)) if rank == 0 else None,
-                             "how": "ntr_dist_gather_records: grouped ncclSend / ncclRecv of the ranks' 16-byte hit records to rank 0"}
-            grp.close()
+        if native_gather is not None:
+            native_gather["ms"] = gather_ms
         if sharded:
             # checksum of checksums over every AO record of the frame (wrapping 64-bit sums)
             ao_sum = ntd.all_sum_int64(ntd.wrap_i64(sum(ntd.records_checksum(b["res_t"]) for b in batches[1:])), dev)
@@ -593,6 +612,8 @@ def main():
     if frame_per_rank is not None and isinstance(extras, dict):
         extras["frame_per_rank"] = frame_per_rank
     if rank != 0:
+        if grp is not None:
+            grp.close()
         if use_dist:
             dist.destroy_process_group()
         return
@@ -609,7 +630,7 @@ def main():
     binding = profiled_shares(pmc, pmc_src, visits if "persistent" in symbol else None)
     traffic = binding.get("hbm_traffic_bytes") if binding else None
     par = ("one frame sharded by screen tile over %d ranks (PixelTable ranges), BVH built on rank 0 and broadcast, %s gather of hit records"
-           % (world, "RCCL" if args.dist_backend == "nccl" else "gloo (host-staged)")
+           % (world, ("RCCL (the library's ntr_dist_* entry points)" if grp is not None else "RCCL (torch.distributed)") if args.dist_backend == "nccl" else "gloo (host-staged)")
            if not (args.scaling == "weak" and world > 1) else "weak scaling: one full frame per rank (camera shifted per rank), BVH replicated")
     out = {
         "metric": "Mrays/sec (primary + 8xAO) on Crytek Sponza",
@@ -649,42 +670,62 @@ def main():
         "sharded_frame_check": frame_check,
         "host_sah_build_s": sah_seconds,
         "trace_stats": st.as_dict(),
+        "value_cold": cold["mrays"] if cold else None,
+        "value_moving_camera": (extras.get("moving_camera") or {}).get("mrays") if isinstance(extras, dict) else None,
+        "value_variants_note": "`value` re-traces the same batches every step (the reference's protocol), so each launch runs in the dispatch order its "
+                               "previous launch measured.  value_cold: the same steps with nothing learned from earlier launches (automatic feedback off, AO "
+                               "hints restarted from their leaf-depth prediction); value_moving_camera: new rays in every launch (eye moves, rays "
+                               "regenerated into the same buffers, order learned from the previous frame) -- what a renderer gets",
         "cold_dispatch_order": cold,
         "overlapped_multi_gpu": overlapped,
         "extras": extras,
         "roofline": None,
     }
-    # Roofline.  The 34 MB BVH of the headline workload is cache-resident: the SURVEY 8(d) HBM figure (algorithmic bytes / time / 8 TB/s)
-    # exceeds 1 and is not an efficiency -- it is kept as `hbm_algorithmic` (cache_served).  The top-level fraction is the same algorithmic
-    # bytes against the data path that serves them, the CUs' vector L1s (64 B/clk each), for the primary launch and -- the larger part of
-    # the step -- for the AO batches; every figure is recomputable from this line.  Busy shares of TA / VALU from a committed PMC summary
-    # of the same kernel symbol and grid sit under `utilisation` (shares, not bounds); when no summary matches the launched symbol they
-    # are null and `utilisation_note` says so.  The launch whose bytes HBM really delivers is `roofline_hbm_resident`.
+    # Roofline.  Top level = the SURVEY 8(d) figure of the step's dominant kernel (the AO launches), bound "hbm": algorithmic bytes per
+    # launch / mean launch duration / 8 TB/s.  The 34 MB BVH of the headline workload is cache-resident, so that fraction exceeds 1
+    # (`cache_served`: true) and is not an efficiency; the same bytes against the paths that serve them (vector L1s, XCD L2s) are nested
+    # under `cache_paths`, busy shares of TA / VALU from a committed PMC summary of the same symbol and grid under `utilisation` (null
+    # with a note when none matches).  The other kernel of the step sits beside it (`primary`); the launches whose bytes HBM really
+    # delivers are `roofline_hbm_resident` and extras.configs[4 | 5].roofline.
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    hbm_alg = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-               "cache_served": True, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic,
-               "note": "SURVEY 8(d) accounting; frac > 1 because L1 / L2 / Infinity Cache serve the bytes (HBM-side bytes per launch in `traffic`)"}
-    roof = l1_roofline(alg_bytes, prim_ms * 1e-3, cus)
-    roof.update({"kernel": "%s (%s), primary batch of rank 0" % (symbol, args.kernel),
-                 "launch_includes": "the dispatch-order work of the launch (prediction or cost feedback, a few small kernels) + the trace kernel, as the "
-                                    "HIP events around the library call see it; rocprofv3's per-kernel average for the trace kernel alone is in profiles/",
-                 "traffic": traffic, "hbm_frac": hbm_alg["frac"], "cache_served": True, "hbm_algorithmic": hbm_alg,
-                 "utilisation": binding,
-                 "utilisation_note": None if binding else "no committed PMC summary under profiles/ matches the launched symbol %s with grid %d: "
-                                                           "utilisation not reported" % (symbol, launched_grid(args.kernel, b0["n"])),
-                 "cache_ceilings": {"l2_gather_peak": L2_GATHER_PEAK_GBS, "frac_of_l2_gather": achieved / L2_GATHER_PEAK_GBS,
-                                    "infinity_cache_gather_peak": MALL_GATHER_PEAK_GBS, "source": "MI355X_MICROARCH.md gather table"}})
+
+    def launch_roofline(alg, sec, launches, sym, grid, label, binding_):
+        """SURVEY 8(d) block of one kernel of the step: algorithmic bytes per launch / mean launch duration against HBM peak.  The 34 MB BVH of
+        the headline workload never leaves the caches, so frac > 1: `cache_served`; the same bytes against the data paths that do serve
+        them (vector L1s, XCD L2s) are nested under `cache_paths` -- shares of those paths, not the 8(d) figure."""
+        ach = alg / sec / 1e9
+        l1 = l1_roofline(alg, sec, cus)
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "cache_served": True,
+                "traffic": (binding_ or {}).get("hbm_traffic_bytes"),
+                "kernel": sym, "launch": label, "launches_per_step": launches,
+                "algorithmic_bytes_per_launch": int(alg / launches), "launch_ms": sec * 1e3 / launches,
+                "note": "SURVEY 8(d): algorithmic bytes (48 + 64 I + 48 T + 16 L + 4 H per ray, exact traversal counters) / launch time / 8 TB/s.  frac > 1: "
+                        "L1 / L2 / Infinity Cache serve the 34 MB BVH (HBM-side bytes per launch in `traffic`, PMC); not an efficiency.  The launch whose "
+                        "bytes HBM really delivers is `roofline_hbm_resident` / extras.configs[*].roofline",
+                "cache_paths": {"l1_data_path": {"frac": l1["frac"], "peak": l1["peak"], "peak_definition": l1["peak_definition"]},
+                                "l2_aggregate": {"frac": ach / L2_STREAM_PEAK_GBS, "peak": L2_STREAM_PEAK_GBS, "source": "MI355X_MICROARCH.md L2 section"},
+                                "l2_gather": {"frac": ach / L2_GATHER_PEAK_GBS, "peak": L2_GATHER_PEAK_GBS, "source": "MI355X_MICROARCH.md gather table"},
+                                "infinity_cache_gather": {"frac": ach / MALL_GATHER_PEAK_GBS, "peak": MALL_GATHER_PEAK_GBS}},
+                "utilisation": binding_,
+                "utilisation_note": None if binding_ else "no committed PMC summary under profiles/ matches the launched symbol %s with grid %d" % (sym, grid)}
+
+    prim_roof = launch_roofline(alg_bytes, prim_ms * 1e-3, 1, "%s (%s)" % (symbol, args.kernel), launched_grid(args.kernel, b0["n"]),
+                                "the primary batch of rank 0 (closest hit); the HIP events around the library call include the launch's dispatch-order "
+                                "work (prediction or cost feedback, a few small kernels)", binding)
+    roof = prim_roof
     if ao_ms > 0:
         ao_sym = launched_symbol(args.kernel, wide, any_hit=True)
-        ao_roof = l1_roofline(ao_alg, ao_ms * 1e-3, cus)
         ao_pmc, ao_src = load_pmc(ao_sym, launched_grid(args.kernel, batches[1]["n"]))
         ao_bind = profiled_shares(ao_pmc, ao_src, (ao_visits // max(len(batches) - 1, 1)) if "persistent" in ao_sym else None) if ao_pmc else None
-        ao_roof.update({"kernel": "%s (%s), the %d AO batches of rank 0 (any hit)" % (ao_sym, args.kernel, len(batches) - 1),
-                        "share_of_step": ao_ms / (ao_ms + prim_ms),
-                        "hbm_algorithmic": {"achieved": ao_alg / (ao_ms * 1e-3) / 1e9, "frac": ao_alg / (ao_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "cache_served": True},
-                        "utilisation": ao_bind,
-                        "utilisation_note": None if ao_bind else "no committed PMC summary under profiles/ matches %s with grid %d" % (ao_sym, launched_grid(args.kernel, batches[1]["n"]))})
-        roof["ao"] = ao_roof
+        ao_roof = launch_roofline(ao_alg, ao_ms * 1e-3, len(batches) - 1, "%s (%s)" % (ao_sym, args.kernel), launched_grid(args.kernel, batches[1]["n"]),
+                                  "the %d AO batches of rank 0 (any hit)" % (len(batches) - 1), ao_bind)
+        ao_roof["share_of_step"] = ao_ms / (ao_ms + prim_ms)
+        prim_roof["share_of_step"] = prim_ms / (ao_ms + prim_ms)
+        # top level = the step's DOMINANT kernel (the AO launches: three quarters of the step), the other one beside it
+        if ao_ms >= prim_ms:
+            roof = dict(ao_roof, primary=prim_roof)
+        else:
+            roof = dict(prim_roof, ao=ao_roof)
     out["roofline"] = roof
     hp = extras.get("hbm_resident_point") if isinstance(extras, dict) else None
     if hp and hp.get("incoherent"):
@@ -719,6 +760,8 @@ def main():
                                             n1 / (c1 - c0) / 1e6),
                                "single_thread_mrays": n1 / (c1 - c0) / 1e6,
                                "parity_mismatches_whole_step": mism, "rays_compared": traced}
+    if grp is not None:
+        grp.close()
     if use_dist:
         dist.destroy_process_group()
     # RCCL writes a version banner to the C stdout stream; push it out first so that the JSON line is the last line of stdout
@@ -729,6 +772,109 @@ def main():
         pass
     sys.stdout.write(json.dumps(out) + "\n")
     sys.stdout.flush()
+
+
+def device_lbvh(nt, torch, up, dev, stream, tri_, pos_, reps, hbm_peak):
+    """On-device LBVH build (leafSize 8, epsilon 0.001) of a scene, best of `reps`; returns (view, result, info, buffers to keep alive)."""
+    capn, capw, capi = nt.lbvh_capacity(tri_.shape[0])
+    d_tri, d_pos = up(tri_), up(pos_)
+    ln = torch.zeros(capn, dtype=torch.uint8, device=dev)
+    lw = torch.zeros(capw, dtype=torch.uint8, device=dev)
+    li = torch.zeros(capi, dtype=torch.uint8, device=dev)
+    best = None
+    for _ in range(reps):
+        r = nt.lbvh_build(tri_.shape[0], d_tri.data_ptr(), pos_.shape[0], d_pos.data_ptr(), pos_.min(0), pos_.max(0), 8, 0.001,
+                          ln.data_ptr(), capn, lw.data_ptr(), capw, li.data_ptr(), capi, stream)
+        best = r if best is None or r.seconds < best.seconds else best
+    lview = nt.BvhView(ln.data_ptr(), best.nodesBytes, lw.data_ptr(), best.triWoopBytes, li.data_ptr())
+    lview.validate(stream)
+    # algorithmic bytes of the build (SURVEY 8d accounting, exact from the counts): Morton 48 rd + 8 wr, 4 radix passes x
+    # (8 rd + 8 wr + 4 rd histogram), Woop 48 rd + 48 wr per triangle; emit 12 rd + 16 wr per inner node, (48+4) rd +
+    # (48+12) wr per triangle, 20 wr per leaf; refit (12+36) rd per triangle, 96 rd per inner child, 48 wr per node.
+    nt_, ni_, nl_ = int(tri_.shape[0]), int(best.numNodes), int(best.numLeaves)
+    lb = nt_ * (56 + 4 * 20 + 96 + 112 + 48) + ni_ * (28 + 48) + nl_ * 20 + max(ni_ - 1, 0) * 96
+    info = {"triangles": nt_, "build_ms": best.seconds * 1e3, "mtris_per_s": nt_ / best.seconds / 1e6,
+            "phases_ms": {"morton+digit_histograms": best.mortonMs, "sort_4_onesweep_passes": best.sortMs,
+                          "leaf_marks+scan": best.emitMs,
+                          "bottom_up_emit(nodes,boxes,woop_rows: agglomerate,runs)": best.refitMs},
+            "nodes": ni_, "leaves": nl_, "algorithmic_bytes": lb,
+            "roofline": {"bound": "hbm", "achieved": lb / best.seconds / 1e9, "peak": hbm_peak, "unit": "GB/s",
+                         "frac": lb / best.seconds / 1e9 / hbm_peak}}
+    return lview, best, info, (ln, lw, li, d_tri, d_pos)
+
+
+def config_point(nt, torch, scenes, dev, stream, up, name, tri_, pos_, cam_, view_, bvh_bytes, secondary, kernels, w, h, ns, hbm_peak, pmc_tag):
+    """One BASELINE.json configuration, driver-timed: the frame's batches -- 1080p primary + the 8 x AO (any hit, aoRadius scaled to the
+    scene) or 8 x diffuse (closest hit, to the camera's far plane: Renderer.cpp:533-537) batches of <= 2^20 rays (Renderer.cpp:45) --
+    traced by every name of `kernels` (the first one is the default selector) in the reference's protocol: per batch one untimed launch,
+    then the median of three timed ones (App.cpp:955-958), Sigma of the per-batch kernel times.  Rooflines per SURVEY 8(d): algorithmic bytes
+    from the exact traversal counters (ntr_trace_bvh_stats) / time / 8 TB/s; `traffic` = HBM bytes per frame from a committed PMC summary
+    (profiles/*<pmc_tag>*_pmc_summary.json) of the same kernel symbol when there is one."""
+    i32 = torch.int32
+    rays, _ = scenes.primary_rays(cam_, w, h)
+    npr = rays.shape[0]
+    d_rays = up(rays)
+    d_res = torch.zeros(npr * 16, dtype=torch.uint8, device=dev)
+    d_nrm = up(scenes.tri_normals(tri_, pos_))
+    diag = float(np.linalg.norm(pos_.max(0).astype(np.float64) - pos_.min(0)))
+    any_hit = secondary == "ao"
+    dist_ = 5.0 * diag / 4300.0 if any_hit else cam_["far"]   # config.conf's aoRadius 5 is in Sponza units: scaled by the scene's diagonal
+    per = (1 << 20) // ns
+    cache = "infinity-cache" if bvh_bytes <= (256 << 20) else "hbm"
+    wide = bool(view_.flags & nt.BVH_WIDE_LEAVES)
+    b_rays = torch.zeros(per * ns * 32, dtype=torch.uint8, device=dev)
+    b_res = torch.zeros(per * ns * 16, dtype=torch.uint8, device=dev)
+    b_a = torch.zeros(per * ns, dtype=i32, device=dev)
+
+    def roof(alg, sec, sym, grid_rays, launches):
+        r = {"bound": "hbm", "achieved": alg / sec / 1e9, "peak": hbm_peak, "unit": "GB/s", "frac": alg / sec / 1e9 / hbm_peak,
+             "algorithmic_bytes": int(alg), "ms": sec * 1e3, "bvh_resident_in": cache, "cache_served": cache != "hbm", "kernel": sym}
+        pmc, src = load_pmc(sym, grid_rays, tag=pmc_tag)
+        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            tb = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * launches
+            r.update({"traffic": tb, "traffic_over_algorithmic": tb / alg if alg else None, "traffic_source": "profiles/" + src,
+                      "traffic_note": "per-dispatch mean of the symbol's launches in the profiled frame x %d launches; 2 x FETCH_SIZE assumes "
+                                      "128-byte requests (the guide's calibration is for streaming reads; for a 64-byte gather it is an assumption)" % launches})
+        else:
+            r["traffic"] = None
+        return r
+
+    out = {"config": name, "triangles": int(tri_.shape[0]), "bvh_bytes": int(bvh_bytes), "secondary": "8 x %s" % secondary,
+           "secondary_distance": dist_, "by_kernel": {}}
+    for ki, kn in enumerate(kernels):
+        view_.trace(kn, npr, False, d_rays.data_ptr(), d_res.data_ptr(), stream)
+        tp = float(np.median([view_.trace(kn, npr, False, d_rays.data_ptr(), d_res.data_ptr(), stream) for _ in range(3)]))
+        row = {"primary_ms": tp * 1e3, "primary_mrays": npr / tp / 1e6}
+        if ki == 0:
+            st = view_.trace_stats(kn, npr, False, d_rays.data_ptr(), d_res.data_ptr(), stream)
+            hits = nt.count_hits(d_res.data_ptr(), npr, stream)
+            out["primary_hit_rate"] = hits / npr
+            row["primary_roofline"] = roof(st.algorithmic_bytes(), tp, launched_symbol(kn, wide), launched_grid(kn, npr), 1)
+        tt, live, launched, alg, nb, per_batch = 0.0, 0, 0, 0, 0, []
+        for lo in range(0, npr, per):
+            cnt = min(per, npr - lo)
+            nt.raygen_ao(b_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(), d_res.data_ptr(), d_nrm.data_ptr(), lo, cnt, ns, dist_,
+                         0xFFF2D5E4, stream)
+            view_.trace(kn, cnt * ns, any_hit, b_rays.data_ptr(), b_res.data_ptr(), stream)
+            t_b = float(np.median([view_.trace(kn, cnt * ns, any_hit, b_rays.data_ptr(), b_res.data_ptr(), stream) for _ in range(3)]))
+            tt += t_b
+            per_batch.append(round(t_b * 1e3, 4))
+            live += nt.count_hits(d_res.data_ptr() + lo * 16, cnt, stream) * ns
+            launched += cnt * ns
+            nb += 1
+            if ki == 0:
+                alg += view_.trace_stats(kn, cnt * ns, any_hit, b_rays.data_ptr(), b_res.data_ptr(), stream).algorithmic_bytes()
+        row.update({"secondary_ms": tt * 1e3, "secondary_batches": nb, "secondary_mrays": live / tt / 1e6 if tt > 0 else None,
+                    "secondary_mrays_all_launched": launched / tt / 1e6 if tt > 0 else None, "secondary_per_batch_ms": per_batch,
+                    "frame_ms": (tp + tt) * 1e3, "frame_mrays": (npr + live) / (tp + tt) / 1e6})
+        if ki == 0:
+            out["rays"] = {"primary": npr, "secondary_nondegenerate": int(live), "secondary_launched": int(launched)}
+            row["secondary_roofline"] = roof(alg, tt, launched_symbol(kn, wide, any_hit=any_hit), launched_grid(kn, per * ns), nb)
+        out["by_kernel"][kn] = row
+    k0 = out["by_kernel"][kernels[0]]
+    dom = "secondary" if k0["secondary_ms"] >= k0["primary_ms"] else "primary"
+    out["roofline"] = dict(k0[dom + "_roofline"], launch="%s batches, %s" % (dom, kernels[0]), share_of_frame=k0[dom + "_ms"] / k0["frame_ms"])
+    return out
 
 
 def overlapped_frame(args, nt, torch, view, frame, dev, stream, try_graph=True):
@@ -942,31 +1088,7 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
 
     # (4) on-device LBVH build of the bench scene + primary rays on the built tree
     def lbvh_of(tri_, pos_, reps):
-        capn, capw, capi = nt.lbvh_capacity(tri_.shape[0])
-        d_tri, d_pos = up(tri_), up(pos_)
-        ln = torch.zeros(capn, dtype=torch.uint8, device=dev)
-        lw = torch.zeros(capw, dtype=torch.uint8, device=dev)
-        li = torch.zeros(capi, dtype=torch.uint8, device=dev)
-        best = None
-        for _ in range(reps):
-            r = nt.lbvh_build(tri_.shape[0], d_tri.data_ptr(), pos_.shape[0], d_pos.data_ptr(), pos_.min(0), pos_.max(0), 8, 0.001,
-                              ln.data_ptr(), capn, lw.data_ptr(), capw, li.data_ptr(), capi, stream)
-            best = r if best is None or r.seconds < best.seconds else best
-        lview = nt.BvhView(ln.data_ptr(), best.nodesBytes, lw.data_ptr(), best.triWoopBytes, li.data_ptr())
-        lview.validate(stream)
-        # algorithmic bytes of the build (SURVEY 8d accounting, exact from the counts): Morton 48 rd + 8 wr, 4 radix passes x
-        # (8 rd + 8 wr + 4 rd histogram), Woop 48 rd + 48 wr per triangle; emit 12 rd + 16 wr per inner node, (48+4) rd +
-        # (48+12) wr per triangle, 20 wr per leaf; refit (12+36) rd per triangle, 96 rd per inner child, 48 wr per node.
-        nt_, ni_, nl_ = int(tri_.shape[0]), int(best.numNodes), int(best.numLeaves)
-        lb = nt_ * (56 + 4 * 20 + 96 + 112 + 48) + ni_ * (28 + 48) + nl_ * 20 + max(ni_ - 1, 0) * 96
-        info = {"triangles": nt_, "build_ms": best.seconds * 1e3, "mtris_per_s": nt_ / best.seconds / 1e6,
-                "phases_ms": {"morton+digit_histograms": best.mortonMs, "sort_4_onesweep_passes": best.sortMs,
-                              "leaf_marks+scan": best.emitMs,
-                              "bottom_up_emit(nodes,boxes,woop_rows: agglomerate,runs)": best.refitMs},
-                "nodes": ni_, "leaves": nl_, "algorithmic_bytes": lb,
-                "roofline": {"bound": "hbm", "achieved": lb / best.seconds / 1e9, "peak": hbm_peak, "unit": "GB/s",
-                             "frac": lb / best.seconds / 1e9 / hbm_peak}}
-        return lview, best, info, (ln, lw, li, d_tri, d_pos)
+        return device_lbvh(nt, torch, up, dev, stream, tri_, pos_, reps, hbm_peak)
 
     lview, best, info, keep = lbvh_of(tri, pos, 3)
     tmp_res = torch.zeros(n_primary * 16, dtype=torch.uint8, device=dev)
@@ -987,6 +1109,38 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         tsec = min(view.trace(args.kernel, b1["n"], True, so.data_ptr(), sres.data_ptr(), stream) for _ in range(5))
         usec = min(view.trace(args.kernel, b1["n"], True, b1["rays"], b1["res"], stream) for _ in range(5))
         extras["ray_sort"] = {"rays": b1["n"], "sort_ms": ssec * 1e3, "trace_sorted_ms": tsec * 1e3, "trace_unsorted_ms": usec * 1e3}
+
+    # (5b) BASELINE.json configs 3 and 4 themselves, driver-timed, each with its roofline (config 5 follows with the 10 M-triangle scene)
+    if not args.no_configs:
+        cfgs = extras.setdefault("configs", {})
+        cfgs["what"] = ("BASELINE.json configurations 3-5 on their seeded stand-ins, one GPU, the frame's batches in the reference's protocol (per batch one "
+                        "untimed launch, then the median of three timed ones; rays of primary hits / sum of kernel times); by_kernel[<first>] is the default "
+                        "selector; roofline = SURVEY 8(d) algorithmic bytes / time / 8 TB/s of the frame's dominant launches")
+        try:
+            tri3, pos3, cam3 = scenes.conference_room()
+            t0 = time.time()
+            bvh3 = nt.sah_build(tri3, pos3, 1, 1)
+            sah3 = time.time() - t0
+            k3 = [up(bvh3.nodes), up(bvh3.woop), up(bvh3.tri_index)]
+            view3 = nt.BvhView(k3[0].data_ptr(), bvh3.nodes.nbytes, k3[1].data_ptr(), bvh3.woop.nbytes, k3[2].data_ptr())
+            view3.validate(stream)
+            cfgs["3"] = config_point(nt, torch, scenes, dev, stream, up, "3 Conference (room-331k stand-in), host SAH, primary + 8xAO", tri3, pos3, cam3, view3,
+                                     bvh3.nodes.nbytes + bvh3.woop.nbytes + bvh3.tri_index.nbytes, "ao",
+                                     (args.kernel, "tesla_persistent_while_while", "kepler_dynamic_fetch"), args.width, args.height, args.ao_samples, hbm_peak, "conference")
+            cfgs["3"]["host_sah_build_s"] = sah3
+            del k3, view3, bvh3
+        except Exception as e:
+            cfgs["3"] = {"error": repr(e)}
+        try:
+            tri4, pos4, cam4 = scenes.hairball()
+            lview4, best4, info4, keep4 = lbvh_of(tri4, pos4, 3)
+            cfgs["4"] = config_point(nt, torch, scenes, dev, stream, up, "4 Hairball (2.8 M stand-in), device LBVH build + 8x diffuse", tri4, pos4, cam4, lview4,
+                                     best4.nodesBytes + best4.triWoopBytes + best4.triIndexBytes, "diffuse", (args.kernel, "kepler_dynamic_fetch"),
+                                     args.width, args.height, args.ao_samples, hbm_peak, "hairball")
+            cfgs["4"]["lbvh_build"] = info4
+            del keep4, lview4
+        except Exception as e:
+            cfgs["4"] = {"error": repr(e)}
 
     # (6) HBM-resident roofline point: the same trace kernel on the 10 M-triangle stand-in for San Miguel.  Its LBVH is 0.75 GB
     # (nodes + Woop + index), three times the 256 MB Infinity Cache, so node and triangle fetches are served by HBM; SURVEY 8(d)
@@ -1049,6 +1203,14 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
                            "ms": secr * 1e3, "mrays": nr / secr / 1e6, "trace_stats": sr.as_dict(), "roofline": r_inc},
             "note": "HBM-side bytes (FETCH_SIZE / WRITE_SIZE / L2 hit rate) of these launches: profiles/*_trace_courtyard_* summaries",
             "lbvh_build": info10}
+        if not args.no_configs:   # BASELINE config 5 itself (primary + 8 x AO on the replicated 10 M-triangle BVH; one GPU traces the whole frame here)
+            try:
+                c5 = config_point(nt, torch, scenes, dev, stream, up, "5 San Miguel (courtyard-10M stand-in), device LBVH, primary + 8xAO", tri10, pos10, cam10, lview,
+                                  best.nodesBytes + best.triWoopBytes + best.triIndexBytes, "ao", (args.kernel, "kepler_dynamic_fetch"), w, h, args.ao_samples, hbm_peak, "courtyard")
+                c5["lbvh_build"] = info10
+                extras.setdefault("configs", {})["5"] = c5
+            except Exception as e:
+                extras.setdefault("configs", {})["5"] = {"error": repr(e)}
         del keep, lview, d_r10, d_o10, d_rr, d_ro
     view.trace(args.kernel, batches[0]["n"], False, batches[0]["rays"], batches[0]["res"], stream)  # restore the SAH-BVH primary results
     torch.cuda.synchronize()

@@ -451,10 +451,15 @@ NTR_API int ntr_dist_broadcast_bvh(NtrDist* dist, void* d_nodes, int64_t nodesBy
  * d_fullPixels; d_slotToPixel is the PixelTable's index-to-pixel map (ntr_pixel_table), d_scratch numPrimary words on
  * every rank.  Asynchronous on `stream`.  As with any collective, every rank of the group makes the matching call: a rank that
  * returns an argument error has posted nothing and its peers wait for it (argument errors must be uniform across ranks; the ranges
- * are, by construction).  Executed so far at world size 1 only (one-GPU test boxes); the N-rank flow around it runs at N = 2-3
- * with host-staged collectives (bench.py --dist-backend gloo --one-device). */
+ * are, by construction).  _records_cuts: the same gather for ranges the host cut itself (cuts[0] = 0 <= cuts[1] <= ... <=
+ * cuts[world] = numPrimary, the same table on every rank: ranges of equal predicted cost instead of equal ray counts).
+ * bench.py --gpus N gathers through these calls (torch.distributed only carries the 128-byte id and the barriers);
+ * tests/test_dist_native_gpu.py runs them over two devices from two host threads wherever the box has two GPUs (on one-GPU boxes:
+ * world size 1, and the N-rank flow at N = 2-3 with host-staged collectives, bench.py --dist-backend gloo --one-device). */
 NTR_API int ntr_dist_gather_records(NtrDist* dist, const NtrRayResult* d_ownRecords, int32_t numPrimary, int32_t align,
                                     NtrRayResult* d_fullRecords, int32_t root, void* stream);
+NTR_API int ntr_dist_gather_records_cuts(NtrDist* dist, const NtrRayResult* d_ownRecords, const int32_t* cuts /* world + 1 */,
+                                         NtrRayResult* d_fullRecords, int32_t root, void* stream);
 NTR_API int ntr_dist_gather_pixels(NtrDist* dist, const uint32_t* d_ownPixels, const int32_t* d_slotToPixel, int32_t numPrimary,
                                    int32_t align, uint32_t* d_fullPixels, uint32_t* d_scratch, int32_t root, void* stream);
 

@@ -94,6 +94,7 @@ SYMBOLS = [
     ("ntr_dist_broadcast", C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     ("ntr_dist_broadcast_bvh", C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp]),
     ("ntr_dist_gather_records", C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp]),
+    ("ntr_dist_gather_records_cuts", C.c_int, [_vp, _vp, C.POINTER(_i32), _vp, _i32, _vp]),
     ("ntr_dist_gather_pixels", C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     ("ntr_tunables_reload", C.c_int, []),
     ("ntr_predict_block_costs", C.c_int, [_i32, _vp, _vp, _i64, _vp, _vp]),
@@ -299,10 +300,23 @@ class DistGroup:
         _check(lib().ntr_dist_unique_id(buf))
         return buf.raw
 
-    def __init__(self, uid, rank, world):
+    def __init__(self, uid, rank, world, _handle=None):
+        if _handle is not None:
+            self._h, self.rank, self.world = _handle, int(rank), int(world)
+            return
         h = _vp()
         _check(lib().ntr_dist_init(C.c_char_p(uid), int(rank), int(world), C.byref(h)))
         self._h, self.rank, self.world = h, int(rank), int(world)
+
+    @staticmethod
+    def init_all(devices):
+        """ntr_dist_init_all: one group object per device of THIS process, for one host thread per GPU (thread i: ntr_set_device(devices[i]),
+        then groups[i])."""
+        n = len(devices)
+        devs = (_i32 * n)(*[int(x) for x in devices])
+        hs = (_vp * n)()
+        _check(lib().ntr_dist_init_all(n, devs, hs))
+        return [DistGroup(None, i, n, _handle=_vp(hs[i])) for i in range(n)]
 
     def broadcast(self, d_buf, nbytes, root=0, stream=0):
         _check(lib().ntr_dist_broadcast(self._h, _vp(d_buf), int(nbytes), int(root), _vp(stream)))
@@ -313,6 +327,13 @@ class DistGroup:
 
     def gather_records(self, d_own, num_primary, d_full, root=0, stream=0, align=64):
         _check(lib().ntr_dist_gather_records(self._h, _vp(d_own), int(num_primary), int(align), _vp(d_full), int(root), _vp(stream)))
+
+    def gather_records_cuts(self, d_own, cuts, d_full, root=0, stream=0):
+        """ntr_dist_gather_records_cuts: ranges cut by the host (world + 1 slot indices, the same table on every rank)."""
+        if len(cuts) != self.world + 1:
+            raise ValueError("gather_records_cuts: %d cut points for %d ranks" % (len(cuts), self.world))
+        c = (_i32 * (self.world + 1))(*[int(x) for x in cuts])
+        _check(lib().ntr_dist_gather_records_cuts(self._h, _vp(d_own), c, _vp(d_full), int(root), _vp(stream)))
 
     def gather_pixels(self, d_own_pixels, d_slot_to_pixel, num_primary, d_full_pixels, d_scratch, root=0, stream=0, align=64):
         _check(lib().ntr_dist_gather_pixels(self._h, _vp(d_own_pixels), _vp(d_slot_to_pixel), int(num_primary), int(align), _vp(d_full_pixels), _vp(d_scratch),

@@ -210,12 +210,23 @@ extern "C" int ntr_dist_broadcast_bvh(NtrDist* d, void* d_nodes, int64_t nodesBy
 // Like every collective: ALL ranks of the group must make the matching call.  A rank that returns an argument error here (a null slice,
 // a null destination on the root) has posted nothing, and its peers wait in ncclSend / ncclRecv for it: argument errors are programming
 // errors that must be uniform across the ranks (the sizes and offsets are, by construction: ntr_frame_shard of the same numPrimary).
+// `cuts` (world + 1 non-decreasing slot indices from 0 to numPrimary, or null): the ranks' ranges when a host cut the frame itself -- ranges of
+// equal predicted cost (ntr_predict_block_costs) instead of equal ray counts; the same table on every rank.
 static int gather_slices(NtrDist* d, const void* d_own, int32_t numPrimary, int32_t align, int32_t elemBytes, void* d_full, int32_t root, void* stream,
-                         const char* who)
+                         const char* who, const int32_t* cuts = nullptr)
 {
     if (!d || numPrimary < 0 || align < 1 || root < 0 || root >= d->world) return ntr::set_error(NTR_ERR_INVALID, "%s: bad argument", who);
+    if (cuts) {
+        if (cuts[0] != 0 || cuts[d->world] != numPrimary) return ntr::set_error(NTR_ERR_INVALID, "%s: the cut table must run from 0 to numPrimary", who);
+        for (int r = 0; r < d->world; r++)
+            if (cuts[r] > cuts[r + 1]) return ntr::set_error(NTR_ERR_INVALID, "%s: the cut table must be non-decreasing", who);
+    }
+    auto range_of = [&](int r, int32_t* l, int32_t* h) -> int {
+        if (cuts) { *l = cuts[r]; *h = cuts[r + 1]; return NTR_OK; }
+        return ntr_frame_shard(numPrimary, r, d->world, align, l, h);
+    };
     int32_t lo = 0, hi = 0;
-    int rc = ntr_frame_shard(numPrimary, d->rank, d->world, align, &lo, &hi);
+    int rc = range_of(d->rank, &lo, &hi);
     if (rc != NTR_OK) return rc;
     if (hi > lo && !d_own) return ntr::set_error(NTR_ERR_INVALID, "%s: null slice", who);
     if (d->rank == root && numPrimary > 0 && !d_full) return ntr::set_error(NTR_ERR_INVALID, "%s: null destination on the root", who);
@@ -228,7 +239,7 @@ static int gather_slices(NtrDist* d, const void* d_own, int32_t numPrimary, int3
         for (int r = 0; r < d->world && re == ncclSuccess; r++) {
             if (r == root) continue;
             int32_t l = 0, h = 0;
-            (void)ntr_frame_shard(numPrimary, r, d->world, align, &l, &h);
+            (void)range_of(r, &l, &h);
             if (h > l) re = g_rccl.recv((char*)d_full + (size_t)l * elemBytes, (size_t)(h - l) * elemBytes, ncclUint8, r, d->comm, s);
         }
         const ncclResult_t ge = g_rccl.groupEnd();
@@ -244,6 +255,13 @@ extern "C" int ntr_dist_gather_records(NtrDist* d, const NtrRayResult* d_ownReco
                                        int32_t root, void* stream)
 {
     return gather_slices(d, d_ownRecords, numPrimary, align, (int32_t)sizeof(NtrRayResult), d_fullRecords, root, stream, "ntr_dist_gather_records");
+}
+
+extern "C" int ntr_dist_gather_records_cuts(NtrDist* d, const NtrRayResult* d_ownRecords, const int32_t* cuts, NtrRayResult* d_fullRecords, int32_t root,
+                                            void* stream)
+{
+    if (!d || !cuts) return ntr::set_error(NTR_ERR_INVALID, "ntr_dist_gather_records_cuts: bad argument");
+    return gather_slices(d, d_ownRecords, cuts[d->world], 1, (int32_t)sizeof(NtrRayResult), d_fullRecords, root, stream, "ntr_dist_gather_records_cuts", cuts);
 }
 
 extern "C" hipError_t ntr_launch_pixels_pack(const uint32_t* d_pixels, const int32_t* d_slotToPixel, int first, int count, uint32_t* d_out, hipStream_t s);
