@@ -60,7 +60,7 @@ def launched_symbol(kernel, wide_leaves=False, any_hit=False):
 def launched_grid(kernel, n_rays, cus=256):
     if kernel.startswith("fermi"):
         return ((n_rays + 255) // 256) * 256
-    return min(cus * 6, (n_rays + 255) // 256) * 256
+    return min(cus * 8, (n_rays + 255) // 256) * 256
 
 
 def load_pmc(symbol, grid, tag=None):

@@ -198,6 +198,8 @@ typedef struct NtrTracePlan {
     int32_t orderBlocks;        /* 256-ray blocks of the batch */
     int32_t chunk, fetchThreshold, leafSwitchBelow, octant, flatFetch, uniformPrologue, splitSlice;
     int32_t numHeads, shardRays, numBlocksIncoherent;   /* persistent kernels: pool heads, rays per head, grid of an incoherent batch */
+    int32_t wholeWave;          /* persistent, dynamic fetch: waves start in whole-wave mode and switch per wave (csrc/trace_kernels.hip) */
+    int32_t prefetchAfter;      /* persistent: iterations into a chunk after which a wave posts the dequeue of its next one (< 0: never) */
     int32_t unified;            /* persistent: unified-step loop (kepler_dynamic_fetch) */
     int32_t minipool;           /* closest-hit per-ray launch that may run as wave-private ray pools */
     int32_t poolKConst;         /* pool depth when it is not decided on the device */
@@ -208,7 +210,11 @@ typedef struct NtrTracePlan {
     int32_t predictable;        /* dispatch-order prediction applies when no measured order is at hand */
     int32_t persistentOrder;    /* ... for a persistent launch: the pool is handed out in predicted order */
     int32_t probeOnRefresh;     /* a hinted batch's pool depth is estimated again on the hint's refresh launches */
-    int32_t coherentRoute;      /* persistent names: a batch the device finds coherent is traced by the per-ray body (see ntr_query_config) */
+    int32_t coherentRoute;      /* routing by coherence (ntr_query_config): 0 = the named body; 1 = BOTH bodies are launched and the device's
+                                 * batch word decides which one works (closest-hit launches large enough for the estimate); 2 = the per-ray
+                                 * body under a persistent name (any-hit launches) */
+    int32_t persistentVariant, persistentBlocks, persistentFetchThreshold;   /* the persistent side of a launch (named, or routed) */
+    int32_t perrayBlocks, perrayFetchThreshold;                              /* the per-ray side of a routed launch */
 } NtrTracePlan;
 #define NTR_PLAN_FLAG_STATS 1        /* ntr_trace_bvh_stats */
 #define NTR_PLAN_FLAG_CAPTURING 2    /* the stream is being captured into a HIP graph */
@@ -277,10 +283,13 @@ NTR_API int ntr_predict_block_costs(int32_t numRays, const NtrRay* d_rays, const
 
 /* Coherence estimate of a batch, without tracing it, from two sample rays (the 100th and the 227th) of every 256-ray block:
  * d_out[0] = blocks whose samples start further apart than 1/8 of the scene's extent, d_out[1] = blocks whose samples start together
- * but point more than 60 degrees apart (reported only), d_out[2] = the pool K large closest-hit launches of the per-ray kernel derive
- * on the device (1 = one ray per lane; K > 1 = a wave owns K x 64 rays and refills its finished lanes from them: chosen when origins
- * are scattered in at least half of the blocks -- 4 on trees of 32 MB of nodes and more for batches of 1.5 M rays and more, else 2;
- * DESIGN.md 4.1).  The launch itself does not call this -- its dispatch-order prediction computes the same words -- it is the query
+ * but point more than 60 degrees apart AND reach further than 1/8 of the scene's extent (bounce rays of a diffuse batch; the short
+ * rays of an AO batch do not count), d_out[2] = the batch word large closest-hit launches derive on the device: bits 0-15 the pool K
+ * of the per-ray kernel (1 = one ray per lane; K > 1 = a wave owns K x 64 rays and refills its finished lanes from them: chosen when
+ * origins are scattered in at least half of the blocks -- 4 on trees of 32 MB of nodes and more for batches of 1.5 M rays and more,
+ * else 2), bit 16 (NTR_BATCH_DIVERGENT) set when d_out[1] is at least a quarter of the blocks.  K > 1 or bit 16 =
+ * "incoherent": such a batch is traced by the persistent dynamic-fetch body under every kernel name, a coherent one by the per-ray
+ * body (ntr_query_config).  The launch itself does not call this -- its dispatch-order prediction computes the same words -- it is the query
  * for tests and for hosts that plan batches.  No counterpart in the reference.  d_out: 3 words.  Asynchronous on `stream`. */
 NTR_API int ntr_predict_batch_coherence(int32_t numRays, const NtrRay* d_rays, const void* d_nodes, int64_t nodesBytes,
                                         uint32_t* d_out, void* stream);
@@ -322,6 +331,8 @@ NTR_API int ntr_trace_bvh_stats(const char* kernelName, int32_t numRays, int32_t
 #define NTR_BVH_NOTINY 4u
 #define NTR_BVH_ORDERED 8u
 #define NTR_BVH_WIDE_LEAVES 16u
+/* bit 16 of the batch word (ntr_predict_batch_coherence d_out[2]): long rays that start together and point apart in a quarter of the blocks */
+#define NTR_BATCH_DIVERGENT 0x10000u
 NTR_API int ntr_bvh_validate(const void* d_nodes, int64_t nodesBytes, uint32_t* flags, void* stream);
 
 /* Device self test: counts quotients x[i]/d[j] for which the FAST divide differs from the

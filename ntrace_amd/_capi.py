@@ -233,8 +233,9 @@ class TracePlan(C.Structure):
     """NtrTracePlan (include/ntrace_amd.h): what ntr_trace_bvh decides before it touches the device."""
     _fields_ = [(n, C.c_int32) for n in (
         "variant", "launchVariant", "launchBlocks", "numBlocks", "orderBlocks", "chunk", "fetchThreshold", "leafSwitchBelow", "octant",
-        "flatFetch", "uniformPrologue", "splitSlice", "numHeads", "shardRays", "numBlocksIncoherent", "unified", "minipool", "poolKConst",
-        "poolKFromDevice", "minipoolWide", "hintable", "useAutoHint", "predictable", "persistentOrder", "probeOnRefresh", "coherentRoute")]
+        "flatFetch", "uniformPrologue", "splitSlice", "numHeads", "shardRays", "numBlocksIncoherent", "wholeWave", "prefetchAfter", "unified", "minipool", "poolKConst",
+        "poolKFromDevice", "minipoolWide", "hintable", "useAutoHint", "predictable", "persistentOrder", "probeOnRefresh", "coherentRoute",
+        "persistentVariant", "persistentBlocks", "persistentFetchThreshold", "perrayBlocks", "perrayFetchThreshold")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

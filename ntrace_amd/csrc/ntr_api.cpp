@@ -140,7 +140,7 @@ static void tunables_load_locked()
     t.chunk = env_int("NTR_TRACE_CHUNK", 64);
     t.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", -1);  // -1: 24 for kepler_dynamic_fetch, 0 otherwise
     t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", -1);     // -1: 32 for closest-hit, 24 for any-hit launches (bench-protocol sweep, scripts/jobs/gpu_job_r02ls.sh)
-    t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 6);
+    t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 8);          // persistent kernels: 8 x 4 waves = every wave slot of a CU (64 VGPRs; 6 until round 5, when the kernels took 67)
     t.blocksPerCUIncoherent = env_int("NTR_TRACE_BLOCKS_PER_CU_INCOHERENT", 3);   // persistent kernels, batches the device finds incoherent (scattered origins): fewer rays in flight = less queueing per step (scripts/studies/inflight_sweep.py)
     t.octant = env_int("NTR_TRACE_OCTANT", 1);
     t.closestWaves = env_int("NTR_TRACE_CLOSEST_WAVES", 1);      // likewise for closest-hit launches: primary +2.1 % with 1
@@ -148,6 +148,8 @@ static void tunables_load_locked()
     t.flatFetch = env_int("NTR_TRACE_FLAT_FETCH", 1);             // unified-step loop: one group of global loads per iteration (0 = two masked groups of range-checked buffer loads)
     t.uniformPrologue = env_int("NTR_TRACE_UNIFORM_PROLOGUE", 1);  // per-ray kernels: scalar node fetches while the lanes of a fresh wave all hold the same inner node
     t.splitSlice = env_int("NTR_TRACE_SPLIT_SLICE", 8);   // persistent kernels, unified-step loop: once the pool is dry, lanes without a ray take over stack entries of the wave's live rays; looked at every N steps (0 = off)
+    t.wholeWave = env_int("NTR_TRACE_WHOLE_WAVE", 1);      // kepler_dynamic_fetch: waves start in whole-wave mode and switch to single-lane refills per wave (0 = dynamic fetch from the start, as until round 5)
+    t.prefetchAfter = env_int("NTR_TRACE_PREFETCH_AFTER", 8);   // persistent kernels: iterations into a chunk after which a wave posts the dequeue of its next one (-1 = never)
     t.minipool = env_int("NTR_TRACE_MINIPOOL", -1);              // closest-hit per-ray launches: rays owned by a wave / 64.  -1: decided per batch on the device (1, or minipoolWide when the prediction finds the batch incoherent); 0: the plain per-ray kernel; 1 ... 16: forced
     t.minipoolWide = env_int("NTR_TRACE_MINIPOOL_WIDE", -1);     // K of an incoherent batch: 2 / 4, or -1 = by tree size (4 from 32 MB of nodes up)
     t.minipoolThreshold = env_int("NTR_TRACE_MINIPOOL_THRESHOLD", 48);   // refill a wave's finished lanes when fewer than this many are live
@@ -156,6 +158,8 @@ static void tunables_load_locked()
     t.poolHeads = env_int("NTR_TRACE_POOL_HEADS", 128);           // persistent kernels: 8..1024, a multiple of 8 (sweep: scripts/studies/persist_diag.py)
     t.autoHint = env_int("NTR_TRACE_AUTO_HINT", 1);               // dispatch order learned from the previous launch of the same batch (stream, rays, count, BVH)
     t.autoHintMinRays = env_int("NTR_TRACE_AUTO_HINT_MIN_RAYS", 1 << 17);
+    t.route = env_int("NTR_TRACE_ROUTE", 1);   // batches are traced by the body that is fast on them, whatever the kernel name (trace_plan.h ROUTING); 0 = the named body always
+    t.persistentHints = env_int("NTR_TRACE_PERSISTENT_HINTS", 1);   // the persistent kernels honour scheduling hints too (pool handed out in the hint's order, chunk lives recorded as block costs)
     t.predict = env_int("NTR_TRACE_PREDICT", 1);
     t.predictPersistent = env_int("NTR_TRACE_PREDICT_PERSISTENT", 1);   // persistent kernels: pool in predicted-cost order (closest-hit launches of >= predictMinRays)
     t.predictDepth = env_int("NTR_TRACE_PREDICT_DEPTH", 9);
@@ -679,7 +683,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     bd.callerHint = hint != nullptr;
     bd.numCUs = ds->numCUs;
     const TracePlan pl = plan_trace(tun, bd);
-    const int variant = pl.variant, numBlocks = pl.numBlocks, orderBlocks = pl.orderBlocks;
+    const int variant = pl.variant, orderBlocks = pl.orderBlocks;
 
     // ---- launch: bind the run-time state the plan asks for (counters, hints, prediction scratch), then the kernels ------------------
     TraceParams p;
@@ -694,13 +698,15 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.triIndex = d_triIndex;
     p.status = ds->status;
     p.counter = nullptr;
-    p.shardRays = pl.shardRays;
+    p.shardRays = 0;
     p.numHeads = pl.numHeads;
-    p.numBlocks = variant == NTR_VARIANT_PERSISTENT ? pl.numBlocks : 0;
-    p.numBlocksIncoherent = pl.numBlocksIncoherent;
+    p.numBlocks = 0;
+    p.numBlocksIncoherent = 0;
     p.orderBlocks = 0;
     p.chunk = pl.chunk;
     p.fetchThreshold = pl.fetchThreshold;
+    p.wholeWave = pl.wholeWave;
+    p.prefetchAfter = pl.prefetchAfter;
     p.bvhFlags = bvhFlags;
     p.flatFetch = pl.flatFetch;
     p.uniformPrologue = pl.uniformPrologue;
@@ -712,44 +718,27 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.cost = nullptr;
     p.poolK = nullptr;
     p.poolKConst = pl.poolKConst;
+    p.routeSkip = 0;
     if (stats) NTR_HIP(hipMemsetAsync(ds->stats, 0, 4 * sizeof(unsigned long long), s));
-
-    if (variant == NTR_VARIANT_PERSISTENT) {
-        {
-            // a launch that is being captured into a HIP graph keeps its pool heads for the graph's lifetime
-            std::lock_guard<std::mutex> lk(g_mu);
-            if (bd.capturing) {
-                if (ds->nextPinned >= kPinnedCounters)
-                    return set_error(NTR_ERR_NOMEM, "ntr_trace_bvh: more than %d persistent launches captured into HIP graphs", kPinnedCounters);
-                p.counter = ds->counters + kPoolHeadsMax * 16 * (kNumCounters + ds->nextPinned++);
-            } else {
-                p.counter = ds->counters + kPoolHeadsMax * 16 * ds->next;
-                ds->next = (ds->next + 1) % kNumCounters;
-            }
-        }
-        // cleared by a kernel: memset nodes do not survive HIP graph replays (see sched_kernels.hip)
-        const hipError_t ze = ntr_launch_zero_words(p.counter, kPoolHeadsMax * 16, s);
-        if (ze != hipSuccess) return hip_fail(ze, "zero_words launch");
-    }
 
     // no hint from the caller: the library's own, keyed by (stream, batch, BVH)
     if (pl.useAutoHint) {
-        rc = auto_hint_get(d_rays, d_nodes, numRays, anyHit ? 1 : 0, s, numBlocks, &hint);
+        rc = auto_hint_get(d_rays, d_nodes, numRays, anyHit ? 1 : 0, s, orderBlocks, &hint);
         if (rc != NTR_OK) return rc;
     }
-    // Scheduling hint: the per-ray kernel dispatches blocks in the hint's order; on refresh launches it
-    // also records per-block costs, from which the next order is derived right after the launch.
+    // Scheduling hint: the per-ray kernel dispatches blocks in the hint's order, the persistent kernels hand their pool out in it; on
+    // refresh launches per-block costs are recorded, from which the next order is derived right after the launch.
     bool refresh = false;
     if (hint && pl.hintable) {
         int dev = 0;
         NTR_HIP(hipGetDevice(&dev));
-        if (hint->numBlocks != numBlocks || hint->device != dev) {
-            rc = sched_hint_bind(hint, numBlocks, dev);   // (automatic hints arrive bound: auto_hint_get)
+        if (hint->numBlocks != orderBlocks || hint->device != dev) {
+            rc = sched_hint_bind(hint, orderBlocks, dev);   // (automatic hints arrive bound: auto_hint_get)
             if (rc != NTR_OK) return rc;
         }
         const HintStep hs = plan_hint_step(tun, hint->valid, hint->predicted, hint->uses);
         if (hs.zeroK) {
-            const hipError_t zk = ntr_launch_zero_words(hint->order + numBlocks, 3, s);
+            const hipError_t zk = ntr_launch_zero_words(hint->order + orderBlocks, 3, s);
             if (zk != hipSuccess) return hip_fail(zk, "zero_words launch");
         }
         refresh = hs.refresh;
@@ -757,7 +746,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         hint->uses++;
         if (hs.useOrder) p.order = hint->order;
         if (refresh) {
-            const hipError_t ze = ntr_launch_zero_words(hint->cost, numBlocks, s);
+            const hipError_t ze = ntr_launch_zero_words(hint->cost, orderBlocks, s);
             if (ze != hipSuccess) return hip_fail(ze, "zero_words launch");
             p.cost = hint->cost;
         }
@@ -772,29 +761,55 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         if (rc != NTR_OK) return rc;
         rc = predict_scratch_get(s, orderBlocks, &predScratch);
         if (rc != NTR_OK) return rc;
-        if (predScratch) {
-            p.order = predScratch->order;
-            if (variant == NTR_VARIANT_PERSISTENT) {   // every head walks its share of the order: ranges of whole 256-ray blocks
-                p.orderBlocks = orderBlocks;
-                p.shardRays = ((orderBlocks + p.numHeads - 1) / p.numHeads) * 256;
-                p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 2;   // the batch's coherence word: an incoherent batch runs on the smaller grid
-            }
-        } else {
-            predTable = nullptr;   // (a captured launch that found no spare scratch: buffer order)
-        }
+        if (predScratch) p.order = predScratch->order;
+        else predTable = nullptr;   // (a captured launch that found no spare scratch: buffer order)
     }
 
-    // A hinted batch is predicted once (its hint then holds a measured order); its coherence words -- the mini-pool K -- are estimated again
-    // on the hint's refresh launches by a probe of their own (three small launches, every 16th launch): rays drift.
+    // A hinted batch is predicted once (its hint then holds a measured order); its coherence words -- the batch word: mini-pool K, routing --
+    // are estimated again on the hint's refresh launches by a probe of their own (three small launches, every 16th launch): rays drift.
     const bool probeCoherence = !predScratch && hint && refresh && pl.probeOnRefresh;
     if (probeCoherence) {
         rc = top_table_get(d_nodes, nodesBytes, s, false, &predTable);
         if (rc != NTR_OK) return rc;
     }
-    // pool depth K of a mini-pool launch: the prediction of this launch wrote it, or the batch's hint kept it from its first launch
-    if (pl.minipool && pl.poolKFromDevice) {
-        if (predScratch) p.poolK = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 2;
-        else if (hint && hint->numBlocks == numBlocks && hint->order) p.poolK = hint->order + numBlocks + 2;
+    // The batch word (sched_kernels.hip pool_k): the prediction of this launch writes it, or the batch's hint kept it from its first,
+    // predicted launch (zero -- "coherent", K = 1 -- when there never was one).  It sets the mini-pool depth of the per-ray launch, the grid
+    // and refill policy of a persistent launch, and -- routed launches -- which of the two bodies works.
+    const unsigned int* word = nullptr;
+    if (predScratch) word = predScratch->classCount + NTR_SCHED_PRED_CLASSES + 2;
+    else if (hint && pl.hintable && hint->numBlocks == orderBlocks && hint->order) word = hint->order + orderBlocks + 2;
+    const bool routed = pl.coherentRoute == 1 && word != nullptr;
+    const bool persistentSide = variant == NTR_VARIANT_PERSISTENT || routed;
+    const bool perraySide = variant != NTR_VARIANT_PERSISTENT || routed;
+    if ((pl.minipool && pl.poolKFromDevice) || persistentSide) p.poolK = word;
+
+    TraceParams pp = p;   // the persistent side's parameters
+    if (persistentSide) {
+        {
+            // a launch that is being captured into a HIP graph keeps its pool heads for the graph's lifetime
+            std::lock_guard<std::mutex> lk(g_mu);
+            if (bd.capturing) {
+                if (ds->nextPinned >= kPinnedCounters)
+                    return set_error(NTR_ERR_NOMEM, "ntr_trace_bvh: more than %d persistent launches captured into HIP graphs", kPinnedCounters);
+                pp.counter = ds->counters + kPoolHeadsMax * 16 * (kNumCounters + ds->nextPinned++);
+            } else {
+                pp.counter = ds->counters + kPoolHeadsMax * 16 * ds->next;
+                ds->next = (ds->next + 1) % kNumCounters;
+            }
+        }
+        pp.numBlocks = pl.persistentBlocks;
+        pp.numBlocksIncoherent = pl.numBlocksIncoherent;
+        pp.fetchThreshold = pl.persistentFetchThreshold;
+        pp.shardRays = pl.shardRays;
+        if (pp.order) {   // every head walks its share of the order: ranges of whole 256-ray blocks
+            pp.orderBlocks = orderBlocks;
+            pp.shardRays = ((orderBlocks + pp.numHeads - 1) / pp.numHeads) * 256;
+        }
+        pp.routeSkip = routed ? NTR_ROUTE_SKIP_COHERENT : 0;
+    }
+    if (routed) {
+        p.routeSkip = NTR_ROUTE_SKIP_INCOHERENT;
+        if (variant == NTR_VARIANT_PERSISTENT) { p.fetchThreshold = pl.perrayFetchThreshold; p.poolKConst = 1; }
     }
 
     struct EventPair {   // destroyed on every return path of the timed bracket
@@ -812,18 +827,29 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     if (predScratch) {  // inside the timed bracket: the prediction is part of what the launch costs
         const hipError_t pe = ntr_launch_predict(d_rays, numRays, orderBlocks, predTable->table, predTable->count, predScratch->classCount,
                                                  predScratch->classList, predScratch->order,
-                                                 (hint && pl.hintable) ? hint->order + numBlocks + 2 : nullptr, pl.minipoolWide, s);
+                                                 (hint && pl.hintable) ? hint->order + orderBlocks + 2 : nullptr, pl.minipoolWide, s);
         if (pe != hipSuccess) return hip_fail(pe, "predict launch");
     } else if (probeCoherence) {   // (also inside the bracket)
-        const hipError_t ce = ntr_launch_coherence(d_rays, numRays, orderBlocks, predTable->table, predTable->count, hint->order + numBlocks,
+        const hipError_t ce = ntr_launch_coherence(d_rays, numRays, orderBlocks, predTable->table, predTable->count, hint->order + orderBlocks,
                                                   pl.minipoolWide, s);
         if (ce != hipSuccess) return hip_fail(ce, "coherence launch");
     }
-    hipError_t le = ntr_launch_trace(pl.launchVariant, &p, pl.launchBlocks, s);
-    if (le != hipSuccess) return hip_fail(le, "trace_bvh launch");
+    hipError_t le = hipSuccess;
+    if (persistentSide) {
+        // the pool heads are cleared by a kernel: memset nodes do not survive HIP graph replays (see sched_kernels.hip)
+        le = ntr_launch_zero_words(pp.counter, kPoolHeadsMax * 16, s);
+        if (le != hipSuccess) return hip_fail(le, "zero_words launch");
+        le = ntr_launch_trace(pl.persistentVariant, &pp, pl.persistentBlocks, s);
+        if (le != hipSuccess) return hip_fail(le, "trace_bvh launch");
+    }
+    if (perraySide) {
+        le = variant == NTR_VARIANT_PERSISTENT ? ntr_launch_trace(NTR_VARIANT_PERRAY_UNIFIED_MINI, &p, pl.perrayBlocks, s)
+                                               : ntr_launch_trace(pl.launchVariant, &p, pl.launchBlocks, s);
+        if (le != hipSuccess) return hip_fail(le, "trace_bvh launch");
+    }
     if (seconds) NTR_HIP(hipEventRecord(ev1, s));
     if (refresh) {
-        le = ntr_launch_sched_order(hint->cost, numBlocks, tun.schedClasses, hint->order, s);
+        le = ntr_launch_sched_order(hint->cost, orderBlocks, tun.schedClasses, hint->order, s);
         if (le != hipSuccess) return hip_fail(le, "sched_order launch");
         hint->valid = true;
     }

@@ -86,7 +86,11 @@ __device__ __forceinline__ unsigned int block_incoherence(const float4* __restri
     if (dist > 0.125f * ext) return 1u;   // (comparisons are false for NaN: coherent)
     const float dot = d.x * d2.x + d.y * d2.y + d.z * d2.z;
     const float l1 = d.x * d.x + d.y * d.y + d.z * d.z, l2 = d2.x * d2.x + d2.y * d2.y + d2.z * d2.z;
-    return (dot < 0.0f || 4.0f * dot * dot < l1 * l2) ? 2u : 0u;   // cos < 1/2, directions of any length
+    if (!(dot < 0.0f || 4.0f * dot * dot < l1 * l2)) return 0u;   // cos >= 1/2, directions of any length
+    // ... and the sample ray is LONG (more than 1/8 of the scene's extent): short rays that point apart -- an AO batch's -- stay in the
+    // leaves they start in and end together; long ones -- a diffuse batch's -- wander through different parts of the tree (bit 2)
+    const float reach = (d.w - o.w) * (d.w - o.w) * l1;
+    return reach > (0.125f * ext) * (0.125f * ext) ? 6u : 2u;
 }
 
 __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* __restrict__ rays, int numRays, int numBlocks,
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* 
     }
     if (wave == 0) {
         const unsigned int inc = (block < numBlocks && nBoxes >= 2) ? block_incoherence(rays, numRays, block, o, d, table) : 0u;
-        const unsigned long long m1 = __ballot(inc == 1u), m2 = __ballot(inc == 2u);
+        const unsigned long long m1 = __ballot(inc == 1u), m2 = __ballot(inc == 6u);
         if (lane == 0 && m1) atomicAdd(&classCount[NTR_SCHED_PRED_CLASSES], (unsigned int)__popcll(m1));
         if (lane == 0 && m2) atomicAdd(&classCount[NTR_SCHED_PRED_CLASSES + 1], (unsigned int)__popcll(m2));
     }
@@ -170,10 +174,14 @@ constexpr int FLATTEN_THREADS = 1024;
 // 2.8 M / 10 M-triangle LBVHs with K = 4, +9-12 % on the 262 k / 331 k SAH trees with K = 2; camera rays lose with any K > 1 (-15 % to
 // -50 %).  Blocks whose rays start together but point apart (bounce rays: 44 % of the blocks of a diffuse batch) are counted and reported,
 // not acted on: K = 2 for such batches measured between 0 and +4 %, inside the run-to-run noise.
-__device__ __forceinline__ unsigned int pool_k(unsigned int originApart, unsigned int dirApart, int numBlocks, int poolKWide)
+// Round 6: the word also carries NTR_BATCH_DIVERGENT (bit 16) when a quarter of the blocks hold LONG rays that start together and point
+// apart (a diffuse batch: 44 %).  The mini-pool depth ignores it, as before; the choice between the per-ray body and the persistent
+// dynamic-fetch body (trace_kernels.hip, TraceParams::routeSkip) does not: those batches are 20-35 % faster with single-lane refills and
+// ray splitting in the drain phase.
+__device__ __forceinline__ unsigned int pool_k(unsigned int originApart, unsigned int dirApartLong, int numBlocks, int poolKWide)
 {
-    (void)dirApart;
-    return (originApart > 0u && 2u * originApart >= (unsigned int)numBlocks) ? (unsigned int)poolKWide : 1u;
+    const unsigned int k = (originApart > 0u && 2u * originApart >= (unsigned int)numBlocks) ? (unsigned int)poolKWide : 1u;
+    return k | ((dirApartLong > 0u && 4u * dirApartLong >= (unsigned int)numBlocks) ? (unsigned int)NTR_BATCH_DIVERGENT : 0u);
 }
 __global__ __launch_bounds__(FLATTEN_THREADS) void flatten_kernel(unsigned int* __restrict__ classCount, const unsigned int* __restrict__ classList,
                                                                   int numBlocks, unsigned int* __restrict__ order,
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256) void coherence_kernel(const float4* __restrict
         const int r = min(block * 256 + PRED_SAMPLE, numRays - 1);
         inc = block_incoherence(rays, numRays, block, rays[2 * r], rays[2 * r + 1], table);
     }
-    const unsigned long long m1 = __ballot(inc == 1u), m2 = __ballot(inc == 2u);
+    const unsigned long long m1 = __ballot(inc == 1u), m2 = __ballot(inc == 6u);
     if ((threadIdx.x & 63) == 0 && m1) atomicAdd(&out[0], (unsigned int)__popcll(m1));
     if ((threadIdx.x & 63) == 0 && m2) atomicAdd(&out[1], (unsigned int)__popcll(m2));
 }

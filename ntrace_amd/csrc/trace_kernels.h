@@ -11,6 +11,11 @@
 #ifndef NTR_TRACE_MIN_WAVES_PER_SIMD
 #define NTR_TRACE_MIN_WAVES_PER_SIMD 1
 #endif
+// the persistent kernels are held to 64 VGPRs -- eight waves per SIMD, eight 256-thread workgroups per CU (8 x 16 KB of LDS stacks): the
+// unified-step instantiation would take 69 (seven waves) and fits 64 without a spill
+#ifndef NTR_TRACE_PERSISTENT_MIN_WAVES_PER_SIMD
+#define NTR_TRACE_PERSISTENT_MIN_WAVES_PER_SIMD 8
+#endif
 
 // kernel variants (selected by the reference's kernel file names, see ntr_query_config)
 #define NTR_VARIANT_PERRAY 0      // one ray per lane, while-while
@@ -23,6 +28,12 @@
 #define NTR_MINIPOOL_MAX_K 16             // a wave's private pool: at most this many 64-ray chunks
 #define NTR_VARIANT_PERRAY_UNIFIED_MINI 7 // the same launch, which runs as the wave-private mini-pool instead when the batch's pool K (TraceParams::poolK,
                                           // decided on the device) is 2 ... 16: a wave owns K x 64 rays and refills its finished lanes from them
+
+#define NTR_ROUTE_SKIP_COHERENT 1
+#define NTR_ROUTE_SKIP_INCOHERENT 2
+// the batch word (sched_kernels.hip pool_k): bits 0-15 the mini-pool depth K (> 1: origins scattered), bit 16 NTR_BATCH_DIVERGENT
+#define NTR_BATCH_WORD_K(w) ((w) & 0xFFFFu)
+#define NTR_BATCH_WORD_INCOHERENT(w) (NTR_BATCH_WORD_K(w) > 1u || ((w) & NTR_BATCH_DIVERGENT) != 0u)
 
 // bits of the device status word
 #define NTR_STATUS_STACK_OVERFLOW 1u
@@ -49,6 +60,9 @@ struct TraceParams {
     int32_t numBlocksIncoherent;   // persistent: the grid that works on a batch whose pool word (poolK) says incoherent (0 = the whole grid)
     int32_t orderBlocks;     // persistent, with `order`: number of 256-ray blocks in order[]
     int32_t fetchThreshold;  // persistent: refill when fewer lanes are live
+    int32_t wholeWave;       // persistent, dynamic fetch: 1 = single-lane refills only on batches the device found incoherent (poolK > 1), whole-wave
+                             // refills otherwise; 0 = dynamic fetch always (as until round 5)
+    int32_t prefetchAfter;   // persistent: iterations into a chunk after which the wave posts the dequeue of its next one (< 0: no dequeue-ahead)
     uint32_t bvhFlags;
     int32_t leafSwitchBelow; // serve waiting leaves when fewer lanes than this still hold an inner node
     int32_t octant;          // per-ray kernel: specialise the slab test for waves whose rays share their direction signs
@@ -63,6 +77,9 @@ struct TraceParams {
     const unsigned int* poolK;  // mini-pool kernel: device word holding the rays a wave owns / 64 (1 .. NTR_MINIPOOL_MAX_K; anything else reads as 1),
                                 // written by the dispatch-order prediction of this launch or kept in the launch's hint; null = poolKConst
     int32_t poolKConst;
+    int32_t routeSkip;          // batch routing by the device's coherence word (*poolK; ntr_api.cpp launches BOTH bodies for such a batch): 0 = none,
+                                // NTR_ROUTE_SKIP_COHERENT = this launch leaves at once when the word says coherent (the persistent bodies),
+                                // NTR_ROUTE_SKIP_INCOHERENT = ... when it says incoherent (the per-ray body)
 };
 
 }  // namespace ntr

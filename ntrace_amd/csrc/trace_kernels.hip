@@ -325,14 +325,17 @@ __device__ __forceinline__ void load_ray(const NtrRay* __restrict__ rays, int ra
 // While-while traversal of the lanes' current rays until every lane is done (or, in the
 // persistent kernel, until too few lanes are live).  Both loops are wave-uniform (ballots); per-ray
 // visiting order is exactly the CPU tracer's depth-first order, whatever the other lanes do.
-template <bool FAST, bool STATS, bool DYNAMIC_FETCH, int OCT = 8>
+// SLICED (persistent kernels): the loop also ends after `slice` rounds of it (`slice` counts down; the caller looks at the wave -- posts the
+// dequeue of its next chunk -- and calls again).
+template <bool FAST, bool STATS, bool DYNAMIC_FETCH, int OCT = 8, bool SLICED = false>
 __device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, RayRegs& r, int& node,
                                          LaneStack& st, int (&spill)[SPILL_DEPTH], bool anyHit,
                                          int& hitAddr, float& hitU, float& hitV, LaneStats& ls, unsigned int* status,
-                                         bool poolEmpty, int fetchThreshold, int leafSwitchBelow)
+                                         bool poolEmpty, int fetchThreshold, int leafSwitchBelow, int& slice)
 {
     unsigned long long live = __ballot(node != kSentinel);
     while (live != 0ull) {
+        if (SLICED && --slice < 0) break;
         for (;;) {
             const bool inner = (unsigned)node < (unsigned)kSentinel;
             const unsigned long long innerMask = __ballot(inner);
@@ -353,6 +356,16 @@ __device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, RayRegs& r, int&
         // in the pool -> leave the loop so that the idle lanes are refilled.
         if (DYNAMIC_FETCH && !poolEmpty && __popcll(live) < fetchThreshold) break;
     }
+}
+template <bool FAST, bool STATS, bool DYNAMIC_FETCH, int OCT = 8>
+__device__ __forceinline__ void traverse(Rsrc nodes, Rsrc woop, RayRegs& r, int& node,
+                                         LaneStack& st, int (&spill)[SPILL_DEPTH], bool anyHit,
+                                         int& hitAddr, float& hitU, float& hitV, LaneStats& ls, unsigned int* status,
+                                         bool poolEmpty, int fetchThreshold, int leafSwitchBelow)
+{
+    int never = 0;
+    traverse<FAST, STATS, DYNAMIC_FETCH, OCT, false>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, status, poolEmpty, fetchThreshold,
+                                                     leafSwitchBelow, never);
 }
 
 // Unified-step traversal (the dynamic-fetch kernel's loop).  The while-while loop above lets a wave alternate between an
@@ -598,12 +611,12 @@ __device__ __forceinline__ void uniform_prologue(const UnifiedBufs& ub, const Ra
     }
 }
 
-// SLICED: the loop also ends after `slice` iterations (the drain phase of the persistent kernels looks at the wave's lanes again:
-// split_settle / split_donate, trace_split.h).
-template <bool FAST, bool FLAT, int OCT = 8, bool PROLOGUE = false, bool SLICED = false>
+// SLICED (persistent kernels): the loop also ends after `slice` iterations (`slice` counts down: the caller posts the dequeue of the wave's
+// next chunk, or -- drain phase -- looks at the wave's lanes again: split_settle / split_donate, trace_split.h).
+template <bool FAST, bool FLAT, int OCT, bool PROLOGUE, bool SLICED>
 __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs& r, int& node, LaneStack& st,
                                                  int (&spill)[SPILL_DEPTH], bool anyHit, int& hitAddr, float& hitU, float& hitV,
-                                                 unsigned int* status, bool poolEmpty, int fetchThreshold, int slice = 0)
+                                                 unsigned int* status, bool poolEmpty, int fetchThreshold, int& slice)
 {
     if (PROLOGUE && ub.uniformPrologue) uniform_prologue<FAST, OCT>(ub, r, node, st, spill, status);
     for (;;) {
@@ -617,6 +630,14 @@ __device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs&
         if (FLAT) { keep(a); keep(b); keep(c); keep(d); }
         unified_advance<FAST, OCT>(a, b, c, d, r, node, st, spill, anyHit, hitAddr, hitU, hitV, status);
     }
+}
+template <bool FAST, bool FLAT, int OCT = 8, bool PROLOGUE = false>
+__device__ __forceinline__ void traverse_unified(const UnifiedBufs& ub, RayRegs& r, int& node, LaneStack& st,
+                                                 int (&spill)[SPILL_DEPTH], bool anyHit, int& hitAddr, float& hitU, float& hitV,
+                                                 unsigned int* status, bool poolEmpty, int fetchThreshold)
+{
+    int never = 0;
+    traverse_unified<FAST, FLAT, OCT, PROLOGUE, false>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, status, poolEmpty, fetchThreshold, never);
 }
 
 }  // namespace ntr
@@ -639,7 +660,11 @@ __device__ __forceinline__ void perray_body(const TraceParams& p)
     if constexpr (MINI) {
         static_assert(WAVES == 1 && UNIFIED && !STATS, "the mini-pool shares the one-wave unified-step launch");
         unsigned int K = (unsigned int)p.poolKConst;
-        if (p.poolK) K = *p.poolK;   // wave-uniform (scalar load)
+        if (p.poolK) {               // wave-uniform (scalar load)
+            const unsigned int word = *p.poolK;
+            if (p.routeSkip == NTR_ROUTE_SKIP_INCOHERENT && NTR_BATCH_WORD_INCOHERENT(word)) return;   // the persistent body behind this launch traces the batch
+            K = NTR_BATCH_WORD_K(word);
+        }
         bool pooled = K >= 2u && K <= (unsigned int)NTR_MINIPOOL_MAX_K;
         if (pooled) {
             minipool_body<FLATF>(p, K, (lds_int*)&s_stack[0][0][threadIdx.x]);
@@ -764,8 +789,23 @@ __global__ NTR_MINI_BOUNDS void trace_bvh_perray_mini_desc(TraceParams p)
 // paying an atomic round trip per dry head.
 // ---------------------------------------------------------------------------------
 // UNIFIED: the unified-step loop (traverse_unified) instead of the while-while loop -- what kepler_dynamic_fetch launches.
+// Round 6: what a persistent wave does between two chunks used to be 40 % of its life on coherent batches (an AO batch of the headline
+// frame: 7 us per refill -- the returning atomic on the pool head, then the ray load, one dependent round trip after the other -- of
+// a 20 us chunk; profiles/r05_persist_ao_timeline.jsonl), and a refilled wave ran the general loop where a fresh wave of the per-ray
+// kernel runs the octant-specialised one behind the uniform prologue.  Now:
+//   * WHOLE-WAVE refills are fresh waves: a wave that was empty and took its rays from one chunk walks the top of the tree through the
+//     scalar cache exactly like a wave of the per-ray kernel (uniform_prologue; the octant-specialised slab test is left to the
+//     per-ray kernel: eight more loop bodies cost these kernels 6-7 VGPRs, i.e. a wave per SIMD, for +3 %);
+//   * the NEXT chunk is dequeued while the current one is traced: `prefetchAfter` iterations into a chunk lane 0 posts the atomic for the
+//     wave's next chunk, and the value is there when the wave comes back (not at the start of the chunk: that would commit every wave
+//     to two chunks at launch -- 16 384 chunks of an AO batch over 8 192 waves -- and give up the dynamic balancing a pool is for);
+//   * kepler_dynamic_fetch refills single lanes (ballot / mbcnt, fetchThreshold) only on batches the device's coherence estimate (poolK)
+//     found incoherent -- dynamic fetch pays exactly where the rays of one chunk differ in length, and costs ~10 % where they do not
+//     (refilled lanes de-cohere a wave's node fetches) -- and refills whole waves otherwise.  (A per-wave switch decided by how busy a
+//     chunk kept its lanes was built first: changing the policy inside the wave's main loop costs 13 VGPRs, i.e. a wave per SIMD.)
+// None of this touches a ray's own visiting order: records cannot change.
 template <int WAVES, bool UNIFIED = false, bool FLATF = true>
-__global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trace_bvh_persistent(TraceParams p)
+__global__ __launch_bounds__(WAVES * 64, NTR_TRACE_PERSISTENT_MIN_WAVES_PER_SIMD) void trace_bvh_persistent(TraceParams p)
 {
     __shared__ int s_stack[WAVES][LDS_DEPTH][64];  // [wave][entry][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -778,7 +818,10 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     // courtyard-10M box rays 5.12 -> 4.60 ms, hairball 4.16 -> 3.43 ms; coherent batches keep the full grid (atrium primary 0.57 against
     // 0.67 ms with half).  Workgroups beyond the effective grid leave at once; everything below counts with the effective grid.
     int numBlocksEff = p.numBlocks;   // wave-uniform
-    if (p.poolK && *p.poolK > 1u && p.numBlocksIncoherent > 0 && p.numBlocksIncoherent < numBlocksEff) numBlocksEff = p.numBlocksIncoherent;
+    const unsigned int batchWord = p.poolK ? *p.poolK : 1u;
+    const bool incoherentBatch = NTR_BATCH_WORD_INCOHERENT(batchWord);   // scattered origins, or long rays that point apart: single-lane refills
+    if (p.routeSkip == NTR_ROUTE_SKIP_COHERENT && !incoherentBatch) return;   // the per-ray body beside this launch traces the batch
+    if (NTR_BATCH_WORD_K(batchWord) > 1u && p.numBlocksIncoherent > 0 && p.numBlocksIncoherent < numBlocksEff) numBlocksEff = p.numBlocksIncoherent;
     if ((int)blockIdx.x >= numBlocksEff) return;
 
     LaneStack st;
@@ -796,15 +839,29 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     const int numHeads = p.numHeads;
     int shard = (int)(blockIdx.x % (unsigned)numHeads);  // wave-uniform
     bool firstChunk = true;
-    // Pool positions.  Buffer order (p.order == null): position = ray index; range of head h: the heads of one XCD (h % 8) are
-    // neighbours in the index space.  Predicted-cost order (p.order: the 256-ray blocks heaviest class first, sched_kernels.hip): the
-    // positions of head h are the blocks order[h], order[h + numHeads], order[h + 2 numHeads], ... -- every head hands its blocks
-    // out from heavy to light, so the long-lived rays of the batch start first instead of forming the tail of the launch.  The pool
-    // then spans numHeads * shardRays positions (shardRays a multiple of 256) and a position may lie beyond the batch: it is skipped.
+    // Pool positions: head h owns positions [h * shardRays, (h + 1) * shardRays).  Buffer order (p.order == null): the k-th chunk of head h
+    // is chunk k * numHeads + h of the batch -- the heads interleave, so every head holds an even sample of the batch and all of them
+    // run dry together.  (Until round 6 a head owned a CONTIGUOUS range of the batch, "so that an XCD's L2 sees one screen region": the
+    // heads of cheap screen regions then ran dry early, their waves all moved to the same next head -- a returning atomic on one address
+    // is served at ~88 per us -- and a coherent launch spent most of its time in that queue whatever its occupancy: AO batches 145 us
+    // with 6, 7 or 8 workgroups per CU alike, against 52 us for the per-ray kernel, whose workgroups interleave over the XCDs the same
+    // way.)  Predicted-cost order (p.order: the 256-ray blocks heaviest class first, sched_kernels.hip): the positions of head h are the
+    // blocks order[h], order[h + numHeads], order[h + 2 numHeads], ... -- every head hands its blocks out from heavy to light, so the
+    // long-lived rays of the batch start first instead of forming the tail of the launch.  Either way the pool spans numHeads * shardRays
+    // positions and a position may lie beyond the batch: it is skipped.
     const unsigned int* const order = p.order;
-    const int poolEnd = order ? numHeads * p.shardRays : p.numRays;
-    auto range_beg = [&](int h) { return order ? h * p.shardRays : ((h & 7) * (numHeads >> 3) + (h >> 3)) * p.shardRays; };
-    int chunkHead = 0;                // wave-uniform: the head the current chunk was taken from
+    const int poolEnd = numHeads * p.shardRays;
+    auto range_beg = [&](int h) { return h * p.shardRays; };
+    int chunkDelta = 0;               // wave-uniform: ray index - pool position inside the current chunk (a chunk never spans two 256-ray blocks)
+    // the chunk at position `base` of head h: where its rays are in the batch.  One scalar load per chunk in the ordered pool (until round 6
+    // every lane looked its block up in order[] itself: a dependent vector load on the refill's critical path)
+    auto chunk_delta = [&](int base, int h) {
+        const int off = base - h * p.shardRays;
+        if (!order) return ((off / p.chunk) * numHeads + h) * p.chunk - base;
+        const int q = (off >> 8) * numHeads + h;                  // the block's place in the predicted / learned order
+        if (q >= p.orderBlocks) return 0x3FFFFFFF - base;          // beyond the batch: every position of the chunk maps past numRays
+        return (int)order[q] * 256 + (off & 255) - base;
+    };
     // chunks of head h handed out statically: one per wave of every block with blockIdx % numHeads == h
     auto static_rays = [&](int h) { return ((numBlocksEff - h + numHeads - 1) / numHeads) * WAVES * p.chunk; };
     LaneStats ls = {0u, 0u, 0u};
@@ -814,77 +871,85 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
     bool splitOn = false;             // wave-uniform
     const int splitSlice = UNIFIED ? p.splitSlice : 0;
 
+    // refill policy (wave-uniform): whole-wave (a wave takes rays only when it holds none) or dynamic fetch (fewer than fetchThreshold
+    // lanes live -> the idle lanes take rays; kepler_dynamic_fetch.cu:310)
+    const bool dynamicFetch = p.fetchThreshold > 0 && (!UNIFIED || p.wholeWave == 0 || incoherentBatch);
+    // dequeue-ahead: the atomic of the wave's next chunk, posted `prefetchAfter` iterations into the current one
+    int prefetched = 0;               // lane 0: what the atomic returned
+    bool havePrefetch = false;        // wave-uniform
+    int prefetchHead = 0;             // wave-uniform: the head it was posted on
+    int prefetchIn = -1;              // wave-uniform: iterations until the prefetch is posted (< 0: none pending)
+    // scheduling feedback (a hint's refresh launch, whole-wave mode): a 256-ray block's cost is the life of the longest chunk taken from it
+    int costBlock = -1;               // wave-uniform: the block of the chunk in flight (-1: none / not recorded)
+    unsigned long long costT0 = 0;
+
+    // The wave's next chunk: its statically assigned first one, the one it dequeued ahead, or an atomic on its head -- and when that head
+    // is dry, on the next head that still has rays.  Sets chunkNext / chunkEnd / chunkHead / chunkDelta; false = the pool is dry.
+    // The ray index space is dealt to numHeads pool heads (a single head saturates near 88 dequeues/us, MI355X_MICROARCH price list "dequeue").
+    auto grab = [&]() -> bool {
+        bool got = false;
+        auto take = [&](int base, int h) {
+            const int rangeBeg = range_beg(h);
+            const int rangeEnd = min(rangeBeg + p.shardRays, poolEnd);
+            if (base >= rangeEnd) return false;
+            chunkNext = base;
+            chunkEnd = min(base + p.chunk, rangeEnd);
+            chunkDelta = chunk_delta(base, h);
+            return true;
+        };
+        if (firstChunk) {  // static: the (blockIdx / numHeads * WAVES + wave)-th chunk of the block's head
+            firstChunk = false;
+            got = take(range_beg(shard) + ((int)(blockIdx.x / (unsigned)numHeads) * WAVES + __builtin_amdgcn_readfirstlane(wave)) * p.chunk, shard);
+        } else if (havePrefetch) {   // the dequeue posted while the previous chunk was traced
+            havePrefetch = false;    // (a head that ran dry meanwhile: the search below starts on it and moves on)
+            got = take(__builtin_amdgcn_readfirstlane(prefetched) + static_rays(prefetchHead) + range_beg(prefetchHead), prefetchHead);
+        }
+        while (!got) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(p.counter + shard * 16, p.chunk);
+            if (take(__builtin_amdgcn_readfirstlane(base) + static_rays(shard) + range_beg(shard), shard)) { got = true; break; }
+            // dry: lane l looks at head (shard + 1 + l) % numHeads; counters only grow, so a head seen dry stays dry
+            unsigned long long live = 0ull;
+            int ofs = 1;
+            for (; ofs < numHeads && live == 0ull; ofs += 64) {
+                bool has = false;
+                if (ofs + lane < numHeads) {
+                    const int h = (shard + ofs + lane) % numHeads;
+                    const int hb = range_beg(h);
+                    const int he = min(hb + p.shardRays, poolEnd);
+                    const int taken = __hip_atomic_load(p.counter + h * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    has = hb + static_rays(h) + taken < he;
+                }
+                live = __ballot(has);
+            }
+            if (live == 0ull) break;
+            shard = (shard + ofs - 64 + (int)__builtin_ctzll(live)) % numHeads;
+        }
+        if (got) prefetchIn = p.prefetchAfter;   // (negative: no dequeue-ahead)
+        return got;
+    };
+    // scheduling feedback: the 256-ray block of the chunk just grabbed
+    auto cost_open = [&]() {
+        costBlock = (chunkEnd - p.chunk + chunkDelta) >> 8;
+        if ((unsigned)costBlock >= (unsigned)((p.numRays + 255) >> 8)) costBlock = -1;
+        costT0 = __builtin_amdgcn_s_memrealtime();
+    };
+
     // Invariant at the top of the loop: a lane either holds a live ray
     // (rayIdx >= 0, node != sentinel) or is empty (rayIdx < 0, node == sentinel).
     for (;;) {
         // ---- refill empty lanes from the wave's chunk ----------------------------
         unsigned long long empty = __ballot(rayIdx < 0);
-        while (empty != 0ull && !poolEmpty) {
-            if (chunkNext >= chunkEnd) {  // wave-uniform: grab the next chunk
-                // The ray index space is cut into 8 contiguous ranges with one pool head each
-                // (a single head saturates near 88 dequeues/us, MI355X_MICROARCH price list
-                // "dequeue").  A wave starts on the range of its own XCD -- so an XCD's L2 sees
-                // one screen region -- and moves on to the next range when that one runs dry.
-                bool got = false;
-                if (firstChunk) {  // static: the (blockIdx / numHeads * WAVES + wave)-th chunk of the block's head
-                    firstChunk = false;
-                    const int rangeBeg = range_beg(shard);
-                    const int rangeEnd = min(rangeBeg + p.shardRays, poolEnd);
-                    const int base = rangeBeg + ((int)(blockIdx.x / (unsigned)numHeads) * WAVES + __builtin_amdgcn_readfirstlane(wave)) * p.chunk;
-                    if (base < rangeEnd) {
-                        chunkNext = base;
-                        chunkEnd = min(base + p.chunk, rangeEnd);
-                        chunkHead = shard;
-                        got = true;
-                    }
-                }
-                while (!got) {
-                    const int rangeBeg = range_beg(shard);
-                    const int rangeEnd = min(rangeBeg + p.shardRays, poolEnd);
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(p.counter + shard * 16, p.chunk);
-                    base = __builtin_amdgcn_readfirstlane(base) + static_rays(shard) + rangeBeg;
-                    if (base < rangeEnd) {
-                        chunkNext = base;
-                        chunkEnd = min(base + p.chunk, rangeEnd);
-                        chunkHead = shard;
-                        got = true;
-                        break;
-                    }
-                    // dry: lane l looks at head (shard + 1 + l) % numHeads; counters only grow, so a head seen dry stays dry
-                    unsigned long long live = 0ull;
-                    int ofs = 1;
-                    for (; ofs < numHeads && live == 0ull; ofs += 64) {
-                        bool has = false;
-                        if (ofs + lane < numHeads) {
-                            const int h = (shard + ofs + lane) % numHeads;
-                            const int hb = range_beg(h);
-                            const int he = min(hb + p.shardRays, poolEnd);
-                            const int taken = __hip_atomic_load(p.counter + h * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            has = hb + static_rays(h) + taken < he;
-                        }
-                        live = __ballot(has);
-                    }
-                    if (live == 0ull) break;
-                    shard = (shard + ofs - 64 + (int)__builtin_ctzll(live)) % numHeads;
-                }
-                if (!got) { poolEmpty = true; break; }
-            }
+        const bool wholeWave = empty == ~0ull;
+        const bool refill = !poolEmpty && (wholeWave || (dynamicFetch && 64 - __popcll(empty) < p.fetchThreshold));
+        while (refill && empty != 0ull && !poolEmpty) {
+            if (chunkNext >= chunkEnd && !grab()) { poolEmpty = true; break; }
             // rank of this lane among the empty lanes (wave64 prefix popcount)
             const int prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(empty >> 32),
                                __builtin_amdgcn_mbcnt_lo((unsigned)empty, 0));
             const int avail = chunkEnd - chunkNext;
-            int pos = chunkNext + prefix;   // pool position -> ray index (-1: beyond the batch)
-            if (order) {
-                const int off = pos - chunkHead * p.shardRays;         // inside the head's range: its block off / 256
-                const int q = (off >> 8) * numHeads + chunkHead;       // that block's place in the predicted order
-                pos = -1;
-                if (q < p.orderBlocks) {
-                    const int a = (int)order[q] * 256 + (off & 255);
-                    pos = a < p.numRays ? a : -1;
-                }
-            }
-            if (rayIdx < 0 && prefix < avail && pos >= 0) {
+            const int pos = chunkNext + prefix + chunkDelta;   // pool position -> ray index (beyond the batch: skipped)
+            if (rayIdx < 0 && prefix < avail && pos < p.numRays) {
                 rayIdx = pos;
                 load_ray(p.rays, rayIdx, r);
                 hitAddr = -1;
@@ -897,32 +962,62 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_MIN_WAVES_PER_SIMD) void trac
             }
             chunkNext += min(__popcll(empty), avail);
             empty = __ballot(rayIdx < 0);
+            if (wholeWave && !dynamicFetch) break;   // whole-wave mode takes rays ONCE per refill (a short last chunk stays short)
         }
+        const bool fresh = refill && wholeWave;   // every ray the wave holds starts at the root now
+        if (p.cost && refill && wholeWave && !dynamicFetch && !poolEmpty) cost_open();
 
-        // ---- while-while traversal ------------------------------------------------
+        // ---- drain phase: lanes without a ray take over stack entries of the wave's live rays (unified-step loop) ------------------
         if (UNIFIED && poolEmpty && splitSlice > 0) {
             if (!splitOn) { splitOn = true; split_reset(split); }
             split_donate(split, r, node, st, rayIdx, hitAddr, hitU, hitV, nice);
         }
         const bool fastWave = bvhFast && __ballot(node != kSentinel && !nice) == 0ull;
+        // dequeue-ahead: the traversal comes back after `prefetchIn` iterations, the atomic is posted, the traversal goes on
+        int slice = 0x7FFFFFFF;
+        if (splitOn) slice = splitSlice;   // drain phase with splitting: the lanes are looked at again every `slice` steps
+        else if (prefetchIn >= 0 && !poolEmpty) slice = prefetchIn;
+        const int fetchBelow = dynamicFetch ? p.fetchThreshold : 0;
         if (UNIFIED) {
             const UnifiedBufs ub = unified_bufs(p);
-            const int slice = splitOn ? splitSlice : 0x7FFFFFFF;   // drain phase with splitting: the lanes are looked at again every `slice` steps
-            if (fastWave) traverse_unified<true, FLATF, 8, false, true>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold, slice);
-            else traverse_unified<false, FLATF, 8, false, true>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, p.fetchThreshold, slice);
+            if (fresh && p.uniformPrologue) {   // the top of the tree through the scalar cache while the wave's rays agree (uniform_prologue)
+                if (fastWave) uniform_prologue<true, 8>(ub, r, node, st, spill, p.status);
+                else uniform_prologue<false, 8>(ub, r, node, st, spill, p.status);
+            }
+            if (fastWave) traverse_unified<true, FLATF, 8, false, true>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, fetchBelow, slice);
+            else traverse_unified<false, FLATF, 8, false, true>(ub, r, node, st, spill, anyHit, hitAddr, hitU, hitV, p.status, poolEmpty, fetchBelow, slice);
             if (splitOn) split_settle(split, r, node, st, hitAddr, hitU, hitV, anyHit);
-        } else if (fastWave) traverse<true, false, true>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
-        else traverse<false, false, true>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, p.fetchThreshold, p.leafSwitchBelow);
+        } else {
+            if (fresh && p.uniformPrologue) {   // the top of the tree through the scalar cache while the wave's rays agree (uniform_prologue)
+                const UnifiedBufs ub = unified_bufs(p);
+                if (fastWave) uniform_prologue<true, 8>(ub, r, node, st, spill, p.status);
+                else uniform_prologue<false, 8>(ub, r, node, st, spill, p.status);
+            }
+            if (fastWave) traverse<true, false, true, 8, true>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, fetchBelow, p.leafSwitchBelow, slice);
+            else traverse<false, false, true, 8, true>(nodes, woop, r, node, st, spill, anyHit, hitAddr, hitU, hitV, ls, p.status, poolEmpty, fetchBelow, p.leafSwitchBelow, slice);
+        }
+        // ---- dequeue-ahead: post the atomic of the wave's next chunk now (its latency hides behind the rest of this chunk) -------------
+        if (!splitOn && prefetchIn >= 0 && !poolEmpty) {
+            prefetchIn = -1;
+            if (!havePrefetch && __ballot(node != kSentinel) != 0ull) {   // (a wave that is done already dequeues in the refill above)
+                if (lane == 0) prefetched = atomicAdd(p.counter + shard * 16, p.chunk);
+                havePrefetch = true;
+                prefetchHead = shard;
+            }
+        }
 
         // ---- retire finished rays (an owner whose helpers are still out waits for their reports) ------
         if (rayIdx >= 0 && node == kSentinel && (!splitOn || split.base == 0)) {
             store_result(p.results, p.triIndex, rayIdx, hitAddr, r.tmax, hitU, hitV);
             rayIdx = -1;
         }
+        if (costBlock >= 0 && __ballot(rayIdx >= 0) == 0ull) {   // the chunk is done
+            if (lane == 0) atomicMax(&p.cost[costBlock], (unsigned int)(__builtin_amdgcn_s_memrealtime() - costT0));
+            costBlock = -1;
+        }
         if (poolEmpty && __ballot(rayIdx >= 0) == 0ull) break;
     }
 }
-
 
 // ---------------------------------------------------------------------------------
 // Variant 3: per-ray kernel with a wave-private mini-pool (round 3).  A hardware-scheduled 64-thread workgroup owns K x 64 consecutive

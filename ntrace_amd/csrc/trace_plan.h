@@ -47,12 +47,7 @@ inline TracePlan plan_trace(const Tunables& tun, const TraceBatchDesc& b)
 {
     TracePlan pl;
     memset(&pl, 0, sizeof(pl));
-    const bool dynamicFetch = b.dynamicFetch;
-    pl.unified = dynamicFetch && tun.unified != 0;
     pl.chunk = tun.chunk;
-    // persistent kernels (scripts/studies/persist_sweep.py): 64-ray chunks, 6 workgroups per CU; dynamic fetch only for the kernel
-    // named after it (it costs about 10 % on coherent batches: refilled lanes de-cohere a wave's node fetches)
-    pl.fetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (dynamicFetch ? (pl.unified ? 48 : 24) : 0);
     {   // the flat fetch addresses both buffers from one scalar base with 32-bit lane offsets: they must lie inside one 4 GiB window
         // (two allocations of one heap practically always do; otherwise the two-descriptor fetch, which has no such condition)
         const uint64_t an = b.nodesAddr, aw = b.woopAddr;
@@ -62,37 +57,70 @@ inline TracePlan plan_trace(const Tunables& tun, const TraceBatchDesc& b)
         pl.flatFetch = (tun.flatFetch != 0 && b.nodesBytes >= 64 && b.triWoopBytes >= 64 && oneWindow) ? 1 : 0;
     }
     pl.uniformPrologue = tun.uniformPrologue != 0 ? 1 : 0;
+    pl.wholeWave = tun.wholeWave != 0 ? 1 : 0;
+    pl.prefetchAfter = tun.prefetchAfter;
     pl.splitSlice = tun.splitSlice > 0 ? tun.splitSlice : 0;
     pl.leafSwitchBelow = tun.leafSwitchBelow >= 0 ? tun.leafSwitchBelow : (b.anyHit ? 24 : 32);
     pl.octant = tun.octant;
     pl.numHeads = 8;
     pl.poolKConst = 1;
     pl.minipoolWide = minipool_wide(tun, b.nodesBytes, b.numRays);
+    pl.orderBlocks = (b.numRays + 255) / 256;
+    const bool bigEnough = b.numRays >= tun.predictMinRays && b.nodesBytes >= (int64_t)tun.predictMinNodes * 64 && tun.predict != 0;
 
     // RayStats counters (src/rt/bvh/BVH.hpp:44-, filled at CudaBVH.cpp:746-757,1107-1111) are produced by the instrumented per-ray
     // kernel; every variant visits nodes in the same per-ray order, so the counts do not depend on the variant.
     pl.variant = b.wantStats ? NTR_VARIANT_PERRAY_STATS : b.variant;
+
+    // ROUTING (round 6).  The kernel names select semantics, and the semantics of all of them are the same here (identical records by
+    // construction); what differs is which batches a body is fast on: the per-ray body on coherent ones (15 against 7.5-8 Grays/s on the
+    // headline frame -- a persistent wave idles half of a launch that holds only two to four chunks per wave slot), the persistent
+    // dynamic-fetch body with ray splitting on incoherent ones (2.8 against 3.6 ms on 2^21 box rays through the hairball tree).  So, unless
+    // NTR_TRACE_ROUTE=0 forces the named body:
+    //   * any-hit launches run the per-ray body under every name (coherentRoute 2, decided here);
+    //   * closest-hit launches large enough for the device's coherence estimate (the dispatch-order prediction computes it) are launched as
+    //     BOTH bodies -- the per-ray one and the name's persistent one (kepler_dynamic_fetch's for the per-ray name) --, each of which leaves
+    //     at once when the batch word says the batch is the other's (coherentRoute 1; an empty launch costs 3-10 us);
+    //   * everything else runs the named body.
+    const bool route = tun.route != 0 && !b.wantStats;
+    if (route && b.variant == NTR_VARIANT_PERSISTENT && b.anyHit) {
+        pl.variant = NTR_VARIANT_PERRAY;
+        pl.coherentRoute = 2;
+    }
+    // the persistent body of this launch: the name's own, or -- routed launches of the per-ray name -- kepler_dynamic_fetch's
+    const bool persistentDynamic = b.variant == NTR_VARIANT_PERSISTENT ? b.dynamicFetch : true;
+    pl.unified = persistentDynamic && tun.unified != 0;
+    pl.persistentFetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (persistentDynamic ? (pl.unified ? 48 : 24) : 0);
+    pl.fetchThreshold = pl.persistentFetchThreshold;
+
     constexpr int blockThreads = NTR_TRACE_WAVES_PER_BLOCK * 64;
-    pl.orderBlocks = (b.numRays + 255) / 256;
-    if (pl.variant == NTR_VARIANT_PERSISTENT) {
+    auto persistent_grid = [&]() {
         // Persistent grid: CUs x resident blocks per CU (the reference hard-codes 720 warps for GT200/Fermi, CudaBVHTracer.cpp:155-159).
         const int blocksPerCU = tun.blocksPerCU;
-        pl.numBlocks = b.numCUs * blocksPerCU;
+        pl.persistentBlocks = b.numCUs * blocksPerCU;
         const int needed = (b.numRays + blockThreads - 1) / blockThreads;
-        if (pl.numBlocks > needed) pl.numBlocks = needed;
+        if (pl.persistentBlocks > needed) pl.persistentBlocks = needed;
         const int chunksTotal = (b.numRays + pl.chunk - 1) / pl.chunk;
         pl.numHeads = tun.poolHeads < 8 ? 8 : (tun.poolHeads > kPoolHeadsMax ? kPoolHeadsMax : tun.poolHeads & ~7);
         // (only the dynamic-fetch kernel: its waves stay full from the pool; the while-while persistent kernel refills a wave only when it is
         // empty and loses with fewer waves -- hairball box rays 9.3 -> 14.7 ms)
-        if (dynamicFetch && tun.blocksPerCUIncoherent > 0 && tun.blocksPerCUIncoherent < blocksPerCU) {
+        if (persistentDynamic && tun.blocksPerCUIncoherent > 0 && tun.blocksPerCUIncoherent < blocksPerCU) {
             pl.numBlocksIncoherent = b.numCUs * tun.blocksPerCUIncoherent;
-            if (pl.numBlocksIncoherent > pl.numBlocks) pl.numBlocksIncoherent = pl.numBlocks;
+            if (pl.numBlocksIncoherent > pl.persistentBlocks) pl.numBlocksIncoherent = pl.persistentBlocks;
         }
         pl.shardRays = ((chunksTotal + pl.numHeads - 1) / pl.numHeads) * pl.chunk;
+        pl.persistentVariant = pl.unified ? NTR_VARIANT_PERSISTENT_UNIFIED : NTR_VARIANT_PERSISTENT;
+    };
+    if (pl.variant == NTR_VARIANT_PERSISTENT) {
+        persistent_grid();
+        pl.numBlocks = pl.persistentBlocks;
     } else {
         pl.numBlocks = (b.numRays + blockThreads - 1) / blockThreads;
     }
-    pl.hintable = pl.variant == NTR_VARIANT_PERRAY;
+    // the per-ray kernel dispatches its blocks in a hint's order; the persistent kernels hand their pool out in it (heavy blocks first:
+    // with two to four 64-ray chunks per wave slot the launch ends with whatever long chunk was taken last) and record a block's cost as
+    // the life of the whole-wave chunks taken from it
+    pl.hintable = pl.variant == NTR_VARIANT_PERRAY || (pl.variant == NTR_VARIANT_PERSISTENT && (256 % pl.chunk) == 0 && tun.persistentHints != 0);
     pl.useAutoHint = !b.callerHint && !b.wantStats && tun.autoHint != 0 && pl.hintable && b.numRays >= tun.autoHintMinRays && !b.capturing;
 
     // Dispatch-order prediction (sched_kernels.hip): closest-hit launches of the per-ray kernel that are large enough for the tail to
@@ -101,7 +129,6 @@ inline TracePlan plan_trace(const Tunables& tun, const TraceBatchDesc& b)
     // pool out in the same predicted order (the heavy blocks' long rays start first instead of being the chunks fetched last): there the
     // prediction covers batches of all 256-ray blocks and needs pool chunks that divide 256.
     pl.persistentOrder = pl.variant == NTR_VARIANT_PERSISTENT && tun.predictPersistent != 0 && (256 % pl.chunk) == 0;
-    const bool bigEnough = b.numRays >= tun.predictMinRays && b.nodesBytes >= (int64_t)tun.predictMinNodes * 64 && tun.predict != 0;
     pl.predictable = (pl.variant == NTR_VARIANT_PERRAY || pl.persistentOrder) && !b.anyHit && bigEnough;
     pl.probeOnRefresh = pl.variant == NTR_VARIANT_PERRAY && !b.anyHit && tun.minipool < 0 && bigEnough;
 
@@ -109,7 +136,7 @@ inline TracePlan plan_trace(const Tunables& tun, const TraceBatchDesc& b)
     // feedback stay in units of 256 rays: numBlocks counts those, the launch has 4 / waves workgroups per unit.
     pl.launchVariant = pl.variant;
     pl.launchBlocks = pl.numBlocks;
-    if (pl.variant == NTR_VARIANT_PERSISTENT && pl.unified) pl.launchVariant = NTR_VARIANT_PERSISTENT_UNIFIED;
+    if (pl.variant == NTR_VARIANT_PERSISTENT) pl.launchVariant = pl.persistentVariant;
     const int wantWaves = b.anyHit ? tun.anyHitWaves : tun.closestWaves;
     if (pl.variant == NTR_VARIANT_PERRAY && wantWaves < NTR_TRACE_WAVES_PER_BLOCK) {
         const int waves = wantWaves <= 1 ? 1 : 2;
@@ -132,6 +159,21 @@ inline TracePlan plan_trace(const Tunables& tun, const TraceBatchDesc& b)
                 pl.poolKFromDevice = tun.minipool < 0;
             }
         }
+    }
+
+    // closest-hit launches the device can classify: both bodies (see ROUTING above).  The per-ray side is the mini-pool launch -- the
+    // instantiation that reads the batch word --, the persistent side the name's own body, or kepler_dynamic_fetch's
+    if (route && !b.anyHit && bigEnough && (256 % pl.chunk) == 0) {
+        if (pl.variant == NTR_VARIANT_PERRAY && pl.launchVariant == NTR_VARIANT_PERRAY_UNIFIED_MINI && pl.poolKFromDevice) {
+            pl.coherentRoute = 1;
+            persistent_grid();
+        } else if (pl.variant == NTR_VARIANT_PERSISTENT && tun.perrayUnified != 0 && tun.minipool < 0 && pl.predictable) {
+            pl.coherentRoute = 1;
+        }
+    }
+    if (pl.coherentRoute == 1) {   // the per-ray side's launch shape (what a fermi launch of this batch has)
+        pl.perrayBlocks = pl.orderBlocks * 4;
+        pl.perrayFetchThreshold = tun.minipoolThreshold;
     }
     return pl;
 }

@@ -47,22 +47,26 @@ def test_bench_scene_obj_path(tmp_path, camera):
         assert out["config"]["primary_hits_rank0"] > 1000   # looking down the long axis from inside the box
 
 
-def test_bench_rccl_path_at_world_size_one():
-    """The multi-GPU code path of bench.py -- RCCL process group, barriers, BVH broadcast, MAX / SUM reductions, the gather of hit
-    records to rank 0 and the assembled-frame check -- exercised on one GPU (NTR_BENCH_FORCE_DIST=1), so that the GPU test tier
-    loads RCCL and runs every collective the 2 / 4 / 8-GPU runs use."""
+@pytest.mark.parametrize("balance", ["count", "predicted"])
+def test_bench_rccl_path_at_world_size_one(balance):
+    """The multi-GPU code path of bench.py -- RCCL process group, barriers, the library's own BVH broadcast and gather of hit records
+    (ntr_dist_broadcast_bvh, ntr_dist_gather_records / _cuts: the default whenever the ranks run on RCCL), MAX / SUM reductions and the
+    assembled-frame check -- exercised on one GPU (NTR_BENCH_FORCE_DIST=1), so that the GPU test tier loads RCCL and runs every
+    collective the 2 / 4 / 8-GPU runs use, with equal ranges and with a cut table."""
     env = dict(os.environ, NTR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               HSA_ENABLE_IPC_MODE_LEGACY="0", NTR_BENCH_NATIVE_GATHER="1")
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", "640", "--height", "360", "--steps", "2", "--warmup", "1",
-                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+                        "--no-extras", "--no-cpu-baseline", "--balance", balance], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["gather_ms"] is not None and out["gather_ms"] > 0
+    # the frame rank 0 checks bit for bit against its own single-GPU trace IS the one the library's gather assembled
     chk = out["sharded_frame_check"]
     assert chk and chk["primary_records_equal_single_gpu_frame"] and chk["ao_checksum_equal_single_gpu_frame"]
     assert chk["records_compared"] == 640 * 360
-    # the library's own gather (ntr_dist_gather_records, RCCL bound by the C-ABI) assembled the same frame
-    assert out["gather_native"] and out["gather_native"]["equal_torch_gather"] is True
+    want = "ntr_dist_gather_records_cuts" if balance == "predicted" else "ntr_dist_gather_records "
+    assert out["gather_native"] and want in out["gather_native"]["how"] and out["gather_native"]["bvh_broadcast"] == "ntr_dist_broadcast_bvh"
+    assert "ntr_dist" in out["config"]["parallelism"]
     # the frame-per-rank mode reported beside `value` for N > 1 (here: one rank, one whole frame)
     fpr = out["extras"]["frame_per_rank"]
     assert fpr["ranks"] == 1 and fpr["steps"] == 2 and fpr["mrays"] > 0 and fpr["ms_per_frame"] > 0

@@ -634,8 +634,9 @@ def test_stream_release_returns_a_streams_scheduling_state(monkeypatch):
 def test_batch_coherence_estimate_separates_camera_rays_from_scattered_ones(soup, monkeypatch):
     """ntr_predict_batch_coherence (the words the dispatch-order prediction derives on the device): rays from one camera start together
     and point alike -- no incoherent block, K = 1; rays that start anywhere in the scene's box are incoherent in nearly every block --
-    K = the wide pool (2 on a small tree, 4 when asked for); rays that start together and point anywhere are counted as direction-incoherent
-    and stay at K = 1; an empty batch is coherent."""
+    K = the wide pool (2 on a small tree, 4 when asked for); LONG rays that start together and point anywhere (a diffuse batch) are counted
+    as direction-incoherent: the pool K stays 1 and the word's NTR_BATCH_DIVERGENT bit (16) is set -- SHORT ones (an AO batch) are not; an
+    empty batch is coherent."""
     import torch
     from gpu_util import up
     dbvh, cam = soup
@@ -657,10 +658,14 @@ def test_batch_coherence_estimate_separates_camera_rays_from_scattered_ones(soup
     o, d, k = query(rnd)
     assert o >= 0.8 * blocks and k == 2, (o, d, k)   # (a small tree: the wide pool is 2)
     o, d, k = query(fan)
-    assert o == 0 and d >= 0.6 * blocks and k == 1, (o, d, k)
+    assert o == 0 and d >= 0.6 * blocks and k == (1 | 0x10000), (o, d, k)
+    short = fan.copy()
+    short["tmin"] = 0.0
+    short["tmax"] = 1e-3 * float(np.abs(prim["ox"][0]) + np.abs(prim["oy"][0]) + np.abs(prim["oz"][0]) + 1.0)
+    assert query(short) == [0, 0, 1]
     monkeypatch.setenv("NTR_TRACE_MINIPOOL_WIDE", "4")
     nt.set_tunables()
-    assert query(rnd)[2] == 4 and query(fan)[2] == 1 and query(prim)[2] == 1
+    assert query(rnd)[2] == 4 and query(fan)[2] == (1 | 0x10000) and query(prim)[2] == 1
     assert query(prim[:0]) == [0, 0, 1]
 
 

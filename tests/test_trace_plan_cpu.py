@@ -56,15 +56,41 @@ def test_persistent_selectors_grid_and_pool():
     for name, unified, thr in (("tesla_persistent_while_while", 0, 0), ("tesla_persistent_speculative_while_while", 0, 0),
                                ("kepler_dynamic_fetch", 1, 48)):
         p = nt.trace_plan(name, 2 * MB, False, 600 * MB, 700 * MB, num_cus=256)
-        assert p.variant == PERSISTENT and p.unified == unified and p.fetchThreshold == thr
-        assert p.launchVariant == (PERSISTENT_UNIFIED if unified else PERSISTENT)
-        assert p.numBlocks == p.launchBlocks == 256 * 6 and p.numHeads == 128 and p.chunk == 64
+        assert p.variant == PERSISTENT and p.unified == unified and p.fetchThreshold == thr and p.persistentFetchThreshold == thr
+        assert p.launchVariant == p.persistentVariant == (PERSISTENT_UNIFIED if unified else PERSISTENT)
+        assert p.numBlocks == p.launchBlocks == p.persistentBlocks == 256 * 8 and p.numHeads == 128 and p.chunk == 64
         assert p.shardRays * p.numHeads >= 2 * MB and p.shardRays % 64 == 0
         assert p.numBlocksIncoherent == (256 * 3 if unified else 0)      # only the dynamic-fetch kernel halves its grid
-        assert p.persistentOrder and p.predictable and not p.hintable and not p.useAutoHint
-    # a batch smaller than the grid: one workgroup per 256 rays
-    p = nt.trace_plan("kepler_dynamic_fetch", 1000, True, 17 * MB, 17 * MB, num_cus=256)
-    assert p.numBlocks == 4 and p.numBlocksIncoherent == 4 and not p.predictable
+        assert p.persistentOrder and p.predictable and p.hintable and p.useAutoHint     # (round 6: the pool is handed out in a hint's order too)
+        # large closest-hit launch: BOTH bodies, the device's batch word decides (the per-ray side has a fermi launch's shape)
+        assert p.coherentRoute == 1 and p.perrayBlocks == 4 * p.orderBlocks and p.perrayFetchThreshold == 48
+    # a batch smaller than the grid: one workgroup per 256 rays; too small for the estimate: the named body alone
+    p = nt.trace_plan("kepler_dynamic_fetch", 1000, False, 17 * MB, 17 * MB, num_cus=256)
+    assert p.variant == PERSISTENT and p.numBlocks == 4 and p.numBlocksIncoherent == 4 and not p.predictable and p.coherentRoute == 0
+
+
+def test_routing_by_coherence():
+    # any-hit launches run the per-ray body under every name
+    a = nt.trace_plan("fermi_speculative_while_while", MB, True, 17 * MB, 17 * MB)
+    for name in ("tesla_persistent_while_while", "kepler_dynamic_fetch"):
+        p = nt.trace_plan(name, MB, True, 17 * MB, 17 * MB)
+        assert p.coherentRoute == 2 and (p.variant, p.launchVariant, p.launchBlocks) == (a.variant, a.launchVariant, a.launchBlocks)
+        assert p.hintable and p.useAutoHint
+    # the per-ray name: large closest-hit launches carry kepler_dynamic_fetch's body beside their own
+    f = nt.trace_plan("fermi_speculative_while_while", 2 * MB, False, 600 * MB, 700 * MB, num_cus=256)
+    assert f.coherentRoute == 1 and f.launchVariant == UNIFIED_MINI and f.persistentVariant == PERSISTENT_UNIFIED
+    assert f.persistentBlocks == 256 * 8 and f.numBlocksIncoherent == 256 * 3 and f.persistentFetchThreshold == 48 and f.numHeads == 128
+    small = nt.trace_plan("fermi_speculative_while_while", 1000, False, 17 * MB, 17 * MB)
+    assert small.coherentRoute == 0
+    # NTR_TRACE_ROUTE=0: the named body, always
+    nt.set_tunables(NTR_TRACE_ROUTE=0)
+    p = nt.trace_plan("kepler_dynamic_fetch", MB, True, 17 * MB, 17 * MB)
+    assert p.coherentRoute == 0 and p.variant == PERSISTENT and p.launchVariant == PERSISTENT_UNIFIED
+    assert nt.trace_plan("fermi_speculative_while_while", 2 * MB, False, 600 * MB, 700 * MB).coherentRoute == 0
+    assert nt.trace_plan("tesla_persistent_while_while", 2 * MB, False, 600 * MB, 700 * MB).coherentRoute == 0
+    nt.set_tunables(NTR_TRACE_ROUTE=None)
+    # the stats variant is never routed
+    assert nt.trace_plan("kepler_dynamic_fetch", MB, True, 17 * MB, 17 * MB, flags=nt._capi.PLAN_FLAG_STATS).coherentRoute == 0
 
 
 def test_flat_fetch_needs_one_4gib_window():
@@ -79,7 +105,12 @@ def test_tunables_steer_the_plan(monkeypatch):
     p = nt.trace_plan("fermi_speculative_while_while", 2 * MB, False, 17 * MB, 17 * MB)
     assert p.launchVariant == UNIFIED_W1 and not p.minipool and not p.predictable
     q = nt.trace_plan("tesla_persistent_while_while", 2 * MB, False, 17 * MB, 17 * MB, num_cus=256)
-    assert q.numBlocks == 1024 and q.numHeads == 1024 and not q.predictable
+    assert q.numBlocks == 1024 and q.numHeads == 1024 and not q.predictable and q.coherentRoute == 0
+    nt.set_tunables(NTR_TRACE_MINIPOOL=None, NTR_TRACE_BLOCKS_PER_CU=None, NTR_TRACE_POOL_HEADS=None, NTR_TRACE_PREDICT=None)
+    nt.set_tunables(NTR_TRACE_PERSISTENT_HINTS=0)
+    q = nt.trace_plan("kepler_dynamic_fetch", 2 * MB, False, 17 * MB, 17 * MB)
+    assert not q.hintable and not q.useAutoHint and q.predictable
+    nt.set_tunables(NTR_TRACE_PERSISTENT_HINTS=None)
     nt.set_tunables(NTR_TRACE_MINIPOOL=4, NTR_TRACE_PERRAY_UNIFIED=-1)
     p = nt.trace_plan("fermi_speculative_while_while", 2 * MB, False, 17 * MB, 17 * MB)
     assert p.minipool and p.poolKConst == 4 and not p.poolKFromDevice
