@@ -1138,6 +1138,38 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
                                      best4.nodesBytes + best4.triWoopBytes + best4.triIndexBytes, "diffuse", (args.kernel, "kepler_dynamic_fetch"),
                                      args.width, args.height, args.ao_samples, hbm_peak, "hairball")
             cfgs["4"]["lbvh_build"] = info4
+            # (f-3) where the secondary-ray Morton sort could pay: one diffuse batch of this frame (long incoherent rays in a deep tree), sorted
+            # by ntr_ray_morton_sort (the reference's 192-bit key, RayBuffer.cpp:103-165; outside the timed trace like ray generation) against unsorted
+            try:
+                r4, _ = scenes.primary_rays(cam4, args.width, args.height)
+                d_r4 = up(r4)
+                d_p4 = torch.zeros(r4.shape[0] * 16, dtype=torch.uint8, device=dev)
+                lview4.trace(args.kernel, r4.shape[0], False, d_r4.data_ptr(), d_p4.data_ptr(), stream)
+                d_n4 = up(scenes.tri_normals(tri4, pos4))
+                per4 = (1 << 20) // args.ao_samples
+                lo4 = (r4.shape[0] // 2) // per4 * per4
+                nb4 = per4 * args.ao_samples
+                b_r = torch.zeros(nb4 * 32, dtype=torch.uint8, device=dev)
+                b_o = torch.zeros(nb4 * 16, dtype=torch.uint8, device=dev)
+                b_a = torch.zeros(nb4, dtype=i32, device=dev)
+                nt.raygen_ao(b_r.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_r4.data_ptr(), d_p4.data_ptr(), d_n4.data_ptr(), lo4, per4, args.ao_samples,
+                             cam4["far"], 0xFFF2D5E4, stream)
+                so4 = torch.zeros_like(b_r)
+                sa4 = torch.zeros(nb4, dtype=i32, device=dev)
+                sb4 = torch.zeros(nb4, dtype=i32, device=dev)
+                id4 = torch.arange(nb4, dtype=i32, device=dev)
+                ss4 = min(nt.ray_morton_sort(nb4, b_r.data_ptr(), id4.data_ptr(), so4.data_ptr(), sa4.data_ptr(), sb4.data_ptr(), stream) for _ in range(3))
+                rs = {"rays": nb4, "sort_ms": ss4 * 1e3}
+                for kn in (args.kernel, "kepler_dynamic_fetch"):
+                    lview4.trace(kn, nb4, False, so4.data_ptr(), b_o.data_ptr(), stream)
+                    ts_ = float(np.median([lview4.trace(kn, nb4, False, so4.data_ptr(), b_o.data_ptr(), stream) for _ in range(5)]))
+                    lview4.trace(kn, nb4, False, b_r.data_ptr(), b_o.data_ptr(), stream)
+                    tu_ = float(np.median([lview4.trace(kn, nb4, False, b_r.data_ptr(), b_o.data_ptr(), stream) for _ in range(5)]))
+                    rs[kn] = {"trace_sorted_ms": ts_ * 1e3, "trace_unsorted_ms": tu_ * 1e3}
+                cfgs["4"]["ray_sort_one_diffuse_batch"] = rs
+                del d_r4, d_p4, d_n4, b_r, b_o, b_a, so4, sa4, sb4, id4
+            except Exception as e:
+                cfgs["4"]["ray_sort_one_diffuse_batch"] = {"error": repr(e)}
             del keep4, lview4
         except Exception as e:
             cfgs["4"] = {"error": repr(e)}

@@ -242,7 +242,10 @@ NTR_API int ntr_tunables_reload(void);
  * the hit records are identical.  A hint made for other rays is harmless (any order is valid); it
  * adapts after a launch or two.  The caller owns the hint and passes one per logical batch; it is
  * bound to the first (numRays) it is used with and re-initialises itself when that changes.
- * Kernels other than the per-ray kernel ignore the hint. */
+ * The persistent kernels honour a hint too (round 6): their pool is handed out in the hint's order and whole-wave chunks record
+ * their lives as block costs.  ONE STREAM AT A TIME: a hint's arrays are read by the launches it was passed to and rewritten when it is
+ * rebound (another ray count) or refreshed; use a hint on one stream only, or synchronise that stream before passing the hint to a
+ * launch on another (the launch path itself never synchronises or records events: ADVICE r05). */
 typedef struct NtrSchedHint NtrSchedHint;
 NTR_API int ntr_sched_hint_create(NtrSchedHint** out);
 NTR_API int ntr_sched_hint_destroy(NtrSchedHint* hint);

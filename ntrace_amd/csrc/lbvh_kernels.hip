@@ -763,6 +763,10 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
         // and left it at the run's first position: one load instead of a walk up to thirty parents.
         const bool walk = q.x >= 0 && agg_run_height(q.w - q.z, c.leafSize) > parentBit;
         const int depth = walk ? (int)c.runDepth[q.z] : 0;
+        if (depth == 0xFF) {                            // lbvh_leafmark_kernel did not count this run's depth: the two depth tests disagree
+            if (lane == 0) atomicOr(&c.st->overflow, 4u);
+            continue;
+        }
         int* parentLink = q.x >= 0 ? c.nodes + (size_t)q.x * 16 + 12 + q.y : nullptr;
         if (depth >= 30) {                              // the parent's level bit is 0: a leaf whatever its size
             if (lane == 0) *parentLink = ~agg_leaf_storage(c, q.z);
@@ -963,6 +967,10 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
                 const int dS = s0 > 0 ? hbit(keys[s0 - 1] ^ myKey) : 64, dE = e0 < n ? hbit(keys[e0] ^ myKey) : 64;
                 const int parentBit = min(dS, dE);
                 deepRun = parentBit != 64 && agg_run_height(e0 - s0, leafSize) > parentBit;
+                // (a run whose depth is NOT counted says so at its first position: lbvh_runs_kernel derives "is the depth needed" from the
+                // parent bit the agglomerate kernel carries, not from the neighbouring keys as above -- should the two ever disagree it must
+                // find this mark, not a byte left over from an earlier build, and fail the build loudly: ADVICE r05)
+                if (!deepRun && i == s0) runDepth[s0] = 0xFF;
             }
             if (i > 0 && topBit >= 0 && dAt(i) == topBit) st->rootSplit = (unsigned int)i;
         }

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -355,17 +356,24 @@ struct SchedState {
     PredictScratch scratch[kScratch];
     AutoHint autoHints[kAutoHints];
 };
-static SchedState* g_sched[kMaxDevices];   // created on a device's first use, never destroyed (entries hold device memory of a live context)
+static std::atomic<SchedState*> g_sched[kMaxDevices];   // created on a device's first use, never destroyed (entries hold device memory of a live context)
 
 static int sched_state(int dev, SchedState** out)
 {
     if (dev < 0 || dev >= kMaxDevices) return set_error(NTR_ERR_INVALID, "device index %d out of range", dev);
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_sched[dev]) {
-        g_sched[dev] = new (std::nothrow) SchedState();
-        if (!g_sched[dev]) return set_error(NTR_ERR_NOMEM, "out of host memory (scheduling state of device %d)", dev);
+    // the launch path only reads the pointer (acquire): the host threads of a thread-per-GPU driver share no lock here; the process-wide
+    // mutex is taken once per device, to create its state
+    SchedState* ss = g_sched[dev].load(std::memory_order_acquire);
+    if (!ss) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        ss = g_sched[dev].load(std::memory_order_relaxed);
+        if (!ss) {
+            ss = new (std::nothrow) SchedState();
+            if (!ss) return set_error(NTR_ERR_NOMEM, "out of host memory (scheduling state of device %d)", dev);
+            g_sched[dev].store(ss, std::memory_order_release);
+        }
     }
-    *out = g_sched[dev];
+    *out = ss;
     return NTR_OK;
 }
 static int sched_state_current(SchedState** out, int* devOut = nullptr)

@@ -66,7 +66,10 @@ __device__ __forceinline__ unsigned int os_excl_scan_256(unsigned int v, unsigne
 // MODE 1: the key word of element i is keysIn[valsIn[i] * stride] (multi-word keys stay in place, only the index array moves).
 // MODE 2: the key word is fetched as in MODE 1 and moves with the value from here on (first pass over a word of a multi-word key;
 //         the following passes over that word run in MODE 0 on the dense (word, value) pairs).
-template <int ITEMS, int MODE>
+// SKIP_TRIVIAL (the ray sort's instantiations): a pass whose digit is the same in EVERY key -- the upper digits of a 192-bit ray key over a
+// batch that fills a corner of the scene: 8-11 of its 19 passes -- is the identity permutation; its tiles then only copy (and, MODE 2, fetch
+// the new key word): no ranking, no chained scan.
+template <int ITEMS, int MODE, bool SKIP_TRIVIAL = false>
 __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n, const unsigned int* __restrict__ keysIn,
                                                                            const int* __restrict__ valsIn,
                                                                            unsigned int* __restrict__ keysOut, int* __restrict__ valsOut,
@@ -93,6 +96,18 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
     const unsigned int tile = s_tile;
 
     const long long chunk = (long long)tile * TILE + wave * (64 * ITEMS);
+    if (SKIP_TRIVIAL && __syncthreads_or(digitTotals[tid] == (unsigned int)n)) {
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const long long k = chunk + r * 64 + lane;
+            if (k < n) {
+                const int v = valsIn[k];
+                if (MODE != 1) keysOut[k] = MODE != 0 ? keysIn[(size_t)v * stride] : keysIn[k];
+                valsOut[k] = v;
+            }
+        }
+        return;
+    }
     unsigned int key[ITEMS], rank[ITEMS];
     int val[ITEMS];
     const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));

@@ -273,10 +273,10 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
         if (p > 0 && (p % 7) == 0) NTR_HIP(hipMemsetAsync(state, 0, stateWords * 4, s));
         const int word = p >> 2, shift = (p & 3) * 8;
         if ((p & 3) == 0)
-            hipLaunchKernelGGL((onesweep_pass_kernel<ITEMS, 2>), dim3(tiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)keys.p + word, (const int*)vIn, kOut, vOut,
+            hipLaunchKernelGGL((onesweep_pass_kernel<ITEMS, 2, true>), dim3(tiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)keys.p + word, (const int*)vIn, kOut, vOut,
                                6, shift, p % 7, (const unsigned int*)(histp + (size_t)p * 256), state, misc + p, misc + 31);
         else
-            hipLaunchKernelGGL((onesweep_pass_kernel<ITEMS, 0>), dim3(tiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
+            hipLaunchKernelGGL((onesweep_pass_kernel<ITEMS, 0, true>), dim3(tiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
                                1, shift, p % 7, (const unsigned int*)(histp + (size_t)p * 256), state, misc + p, misc + 31);
         int* t = vIn; vIn = vOut; vOut = t;
         unsigned int* tk = kIn; kIn = kOut; kOut = tk;

@@ -198,7 +198,13 @@ def main(argv=None):
                         # wave-private mini-pool of the closest-hit per-ray launches: by the device's coherence estimate, off, or forced
                         NTR_TRACE_MINIPOOL=int(rng.choice([-1, -1, 0, 1, 2, 3, 4, 5, 8, 16])), NTR_TRACE_MINIPOOL_THRESHOLD=int(rng.choice([48, 48, 1, 33, 64])),
                         # ray splitting in the drain phase of the persistent kernels (trace_split.h): how often the lanes are looked at
-                        NTR_TRACE_SPLIT_SLICE=int(rng.choice([8, 8, 1, 2, 5, 32, 0])))
+                        NTR_TRACE_SPLIT_SLICE=int(rng.choice([8, 8, 1, 2, 5, 32, 0])),
+                        # round 6: routing by coherence (both bodies launched, the device's batch word picks one) or the named body always;
+                        # the persistent kernels' refill policy, dequeue-ahead, pool geometry and hint support
+                        NTR_TRACE_ROUTE=int(rng.choice([1, 1, 0])), NTR_TRACE_WHOLE_WAVE=int(rng.choice([1, 1, 0])),
+                        NTR_TRACE_PREFETCH_AFTER=int(rng.choice([8, 8, -1, 0, 1, 50])), NTR_TRACE_PERSISTENT_HINTS=int(rng.choice([1, 1, 0])),
+                        NTR_TRACE_POOL_HEADS=int(rng.choice([128, 128, 8, 64, 1024])), NTR_TRACE_BLOCKS_PER_CU=int(rng.choice([8, 8, 1, 3, 6])),
+                        NTR_TRACE_CHUNK=int(rng.choice([64, 64, 64, 32, 128, 256, 48])))
             nt.set_tunables(**loop)
             hint = nt.SchedHint() if sched >= 2 else None
             if sched == 3:
