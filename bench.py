@@ -825,6 +825,12 @@ def config_point(nt, torch, scenes, dev, stream, up, name, tri_, pos_, cam_, vie
     b_rays = torch.zeros(per * ns * 32, dtype=torch.uint8, device=dev)
     b_res = torch.zeros(per * ns * 16, dtype=torch.uint8, device=dev)
     b_a = torch.zeros(per * ns, dtype=i32, device=dev)
+    # the reference sorts every secondary batch before it traces it (Renderer.sortRays defaults to true: config.conf:27, AppEnvironment.cpp:68;
+    # Renderer.cpp:562 RayBuffer::mortonSort, outside the timed trace like ray generation): the default selector's batches are timed both ways
+    s_rays = torch.zeros_like(b_rays)
+    s_i2s = torch.zeros(per * ns, dtype=i32, device=dev)
+    s_s2i = torch.zeros(per * ns, dtype=i32, device=dev)
+    s_id = torch.arange(per * ns, dtype=i32, device=dev)
 
     def roof(alg, sec, sym, grid_rays, launches):
         r = {"bound": "hbm", "achieved": alg / sec / 1e9, "peak": hbm_peak, "unit": "GB/s", "frac": alg / sec / 1e9 / hbm_peak,
@@ -851,6 +857,7 @@ def config_point(nt, torch, scenes, dev, stream, up, name, tri_, pos_, cam_, vie
             out["primary_hit_rate"] = hits / npr
             row["primary_roofline"] = roof(st.algorithmic_bytes(), tp, launched_symbol(kn, wide), launched_grid(kn, npr), 1)
         tt, live, launched, alg, nb, per_batch = 0.0, 0, 0, 0, 0, []
+        tt_sorted, sort_s, per_batch_sorted = 0.0, 0.0, []
         for lo in range(0, npr, per):
             cnt = min(per, npr - lo)
             nt.raygen_ao(b_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(), d_res.data_ptr(), d_nrm.data_ptr(), lo, cnt, ns, dist_,
@@ -864,16 +871,31 @@ def config_point(nt, torch, scenes, dev, stream, up, name, tri_, pos_, cam_, vie
             nb += 1
             if ki == 0:
                 alg += view_.trace_stats(kn, cnt * ns, any_hit, b_rays.data_ptr(), b_res.data_ptr(), stream).algorithmic_bytes()
+                sort_s += nt.ray_morton_sort(cnt * ns, b_rays.data_ptr(), s_id.data_ptr(), s_rays.data_ptr(), s_i2s.data_ptr(), s_s2i.data_ptr(), stream)
+                view_.trace(kn, cnt * ns, any_hit, s_rays.data_ptr(), b_res.data_ptr(), stream)
+                t_s = float(np.median([view_.trace(kn, cnt * ns, any_hit, s_rays.data_ptr(), b_res.data_ptr(), stream) for _ in range(3)]))
+                tt_sorted += t_s
+                per_batch_sorted.append(round(t_s * 1e3, 4))
         row.update({"secondary_ms": tt * 1e3, "secondary_batches": nb, "secondary_mrays": live / tt / 1e6 if tt > 0 else None,
                     "secondary_mrays_all_launched": launched / tt / 1e6 if tt > 0 else None, "secondary_per_batch_ms": per_batch,
                     "frame_ms": (tp + tt) * 1e3, "frame_mrays": (npr + live) / (tp + tt) / 1e6})
         if ki == 0:
             out["rays"] = {"primary": npr, "secondary_nondegenerate": int(live), "secondary_launched": int(launched)}
             row["secondary_roofline"] = roof(alg, tt, launched_symbol(kn, wide, any_hit=any_hit), launched_grid(kn, per * ns), nb)
+            row.update({"secondary_sorted_ms": tt_sorted * 1e3, "secondary_sorted_mrays": live / tt_sorted / 1e6 if tt_sorted > 0 else None,
+                        "secondary_sorted_per_batch_ms": per_batch_sorted, "ray_sort_ms_untimed": sort_s * 1e3,
+                        "frame_sorted_ms": (tp + tt_sorted) * 1e3, "frame_sorted_mrays": (npr + live) / (tp + tt_sorted) / 1e6,
+                        "sorted_note": "the same batches Morton-sorted first (ntr_ray_morton_sort: the reference's RayBuffer::mortonSort, its default -- "
+                                       "Renderer.sortRays true --, outside the timed trace): identical rays, hence identical algorithmic bytes"})
+            row["secondary_sorted_roofline"] = roof(alg, tt_sorted, launched_symbol(kn, wide, any_hit=any_hit), launched_grid(kn, per * ns), nb)
         out["by_kernel"][kn] = row
     k0 = out["by_kernel"][kernels[0]]
     dom = "secondary" if k0["secondary_ms"] >= k0["primary_ms"] else "primary"
-    out["roofline"] = dict(k0[dom + "_roofline"], launch="%s batches, %s" % (dom, kernels[0]), share_of_frame=k0[dom + "_ms"] / k0["frame_ms"])
+    out["roofline"] = dict(k0[dom + "_roofline"], launch="%s batches, %s, rays in generation order" % (dom, kernels[0]), share_of_frame=k0[dom + "_ms"] / k0["frame_ms"])
+    if dom == "secondary":
+        out["roofline_sorted_rays"] = dict(k0["secondary_sorted_roofline"], launch="secondary batches, %s, rays Morton-sorted first (the reference's default, "
+                                           "Renderer.sortRays = true; the sort is untimed like ray generation)" % kernels[0],
+                                           share_of_frame=k0["secondary_sorted_ms"] / k0["frame_sorted_ms"])
     return out
 
 

@@ -198,6 +198,7 @@ typedef struct NtrTracePlan {
     int32_t orderBlocks;        /* 256-ray blocks of the batch */
     int32_t chunk, fetchThreshold, leafSwitchBelow, octant, flatFetch, uniformPrologue, splitSlice;
     int32_t numHeads, shardRays, numBlocksIncoherent;   /* persistent kernels: pool heads, rays per head, grid of an incoherent batch */
+    int32_t numBlocksDivergent; /* ... of a batch whose rays start together and wander apart (NTR_BATCH_DIVERGENT only) */
     int32_t wholeWave;          /* persistent, dynamic fetch: waves start in whole-wave mode and switch per wave (csrc/trace_kernels.hip) */
     int32_t prefetchAfter;      /* persistent: iterations into a chunk after which a wave posts the dequeue of its next one (< 0: never) */
     int32_t unified;            /* persistent: unified-step loop (kepler_dynamic_fetch) */
@@ -285,12 +286,14 @@ NTR_API int ntr_predict_block_costs(int32_t numRays, const NtrRay* d_rays, const
                                     uint32_t* d_blockCost, void* stream);
 
 /* Coherence estimate of a batch, without tracing it, from two sample rays (the 100th and the 227th) of every 256-ray block:
- * d_out[0] = blocks whose samples start further apart than 1/8 of the scene's extent, d_out[1] = blocks whose samples start together
- * but point more than 60 degrees apart AND reach further than 1/8 of the scene's extent (bounce rays of a diffuse batch; the short
- * rays of an AO batch do not count), d_out[2] = the batch word large closest-hit launches derive on the device: bits 0-15 the pool K
+ * d_out[0] = blocks whose samples start further apart than 1/8 of the scene's extent, d_out[1] = the divergence score: 4 for every block
+ * whose samples start together but point more than 60 degrees apart AND reach further than 1/8 of the scene's extent (bounce rays of a
+ * diffuse batch; the short rays of an AO batch do not count) + 1 for every block whose sample ray is degenerate (a missed pixel's
+ * secondary ray: no say), d_out[2] = the batch word large closest-hit launches derive on the device: bits 0-15 the pool K
  * of the per-ray kernel (1 = one ray per lane; K > 1 = a wave owns K x 64 rays and refills its finished lanes from them: chosen when
  * origins are scattered in at least half of the blocks -- 4 on trees of 32 MB of nodes and more for batches of 1.5 M rays and more,
- * else 2), bit 16 (NTR_BATCH_DIVERGENT) set when d_out[1] is at least a quarter of the blocks.  K > 1 or bit 16 =
+ * else 2), bit 16 (NTR_BATCH_DIVERGENT) set when 4 x d_out[0] + d_out[1] reaches the number of blocks (a quarter of the blocks with live
+ * rays are incoherent one way or the other).  K > 1 or bit 16 =
  * "incoherent": such a batch is traced by the persistent dynamic-fetch body under every kernel name, a coherent one by the per-ray
  * body (ntr_query_config).  The launch itself does not call this -- its dispatch-order prediction computes the same words -- it is the query
  * for tests and for hosts that plan batches.  No counterpart in the reference.  d_out: 3 words.  Asynchronous on `stream`. */

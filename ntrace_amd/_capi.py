@@ -233,7 +233,7 @@ class TracePlan(C.Structure):
     """NtrTracePlan (include/ntrace_amd.h): what ntr_trace_bvh decides before it touches the device."""
     _fields_ = [(n, C.c_int32) for n in (
         "variant", "launchVariant", "launchBlocks", "numBlocks", "orderBlocks", "chunk", "fetchThreshold", "leafSwitchBelow", "octant",
-        "flatFetch", "uniformPrologue", "splitSlice", "numHeads", "shardRays", "numBlocksIncoherent", "wholeWave", "prefetchAfter", "unified", "minipool", "poolKConst",
+        "flatFetch", "uniformPrologue", "splitSlice", "numHeads", "shardRays", "numBlocksIncoherent", "numBlocksDivergent", "wholeWave", "prefetchAfter", "unified", "minipool", "poolKConst",
         "poolKFromDevice", "minipoolWide", "hintable", "useAutoHint", "predictable", "persistentOrder", "probeOnRefresh", "coherentRoute",
         "persistentVariant", "persistentBlocks", "persistentFetchThreshold", "perrayBlocks", "perrayFetchThreshold")]
 

@@ -143,6 +143,7 @@ static void tunables_load_locked()
     t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", -1);     // -1: 32 for closest-hit, 24 for any-hit launches (bench-protocol sweep, scripts/jobs/gpu_job_r02ls.sh)
     t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 8);          // persistent kernels: 8 x 4 waves = every wave slot of a CU (64 VGPRs; 6 until round 5, when the kernels took 67)
     t.blocksPerCUIncoherent = env_int("NTR_TRACE_BLOCKS_PER_CU_INCOHERENT", 3);   // persistent kernels, batches the device finds incoherent (scattered origins): fewer rays in flight = less queueing per step (scripts/studies/inflight_sweep.py)
+    t.blocksPerCUDivergent = env_int("NTR_TRACE_BLOCKS_PER_CU_DIVERGENT", 4);     // ... batches whose rays start together and wander apart (a diffuse batch)
     t.octant = env_int("NTR_TRACE_OCTANT", 1);
     t.closestWaves = env_int("NTR_TRACE_CLOSEST_WAVES", 1);      // likewise for closest-hit launches: primary +2.1 % with 1
     t.anyHitWaves = env_int("NTR_TRACE_ANYHIT_WAVES", 1);        // waves per workgroup of plain any-hit launches of the per-ray kernel (1, 2, 4): AO +1.7 % with 1
@@ -710,6 +711,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     p.numHeads = pl.numHeads;
     p.numBlocks = 0;
     p.numBlocksIncoherent = 0;
+    p.numBlocksDivergent = 0;
     p.orderBlocks = 0;
     p.chunk = pl.chunk;
     p.fetchThreshold = pl.fetchThreshold;
@@ -807,6 +809,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
         }
         pp.numBlocks = pl.persistentBlocks;
         pp.numBlocksIncoherent = pl.numBlocksIncoherent;
+        pp.numBlocksDivergent = pl.numBlocksDivergent;
         pp.fetchThreshold = pl.persistentFetchThreshold;
         pp.shardRays = pl.shardRays;
         if (pp.order) {   // every head walks its share of the order: ranges of whole 256-ray blocks

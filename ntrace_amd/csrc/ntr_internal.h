@@ -10,7 +10,7 @@ int hip_fail(hipError_t e, const char* what);
 
 // Tunables (environment overrides for sweeps), read once at first use -- see ntr_api.cpp.
 struct Tunables {
-    int chunk, fetchThreshold, leafSwitchBelow, blocksPerCU, blocksPerCUIncoherent, poolHeads, octant, anyHitWaves, closestWaves, unified, perrayUnified, flatFetch, uniformPrologue, splitSlice, wholeWave, prefetchAfter, minipool, minipoolThreshold, minipoolWide;
+    int chunk, fetchThreshold, leafSwitchBelow, blocksPerCU, blocksPerCUIncoherent, blocksPerCUDivergent, poolHeads, octant, anyHitWaves, closestWaves, unified, perrayUnified, flatFetch, uniformPrologue, splitSlice, wholeWave, prefetchAfter, minipool, minipoolThreshold, minipoolWide;
     int autoHint, autoHintMinRays, persistentHints, route, predict, predictPersistent, predictDepth, predictMinRays, predictMinNodes;
     int schedRefreshEvery, schedClasses;
     int lbvhSplit, lbvhSubThreads, lbvhAggLds, lbvhAggStaged;

@@ -77,6 +77,7 @@ constexpr int PRED_SAMPLE2 = 227;       // second sample, for the coherence esti
 __device__ __forceinline__ unsigned int block_incoherence(const float4* __restrict__ rays, int numRays, int block, const float4 o, const float4 d,
                                                           const float4* __restrict__ table)
 {
+    if (!(o.w < d.w)) return 8u;   // a degenerate sample ray (a missed pixel's secondary ray, Util.hpp:65): the block has no say
     const int r2 = min(block * 256 + PRED_SAMPLE2, numRays - 1);
     const float4 o2 = rays[2 * r2], d2 = rays[2 * r2 + 1];
     const float4 a0 = table[0], a1 = table[1], b0 = table[2], b1 = table[3];
@@ -142,9 +143,9 @@ __global__ __launch_bounds__(PRED_WAVES * 64) void predict_kernel(const float4* 
     }
     if (wave == 0) {
         const unsigned int inc = (block < numBlocks && nBoxes >= 2) ? block_incoherence(rays, numRays, block, o, d, table) : 0u;
-        const unsigned long long m1 = __ballot(inc == 1u), m2 = __ballot(inc == 6u);
+        const unsigned long long m1 = __ballot(inc == 1u), m2 = __ballot(inc == 6u), m3 = __ballot(inc == 8u);
         if (lane == 0 && m1) atomicAdd(&classCount[NTR_SCHED_PRED_CLASSES], (unsigned int)__popcll(m1));
-        if (lane == 0 && m2) atomicAdd(&classCount[NTR_SCHED_PRED_CLASSES + 1], (unsigned int)__popcll(m2));
+        if (lane == 0 && (m2 | m3)) atomicAdd(&classCount[NTR_SCHED_PRED_CLASSES + 1], 4u * (unsigned int)__popcll(m2) + (unsigned int)__popcll(m3));   // the divergence score (pool_k)
     }
     unsigned int cls = 0;
     if (tid < 64 && block < numBlocks) {
@@ -178,10 +179,14 @@ constexpr int FLATTEN_THREADS = 1024;
 // apart (a diffuse batch: 44 %).  The mini-pool depth ignores it, as before; the choice between the per-ray body and the persistent
 // dynamic-fetch body (trace_kernels.hip, TraceParams::routeSkip) does not: those batches are 20-35 % faster with single-lane refills and
 // ray splitting in the drain phase.
-__device__ __forceinline__ unsigned int pool_k(unsigned int originApart, unsigned int dirApartLong, int numBlocks, int poolKWide)
+// The divergence score counts 4 for a block of such rays and 1 for a block whose sample ray is degenerate (a missed pixel's); blocks whose
+// rays start apart weigh 4 as well.  Reaching the number of blocks means: a quarter of the blocks that hold LIVE rays are incoherent one
+// way or the other (a hairball frame hits in 30 % of its pixels, and its first and last batches hold a few thousand live rays whose
+// chains are as long as any: 0.88 ms by the per-ray body, 0.53 ms with single-lane refills and ray splitting).
+__device__ __forceinline__ unsigned int pool_k(unsigned int originApart, unsigned int divergenceScore, int numBlocks, int poolKWide)
 {
     const unsigned int k = (originApart > 0u && 2u * originApart >= (unsigned int)numBlocks) ? (unsigned int)poolKWide : 1u;
-    return k | ((dirApartLong > 0u && 4u * dirApartLong >= (unsigned int)numBlocks) ? (unsigned int)NTR_BATCH_DIVERGENT : 0u);
+    return k | ((numBlocks > 0 && 4u * originApart + divergenceScore >= (unsigned int)numBlocks) ? (unsigned int)NTR_BATCH_DIVERGENT : 0u);
 }
 __global__ __launch_bounds__(FLATTEN_THREADS) void flatten_kernel(unsigned int* __restrict__ classCount, const unsigned int* __restrict__ classList,
                                                                   int numBlocks, unsigned int* __restrict__ order,
@@ -232,9 +237,9 @@ __global__ __launch_bounds__(256) void coherence_kernel(const float4* __restrict
         const int r = min(block * 256 + PRED_SAMPLE, numRays - 1);
         inc = block_incoherence(rays, numRays, block, rays[2 * r], rays[2 * r + 1], table);
     }
-    const unsigned long long m1 = __ballot(inc == 1u), m2 = __ballot(inc == 6u);
+    const unsigned long long m1 = __ballot(inc == 1u), m2 = __ballot(inc == 6u), m3 = __ballot(inc == 8u);
     if ((threadIdx.x & 63) == 0 && m1) atomicAdd(&out[0], (unsigned int)__popcll(m1));
-    if ((threadIdx.x & 63) == 0 && m2) atomicAdd(&out[1], (unsigned int)__popcll(m2));
+    if ((threadIdx.x & 63) == 0 && (m2 | m3)) atomicAdd(&out[1], 4u * (unsigned int)__popcll(m2) + (unsigned int)__popcll(m3));
 }
 __global__ void coherence_finish_kernel(unsigned int* __restrict__ out, int numBlocks, int poolKWide)
 {

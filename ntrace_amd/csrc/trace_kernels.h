@@ -58,6 +58,7 @@ struct TraceParams {
     int32_t numHeads;        // persistent: pool heads, a multiple of 8 (one group per XCD), <= 1024
     int32_t numBlocks;       // persistent: grid size (the statically assigned first chunks are counted from it)
     int32_t numBlocksIncoherent;   // persistent: the grid that works on a batch whose pool word (poolK) says incoherent (0 = the whole grid)
+    int32_t numBlocksDivergent;    // ... on a batch whose word only carries NTR_BATCH_DIVERGENT (rays that start together and wander apart)
     int32_t orderBlocks;     // persistent, with `order`: number of 256-ray blocks in order[]
     int32_t fetchThreshold;  // persistent: refill when fewer lanes are live
     int32_t wholeWave;       // persistent, dynamic fetch: 1 = single-lane refills only on batches the device found incoherent (poolK > 1), whole-wave

@@ -821,7 +821,10 @@ __global__ __launch_bounds__(WAVES * 64, NTR_TRACE_PERSISTENT_MIN_WAVES_PER_SIMD
     const unsigned int batchWord = p.poolK ? *p.poolK : 1u;
     const bool incoherentBatch = NTR_BATCH_WORD_INCOHERENT(batchWord);   // scattered origins, or long rays that point apart: single-lane refills
     if (p.routeSkip == NTR_ROUTE_SKIP_COHERENT && !incoherentBatch) return;   // the per-ray body beside this launch traces the batch
-    if (NTR_BATCH_WORD_K(batchWord) > 1u && p.numBlocksIncoherent > 0 && p.numBlocksIncoherent < numBlocksEff) numBlocksEff = p.numBlocksIncoherent;
+    // (round 6: a diffuse batch -- rays that start together and wander apart -- gains from fewer rays in flight too: one hairball batch 2.03 ms with
+    // eight workgroups per CU, 1.57 with four, 1.63-1.74 with three; scattered origins -- box rays -- are best with three: 2.86 against 3.4 ms with four)
+    const int gridIncoherent = NTR_BATCH_WORD_K(batchWord) > 1u ? p.numBlocksIncoherent : p.numBlocksDivergent;
+    if (incoherentBatch && gridIncoherent > 0 && gridIncoherent < numBlocksEff) numBlocksEff = gridIncoherent;
     if ((int)blockIdx.x >= numBlocksEff) return;
 
     LaneStack st;

@@ -108,6 +108,10 @@ inline TracePlan plan_trace(const Tunables& tun, const TraceBatchDesc& b)
             pl.numBlocksIncoherent = b.numCUs * tun.blocksPerCUIncoherent;
             if (pl.numBlocksIncoherent > pl.persistentBlocks) pl.numBlocksIncoherent = pl.persistentBlocks;
         }
+        if (persistentDynamic && tun.blocksPerCUDivergent > 0 && tun.blocksPerCUDivergent < blocksPerCU) {
+            pl.numBlocksDivergent = b.numCUs * tun.blocksPerCUDivergent;
+            if (pl.numBlocksDivergent > pl.persistentBlocks) pl.numBlocksDivergent = pl.persistentBlocks;
+        }
         pl.shardRays = ((chunksTotal + pl.numHeads - 1) / pl.numHeads) * pl.chunk;
         pl.persistentVariant = pl.unified ? NTR_VARIANT_PERSISTENT_UNIFIED : NTR_VARIANT_PERSISTENT;
     };
