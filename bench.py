@@ -44,23 +44,23 @@ NUM_TAS = 256              # one texture-address unit per CU
 PEAK_CLOCK_GHZ = 2.4
 
 
-# kernel symbol a selector launches by default (ntr_api.cpp: 64-thread workgroups of the per-ray kernel; template arguments
-# <WAVES, STATS, UNIFIED, FLATF> / <WAVES, TL, UNIFIED, FLATF>), and the grid it is launched with for n rays
-def launched_symbol(kernel, wide_leaves=False, any_hit=False):
-    """Closest-hit launches of the per-ray kernel run trace_bvh_perray_mini (the unified-step loop in the instantiation that can turn into
-    wave-private ray pools); any-hit launches trace_bvh_perray<WAVES, STATS, UNIFIED, FLATF> with the unified-step loop as well;
-    the persistent selectors trace_bvh_persistent<WAVES, TL, UNIFIED, FLATF> (ntr_api.cpp)."""
-    if kernel.startswith("fermi"):
-        if not any_hit:
-            return "trace_bvh_perray_mini"
-        return "trace_bvh_perray<1, false, true, true>"   # (unified-step loop for any-hit launches too since round 4; `wide_leaves` no longer matters)
-    return "trace_bvh_persistent<4, false, %s, true>" % ("true" if kernel == "kepler_dynamic_fetch" else "false")
+# kernel symbol that WORKS for a batch (ntr_api.cpp / trace_plan.h ROUTING: the names select semantics, the body is chosen by the batch's
+# coherence; template arguments <WAVES, STATS, UNIFIED, FLATF> / <WAVES, UNIFIED, FLATF>), and the grid it is launched with for n rays
+def launched_symbol(kernel, wide_leaves=False, any_hit=False, incoherent=False):
+    """Any-hit launches run trace_bvh_perray<1, false, true, true> (unified-step loop) under every name; coherent closest-hit launches
+    trace_bvh_perray_mini (the instantiation that reads the batch word); closest-hit launches the device finds incoherent the persistent
+    body: kepler_dynamic_fetch's trace_bvh_persistent<4, true, true> (also for the per-ray name), tesla's <4, false, true>."""
+    if any_hit:
+        return "trace_bvh_perray<1, false, true, true>"
+    if not incoherent:
+        return "trace_bvh_perray_mini"
+    return "trace_bvh_persistent<4, %s, true>" % ("false" if kernel.startswith("tesla") else "true")
 
 
-def launched_grid(kernel, n_rays, cus=256):
-    if kernel.startswith("fermi"):
-        return ((n_rays + 255) // 256) * 256
-    return min(cus * 8, (n_rays + 255) // 256) * 256
+def launched_grid(kernel, n_rays, cus=256, symbol=None):
+    if symbol is not None and "persistent" in symbol:
+        return min(cus * 8, (n_rays + 255) // 256) * 256
+    return ((n_rays + 255) // 256) * 256
 
 
 def load_pmc(symbol, grid, tag=None):
@@ -881,13 +881,14 @@ def config_point(nt, torch, scenes, dev, stream, up, name, tri_, pos_, cam_, vie
                     "frame_ms": (tp + tt) * 1e3, "frame_mrays": (npr + live) / (tp + tt) / 1e6})
         if ki == 0:
             out["rays"] = {"primary": npr, "secondary_nondegenerate": int(live), "secondary_launched": int(launched)}
-            row["secondary_roofline"] = roof(alg, tt, launched_symbol(kn, wide, any_hit=any_hit), launched_grid(kn, per * ns), nb)
+            sec_sym = launched_symbol(kn, wide, any_hit=any_hit, incoherent=not any_hit)   # (diffuse batches: routed to the persistent body)
+            row["secondary_roofline"] = roof(alg, tt, sec_sym, launched_grid(kn, per * ns, symbol=sec_sym), nb)
             row.update({"secondary_sorted_ms": tt_sorted * 1e3, "secondary_sorted_mrays": live / tt_sorted / 1e6 if tt_sorted > 0 else None,
                         "secondary_sorted_per_batch_ms": per_batch_sorted, "ray_sort_ms_untimed": sort_s * 1e3,
                         "frame_sorted_ms": (tp + tt_sorted) * 1e3, "frame_sorted_mrays": (npr + live) / (tp + tt_sorted) / 1e6,
                         "sorted_note": "the same batches Morton-sorted first (ntr_ray_morton_sort: the reference's RayBuffer::mortonSort, its default -- "
                                        "Renderer.sortRays true --, outside the timed trace): identical rays, hence identical algorithmic bytes"})
-            row["secondary_sorted_roofline"] = roof(alg, tt_sorted, launched_symbol(kn, wide, any_hit=any_hit), launched_grid(kn, per * ns), nb)
+            row["secondary_sorted_roofline"] = roof(alg, tt_sorted, sec_sym, launched_grid(kn, per * ns, symbol=sec_sym), nb)
         out["by_kernel"][kn] = row
     k0 = out["by_kernel"][kernels[0]]
     dom = "secondary" if k0["secondary_ms"] >= k0["primary_ms"] else "primary"
@@ -1158,7 +1159,7 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
             lview4, best4, info4, keep4 = lbvh_of(tri4, pos4, 3)
             cfgs["4"] = config_point(nt, torch, scenes, dev, stream, up, "4 Hairball (2.8 M stand-in), device LBVH build + 8x diffuse", tri4, pos4, cam4, lview4,
                                      best4.nodesBytes + best4.triWoopBytes + best4.triIndexBytes, "diffuse", (args.kernel, "kepler_dynamic_fetch"),
-                                     args.width, args.height, args.ao_samples, hbm_peak, "hairball")
+                                     args.width, args.height, args.ao_samples, hbm_peak, "hairball_diffuse_frame")
             cfgs["4"]["lbvh_build"] = info4
             # (f-3) where the secondary-ray Morton sort could pay: one diffuse batch of this frame (long incoherent rays in a deep tree), sorted
             # by ntr_ray_morton_sort (the reference's 192-bit key, RayBuffer.cpp:103-165; outside the timed trace like ray generation) against unsorted
@@ -1235,14 +1236,14 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
             return {"bound": "hbm", "achieved": st_.algorithmic_bytes() / s_ / 1e9, "peak": hbm_peak, "unit": "GB/s",
                     "frac": st_.algorithmic_bytes() / s_ / 1e9 / hbm_peak, "algorithmic_bytes_per_launch": st_.algorithmic_bytes()}
         r_inc = roof(sr, secr)
-        sym = launched_symbol(best_kn, wide10)
-        pmc_i, src_i = load_pmc(sym, launched_grid(best_kn, nr), tag="courtyard")
+        sym = launched_symbol(best_kn, wide10, incoherent=True)
+        pmc_i, src_i = load_pmc(sym, launched_grid(best_kn, nr, symbol=sym), tag="courtyard10m")
         bind_i = profiled_shares(pmc_i, src_i, (sr.numInnerVisits + sr.numTriTests) if "persistent" in sym else None) if pmc_i else None
         gr = extras.get("gather_roof", {})
         steps_i = sr.numInnerVisits + sr.numTriTests
         r_inc.update({"kernel": "%s (%s)" % (sym, best_kn), "launch_ms": secr * 1e3,
                       "traffic": bind_i.get("hbm_traffic_bytes") if bind_i else None, "utilisation": bind_i,
-                      "utilisation_note": None if bind_i else "no committed PMC summary under profiles/ matches %s with grid %d" % (sym, launched_grid(best_kn, nr)),
+                      "utilisation_note": None if bind_i else "no committed PMC summary under profiles/ matches %s with grid %d" % (sym, launched_grid(best_kn, nr, symbol=sym)),
                       "gather_roof": gather_like_for_like(steps_i, secr, gr, pmc_i),
                       "workload": "courtyard-10M device LBVH (0.75 GB), 2^21 incoherent closest-hit rays",
                       "note": "the launch whose bytes HBM really delivers: SURVEY 8(d) algorithmic bytes / time / 8 TB/s; `traffic` = PMC bytes of "
@@ -1260,7 +1261,7 @@ def run_extras(args, nt, torch, scenes, view, frame, tri, pos, dev, stream, up, 
         if not args.no_configs:   # BASELINE config 5 itself (primary + 8 x AO on the replicated 10 M-triangle BVH; one GPU traces the whole frame here)
             try:
                 c5 = config_point(nt, torch, scenes, dev, stream, up, "5 San Miguel (courtyard-10M stand-in), device LBVH, primary + 8xAO", tri10, pos10, cam10, lview,
-                                  best.nodesBytes + best.triWoopBytes + best.triIndexBytes, "ao", (args.kernel, "kepler_dynamic_fetch"), w, h, args.ao_samples, hbm_peak, "courtyard")
+                                  best.nodesBytes + best.triWoopBytes + best.triIndexBytes, "ao", (args.kernel, "kepler_dynamic_fetch"), w, h, args.ao_samples, hbm_peak, "courtyard_ao_frame")
                 c5["lbvh_build"] = info10
                 extras.setdefault("configs", {})["5"] = c5
             except Exception as e:

@@ -8,7 +8,7 @@
 #   hair   the same two for hairball-2.8M.
 # PMC passes never share a run with another trace domain than --kernel-trace.
 # Writes gpurun_out/prof_<tag>/{*.kernels.txt, *.pmc.txt, pmc_summary.json}; copy what is to be judged into profiles/<tag>_*.
-# Usage: scripts/profile_round.sh <tag> [lbvh] [trace] [hbm] [hair]
+# Usage: scripts/profile_round.sh <tag> [lbvh] [trace] [hbm] [hair] [diffuse] [aoframe]
 set -u
 TAG=${1:-r03}; shift || true
 WHAT="${*:-lbvh trace hbm}"
@@ -63,12 +63,23 @@ for W in $WHAT; do
     WL_ONLY=incoherent; export WL_ONLY
     trace_all trace_hairball_incoherent_kepler_dynamic_fetch hairball kepler_dynamic_fetch
     unset WL_ONLY ;;
+  diffuse)   # BASELINE config 4's frame: the 16 diffuse batches of the hairball frame under the default selector (routed to the persistent body)
+    WL_ONLY=diffuse; export WL_ONLY
+    trace_all trace_hairball_diffuse_frame_fermi_speculative_while_while hairball fermi_speculative_while_while
+    unset WL_ONLY ;;
+  aoframe)   # BASELINE config 5's frame: the 16 AO batches of the courtyard-10M frame under the default selector
+    WL_ONLY=ao_frame; export WL_ONLY
+    trace_all trace_courtyard_ao_frame_fermi_speculative_while_while courtyard fermi_speculative_while_while
+    unset WL_ONLY ;;
   esac
 done
 # what bench.py reads for roofline.binding: {"kernel symbol|grid|counter": mean per dispatch}
 F=$(ls $OUT/*atrium*.pmc.txt $OUT/lbvh_*.pmc.txt 2>/dev/null); [ -n "$F" ] && $SUM json $F > $OUT/pmc_summary.json
-F=$(ls $OUT/trace_courtyard*.pmc.txt 2>/dev/null); [ -n "$F" ] && $SUM json $F > $OUT/courtyard10m_pmc_summary.json
-F=$(ls $OUT/trace_hairball*.pmc.txt 2>/dev/null); [ -n "$F" ] && $SUM json $F > $OUT/hairball_pmc_summary.json
+F=$(ls $OUT/trace_courtyard*.pmc.txt 2>/dev/null | grep -v ao_frame); [ -n "$F" ] && $SUM json $F > $OUT/courtyard10m_pmc_summary.json
+F=$(ls $OUT/trace_hairball*.pmc.txt 2>/dev/null | grep -v diffuse_frame); [ -n "$F" ] && $SUM json $F > $OUT/hairball_pmc_summary.json
+# whole-frame runs of one launch shape (the persistent symbol has ONE grid for every batch): summaries of their own
+F=$(ls $OUT/trace_hairball_diffuse_frame*.pmc.txt 2>/dev/null); [ -n "$F" ] && $SUM json $F > $OUT/hairball_diffuse_frame_pmc_summary.json
+F=$(ls $OUT/trace_courtyard_ao_frame*.pmc.txt 2>/dev/null); [ -n "$F" ] && $SUM json $F > $OUT/courtyard_ao_frame_pmc_summary.json
 # raw rocprof directories are large: keep the summaries, drop the CSVs of the PMC passes
 du -sh $OUT
 find $OUT -name "*_counter_collection.csv" -size +8M -delete

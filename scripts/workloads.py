@@ -91,6 +91,29 @@ def main():
     d_rays = up(rays)
     d_res = torch.zeros(npr * 16, dtype=torch.uint8, device=dev)
     view.trace(kernel, npr, False, d_rays.data_ptr(), d_res.data_ptr())
+    if only in ("diffuse", "ao_frame"):
+        # BASELINE config 4 / 5's secondary batches, the whole frame: 16 batches of <= 2^20 rays from the primary hits, each traced once cold
+        # and `reps` times (the reference's protocol re-traces a batch): per-dispatch PMC means of the working kernel symbol x 16 launches =
+        # the frame's HBM traffic (bench.py extras.configs[*].roofline.traffic)
+        d_nrm = up(scenes.tri_normals(tri, pos))
+        ns, per = 8, (1 << 20) // 8
+        diag = float(np.linalg.norm(pos.max(0).astype(np.float64) - pos.min(0)))
+        any_hit = only == "ao_frame"
+        dist_ = 5.0 * diag / 4300.0 if any_hit else cam["far"]
+        b_rays = torch.zeros(per * ns * 32, dtype=torch.uint8, device=dev)
+        b_res = torch.zeros(per * ns * 16, dtype=torch.uint8, device=dev)
+        b_a = torch.zeros(per * ns, dtype=torch.int32, device=dev)
+        tot, alg, nb = 0.0, 0, 0
+        for lo in range(0, npr, per):
+            cnt = min(per, npr - lo)
+            nt.raygen_ao(b_rays.data_ptr(), b_a.data_ptr(), b_a.data_ptr(), d_rays.data_ptr(), d_res.data_ptr(), d_nrm.data_ptr(), lo, cnt, ns, dist_, 0xFFF2D5E4)
+            view.trace(kernel, cnt * ns, any_hit, b_rays.data_ptr(), b_res.data_ptr())
+            tot += float(np.median([view.trace(kernel, cnt * ns, any_hit, b_rays.data_ptr(), b_res.data_ptr()) for _ in range(reps)]))
+            alg += view.trace_stats(kernel, cnt * ns, any_hit, b_rays.data_ptr(), b_res.data_ptr()).algorithmic_bytes()
+            nb += 1
+        print(json.dumps(dict(workload="trace", scene=scene, kernel=kernel, only=only, batches=nb, launches_per_batch=reps + 1, frame_ms=tot * 1e3,
+                              algorithmic_bytes=alg, hbm_frac=alg / tot / 8e12)))
+        return
     tp = [view.trace(kernel, npr, False, d_rays.data_ptr(), d_res.data_ptr()) for _ in range(reps)]
     st = view.trace_stats(kernel, npr, False, d_rays.data_ptr(), d_res.data_ptr())
     # one AO batch (2^20 rays, any hit) from the first 131 072 primary hits

@@ -81,3 +81,19 @@ def test_derived_constants():
     assert kat.bits(float(np.float32(5.0) * np.float32(kat.from_bits(0x3EAAAAAB)))) == 0x3FD55556
     assert kat.bits(float(np.float32(5.0) / np.float32(3.0))) == 0x3FD55555
     assert kat.bits(3.4028234663852886e38) == kat.FLT_MAX_BITS
+
+
+def test_lbvh_known_answer_tree_oracle():
+    """The hand-derived LBVH vector (tests/kat_lbvh.py: Morton codes with a clamped cell, the stable sort of a scrambled input, a 30-level
+    chain down to the level-0 node whose children are leaves whatever their size, two median splits, epsilon boxes, Woop rows with their
+    signed zeros) against the C oracle: codes, sorted order, counts, extents, and the whole tree bit for bit."""
+    import kat_lbvh as kl
+    tri, pos = kl.scene()
+    mn, mx = oracle.scene_bbox(pos)
+    assert tuple(float(x) for x in mn) == kl.SCENE_MIN and tuple(float(x) for x in mx) == kl.SCENE_MAX   # the vertex box IS the derived scene box
+    ref = oracle.lbvh_build(tri, pos, kl.LEAF_SIZE, kl.EPSILON)
+    assert [int(x) for x in ref["morton_sorted"]] == kl.CODES_SORTED
+    assert [int(x) for x in ref["tri_sorted"]] == kl.ORIG_OF_SORTED
+    assert (ref["num_inner"], ref["num_leaves"]) == (kl.NUM_INNER, kl.NUM_LEAVES)
+    assert ref["nodes"].nbytes == 64 * kl.NUM_INNER and ref["woop"].nbytes == 16 * (3 * 39 + kl.NUM_LEAVES) and ref["tri_index"].nbytes == 4 * (3 * 39 + kl.NUM_LEAVES)
+    assert kl.compare(ref["nodes"], ref["woop"], ref["tri_index"], "oracle") == (kl.NUM_INNER, kl.NUM_LEAVES)

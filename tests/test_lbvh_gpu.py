@@ -278,3 +278,53 @@ def test_lbvh_atrium_262k_every_triangle_once():
                 ids.append(idx[a])
                 a += 3
     assert np.array_equal(np.sort(np.array(ids)), np.arange(tri.shape[0]))
+
+
+def test_lbvh_hand_derived_known_answer_tree():
+    """tests/kat_lbvh.py: the tree worked out on paper from the reference's expressions (clamped Morton cell, stable sort of a scrambled
+    input, a 30-level chain ending in the level-0 node with its oversize leaf, median splits of equal codes, epsilon boxes, Woop rows with
+    their signed zeros), on every device build path: counts, exact extents, and every word of the tree."""
+    import kat_lbvh as kl
+    tri, pos = kl.scene()
+    nodes, woop, idx, res, keep = gpu_lbvh(tri, pos, kl.LEAF_SIZE, kl.EPSILON)
+    assert (res.numNodes, res.numLeaves) == (kl.NUM_INNER, kl.NUM_LEAVES)
+    assert nodes.nbytes == 64 * kl.NUM_INNER and woop.nbytes == 16 * (3 * 39 + kl.NUM_LEAVES) and idx.nbytes == 4 * (3 * 39 + kl.NUM_LEAVES)
+    assert kl.compare(nodes, woop, idx, "device") == (kl.NUM_INNER, kl.NUM_LEAVES)
+
+
+def test_lbvh_hand_derived_tree_inside_a_large_scene():
+    """The same 39 triangles with 20 000 filler triangles in cells of the upper octant beside them (codes between 1 << 29 and
+    0x3FFFFFFF do not exist in the vector): the scene takes the bottom-up path with many tiles, and the vector's left half -- the 30-level
+    chain with its level-0 node -- must come out of it unchanged, as the subtree under the root's child 0."""
+    import kat_lbvh as kl
+    tri, pos = kl.scene()
+    rng = np.random.default_rng(5)
+    n_f = 20000
+    # filler: cells with z in [513, 1023): codes above 1 << 29 (H's cell has x = y = 0, z = 512: codes of the filler with z >= 513 sort after H)
+    c = np.stack([rng.integers(0, 1023, n_f), rng.integers(0, 1023, n_f), rng.integers(513, 1023, n_f)], axis=1).astype(np.float32)
+    v2 = c + np.float32(0.25)
+    fpos = np.zeros((n_f * 3, 3), dtype=np.float32)
+    fpos[0::3] = v2 + np.array([0.5, 0, 0], dtype=np.float32)
+    fpos[1::3] = v2 + np.array([0, 0.5, 0], dtype=np.float32)
+    fpos[2::3] = v2
+    ftri = (np.arange(n_f * 3, dtype=np.int32).reshape(n_f, 3) + pos.shape[0])
+    tri2 = np.concatenate([tri, ftri]).astype(np.int32)
+    pos2 = np.concatenate([pos, fpos]).astype(np.float32)
+    nodes, woop, idx, res, ref, keep = check_against_oracle(tri2, pos2, kl.LEAF_SIZE, kl.EPSILON)
+    # the root still splits at bit 29 (position 33), and its child 0 is the derived left subtree
+    ni = nodes.view(np.int32)
+    assert int(ni[14]) == 29 % 3 and int(ni[12]) >= 0
+    exp_left = kl.expected_tree()["children"][0]
+
+    def walk(ofs, exp):
+        w = ofs // 4
+        assert int(ni[w + 14]) == exp["word14"]
+        for k in (0, 1):
+            child, ce = int(ni[w + 12 + k]), exp["children"][k]
+            if "leaf" in ce:
+                a = ~child
+                assert child < 0 and [int(idx[a + 3 * j]) for j in range(len(ce["leaf"]))] == ce["leaf"]
+            else:
+                assert child >= 0
+                walk(child, ce)
+    walk(int(ni[12]), exp_left)
