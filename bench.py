@@ -401,14 +401,24 @@ def main():
         sah_seconds = time.time() - t0
     parts = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()) if bvh is not None else None
              for a in ((bvh.nodes, bvh.woop, bvh.tri_index) if bvh is not None else (None, None, None))]
-    if grp is not None:   # ntr_dist_broadcast_bvh: the three Compact buffers from the root, sizes first (24 bytes over torch.distributed)
-        sizes = torch.tensor([p_.numel() for p_ in parts] if rank == 0 else [0, 0, 0], dtype=torch.int64, device=dev)
-        ntd.broadcast_(sizes, 0)
-        d_nodes, d_woop, d_idx = [parts[i].to(dev) if rank == 0 else torch.empty(int(sizes[i].item()), dtype=torch.uint8, device=dev) for i in range(3)]
+    # The three Compact buffers live in ONE device allocation (256-byte aligned slices): the trace kernels' flat fetch addresses nodes and
+    # triangles from one scalar base with 32-bit lane offsets, which needs both inside one 4 GiB window -- two separate allocations usually
+    # are, but need not be (under rocprofv3 they were not, and the launches fell back to the two-descriptor fetch: INTEGRATION.md 3)
+    sizes = torch.tensor([p_.numel() for p_ in parts] if rank == 0 else [0, 0, 0], dtype=torch.int64, device=dev)
+    if use_dist:
+        ntd.broadcast_(sizes, 0)   # (24 bytes over torch.distributed)
+    sz = [int(x) for x in sizes.tolist()]
+    offs = [0, (sz[0] + 255) // 256 * 256, (sz[0] + 255) // 256 * 256 + (sz[1] + 255) // 256 * 256]
+    d_bvh = torch.zeros(offs[2] + sz[2], dtype=torch.uint8, device=dev)
+    d_nodes, d_woop, d_idx = [d_bvh[offs[i]: offs[i] + sz[i]] for i in range(3)]
+    if rank == 0:
+        for t_, p_ in zip((d_nodes, d_woop, d_idx), parts):
+            t_.copy_(p_)
+    if grp is not None:   # ntr_dist_broadcast_bvh: the three buffers from the root
         grp.broadcast_bvh(d_nodes.data_ptr(), d_nodes.numel(), d_woop.data_ptr(), d_woop.numel(), d_idx.data_ptr(), d_idx.numel(), 0, stream)
         torch.cuda.synchronize()
-    else:
-        d_nodes, d_woop, d_idx = [ntd.broadcast_bytes(p, 0, dev) for p in parts]
+    elif use_dist:
+        ntd.broadcast_(d_bvh, 0)
     view = nt.BvhView(d_nodes.data_ptr(), d_nodes.numel(), d_woop.data_ptr(), d_woop.numel(), d_idx.data_ptr())
     view.validate(stream)
     d_nrm = up(scenes.tri_normals(tri, pos))
