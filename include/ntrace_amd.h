@@ -100,7 +100,15 @@ NTR_API int ntr_stream_synchronize(void* stream);
  * (src/rt/cuda/CudaBVHTracer.cpp:52-84).  `kernelName` keeps the reference's
  * file-name selectors: "fermi_speculative_while_while",
  * "tesla_persistent_while_while", "tesla_persistent_speculative_while_while",
- * "kepler_dynamic_fetch" (all mapped to precompiled CDNA4 variants). */
+ * "kepler_dynamic_fetch" (all mapped to precompiled CDNA4 variants).
+ *
+ * The answer describes the NAMED body (per-ray kernel: 64-thread workgroups, not persistent; tesla_* / kepler_*: persistent waves in
+ * 256-thread workgroups) and every name consumes BVHLayout_Compact.  A name selects semantics, and the semantics of all names are
+ * identical here (same hit records, bit for bit); which body actually traces a batch follows the batch (csrc/trace_plan.h ROUTING):
+ * any-hit launches run the per-ray body under every name, closest-hit launches of >= 2^20 rays are launched as both bodies and the
+ * device's batch word (ntr_predict_batch_coherence) decides which one works -- the per-ray body on coherent batches, the persistent
+ * dynamic-fetch body on incoherent ones --, smaller launches run the named body.  NTR_TRACE_ROUTE=0 (environment, read once) forces
+ * the named body always; ntr_trace_plan() reports the decision for a given batch. */
 NTR_API int ntr_query_config(const char* kernelName, NtrKernelConfig* config);
 
 /* Replaces the `trace_bvh` launch of CudaBVHTracer::traceBatch
