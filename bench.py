@@ -59,7 +59,7 @@ def launched_symbol(kernel, wide_leaves=False, any_hit=False, incoherent=False):
 
 def launched_grid(kernel, n_rays, cus=256, symbol=None):
     if symbol is not None and "persistent" in symbol:
-        return min(cus * 8, (n_rays + 255) // 256) * 256
+        return min(cus * 7, (n_rays + 255) // 256) * 256
     return ((n_rays + 255) // 256) * 256
 
 

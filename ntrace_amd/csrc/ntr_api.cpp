@@ -141,7 +141,7 @@ static void tunables_load_locked()
     t.chunk = env_int("NTR_TRACE_CHUNK", 64);
     t.fetchThreshold = env_int("NTR_TRACE_FETCH_THRESHOLD", -1);  // -1: 24 for kepler_dynamic_fetch, 0 otherwise
     t.leafSwitchBelow = env_int("NTR_TRACE_LEAF_SWITCH", -1);     // -1: 32 for closest-hit, 24 for any-hit launches (bench-protocol sweep, scripts/jobs/gpu_job_r02ls.sh)
-    t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 8);          // persistent kernels: 8 x 4 waves = every wave slot of a CU (64 VGPRs; 6 until round 5, when the kernels took 67)
+    t.blocksPerCU = env_int("NTR_TRACE_BLOCKS_PER_CU", 7);          // persistent kernels: 7 x 4 waves per CU -- what 69 VGPRs let be resident (a workgroup that is not resident at launch holds its statically assigned first chunks back until another one leaves)
     t.blocksPerCUIncoherent = env_int("NTR_TRACE_BLOCKS_PER_CU_INCOHERENT", 3);   // persistent kernels, batches the device finds incoherent (scattered origins): fewer rays in flight = less queueing per step (scripts/studies/inflight_sweep.py)
     t.blocksPerCUDivergent = env_int("NTR_TRACE_BLOCKS_PER_CU_DIVERGENT", 4);     // ... batches whose rays start together and wander apart (a diffuse batch)
     t.octant = env_int("NTR_TRACE_OCTANT", 1);

@@ -11,10 +11,12 @@
 #ifndef NTR_TRACE_MIN_WAVES_PER_SIMD
 #define NTR_TRACE_MIN_WAVES_PER_SIMD 1
 #endif
-// the persistent kernels are held to 64 VGPRs -- eight waves per SIMD, eight 256-thread workgroups per CU (8 x 16 KB of LDS stacks): the
-// unified-step instantiation would take 69 (seven waves) and fits 64 without a spill
+// The persistent kernels take the registers the compiler gives them: 69 (unified-step loop) / 62 (while-while), i.e. seven 256-thread
+// workgroups per CU.  Held to 64 (-DNTR_TRACE_PERSISTENT_MIN_WAVES_PER_SIMD=8: no spill, eight workgroups per CU) they are no faster on
+// coherent batches (not occupancy-bound, EXPERIMENTS.md round 6) and 2-4 % slower on the incoherent batches they exist for under routing
+// (courtyard box rays 3.55-3.73 against 3.48-3.59 ms).
 #ifndef NTR_TRACE_PERSISTENT_MIN_WAVES_PER_SIMD
-#define NTR_TRACE_PERSISTENT_MIN_WAVES_PER_SIMD 8
+#define NTR_TRACE_PERSISTENT_MIN_WAVES_PER_SIMD 1
 #endif
 
 // kernel variants (selected by the reference's kernel file names, see ntr_query_config)

@@ -846,3 +846,38 @@ def test_scheduling_feedback_with_two_bvhs_alternating_through_the_same_buffers(
             assert_parity(d_res.cpu().numpy().view(nt.RESULT_DTYPE)[:m], refs[(0, False)][:m], "changing count %d" % m)
     torch.cuda.synchronize()
     assert nt.trace_status() == 0
+
+
+@pytest.mark.parametrize("route", ["1", "0"])
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_routing_by_coherence_keeps_every_record(soup, kernel, route, monkeypatch):
+    """Round 6: closest-hit launches the device can classify are launched as BOTH bodies and the batch word decides which one works; any-hit
+    launches run the per-ray body under every name.  Whatever the name, whatever the batch (camera rays: coherent; box rays: scattered
+    origins; a fan of long rays from one point: divergent), with routing on and with the named body forced -- the oracle's records.  The
+    estimate's size thresholds are lowered so that a test-sized batch is routed; launches are repeated so that the batch's automatic hint
+    forms and its kept batch word, not only a fresh prediction, steers the launch."""
+    from gpu_util import assert_parity, gpu_trace
+    dbvh, cam = soup
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_RAYS", "1")
+    monkeypatch.setenv("NTR_TRACE_PREDICT_MIN_NODES", "1")
+    monkeypatch.setenv("NTR_TRACE_AUTO_HINT_MIN_RAYS", "1")
+    monkeypatch.setenv("NTR_TRACE_ROUTE", route)
+    nt.set_tunables()
+    try:
+        plan = nt.trace_plan(kernel, 100000, False, dbvh.host.nodes.nbytes, dbvh.host.woop.nbytes)
+        assert plan.coherentRoute == (1 if route == "1" else 0)
+        prim = scenes.primary_rays(cam, 320, 240)[0]
+        rnd = scenes.random_rays(70000, seed=5)
+        fan = rnd.copy()
+        for k in ("ox", "oy", "oz"):
+            fan[k] = prim[k][0]
+        for name, rays in (("camera", prim), ("box", rnd), ("fan", fan), ("mixed", np.concatenate([prim, rnd, fan]))):
+            for any_hit in (False, True):
+                ref, _ = oracle.trace(dbvh.host.nodes, dbvh.host.woop, dbvh.host.tri_index, rays, any_hit=any_hit, threads=8)
+                for rep in range(4):
+                    got, _ = gpu_trace(kernel, dbvh, rays, any_hit)
+                    assert_parity(got, ref, "%s %s any_hit=%d route=%s launch %d" % (kernel, name, any_hit, route, rep))
+    finally:
+        for k in ("NTR_TRACE_PREDICT_MIN_RAYS", "NTR_TRACE_PREDICT_MIN_NODES", "NTR_TRACE_AUTO_HINT_MIN_RAYS", "NTR_TRACE_ROUTE"):
+            monkeypatch.delenv(k, raising=False)
+        nt.set_tunables()

@@ -58,7 +58,7 @@ def test_persistent_selectors_grid_and_pool():
         p = nt.trace_plan(name, 2 * MB, False, 600 * MB, 700 * MB, num_cus=256)
         assert p.variant == PERSISTENT and p.unified == unified and p.fetchThreshold == thr and p.persistentFetchThreshold == thr
         assert p.launchVariant == p.persistentVariant == (PERSISTENT_UNIFIED if unified else PERSISTENT)
-        assert p.numBlocks == p.launchBlocks == p.persistentBlocks == 256 * 8 and p.numHeads == 128 and p.chunk == 64
+        assert p.numBlocks == p.launchBlocks == p.persistentBlocks == 256 * 7 and p.numHeads == 128 and p.chunk == 64
         assert p.shardRays * p.numHeads >= 2 * MB and p.shardRays % 64 == 0
         assert p.numBlocksIncoherent == (256 * 3 if unified else 0)      # only the dynamic-fetch kernel halves its grid
         assert p.persistentOrder and p.predictable and p.hintable and p.useAutoHint     # (round 6: the pool is handed out in a hint's order too)
@@ -79,7 +79,7 @@ def test_routing_by_coherence():
     # the per-ray name: large closest-hit launches carry kepler_dynamic_fetch's body beside their own
     f = nt.trace_plan("fermi_speculative_while_while", 2 * MB, False, 600 * MB, 700 * MB, num_cus=256)
     assert f.coherentRoute == 1 and f.launchVariant == UNIFIED_MINI and f.persistentVariant == PERSISTENT_UNIFIED
-    assert f.persistentBlocks == 256 * 8 and f.numBlocksIncoherent == 256 * 3 and f.persistentFetchThreshold == 48 and f.numHeads == 128
+    assert f.persistentBlocks == 256 * 7 and f.numBlocksIncoherent == 256 * 3 and f.persistentFetchThreshold == 48 and f.numHeads == 128
     small = nt.trace_plan("fermi_speculative_while_while", 1000, False, 17 * MB, 17 * MB)
     assert small.coherentRoute == 0
     # NTR_TRACE_ROUTE=0: the named body, always
