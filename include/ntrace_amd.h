@@ -381,6 +381,14 @@ NTR_API int ntr_raygen_ao(NtrRay* d_outRays, int32_t* d_outIDToSlot, int32_t* d_
                           const float* d_triNormals, int32_t firstInputSlot, int32_t numInputRays,
                           int32_t numSamples, float maxDist, uint32_t kernelSeed, void* stream);
 
+/* rayGenShadowKernel (src/rt/ray/RayGenKernels.cu:240-301; RayGen::shadow, RayGen.cpp:114-150): numSamples rays per input ray
+ * [firstInputSlot, +numInputRays) from its hit point (backed off 1e-2 along the ray) towards quasi-random points of the cube of
+ * half-edge lightRadius around lightPos; tmax = the distance to that point, rays of missed inputs are degenerate (tmax = -1).
+ * kernelSeed as for ntr_raygen_ao (Random(seed).getU32(), RayGen.cpp:139).  The output batch is an any-hit batch. */
+NTR_API int ntr_raygen_shadow(NtrRay* d_outRays, int32_t* d_outIDToSlot, int32_t* d_outSlotToID, const NtrRay* d_inRays,
+                              const NtrRayResult* d_inResults, int32_t firstInputSlot, int32_t numInputRays, int32_t numSamples,
+                              const float lightPos[3], float lightRadius, uint32_t kernelSeed, void* stream);
+
 /* countHitsKernel (src/rt/cuda/RendererKernels.cu:174-226; Renderer::getTotalNumRays,
  * Renderer.cpp:676-709): number of results with id != -1.  Blocking. */
 NTR_API int ntr_count_hits(const NtrRayResult* d_results, int32_t numRays, int32_t* count, void* stream);

@@ -9,7 +9,7 @@ import of `ntrace_amd.lib()` fails loudly.
 """
 from ._capi import (BvhView, RAY_DTYPE, RESULT_DTYPE, HostBvh, KernelConfig, NtrError, TraceStats, bvh_validate, lib,
                     lib_path, query_config, sah_build, trace_bvh, trace_bvh_stats, pixel_table,
-                    raygen_primary, raygen_ao, count_hits, selftest_division, selftest_division_hard, bvh_leaf_depths, secondary_block_costs, lbvh_capacity,
+                    raygen_primary, raygen_ao, raygen_shadow, count_hits, selftest_division, selftest_division_hard, bvh_leaf_depths, secondary_block_costs, lbvh_capacity,
                     lbvh_build, LbvhResult, reconstruct, ray_morton_sort, camera_decode, camera_reencode,
                     camera_nscreen_to_world, obj_load, SchedHint, trace_status, trace_plan, trace_plan_hint_step, TracePlan, set_tunables, host_bvh_wrap, use_library, trace_graph_reserve, trace_graph_release_all, stream_release, selftest_auto_hint_table, selftest_gather_rate, frame_shard, frame_ao_batches, DistGroup,
                     lbvh_release_workspace, predict_block_costs, predict_batch_coherence)

@@ -119,6 +119,7 @@ SYMBOLS = [
     ("ntr_raygen_primary", C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i32, _i32,
                                      C.c_float, _u32, _vp]),
     ("ntr_raygen_ao", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _u32, _vp]),
+    ("ntr_raygen_shadow", C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.POINTER(C.c_float * 3), C.c_float, _u32, _vp]),
     ("ntr_count_hits", C.c_int, [_vp, _i32, C.POINTER(_i32), _vp]),
     ("ntr_lbvh_capacity", C.c_int, [_i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     ("ntr_lbvh_build", C.c_int, [_i32, _vp, _i32, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i32, C.c_float,
@@ -452,6 +453,14 @@ def raygen_ao(d_out_rays, d_out_id_to_slot, d_out_slot_to_id, d_in_rays, d_in_re
     _check(lib().ntr_raygen_ao(_vp(d_out_rays), _vp(d_out_id_to_slot), _vp(d_out_slot_to_id), _vp(d_in_rays),
                                _vp(d_in_results), _vp(d_tri_normals), int(first_input_slot), int(num_input_rays),
                                int(num_samples), float(max_dist), int(kernel_seed), _vp(stream)))
+
+
+def raygen_shadow(d_out_rays, d_out_id_to_slot, d_out_slot_to_id, d_in_rays, d_in_results, first_input_slot, num_input_rays, num_samples,
+                  light_pos, light_radius, kernel_seed=0, stream=0):
+    lp = (C.c_float * 3)(*[float(x) for x in light_pos])
+    _check(lib().ntr_raygen_shadow(_vp(d_out_rays), _vp(d_out_id_to_slot), _vp(d_out_slot_to_id), _vp(d_in_rays), _vp(d_in_results),
+                                   int(first_input_slot), int(num_input_rays), int(num_samples), C.byref(lp), float(light_radius),
+                                   int(kernel_seed), _vp(stream)))
 
 
 def count_hits(d_results, num_rays, stream=0):

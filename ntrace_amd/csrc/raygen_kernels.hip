@@ -139,6 +139,56 @@ __global__ __launch_bounds__(256) void raygen_ao_kernel(NtrRay* __restrict__ out
 }
 
 // countHitsKernel (src/rt/cuda/RendererKernels.cu:174-226): number of rays with id != -1.
+// rayGenShadowKernel (src/rt/ray/RayGenKernels.cu:240-301): numSamples rays from every input ray's hit point towards points inside a cube of
+// half-edge lightRadius around the light -- a (0,2)-sequence / Hammersley point per sample (sobol2D :52-73, hammersley :47-50), shifted per
+// input ray by a Jenkins-hashed offset (Cranley-Patterson, :267-286); tmax = the distance to the target, -1 for rays of missed inputs.
+__global__ __launch_bounds__(256) void raygen_shadow_kernel(NtrRay* __restrict__ outRays, int32_t* __restrict__ outIDToSlot,
+                                                            int32_t* __restrict__ outSlotToID, const NtrRay* __restrict__ inRays,
+                                                            const NtrRayResult* __restrict__ inResults, int firstInputSlot, int numInputRays,
+                                                            int numSamples, float lx, float ly, float lz, float lightRadius, uint32_t randomSeed)
+{
+    const int taskIdx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (taskIdx >= numInputRays) return;
+    const int inSlot = taskIdx + firstInputSlot;
+    const float4 ro = reinterpret_cast<const float4*>(inRays + inSlot)[0];
+    const float4 rd = reinterpret_cast<const float4*>(inRays + inSlot)[1];
+    const int4 res = reinterpret_cast<const int4*>(inResults)[inSlot];
+    const int outSlot = taskIdx * numSamples;
+
+    // origin, backed off a little (:259-260: epsilon 1e-2 here, 1e-4 in the AO generator)
+    const float back = fmaxf(__int_as_float(res.y) - 1.0e-2f, 0.0f);
+    const float px = ro.x + rd.x * back, py = ro.y + rd.y * back, pz = ro.z + rd.z * back;
+
+    uint32_t ha = randomSeed + (uint32_t)taskIdx, hb = 0x9e3779b9u, hc = 0x9e3779b9u;
+    jenkins_mix(ha, hb, hc);
+    jenkins_mix(ha, hb, hc);
+    const float offx = (float)ha * 0x1p-32f, offy = (float)hb * 0x1p-32f, offz = (float)hc * 0x1p-32f;
+
+    const int tri = res.x;
+    for (int i = 0; i < numSamples; i++) {
+        unsigned int r1 = 0, r2 = 0;
+        int k = i;
+        for (unsigned int v1 = 1u << 31, v2 = 3u << 30; k; k >>= 1) {
+            if (k & 1) { r1 ^= v1; r2 ^= v2 << 1; }
+            v1 |= v1 >> 1;
+            v2 ^= v2 >> 1;
+        }
+        float sx = (float)r1 * 0x1p-32f + offx, sy = (float)r2 * 0x1p-32f + offy, sz = ((float)i + 0.5f) / (float)numSamples + offz;
+        if (sx >= 1.0f) sx -= 1.0f;
+        if (sy >= 1.0f) sy -= 1.0f;
+        if (sz >= 1.0f) sz -= 1.0f;
+        sx = sx * 2.0f - 1.0f; sy = sy * 2.0f - 1.0f; sz = sz * 2.0f - 1.0f;
+        const float dx = lx + lightRadius * sx - px, dy = ly + lightRadius * sy - py, dz = lz + lightRadius * sz - pz;
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float inv = 1.0f / len;
+        float4* out = reinterpret_cast<float4*>(outRays + outSlot + i);
+        out[0] = make_float4(px, py, pz, 0.0f);
+        out[1] = make_float4(dx * inv, dy * inv, dz * inv, (tri == -1) ? -1.0f : len);
+        outIDToSlot[outSlot + i] = outSlot + i;
+        outSlotToID[outSlot + i] = outSlot + i;
+    }
+}
+
 __global__ __launch_bounds__(256) void count_hits_kernel(const NtrRayResult* __restrict__ results, int numRays,
                                                          int* __restrict__ count)
 {
@@ -225,6 +275,21 @@ int ntr_raygen_ao(NtrRay* d_outRays, int32_t* d_outIDToSlot, int32_t* d_outSlotT
     hipLaunchKernelGGL(raygen_ao_kernel, dim3((numInputRays + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_outRays,
                        d_outIDToSlot, d_outSlotToID, d_inRays, d_inResults, d_triNormals, firstInputSlot, numInputRays,
                        numSamples, maxDist, kernelSeed);
+    NTR_HIP(hipGetLastError());
+    return NTR_OK;
+}
+
+int ntr_raygen_shadow(NtrRay* d_outRays, int32_t* d_outIDToSlot, int32_t* d_outSlotToID, const NtrRay* d_inRays, const NtrRayResult* d_inResults,
+                      int32_t firstInputSlot, int32_t numInputRays, int32_t numSamples, const float lightPos[3], float lightRadius,
+                      uint32_t kernelSeed, void* stream)
+{
+    if (numInputRays < 0 || numSamples < 0 || firstInputSlot < 0) return set_error(NTR_ERR_INVALID, "ntr_raygen_shadow: negative count");
+    if (numInputRays == 0 || numSamples == 0) return NTR_OK;
+    if (!d_outRays || !d_outIDToSlot || !d_outSlotToID || !d_inRays || !d_inResults || !lightPos)
+        return set_error(NTR_ERR_INVALID, "ntr_raygen_shadow: null buffer");
+    hipLaunchKernelGGL(raygen_shadow_kernel, dim3((numInputRays + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_outRays, d_outIDToSlot,
+                       d_outSlotToID, d_inRays, d_inResults, firstInputSlot, numInputRays, numSamples, lightPos[0], lightPos[1], lightPos[2],
+                       lightRadius, kernelSeed);
     NTR_HIP(hipGetLastError());
     return NTR_OK;
 }

@@ -50,6 +50,21 @@ bool RayGen::ao(RayBuffer& orays, RayBuffer& irays, Scene& scene, int numSamples
     return true;
 }
 
+bool RayGen::shadow(RayBuffer& orays, RayBuffer& irays, int numSamples, const Vec3f& lightPos, float lightRadius, bool& newBatch, U32 randomSeed)
+{
+    S32 lo, hi;
+    if (!batching(irays.getSize(), numSamples, m_shadowStartIdx, newBatch, lo, hi)) return false;
+    orays.resize((hi - lo) * numSamples);
+    orays.setNeedClosestHit(false);
+    const float lp[3] = {lightPos.x, lightPos.y, lightPos.z};
+    check(ntr_raygen_shadow((NtrRay*)orays.getRayBuffer().getMutableCudaPtr(), (int32_t*)orays.getIDToSlotBuffer().getMutableCudaPtr(),
+                            (int32_t*)orays.getSlotToIDBuffer().getMutableCudaPtr(), (const NtrRay*)irays.getRayBuffer().getCudaPtr(),
+                            (const NtrRayResult*)irays.getResultBuffer().getCudaPtr(), lo, hi - lo, numSamples, lp, lightRadius,
+                            Random(randomSeed).getU32() /* RayGen.cpp:139 */, NULL), "ntr_raygen_shadow");
+    check(ntr_stream_synchronize(NULL), "sync");
+    return true;
+}
+
 bool RayGen::batching(S32 numInputRays, S32 numSamples, S32& startIdx, bool& newBatch, S32& lo, S32& hi)
 {
     const S32 end = (m_inHi >= 0) ? FW::min(m_inHi, numInputRays) : numInputRays;   // (a rank's own input range, or everything)

@@ -34,7 +34,7 @@ private:
 
 class RayGen {
 public:
-    explicit RayGen(S32 maxBatchSize = 8 * 1024 * 1024) : m_maxBatchSize(maxBatchSize), m_aoStartIdx(0), m_inLo(0), m_inHi(-1) {}
+    explicit RayGen(S32 maxBatchSize = 8 * 1024 * 1024) : m_maxBatchSize(maxBatchSize), m_aoStartIdx(0), m_shadowStartIdx(0), m_inLo(0), m_inHi(-1) {}
 
     // Multi-GPU extension: secondary rays are generated from the input slots [lo, hi) only (a rank's own primary hits); hi < 0 = all.
     void setInputRange(S32 lo, S32 hi) { m_inLo = lo; m_inHi = hi; }
@@ -44,6 +44,8 @@ public:
     void primary(RayBuffer& orays, const Vec3f& origin, const Mat4f& nscreenToWorld, S32 w, S32 h, float maxDist, U32 randomSeed = 0);
     // RayGen::ao (RayGen.cpp:198-232): false when all input rays have been consumed
     bool ao(RayBuffer& orays, RayBuffer& irays, Scene& scene, int numSamples, float maxDist, bool& newBatch, U32 randomSeed = 0);
+    // RayGen::shadow (src/rt/ray/RayGen.cpp:114-150): numSamples any-hit rays per input ray towards the area light
+    bool shadow(RayBuffer& orays, RayBuffer& irays, int numSamples, const Vec3f& lightPos, float lightRadius, bool& newBatch, U32 randomSeed = 0);
 
 private:
     bool batching(S32 numInputRays, S32 numSamples, S32& startIdx, bool& newBatch, S32& lo, S32& hi);  // RayGen.cpp:582-602
@@ -51,6 +53,7 @@ private:
     S32        m_maxBatchSize;
     PixelTable m_pixelTable;
     S32        m_aoStartIdx;
+    S32        m_shadowStartIdx;
     S32        m_inLo, m_inHi;
 };
 

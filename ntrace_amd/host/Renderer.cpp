@@ -11,7 +11,7 @@ namespace FW {
 
 // Renderer::Renderer (Renderer.cpp:44-94): m_raygen(1 << 20), Platform("GPU") with leaf preferences (1,1).
 Renderer::Renderer(const String& builder)
-    : m_builder(builder), m_raygen(1 << 20), m_enableRandom(false), m_scene(NULL), m_cameraFar(0.0f), m_newBatch(true),
+    : m_builder(builder), m_raygen(1 << 20), m_enableRandom(false), m_scene(NULL), m_mesh(NULL), m_ownsScene(false), m_cameraFar(0.0f), m_newBatch(true),
       m_batchRays(NULL), m_batchStart(0), m_accelStruct(NULL), m_cachePath("bvhcache"), m_cacheDataStructure(false),
       m_predictSecondary(true), m_leafDepthOf(NULL), m_secondaryHint(NULL), m_shardRank(0), m_shardWorld(1), m_shardLo(0), m_shardHi(0)
 {
@@ -28,14 +28,31 @@ Renderer::~Renderer(void)
     if (m_secondaryHint) (void)ntr_sched_hint_destroy(m_secondaryHint);
     delete m_accelStruct;
     delete m_cudaTracer;
+    if (m_ownsScene) delete m_scene;    // (the reference's destructor calls setMesh(NULL), Renderer.cpp:96-98)
 }
 
 void Renderer::setScene(Scene* scene)
 {
     if (scene == m_scene) return;
     invalidateBVH();
+    if (m_ownsScene) { delete m_scene; m_ownsScene = false; m_mesh = NULL; }
     m_scene = scene;
     m_cudaTracer->setScene(scene);
+}
+
+void Renderer::setMesh(const WavefrontMesh* mesh)  // Renderer.cpp:98-132
+{
+    if (mesh == m_mesh) return;         // same mesh => done
+    if (m_ownsScene) delete m_scene;    // deinit scene and BVH
+    m_scene = NULL;
+    m_ownsScene = false;
+    invalidateBVH();
+    m_mesh = mesh;
+    if (mesh) {                         // create scene
+        m_scene = mesh->createScene();
+        m_ownsScene = true;
+    }
+    m_cudaTracer->setScene(m_scene);
 }
 
 void Renderer::setShard(int rank, int world)

@@ -4,6 +4,7 @@
 // primary, AO and diffuse ray types.  Out of scope: mesh import, GL display, visualisation, VPL,
 // kd-tree, image reconstruction (updateResult).
 #pragma once
+#include "MeshWavefrontIO.hpp"
 #include "CudaBVHTracer.hpp"
 #include "HLBVHBuilder.hpp"
 #include "RayGen.hpp"
@@ -27,7 +28,11 @@ public:
     explicit Renderer(const String& builder = "SAHBVH");
     ~Renderer(void);
 
-    void   setScene(Scene* scene);  // replaces setMesh(): the Scene is built by the caller
+    void   setScene(Scene* scene);  // a Scene the caller built and owns
+    // Renderer::setMesh (src/rt/cuda/Renderer.cpp:98-132): the same mesh -> nothing; otherwise the Renderer's own Scene of the previous
+    // mesh goes, the BVH is invalidated, and a Scene is made from the mesh (Scene(const MeshBase&), Scene.cpp:101-136: here the OBJ
+    // importer's WavefrontMesh, whose triangle ids are the reference's).  NULL releases the mesh.
+    void   setMesh(const WavefrontMesh* mesh);
     Scene* getScene(void) const { return m_scene; }
     void   setBuildParams(const BVH::BuildParams& params) { invalidateBVH(); m_buildParams = params; }
     BVH::BuildParams& getBuildParams(void) { return m_buildParams; }
@@ -77,6 +82,8 @@ private:
     Params             m_params;
     bool               m_enableRandom;
     Scene*             m_scene;
+    const WavefrontMesh* m_mesh;            // setMesh: the mesh m_scene was made from (the Renderer then owns m_scene)
+    bool               m_ownsScene;
     F32                m_cameraFar;
     RayBuffer          m_primaryRays;
     RayBuffer          m_secondaryRays;

@@ -224,6 +224,25 @@ static void cpuTests()
         std::remove(name.c_str());
         rmdir(dir);
     }
+    // Renderer::setMesh (Renderer.cpp:98-132): the Renderer makes -- and owns -- the Scene of a mesh; the same mesh again changes nothing;
+    // another mesh or NULL releases it; triangle ids are the importer's (submeshes concatenated, polygons fan-triangulated)
+    {
+        const char* obj = "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nf 1 2 3 4\nf 1 2 5\n";
+        WavefrontMesh mesh, other;
+        CHECK(parseWavefrontMesh(mesh, obj, std::vector<String>()) && mesh.numTriangles() == 3);
+        CHECK(parseWavefrontMesh(other, "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n", std::vector<String>()) && other.numTriangles() == 1);
+        Renderer r("SAHBVH");
+        CHECK(r.getScene() == NULL);
+        r.setMesh(&mesh);
+        Scene* s1 = r.getScene();
+        CHECK(s1 != NULL && s1->getNumTriangles() == 3 && s1->getNumVertices() == 5);
+        r.setMesh(&mesh);
+        CHECK(r.getScene() == s1);
+        r.setMesh(&other);
+        CHECK(r.getScene() != NULL && r.getScene()->getNumTriangles() == 1);
+        r.setMesh(NULL);
+        CHECK(r.getScene() == NULL);
+    }
     // multi-GPU partition arithmetic (ntr_frame_shard / ntr_frame_ao_batches): contiguous, 64-aligned ranges that cover the frame; AO
     // batches of a range as RayGen::batching cuts them
     for (int n : {0, 1, 63, 64, 65, 1000, 1920 * 1080}) {

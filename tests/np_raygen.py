@@ -69,3 +69,44 @@ def ao_rays(in_rays, in_results, normals, num_samples, max_dist, kernel_seed, fi
         out_d[i::num_samples] = v
     tmax = np.repeat(np.where(tri == -1, -1.0, max_dist), num_samples)
     return out_o, out_d, tmax
+
+
+def shadow_rays(in_rays, in_results, num_samples, light_pos, light_radius, kernel_seed, first=0, count=None):
+    """rayGenShadowKernel (src/rt/ray/RayGenKernels.cu:240-301) in float64: (origins, unit directions, tmax) of count * num_samples rays."""
+    count = in_rays.shape[0] - first if count is None else count
+    r = in_rays[first:first + count]
+    res = in_results[first:first + count]
+    o = np.stack([r["ox"], r["oy"], r["oz"]], 1).astype(np.float64)
+    d = np.stack([r["dx"], r["dy"], r["dz"]], 1).astype(np.float64)
+    back = np.maximum(res["t"].astype(np.float64) - 1.0e-2, 0.0)
+    origin = o + d * back[:, None]
+    M = np.uint32
+    with np.errstate(over="ignore"):
+        a = (M(kernel_seed) + np.arange(count, dtype=np.uint32)).astype(np.uint32)
+    b = np.full(count, 0x9e3779b9, dtype=np.uint32)
+    c = np.full(count, 0x9e3779b9, dtype=np.uint32)
+    a, b, c = _jenkins(a, b, c)
+    a, b, c = _jenkins(a, b, c)
+    off = np.stack([a, b, c], 1).astype(np.float32).astype(np.float64) * 2.0 ** -32    # (F32)hash * exp2(-32)
+    ro = np.zeros((count, num_samples, 3))
+    rd = np.zeros((count, num_samples, 3))
+    rt = np.zeros((count, num_samples))
+    lp = np.asarray(light_pos, dtype=np.float64)
+    for i in range(num_samples):
+        r1, r2, v1, v2, k = 0, 0, 1 << 31, 3 << 30, i
+        while k:
+            if k & 1:
+                r1 ^= v1
+                r2 ^= (v2 << 1) & 0xFFFFFFFF
+            v1 |= v1 >> 1
+            v2 ^= v2 >> 1
+            k >>= 1
+        pos = np.array([float(np.float32(r1)) * 2.0 ** -32, float(np.float32(r2)) * 2.0 ** -32, (i + 0.5) / num_samples])[None, :] + off
+        pos = np.where(pos >= 1.0, pos - 1.0, pos)
+        pos = pos * 2.0 - 1.0
+        direction = lp[None, :] + light_radius * pos - origin
+        length = np.linalg.norm(direction, axis=1)
+        ro[:, i] = origin
+        rd[:, i] = direction / length[:, None]
+        rt[:, i] = np.where(res["id"] == -1, -1.0, length)
+    return ro.reshape(-1, 3), rd.reshape(-1, 3), rt.reshape(-1)
