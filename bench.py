@@ -377,11 +377,30 @@ def main():
     # shape uses) carry the BVH broadcast and the frame's one collective whenever the ranks run on RCCL; torch.distributed
     # then only hands out the 128-byte group id, the barriers and the scalar reductions of the report.  gloo runs (CPU tier, --one-device)
     # keep the host-staged torch.distributed path: RCCL refuses two ranks on one GPU.
-    grp = None
+    grp, native_note = None, None
     if use_dist and args.dist_backend == "nccl" and os.environ.get("NTR_BENCH_TORCH_GATHER") != "1":
-        uid = torch.frombuffer(bytearray(nt.DistGroup.unique_id() if rank == 0 else bytes(128)), dtype=torch.uint8).to(dev)
+        # (a rank whose native group cannot be made -- RCCL not loadable by the C-ABI, say -- must not leave the others inside a collective:
+        # every rank reports, and unless ALL succeeded the run uses the torch.distributed collectives and says so in the line)
+        ok, err = 1, ""
+        try:
+            uid = torch.frombuffer(bytearray(nt.DistGroup.unique_id() if rank == 0 else bytes(128)), dtype=torch.uint8).to(dev)
+        except Exception as e:
+            uid, ok, err = torch.zeros(128, dtype=torch.uint8, device=dev), 0, repr(e)
         ntd.broadcast_(uid, 0)
-        grp = nt.DistGroup(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        ntd.all_reduce_(flag, dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            try:
+                grp = nt.DistGroup(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            except Exception as e:
+                grp, ok, err = None, 0, repr(e)
+            flag = torch.tensor([1 if grp is not None else 0], dtype=torch.int32, device=dev)
+            ntd.all_reduce_(flag, dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and grp is not None:
+                grp.close()
+                grp = None
+        if grp is None:
+            native_note = "the library's RCCL group could not be made on every rank (%s): torch.distributed collectives used instead" % (err or "another rank failed")
 
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
@@ -676,7 +695,7 @@ def main():
         "kernel_ms": {"primary": prim_ms, "ao_total": ao_ms, "per_step_rank0": float(kern_ms.sum(axis=1).mean()),
                       "per_batch": [round(float(x), 4) for x in kern_ms.mean(axis=0)]},
         "gather_ms": gather_ms,
-        "gather_native": native_gather,
+        "gather_native": native_gather if native_gather is not None else ({"fallback": native_note} if native_note else None),
         "sharded_frame_check": frame_check,
         "host_sah_build_s": sah_seconds,
         "trace_stats": st.as_dict(),

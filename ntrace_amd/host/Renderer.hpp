@@ -1,8 +1,8 @@
 // Renderer.hpp -- frame driver with the reference's batching semantics
 // (src/rt/cuda/Renderer.hpp:78-115; Renderer.cpp:44-94, 147-305, 405-497, 501-579, 676-710).
-// Kept: setParams / getCudaBVH / beginFrame / nextBatch / traceBatch / getTotalNumRays for the
-// primary, AO and diffuse ray types.  Out of scope: mesh import, GL display, visualisation, VPL,
-// kd-tree, image reconstruction (updateResult).
+// Kept: setMesh / setScene / setParams / getCudaBVH / beginFrame / nextBatch / traceBatch / updateResult (countHits + reconstruct:
+// SURVEY 8(f-2)) / getTotalNumRays for the primary, AO and diffuse ray types; setShard for the multi-GPU extension.
+// Out of scope: GL display, visualisation, VPL, kd-tree.
 #pragma once
 #include "MeshWavefrontIO.hpp"
 #include "CudaBVHTracer.hpp"
