@@ -79,16 +79,19 @@ inline TracePlan plan_trace(const Tunables& tun, const TraceBatchDesc& b)
     // NTR_TRACE_ROUTE=0 forces the named body:
     //   * any-hit launches run the per-ray body under every name (coherentRoute 2, decided here);
     //   * closest-hit launches large enough for the device's coherence estimate (the dispatch-order prediction computes it) are launched as
-    //     BOTH bodies -- the per-ray one and the name's persistent one (kepler_dynamic_fetch's for the per-ray name) --, each of which leaves
-    //     at once when the batch word says the batch is the other's (coherentRoute 1; an empty launch costs 3-10 us);
+    //     BOTH bodies -- the per-ray one and kepler_dynamic_fetch's persistent one --, each of which leaves at once when the batch word says
+    //     the batch is the other's (coherentRoute 1; an empty launch costs 3-10 us);
     //   * everything else runs the named body.
     const bool route = tun.route != 0 && !b.wantStats;
     if (route && b.variant == NTR_VARIANT_PERSISTENT && b.anyHit) {
         pl.variant = NTR_VARIANT_PERRAY;
         pl.coherentRoute = 2;
     }
-    // the persistent body of this launch: the name's own, or -- routed launches of the per-ray name -- kepler_dynamic_fetch's
-    const bool persistentDynamic = b.variant == NTR_VARIANT_PERSISTENT ? b.dynamicFetch : true;
+    // the persistent body of this launch: the name's own when the named body runs, kepler_dynamic_fetch's -- dynamic fetch, unified-step loop,
+    // ray splitting: the body that is fast on incoherent batches -- in every routed launch, whatever the name
+    const bool routedPersistentName = route && b.variant == NTR_VARIANT_PERSISTENT && !b.anyHit && bigEnough && (256 % pl.chunk) == 0 &&
+                                      tun.perrayUnified != 0 && tun.minipool < 0 && tun.predictPersistent != 0;
+    const bool persistentDynamic = (b.variant == NTR_VARIANT_PERSISTENT && !routedPersistentName) ? b.dynamicFetch : true;
     pl.unified = persistentDynamic && tun.unified != 0;
     pl.persistentFetchThreshold = tun.fetchThreshold >= 0 ? tun.fetchThreshold : (persistentDynamic ? (pl.unified ? 48 : 24) : 0);
     pl.fetchThreshold = pl.persistentFetchThreshold;

@@ -53,20 +53,29 @@ def test_flags_stats_capture_and_caller_hint():
 
 
 def test_persistent_selectors_grid_and_pool():
-    for name, unified, thr in (("tesla_persistent_while_while", 0, 0), ("tesla_persistent_speculative_while_while", 0, 0),
-                               ("kepler_dynamic_fetch", 1, 48)):
-        p = nt.trace_plan(name, 2 * MB, False, 600 * MB, 700 * MB, num_cus=256)
-        assert p.variant == PERSISTENT and p.unified == unified and p.fetchThreshold == thr and p.persistentFetchThreshold == thr
-        assert p.launchVariant == p.persistentVariant == (PERSISTENT_UNIFIED if unified else PERSISTENT)
-        assert p.numBlocks == p.launchBlocks == p.persistentBlocks == 256 * 7 and p.numHeads == 128 and p.chunk == 64
-        assert p.shardRays * p.numHeads >= 2 * MB and p.shardRays % 64 == 0
-        assert p.numBlocksIncoherent == (256 * 3 if unified else 0)      # only the dynamic-fetch kernel halves its grid
-        assert p.persistentOrder and p.predictable and p.hintable and p.useAutoHint     # (round 6: the pool is handed out in a hint's order too)
-        # large closest-hit launch: BOTH bodies, the device's batch word decides (the per-ray side has a fermi launch's shape)
-        assert p.coherentRoute == 1 and p.perrayBlocks == 4 * p.orderBlocks and p.perrayFetchThreshold == 48
-    # a batch smaller than the grid: one workgroup per 256 rays; too small for the estimate: the named body alone
-    p = nt.trace_plan("kepler_dynamic_fetch", 1000, False, 17 * MB, 17 * MB, num_cus=256)
-    assert p.variant == PERSISTENT and p.numBlocks == 4 and p.numBlocksIncoherent == 4 and not p.predictable and p.coherentRoute == 0
+    for route in ("1", "0"):
+        nt.set_tunables(NTR_TRACE_ROUTE=route)
+        for name, unified, thr in (("tesla_persistent_while_while", 0, 0), ("tesla_persistent_speculative_while_while", 0, 0),
+                                   ("kepler_dynamic_fetch", 1, 48)):
+            p = nt.trace_plan(name, 2 * MB, False, 600 * MB, 700 * MB, num_cus=256)
+            if route == "1":    # a large closest-hit launch is routed: kepler_dynamic_fetch's body is the persistent side under every name
+                unified, thr = 1, 48
+            assert p.variant == PERSISTENT and p.unified == unified and p.fetchThreshold == thr and p.persistentFetchThreshold == thr
+            assert p.launchVariant == p.persistentVariant == (PERSISTENT_UNIFIED if unified else PERSISTENT)
+            assert p.numBlocks == p.launchBlocks == p.persistentBlocks == 256 * 7 and p.numHeads == 128 and p.chunk == 64
+            assert p.shardRays * p.numHeads >= 2 * MB and p.shardRays % 64 == 0
+            assert p.numBlocksIncoherent == (256 * 3 if unified else 0) and p.numBlocksDivergent == (256 * 4 if unified else 0)   # only the dynamic-fetch body
+            assert p.persistentOrder and p.predictable and p.hintable and p.useAutoHint     # (round 6: the pool is handed out in a hint's order too)
+            # large closest-hit launch: BOTH bodies, the device's batch word decides (the per-ray side has a fermi launch's shape)
+            assert p.coherentRoute == (1 if route == "1" else 0)
+            if route == "1":
+                assert p.perrayBlocks == 4 * p.orderBlocks and p.perrayFetchThreshold == 48
+        # a batch smaller than the grid: one workgroup per 256 rays; too small for the estimate: the named body alone
+        p = nt.trace_plan("kepler_dynamic_fetch", 1000, False, 17 * MB, 17 * MB, num_cus=256)
+        assert p.variant == PERSISTENT and p.numBlocks == 4 and p.numBlocksIncoherent == 4 and not p.predictable and p.coherentRoute == 0
+        t = nt.trace_plan("tesla_persistent_while_while", 1000, False, 17 * MB, 17 * MB, num_cus=256)
+        assert t.unified == 0 and t.fetchThreshold == 0 and t.launchVariant == PERSISTENT
+    nt.set_tunables(NTR_TRACE_ROUTE=None)
 
 
 def test_routing_by_coherence():
