@@ -86,12 +86,12 @@ __global__ __launch_bounds__(MORTON_THREADS) void lbvh_morton_hist_kernel(int n,
                                                                           int* __restrict__ idx, float2* __restrict__ boxMesh /* or null */,
                                                                           TriVerts* __restrict__ triVerts /* mesh order, or null */,
                                                                           unsigned int* __restrict__ hist /* [4][256] */,
-                                                                          unsigned int* __restrict__ tileState, int tileStateWords)
+                                                                          unsigned long long* __restrict__ tileState, int tileStateWords)
 {
     __shared__ unsigned int s_hist[4][256];
     for (int i = threadIdx.x; i < 1024; i += MORTON_THREADS) (&s_hist[0][0])[i] = 0;
     const int gtid = blockIdx.x * MORTON_THREADS + threadIdx.x, gstride = gridDim.x * MORTON_THREADS;
-    for (int i = gtid; i < tileStateWords; i += gstride) tileState[i] = 0;
+    for (int i = gtid; i < tileStateWords; i += gstride) tileState[i] = 0ull;
     __syncthreads();
     const float l[3] = {lo.x, lo.y, lo.z}, s[3] = {step.x, step.y, step.z};
     for (int t = gtid; t < n; t += gstride) {
@@ -1035,6 +1035,15 @@ extern "C" {
 
 int ntr_lbvh_release_workspace(void) { return workspace_release(); }
 
+#ifdef NTR_OS_TIMELINE
+__attribute__((visibility("default"))) int ntr_debug_os_timeline(void* d_buf)
+{
+    unsigned long long* p = (unsigned long long*)d_buf;
+    NTR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_osTimeline), &p, sizeof(p)));
+    return NTR_OK;
+}
+#endif
+
 int ntr_lbvh_capacity(int32_t numTris, int64_t* nodesBytes, int64_t* triWoopBytes, int64_t* triIndexBytes)
 {
     if (numTris < 1) return set_error(NTR_ERR_INVALID, "ntr_lbvh_capacity: numTris < 1");
@@ -1064,9 +1073,10 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     if (n >= (1 << 28)) return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: at most 2^28 - 1 triangles");
     // one-sweep tiles: 2048 keys while the launch is latency-bound; 6144 / 8192 for large inputs (fewer tiles to look back over, longer
     // runs per digit in the scatter: 10 M keys 80 -> 71 us per pass, scripts/jobs/gpu_job_r02sort.sh)
-    const int osItems = n >= (1 << 23) ? 32 : (n >= (1 << 21) ? 24 : 8);
-    const int osTiles = (n + OS_THREADS * osItems - 1) / (OS_THREADS * osItems);
     const Tunables tun = tunables();
+    const int osItems = (tun.lbvhSortItems == 8 || tun.lbvhSortItems == 16 || tun.lbvhSortItems == 24 || tun.lbvhSortItems == 32)
+                            ? tun.lbvhSortItems : (n >= (1 << 23) ? 32 : (n >= (1 << 21) ? 24 : 8));
+    const int osTiles = (n + OS_THREADS * osItems - 1) / (OS_THREADS * osItems);
     if (n >= (1 << 27)) return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: at most 2^27 - 1 triangles");
 
     int spillSize = tun.lbvhSplit;
@@ -1100,7 +1110,7 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     const size_t oAggMisc = takeIf(bottomUp, 64);           // [0] number of runs of more than leafSize equal keys
     const int cntTiles = (n + 1 + RANK_BLOCK - 1) / RANK_BLOCK;    // prefix-count blocks
     const size_t oAggZeroEnd = cv.off;
-    const size_t oOsState = cv.take((size_t)osTiles * 256 * 4);
+    const size_t oOsState = cv.take((size_t)osTiles * 256 * 8);
     const size_t oSubList = takeIf(topDown, ((size_t)n / 2 + 2) * 16);
     const size_t oTopLst = takeIf(topDown, ((size_t)n + 2) * 4);
     const size_t oTriBox = takeIf(topDown, (size_t)n * 24), oTriOut = takeIf(topDown, (size_t)n * 4);
@@ -1138,27 +1148,22 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
         if (mb > MORTON_MAX_BLOCKS) mb = MORTON_MAX_BLOCKS;
         hipLaunchKernelGGL(lbvh_morton_hist_kernel, dim3(mb), dim3(MORTON_THREADS), 0, s, n, d_triVtxIndex, d_vtxPos, lo, step, epsilon, kIn, vIn,
                            bottomUp ? (float2*)nullptr : (float2*)(ws + oWoop), bottomUp ? (TriVerts*)(ws + oTriVerts) : (TriVerts*)nullptr, osHist,
-                           (unsigned int*)(ws + oOsState), osTiles * 256);
+                           (unsigned long long*)(ws + oOsState), osTiles * 256);
     }
     pe.mark(1);
 
     // L2: stable radix sort by key, 4 passes of 8 bits (the 30-bit code fits)
     for (int pass = 0; pass < 4; pass++) {
         const int shift = pass * 8;
-        {
-            if (osItems == 32)
-                hipLaunchKernelGGL((onesweep_pass_kernel<32, 0>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
-                                   1, shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
-            else if (osItems == 24)
-                hipLaunchKernelGGL((onesweep_pass_kernel<24, 0>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
-                                   1, shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
-            else if (osItems == 16)
-                hipLaunchKernelGGL((onesweep_pass_kernel<16, 0>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
-                                   1, shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
-            else
-                hipLaunchKernelGGL((onesweep_pass_kernel<8, 0>), dim3(osTiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
-                                   1, shift, pass, (const unsigned int*)(osHist + pass * 256), (unsigned int*)(ws + oOsState), osMisc + pass, osMisc + 4);
-        }
+        const unsigned int* dt = osHist + pass * 256;
+        unsigned long long* st = (unsigned long long*)(ws + oOsState);
+#define NTR_OS_LAUNCH(ITEMS)                                                                                                                \
+        onesweep_launch<ITEMS, 0, false>(s, osTiles, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut, 1, shift, pass, dt, st, osMisc + pass, osMisc + 4)
+        if (osItems == 32) NTR_OS_LAUNCH(32);
+        else if (osItems == 24) NTR_OS_LAUNCH(24);
+        else if (osItems == 16) NTR_OS_LAUNCH(16);
+        else NTR_OS_LAUNCH(8);
+#undef NTR_OS_LAUNCH
         unsigned int* tk = kIn; kIn = kOut; kOut = tk;
         int* tv = vIn; vIn = vOut; vOut = tv;
     }

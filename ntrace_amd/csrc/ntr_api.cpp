@@ -172,6 +172,7 @@ static void tunables_load_locked()
     t.lbvhSplit = env_int("NTR_LBVH_SPLIT", 3072);
     t.lbvhSubThreads = env_int("NTR_LBVH_SUB_THREADS", 128);
     t.lbvhAggLds = env_int("NTR_LBVH_AGG_LDS", 1);     // bottom-up emit: meetings inside a tile through LDS
+    t.lbvhSortItems = env_int("NTR_LBVH_SORT_ITEMS", 0);   // keys per thread of a one-sweep tile (8 / 16 / 24 / 32; 0 = by size)
     t.lbvhAggStaged = env_int("NTR_LBVH_AGG_STAGED", -1);  // bottom-up emit in two launches: -1 = from 2^20 triangles, 0 / 1 = never / always
     if (t.chunk < 1) t.chunk = 1;
     g_tun = t;

@@ -240,12 +240,12 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
     NTR_HIP(hipMalloc(&idxA.p, (size_t)n * 4));
     NTR_HIP(hipMalloc(&idxB.p, (size_t)n * 4));
     // one zeroed block: digit histograms, per-pass tickets, error flag, then the tile state of the chained scans
-    const size_t histWords = (size_t)RAY_KEY_DIGITS * 256, miscWords = 32, stateWords = (size_t)tiles * 256;
+    const size_t histWords = (size_t)RAY_KEY_DIGITS * 256, miscWords = 32, stateWords = (size_t)tiles * 256 * 2;   // 64-bit state words
     NTR_HIP(hipMalloc(&scratch.p, (histWords + miscWords + stateWords) * 4));
     NTR_HIP(hipMalloc(&box.p, 64));
     unsigned int* histp = (unsigned int*)scratch.p;
     unsigned int* misc = histp + histWords;      // [0..18] tickets, [31] error flag
-    unsigned int* state = misc + miscWords;
+    unsigned long long* state = (unsigned long long*)(misc + miscWords);   // 8-byte aligned: histWords and miscWords are even
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (seconds) { NTR_HIP(hipEventCreate(&e0)); NTR_HIP(hipEventCreate(&e1)); NTR_HIP(hipEventRecord(e0, s)); }
     NTR_HIP(hipMemsetAsync(scratch.p, 0, (histWords + miscWords + stateWords) * 4, s));
@@ -263,21 +263,19 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
     hipLaunchKernelGGL(ray_keys_kernel, dim3(kblocks), dim3(256), 0, s, n, d_inRays, (const float*)fbox, (unsigned int*)keys.p, (int*)idxA.p, histp);
     // stable LSD sort of the index array by the 192-bit key: words 0..3 fully, word 4 bits 0..23
     // (the highest set bit is 5 + 6*24 = 149: a* < 2^25, b* < 2^22); word 5 is always zero.
-    // The tile-state words carry the pass number in their status bits, so one clearing serves all passes (pass p uses status 2p+1, 2p+2
-    // of a 4-bit field: the passes are numbered modulo 7 and the state is cleared again every 7 passes).
+    // The tile-state words carry the pass number in their status bits (8 of them: pass p uses 2p+1, 2p+2), so one clearing serves all passes.
     // Word by word: the first pass over a word fetches it through the index array (one random 4-byte read per ray) and from then on
     // the word travels with the index, so the other passes over it are plain streaming passes -- 5 gathers instead of 19.
     int *vIn = (int*)idxA.p, *vOut = (int*)idxB.p;
     unsigned int *kIn = (unsigned int*)wordA.p, *kOut = (unsigned int*)wordB.p;
     for (int p = 0; p < RAY_KEY_DIGITS; p++) {
-        if (p > 0 && (p % 7) == 0) NTR_HIP(hipMemsetAsync(state, 0, stateWords * 4, s));
         const int word = p >> 2, shift = (p & 3) * 8;
         if ((p & 3) == 0)
-            hipLaunchKernelGGL((onesweep_pass_kernel<ITEMS, 2, true>), dim3(tiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)keys.p + word, (const int*)vIn, kOut, vOut,
-                               6, shift, p % 7, (const unsigned int*)(histp + (size_t)p * 256), state, misc + p, misc + 31);
+            onesweep_launch<ITEMS, 2, true>(s, tiles, n, (const unsigned int*)keys.p + word, (const int*)vIn, kOut, vOut, 6, shift, p,
+                                            (const unsigned int*)(histp + (size_t)p * 256), state, misc + p, misc + 31);
         else
-            hipLaunchKernelGGL((onesweep_pass_kernel<ITEMS, 0, true>), dim3(tiles), dim3(OS_THREADS), 0, s, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut,
-                               1, shift, p % 7, (const unsigned int*)(histp + (size_t)p * 256), state, misc + p, misc + 31);
+            onesweep_launch<ITEMS, 0, true>(s, tiles, n, (const unsigned int*)kIn, (const int*)vIn, kOut, vOut, 1, shift, p,
+                                            (const unsigned int*)(histp + (size_t)p * 256), state, misc + p, misc + 31);
         int* t = vIn; vIn = vOut; vOut = t;
         unsigned int* tk = kIn; kIn = kOut; kOut = tk;
     }
