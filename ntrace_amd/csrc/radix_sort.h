@@ -68,7 +68,8 @@ __device__ __forceinline__ unsigned int os_excl_scan_256(unsigned int v, unsigne
     return before + incl - v;
 }
 
-// MODE 0: keysIn[i] is the key of element i; keys and values both move.
+// MODE 0: keysIn[i] is the key of element i; keys and values both move (valsIn == nullptr: the value of element i is i -- a sort's first
+//         pass needs no index array written and read back).
 // MODE 1: the key word of element i is keysIn[valsIn[i] * stride] (multi-word keys stay in place, only the index array moves).
 // MODE 2: the key word is fetched as in MODE 1 and moves with the value from here on (first pass over a word of a multi-word key;
 //         the following passes over that word run in MODE 0 on the dense (word, value) pairs).
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
         for (int r = 0; r < ITEMS; r++) {
             const long long k = chunk + r * 64 + lane;
             if (k < n) {
-                const int v = valsIn[k];
+                const int v = (MODE == 0 && !valsIn) ? (int)k : valsIn[k];
                 if (MODE != 1) keysOut[k] = MODE != 0 ? keysIn[(size_t)v * stride] : keysIn[k];
                 valsOut[k] = v;
             }
@@ -136,16 +137,15 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
     for (int r = 0; r < ITEMS; r++) {
         const bool valid = r * 64 + lane < myCount;
         const long long k = chunk + r * 64 + lane;
-        val[r] = valid ? valsIn[k] : 0;
+        val[r] = valid ? (MODE == 0 && !valsIn ? (int)k : valsIn[k]) : 0;   // MODE 0 without values: element k carries k
         key[r] = valid ? (MODE != 0 ? keysIn[(size_t)val[r] * stride] : keysIn[k]) : 0xFFFFFFFFu;
     }
     // Stable ranking of a round's 64 keys by their digit (round 6): every lane ORs its lane bit into the LDS word of its digit -- an
     // atomic OR commutes, so the word a lane reads back with the wave's next LDS instruction (a wave's LDS operations execute in order)
     // is the set of lanes holding the same digit whatever order the hardware took the lanes in -- and its rank is the digit's count of
     // the earlier rounds plus the set's lanes below it.  The first lane of a set clears the word and advances the count.  (Until round 6
-    // the set came from eight ballots and a 64-bit select-and-AND per bit: ~60 vector instructions per round against ~15; a pass over
-    // 10 M keys was bound by instruction issue, `profiles/r06_lbvh_courtyard_pmc.txt`.)  Two word arrays alternate so that a round's OR
-    // never waits for the previous round's clear.
+    // the set came from eight ballots and a 64-bit select-and-AND per bit: ~60 vector instructions per round against ~15.)  Two word
+    // arrays alternate so that a round's OR never waits for the previous round's clear.
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const bool valid = r * 64 + lane < myCount;
