@@ -120,6 +120,31 @@ def test_config4_hairball_gpu_lbvh_refit_then_diffuse():
     assert batches == (n + per - 1) // per and live > 1000000
 
 
+def test_lbvh_sort_tile_sizes_and_ticket_path_3_5m_triangles():
+    """The one-sweep sort's tile sizes on 3.5 M triangles: 8 / 16 / 24 / 32 keys per thread = 1 709 / 855 / 570 / 428 tiles, of which the first
+    and the third are more than the device holds at once (their passes take tiles by ticket) and the others are not (workgroup b sorts
+    tile b) -- radix_sort.h onesweep_launch.  Every setting must give the default's buffers byte for byte, and those the oracle's tree."""
+    import torch
+    tri, pos, cam = scenes.hairball(3_500_000, seed=35)
+    ref = None
+    try:
+        for items in (0, 8, 16, 24, 32):
+            nt.set_tunables(NTR_LBVH_SORT_ITEMS=items if items else None)
+            view, res, keep = device_lbvh(tri, pos)
+            torch.cuda.synchronize()
+            got = (keep[0][:res.nodesBytes].clone(), keep[1][:res.triWoopBytes].clone(), keep[2][:res.triIndexBytes].clone())
+            if ref is None:
+                ref = got
+                exp = oracle.lbvh_build(tri, pos, 8, 0.001)
+                assert oracle.bvh_canonical_hash(got[0].cpu().numpy(), got[1].cpu().numpy(), got[2].cpu().numpy().view(np.int32)) == \
+                    oracle.bvh_canonical_hash(exp["nodes"], exp["woop"], exp["tri_index"])
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), items
+            del view, keep
+    finally:
+        nt.set_tunables(NTR_LBVH_SORT_ITEMS=None)
+
+
 def test_config5_san_miguel_class_10m_triangles():
     """San-Miguel-class (10 M tris): BVH built once on the device (the host SAH builder is O(n log^2 n)),
     1080p primary; per-rank ray shards traced separately equal the whole-frame trace (what the 8-GPU

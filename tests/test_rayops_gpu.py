@@ -75,12 +75,18 @@ def test_reconstruct_matches_numpy(ray_type):
     assert np.array_equal(got, exp)
 
 
-def np_ray_keys(rays):
+def np_ray_box(rays):
     o = np.stack([rays["ox"], rays["oy"], rays["oz"]], 1).astype(F)
     d = np.stack([rays["dx"], rays["dy"], rays["dz"]], 1).astype(F)
     e = (o + d * rays["tmax"][:, None]).astype(F)
-    lo = np.minimum(o.min(0), e.min(0)).astype(F)
-    hi = np.maximum(o.max(0), e.max(0)).astype(F)
+    return np.minimum(o.min(0), e.min(0)).astype(F), np.maximum(o.max(0), e.max(0)).astype(F)
+
+
+def np_ray_keys(rays, box=None):
+    """the 192-bit sort keys (RayBuffer.cpp:103-165) as Python integers; `box`: the (lo, hi) of the batch the rays are a sample of"""
+    o = np.stack([rays["ox"], rays["oy"], rays["oz"]], 1).astype(F)
+    d = np.stack([rays["dx"], rays["dy"], rays["dz"]], 1).astype(F)
+    lo, hi = box if box is not None else np_ray_box(rays)
     with np.errstate(all="ignore"):
         a = ((o - lo) / (hi - lo)).astype(F)
         ln = np.sqrt(((d[:, 0] * d[:, 0]).astype(F) + (d[:, 1] * d[:, 1]).astype(F)).astype(F) + (d[:, 2] * d[:, 2]).astype(F)).astype(F)
@@ -121,6 +127,37 @@ def test_ray_morton_sort_matches_numpy():
     s2i = d_s2i_out.cpu().numpy()
     assert np.array_equal(s2i, slot_to_id[order])
     assert np.array_equal(d_i2s.cpu().numpy()[s2i], np.arange(n))
+
+
+def test_ray_morton_sort_large_batch_ticket_path():
+    """3 M rays: more one-sweep tiles (1 465 of 2 048 keys) than the device holds at once, so the passes take their tiles by ticket
+    (radix_sort.h onesweep_launch) -- the 2^20-ray batches of the frames never do.  Checked: the output is a permutation, the keys of
+    sampled neighbours (numpy restatement, the whole batch's box) do not decrease, and rays with equal keys keep their slot order."""
+    import torch
+    from gpu_util import up
+    n = 3_000_000
+    rays = scenes.random_rays(n, seed=77, tmax=3.0)
+    rays[1_000_000:1_000_600] = rays[17]          # 600 identical rays: ties keep slot order
+    d_in = up(rays)
+    d_id = torch.arange(n, dtype=torch.int32, device="cuda:0")
+    d_out = torch.zeros(n * 32, dtype=torch.uint8, device="cuda:0")
+    d_i2s = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    d_s2i = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    nt.ray_morton_sort(n, d_in.data_ptr(), d_id.data_ptr(), d_out.data_ptr(), d_i2s.data_ptr(), d_s2i.data_ptr())
+    s2i = d_s2i.cpu().numpy()
+    assert np.array_equal(np.sort(s2i), np.arange(n, dtype=np.int32))
+    assert np.array_equal(d_i2s.cpu().numpy()[s2i], np.arange(n))
+    got = d_out.cpu().numpy().view(nt.RAY_DTYPE)
+    assert np.array_equal(got, rays[s2i])
+    box = np_ray_box(rays)
+    rng = np.random.default_rng(5)
+    at = np.unique(np.concatenate([rng.integers(0, n - 1, 1500), np.nonzero(s2i == 17)[0], np.nonzero(s2i == 17)[0] + 300]))
+    at = at[at < n - 1]
+    ka, kb = np_ray_keys(got[at], box), np_ray_keys(got[at + 1], box)
+    for i, a, b in zip(at, ka, kb):
+        assert a < b or (a == b and s2i[i] < s2i[i + 1]), int(i)
+    tie = np.nonzero(s2i == 17)[0][0]
+    assert np.array_equal(s2i[tie + 1:tie + 601], np.arange(1_000_000, 1_000_600))
 
 
 def test_sorted_ao_batch_traces_to_same_hits():
