@@ -428,7 +428,8 @@ NTR_API int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_
 
 /* The builder keeps one grow-only scratch workspace per device between builds (a rebuild per frame must not pay allocations):
  * about 175 B per triangle on the default path (1.75 GB after a 10 M-triangle build).  A host that builds once and then only
- * traces returns it with this call (it waits for the device first); the next build allocates again. */
+ * traces returns it with this call (it waits for the device first); the next build allocates again.  ntr_ray_morton_sort keeps its
+ * temporaries the same way (about 40 B per ray of the largest batch sorted so far); this call returns them too. */
 NTR_API int ntr_lbvh_release_workspace(void);
 
 /* reconstructKernel (src/rt/cuda/RendererKernels.cu:59-172; ReconstructInput, RendererKernels.hpp:46-70;

@@ -1033,7 +1033,12 @@ using namespace ntr;
 
 extern "C" {
 
-int ntr_lbvh_release_workspace(void) { return workspace_release(); }
+int ntr_lbvh_release_workspace(void)
+{
+    const int rc = workspace_release();
+    const int rc2 = ntr::raysort_scratch_release();
+    return rc != NTR_OK ? rc : rc2;
+}
 
 #ifdef NTR_OS_TIMELINE
 __attribute__((visibility("default"))) int ntr_debug_os_timeline(void* d_buf)

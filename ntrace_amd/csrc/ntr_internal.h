@@ -20,6 +20,9 @@ Tunables tunables();
 // true when `s` is being captured into a HIP graph: scratch handed to such a launch must stay valid for the
 // lifetime of the graph, so it is taken from never-recycled storage.
 bool stream_is_capturing(hipStream_t s);
+
+// rayops_kernels.hip: returns the per-device scratch of ntr_ray_morton_sort (ntr_lbvh_release_workspace calls it)
+int raysort_scratch_release();
 }  // namespace ntr
 
 // ntr_api.cpp: (re)build the top-of-tree box table cached for this node buffer (dispatch-order prediction)

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
+#include <mutex>
 
 #include "ntr_internal.h"
 #include "radix_sort.h"
@@ -169,11 +170,54 @@ __global__ __launch_bounds__(256) void ray_reorder_kernel(int n, const int* __re
 using namespace ntr;
 
 namespace {
-struct DevMem {
+// Grow-only scratch of ntr_ray_morton_sort, one per device, kept between calls: a renderer sorts sixteen batches per frame and must not
+// pay seven hipMalloc / hipFree pairs (each a device synchronisation) for every one of them.  Same rules as the LBVH builder's workspace
+// (lbvh_workspace.h): one caller per device at a time; regrown only after the device has drained; ntr_lbvh_release_workspace returns it.
+struct SortScratch {
     void* p = nullptr;
-    ~DevMem() { if (p) (void)hipFree(p); }
+    size_t bytes = 0;
 };
+constexpr int kSortMaxDevices = 64;
+SortScratch g_sortScratch[kSortMaxDevices];
+std::mutex g_sortScratchMu;
+
+int sort_scratch_reserve(size_t bytes, void** out)
+{
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kSortMaxDevices) return set_error(NTR_ERR_INVALID, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_sortScratchMu);
+    SortScratch& w = g_sortScratch[dev];
+    if (w.p && w.bytes < bytes) {
+        NTR_HIP(hipDeviceSynchronize());
+        NTR_HIP(hipFree(w.p));
+        w.p = nullptr; w.bytes = 0;
+    }
+    if (!w.p) {
+        NTR_HIP(hipMalloc(&w.p, bytes));
+        w.bytes = bytes;
+    }
+    *out = w.p;
+    return NTR_OK;
+}
 }  // namespace
+
+namespace ntr {
+int raysort_scratch_release()
+{
+    int dev = 0;
+    NTR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kSortMaxDevices) return set_error(NTR_ERR_INVALID, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_sortScratchMu);
+    SortScratch& w = g_sortScratch[dev];
+    if (w.p) {
+        NTR_HIP(hipDeviceSynchronize());
+        NTR_HIP(hipFree(w.p));
+        w.p = nullptr; w.bytes = 0;
+    }
+    return NTR_OK;
+}
+}  // namespace ntr
 
 // Framebuffer gather of the multi-GPU path (ntr_dist.cpp): a rank's pixels packed in slot order / scattered back on the root.
 __global__ __launch_bounds__(256) void pixels_pack_kernel(const uint32_t* __restrict__ pixels, const int32_t* __restrict__ slotToPixel, int first, int count,
@@ -233,16 +277,19 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
     if (n >= (1 << 28)) return set_error(NTR_ERR_INVALID, "ntr_ray_morton_sort: at most 2^28 - 1 rays");
     constexpr int ITEMS = 8;
     const int tiles = (n + OS_THREADS * ITEMS - 1) / (OS_THREADS * ITEMS);
-    DevMem keys, idxA, idxB, wordA, wordB, scratch, box;
-    NTR_HIP(hipMalloc(&keys.p, (size_t)n * 24));
-    NTR_HIP(hipMalloc(&wordA.p, (size_t)n * 4));
-    NTR_HIP(hipMalloc(&wordB.p, (size_t)n * 4));
-    NTR_HIP(hipMalloc(&idxA.p, (size_t)n * 4));
-    NTR_HIP(hipMalloc(&idxB.p, (size_t)n * 4));
     // one zeroed block: digit histograms, per-pass tickets, error flag, then the tile state of the chained scans
     const size_t histWords = (size_t)RAY_KEY_DIGITS * 256, miscWords = 32, stateWords = (size_t)tiles * 256 * 2;   // 64-bit state words
-    NTR_HIP(hipMalloc(&scratch.p, (histWords + miscWords + stateWords) * 4));
-    NTR_HIP(hipMalloc(&box.p, 64));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t oKeys = take((size_t)n * 24), oWordA = take((size_t)n * 4), oWordB = take((size_t)n * 4), oIdxA = take((size_t)n * 4), oIdxB = take((size_t)n * 4);
+    const size_t oZero = take((histWords + miscWords + stateWords) * 4), oBox = take(64);
+    void* base = nullptr;
+    {
+        const int rc = sort_scratch_reserve(off, &base);
+        if (rc != NTR_OK) return rc;
+    }
+    char* ws = (char*)base;
+    struct { void* p; } keys{ws + oKeys}, wordA{ws + oWordA}, wordB{ws + oWordB}, idxA{ws + oIdxA}, idxB{ws + oIdxB}, scratch{ws + oZero}, box{ws + oBox};
     unsigned int* histp = (unsigned int*)scratch.p;
     unsigned int* misc = histp + histWords;      // [0..18] tickets, [31] error flag
     unsigned long long* state = (unsigned long long*)(misc + miscWords);   // 8-byte aligned: histWords and miscWords are even
@@ -293,7 +340,7 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
     }
     unsigned int sortErr = 0;
     NTR_HIP(hipMemcpyAsync(&sortErr, misc + 31, sizeof(sortErr), hipMemcpyDeviceToHost, s));
-    NTR_HIP(hipStreamSynchronize(s));  // temporaries are freed on return
+    NTR_HIP(hipStreamSynchronize(s));  // (the error word is read back: a timed-out chained scan must not go unnoticed)
     if (sortErr) return set_error(NTR_ERR_HIP, "ntr_ray_morton_sort: a chained scan timed out waiting for a predecessor tile");
     return NTR_OK;
 }
