@@ -1286,9 +1286,16 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
     }
     NTR_HIP(hipGetLastError());
     unsigned int sortErr = 0;
-    NTR_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, s));
-    NTR_HIP(hipMemcpyAsync(&sortErr, osMisc + 4, sizeof(sortErr), hipMemcpyDeviceToHost, s));
-    NTR_HIP(hipStreamSynchronize(s));
+    {   // builder state and the sort's error word in ONE read-back (they lie in the same cleared block: state, digit histograms, misc)
+        static_assert(sizeof(LbvhState) <= 1024, "read-back buffer");
+        unsigned char back[1024 + 4 * 256 * 4 + 256 + 64];
+        const size_t span = oOsMisc + 64 - oState;
+        if (span > sizeof(back)) return set_error(NTR_ERR_INVALID, "ntr_lbvh_build: internal read-back span");
+        NTR_HIP(hipMemcpyAsync(back, ws + oState, span, hipMemcpyDeviceToHost, s));
+        NTR_HIP(hipStreamSynchronize(s));
+        memcpy(&h, back, sizeof(h));
+        memcpy(&sortErr, back + (oOsMisc - oState) + 4 * sizeof(unsigned int), sizeof(sortErr));
+    }
     result->mortonMs = pe.ms(0, 1);
     result->sortMs = pe.ms(1, 2);
     result->woopMs = pe.ms(2, 3);

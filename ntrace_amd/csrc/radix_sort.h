@@ -12,7 +12,9 @@
 //   * workgroups take tiles in ticket order (one returning atomic), so every predecessor of a tile is resident
 //     or finished: waiting on predecessors cannot deadlock -- unless the whole grid fits the device at once (onesweep_launch
 //     asks the runtime), where every tile becomes resident whatever the dispatch order and workgroup b simply takes tile b: the
-//     one counter serves ~88 atomics per microsecond, 2-5 us of a tile's life at 128-512 tiles (scripts/studies/onesweep_timeline.py);
+//     one counter serves ~88 atomics per microsecond, 2-5 us of a tile's life at 128-512 tiles (scripts/studies/onesweep_timeline.py).
+//     (Another kernel holding part of the device only delays that: a grid's workgroups are dispatched in index order, so the tiles
+//     that are resident are always a prefix of the pass and wait for nothing that is not; and a wait that never ends raises *errFlag.)
 //   * per tile and digit ONE 64-bit word carries status, reach and count together (8 status bits tagged with the pass, 24 bits
 //     "lowest tile the count covers", 32 count bits), published and polled with agent-scope atomics: no ordering against other
 //     memory is needed, and the array is cleared once per sort, not per pass;
