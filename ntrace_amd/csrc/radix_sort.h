@@ -257,14 +257,14 @@ static inline void onesweep_launch(hipStream_t s, int tiles, int n, const unsign
                                    int stride, int shift, int pass, const unsigned int* digitTotals, unsigned long long* tileState,
                                    unsigned int* ticket, unsigned int* errFlag)
 {
-    static int residentTiles = -1;   // per instantiation (one device type per process)
-    if (residentTiles < 0) {
+    // tiles the device holds at once: per instantiation, asked once (one device type per process; the initialisation is thread-safe)
+    static const int residentTiles = [] {
         int perCU = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, onesweep_pass_kernel<ITEMS, MODE, SKIP_TRIVIAL, OS_LOOK>, OS_THREADS, 0) != hipSuccess ||
             hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            perCU = cus = 0;
-        residentTiles = perCU * cus;
-    }
+            return 0;
+        return perCU * cus;
+    }();
     hipLaunchKernelGGL((onesweep_pass_kernel<ITEMS, MODE, SKIP_TRIVIAL, OS_LOOK>), dim3(tiles), dim3(OS_THREADS), 0, s, n, keysIn, valsIn, keysOut, valsOut, stride,
                        shift, pass, digitTotals, tileState, tiles <= residentTiles ? (unsigned int*)nullptr : ticket, errFlag);
 }

@@ -160,6 +160,45 @@ def test_ray_morton_sort_large_batch_ticket_path():
     assert np.array_equal(s2i[tie + 1:tie + 601], np.arange(1_000_000, 1_000_600))
 
 
+def test_scratch_is_kept_between_sorts_and_builds_and_can_be_returned():
+    """ntr_ray_morton_sort and ntr_lbvh_build keep their temporaries per device between calls; ntr_lbvh_release_workspace returns both, and
+    the next call allocates again: same order, same tree, before and after, and with a larger batch in between (the scratch grows)."""
+    import torch
+    from gpu_util import up
+    tri, pos, cam = scenes.random_soup(9000, seed=21)
+    d_tri, d_pos = up(tri), up(pos)
+    capn, capw, capi = nt.lbvh_capacity(tri.shape[0])
+    bufs = [torch.zeros(c, dtype=torch.uint8, device="cuda:0") for c in (capn, capw, capi)]
+    mn, mx = pos.min(0), pos.max(0)
+
+    def build():
+        r = nt.lbvh_build(tri.shape[0], d_tri.data_ptr(), pos.shape[0], d_pos.data_ptr(), mn, mx, 8, 0.001, bufs[0].data_ptr(), capn, bufs[1].data_ptr(), capw,
+                          bufs[2].data_ptr(), capi)
+        torch.cuda.synchronize()
+        return [b[:k].clone() for b, k in zip(bufs, (r.nodesBytes, r.triWoopBytes, r.triIndexBytes))]
+
+    def sort(n, seed):
+        rays = scenes.random_rays(n, seed=seed, tmax=6.0)
+        d_in = up(rays)
+        ident = torch.arange(n, dtype=torch.int32, device="cuda:0")
+        d_out = torch.zeros(n * 32, dtype=torch.uint8, device="cuda:0")
+        a = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        b = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        nt.ray_morton_sort(n, d_in.data_ptr(), ident.data_ptr(), d_out.data_ptr(), a.data_ptr(), b.data_ptr())
+        return b.cpu().numpy()
+
+    t0, s0 = build(), sort(5000, 1)
+    big = sort(70000, 2)                      # the scratch grows
+    assert np.array_equal(np.sort(big), np.arange(70000))
+    assert np.array_equal(sort(5000, 1), s0)  # ... and a smaller batch in the larger scratch sorts as before
+    nt.lbvh_release_workspace()
+    t1, s1 = build(), sort(5000, 1)
+    assert np.array_equal(s1, s0)
+    for x, y in zip(t0, t1):
+        assert torch.equal(x, y)
+    nt.lbvh_release_workspace()
+
+
 def test_sorted_ao_batch_traces_to_same_hits():
     """Sorting changes slots, not results: per ray id the hit record is identical."""
     import torch
