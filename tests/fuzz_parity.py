@@ -152,7 +152,9 @@ def main(argv=None):
                 # cell-table top pass, with the default or a small hand-over size
                 nt.set_tunables(NTR_LBVH_SPLIT=int(rng.choice([2, 16, 100, 3000])) if rng.random() < 0.3 else None,
                                 NTR_LBVH_AGG_LDS=int(rng.choice([1, 1, 0])),
-                                NTR_LBVH_AGG_STAGED=int(rng.choice([-1, 0, 1])))
+                                NTR_LBVH_AGG_STAGED=int(rng.choice([-1, 0, 1])),
+                                NTR_LBVH_SORT_ITEMS=int(rng.choice([0, 0, 8, 16, 24, 32])),
+                                NTR_LBVH_MORTON_THREADS=int(rng.choice([0, 0, 256, 512, 1024])), NTR_LBVH_MORTON_KEYS=int(rng.choice([0, 0, 1, 2, 16])))
                 if os.environ.get("NTR_FUZZ_VERBOSE"):
                     print("lbvh n=%d leaf=%d eps=%g %s" % (tri.shape[0], leaf, eps, {k: v for k, v in os.environ.items() if k.startswith("NTR_LBVH")}),
                           file=sys.stderr, flush=True)

@@ -145,6 +145,30 @@ def test_lbvh_sort_tile_sizes_and_ticket_path_3_5m_triangles():
         nt.set_tunables(NTR_LBVH_SORT_ITEMS=None)
 
 
+@pytest.mark.parametrize("n", [4095, 4096, 4097, 6143, 6144, 6145, 8191, 8192, 8193, 16385, 40000])
+def test_lbvh_sort_tile_sizes_ragged_counts(n):
+    """Triangle counts one below, at and above the one-sweep tile sizes (2 048 / 4 096 / 6 144 / 8 192 keys): a ragged last tile, a last tile
+    of one key, waves of a tile that hold no key at all -- for every tile size, against the default's buffers and the oracle's tree."""
+    import torch
+    tri, pos, cam = scenes.random_soup(n, seed=n)
+    ref = None
+    try:
+        for items in (0, 8, 16, 24, 32):
+            nt.set_tunables(NTR_LBVH_SORT_ITEMS=items if items else None)
+            view, res, keep = device_lbvh(tri, pos)
+            torch.cuda.synchronize()
+            got = (keep[0][:res.nodesBytes].clone(), keep[1][:res.triWoopBytes].clone(), keep[2][:res.triIndexBytes].clone())
+            if ref is None:
+                ref = got
+                exp = oracle.lbvh_build(tri, pos, 8, 0.001)
+                assert oracle.bvh_canonical_hash(got[0].cpu().numpy(), got[1].cpu().numpy(), got[2].cpu().numpy().view(np.int32)) == \
+                    oracle.bvh_canonical_hash(exp["nodes"], exp["woop"], exp["tri_index"])
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), items
+    finally:
+        nt.set_tunables(NTR_LBVH_SORT_ITEMS=None)
+
+
 def test_config5_san_miguel_class_10m_triangles():
     """San-Miguel-class (10 M tris): BVH built once on the device (the host SAH builder is O(n log^2 n)),
     1080p primary; per-rank ray shards traced separately equal the whole-frame trace (what the 8-GPU
