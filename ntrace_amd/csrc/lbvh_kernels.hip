@@ -1040,14 +1040,6 @@ int ntr_lbvh_release_workspace(void)
     return rc != NTR_OK ? rc : rc2;
 }
 
-#ifdef NTR_OS_TIMELINE
-__attribute__((visibility("default"))) int ntr_debug_os_timeline(void* d_buf)
-{
-    unsigned long long* p = (unsigned long long*)d_buf;
-    NTR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_osTimeline), &p, sizeof(p)));
-    return NTR_OK;
-}
-#endif
 
 int ntr_lbvh_capacity(int32_t numTris, int64_t* nodesBytes, int64_t* triWoopBytes, int64_t* triIndexBytes)
 {

@@ -34,12 +34,6 @@
 // Stable; n < 2^28.
 // ------------------------------------------------------------------------------------------------------------
 static constexpr int OS_THREADS = 256;
-#ifdef NTR_OS_TIMELINE   // study builds only (scripts/studies/onesweep_timeline.py): 100 MHz time stamps of a tile's phases
-static __device__ unsigned long long* g_osTimeline = nullptr;   // [pass][tiles][8]
-#define OS_TL(k) do { if (g_osTimeline && threadIdx.x == 0) g_osTimeline[((size_t)pass * gridDim.x + s_tile) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define OS_TL(k) do { } while (0)
-#endif
 static constexpr unsigned int OS_SPIN_LIMIT = 1u << 22;
 static constexpr int OS_MAX_PASSES = 126;        // 8 status bits: pass p publishes 2p + 1 (partial) and 2p + 2 (inclusive); 0 = nothing yet
 static constexpr unsigned int OS_REACH_MASK = 0x00FFFFFFu;
@@ -102,19 +96,12 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
     unsigned long long (*s_match)[MATCH_BUFS][256] = reinterpret_cast<unsigned long long (*)[MATCH_BUFS][256]>(s_keys);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-#ifdef NTR_OS_TIMELINE
-    const unsigned long long tlEntry = __builtin_amdgcn_s_memrealtime();
-#endif
     if (tid == 0) s_tile = ticket ? atomicAdd(ticket, 1u) : blockIdx.x;   // ticket == nullptr: every tile of the grid is resident at once
     for (int i = tid; i < WAVES * 256; i += OS_THREADS) (&s_cnt[0][0])[i] = 0;
     for (int i = tid; i < WAVES * MATCH_BUFS * 256; i += OS_THREADS) (&s_match[0][0][0])[i] = 0ull;
     // global base of digit `tid`: exclusive scan of the digit totals
     const unsigned int digitBase = os_excl_scan_256(digitTotals[tid], s_wt[0]);   // (its barrier also publishes s_tile, s_cnt and s_match)
     const unsigned int tile = s_tile;
-#ifdef NTR_OS_TIMELINE
-    if (g_osTimeline && tid == 0) g_osTimeline[((size_t)pass * gridDim.x + tile) * 8 + 0] = tlEntry;
-#endif
-    OS_TL(1);
 
     const long long chunk = (long long)tile * TILE + wave * (64 * ITEMS);
     if (SKIP_TRIVIAL && __syncthreads_or(digitTotals[tid] == (unsigned int)n)) {
@@ -163,7 +150,6 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
         }
     }
     __syncthreads();
-    OS_TL(2);
 
     // digit `tid`: the tile's count
     unsigned int cnt = 0;
@@ -185,7 +171,6 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
         }
     }
 
-    OS_TL(3);
     // stage in tile-sorted order -- BEFORE the look-back: the positions inside the tile are known, and while this tile moves its keys
     // its predecessors get on with their own look-backs (what it then reads from them reaches further back)
     __syncthreads();   // the waves' digit positions (s_cnt) are complete; the match words in the staging area are dead
@@ -203,7 +188,6 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
     // tile first.  A word says how many keys of the digit tiles reach .. t' hold: it is added and the walk continues at reach - 1 (inside
     // the loaded window, or with the next round trip); an inclusive word ends it, an unpublished one is read again.  After every round
     // trip that made progress the tile publishes what IT covers by now, so that its successors jump over all of it.
-    OS_TL(4);
     unsigned int excl = 0;
     if (tile > 0) {
         int cur = (int)tile - 1;
@@ -235,10 +219,8 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
         }
         __hip_atomic_store(myState, os_word(tagInc, 0u, excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    OS_TL(5);
     s_dst[tid] = digitBase + excl - tileStart;
     __syncthreads();
-    OS_TL(6);
 
     const long long tileBeg = (long long)tile * TILE;
     const int tileCount = (int)((n - tileBeg) < (long long)TILE ? (n - tileBeg) : (long long)TILE);
@@ -248,7 +230,6 @@ __global__ __launch_bounds__(OS_THREADS) static void onesweep_pass_kernel(int n,
         if (MODE != 1) keysOut[dst] = k;
         valsOut[dst] = s_vals[i];
     }
-    OS_TL(7);
 }
 
 // One pass on `s`.  `ticket` is only used when the grid does not fit the device at once (see the kernel's header).

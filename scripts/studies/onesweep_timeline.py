@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Where does a one-sweep pass spend its time?  Needs the study build (time stamps compiled in):
-   make -C ntrace_amd/csrc clean && make -C ntrace_amd/csrc -j8 EXTRA=-DNTR_OS_TIMELINE LIB=../libntrace_amd_diag.so && make -C ntrace_amd/csrc clean && make -C ntrace_amd/csrc -j8
+"""Where does a one-sweep pass spend its time?  Needs a study build with the time stamps of rejected_patches/onesweep_timeline.patch
+(the product sources carry no instrumentation):
+   git apply scripts/studies/rejected_patches/onesweep_timeline.patch && make -C ntrace_amd/csrc clean && \
+   make -C ntrace_amd/csrc -j8 EXTRA=-DNTR_OS_TIMELINE LIB=../libntrace_amd_diag.so ; git apply -R scripts/studies/rejected_patches/onesweep_timeline.patch && \
+   make -C ntrace_amd/csrc clean && make -C ntrace_amd/csrc -j8
    NTR_LIB_OVERRIDE=ntrace_amd/libntrace_amd_diag.so python3 scripts/studies/onesweep_timeline.py [atrium hairball courtyard]
 Per scene and pass: the pass's span, tiles in flight on average, and the mean duration of a tile's phases (100 MHz stamps by thread 0):
 entry -> ticket + digit scan -> keys loaded and ranked -> published + tile scan -> staged -> look-back of digit 0 -> all digits -> written."""
