@@ -842,8 +842,8 @@ __global__ __launch_bounds__(64) void lbvh_runs_kernel(AggCtx c)
 // relocation pass of five kernels, which the bench scene paid on every build).  Also finds the root's split position, the one boundary
 // where the highest bit in which the first and the last key differ flips.  One workgroup per RANK_BLOCK positions: bit masks, the
 // block's count and the counts before each 256 positions inside it.
-constexpr int MARK_THREADS = 256;              // one workgroup marks one prefix-count block, four positions per thread
-constexpr int MARK_SUBS = RANK_BLOCK / MARK_THREADS;
+constexpr int MARK_THREADS = 256;              // threads of the mark scan's workgroup
+constexpr int MARK_SUBS = RANK_BLOCK / 256;    // prefix counts inside a block: one per 256 positions
 // Exclusive scan of the block counts by one workgroup, four per thread and round with the next round's loads already in flight; the
 // total gives the builder state's nodeCount (one inner node per leaf but the first) and leafPtr.  (Folding this into the mark kernel --
 // the last block to report in scans -- was measured slower than the extra launch: 103 against 67 us at 10 M triangles.)
@@ -899,7 +899,9 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_markscan_kernel(int n, int 
     }
 }
 
-__global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int leafSize, const unsigned int* __restrict__ keys,
+// THREADS: 256 (four positions per thread, one after the other) or 1024 (one position per thread: the four rounds of a block side by side)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void lbvh_leafmark_kernel(int n, int leafSize, const unsigned int* __restrict__ keys,
                                                                      unsigned long long* __restrict__ sBits, unsigned long long* __restrict__ rBits,
                                                                      unsigned int* __restrict__ blockCount, unsigned int* __restrict__ subBase,
                                                                      unsigned char* __restrict__ runDepth, LbvhState* st)
@@ -907,16 +909,17 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
     constexpr int SPAN = RANK_BLOCK + 2 * AGG_HALO;
     __shared__ unsigned int sKeys[SPAN];
     __shared__ int sD[SPAN + 2];                              // sD[k] = d(beg - AGG_HALO + k), valid for 1 <= k < SPAN
-    __shared__ unsigned int s_c[MARK_SUBS][MARK_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ unsigned int s_c[MARK_SUBS][4];                // [256 positions][their four waves]
+    constexpr int ROUNDS = RANK_BLOCK / THREADS;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int beg = blockIdx.x * RANK_BLOCK;
-    for (int k = tid; k < SPAN; k += MARK_THREADS) {
+    for (int k = tid; k < SPAN; k += THREADS) {
         const int x = beg - AGG_HALO + k;
         sKeys[k] = (x >= 0 && x < n) ? keys[x] : 0u;
     }
     __syncthreads();
     auto hbit = [](unsigned int x) -> int { return x ? 31 - __clz((int)x) : -1; };
-    for (int k = tid; k < SPAN + 2; k += MARK_THREADS) {
+    for (int k = tid; k < SPAN + 2; k += THREADS) {
         const int x = beg - AGG_HALO + k;
         sD[k] = (k >= 1 && k < SPAN && x > 0 && x < n) ? hbit(sKeys[k - 1] ^ sKeys[k]) : 64;
     }
@@ -925,14 +928,15 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
     auto dAt = [&](int x) -> int { return sD[x - beg + AGG_HALO]; };
     const int topBit = hbit(keys[0] ^ keys[n - 1]);
     if (blockIdx.x == 0 && tid == 0 && topBit < 0) st->rootSplit = (unsigned int)(n >> 1);   // all keys equal: the first median
-    for (int r = 0; r < MARK_SUBS; r++) {
-        const int i = beg + r * MARK_THREADS + tid;
+    for (int rr = 0; rr < ROUNDS; rr++) {
+        const int rel = rr * THREADS + tid;       // position inside the block
+        const int i = beg + rel;
         bool mark = false, isRun = false;
         int s0 = 0, e0 = 0;               // the run of equal keys position i lies in (isRun)
         bool deepRun = false;             // ... and the depth rule could cut its subtree short: its depth is needed
         unsigned int myKey = 0;
         if (i < n) {
-            myKey = sKeys[AGG_HALO + r * MARK_THREADS + tid];
+            myKey = sKeys[AGG_HALO + rel];
             int ls = 0, le = 0;
             agg_leaf_of(i, leafSize, dAt, isRun, ls, le);
             if (!isRun) {
@@ -1009,9 +1013,9 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
         }
         const unsigned long long mb = __ballot(mark), rb = __ballot(isRun);
         if (lane == 0) {
-            sBits[(size_t)((beg + r * MARK_THREADS + wave * 64) >> 6)] = mb;
-            rBits[(size_t)((beg + r * MARK_THREADS + wave * 64) >> 6)] = rb;
-            s_c[r][wave] = (unsigned int)__popcll(mb);
+            sBits[(size_t)((beg + rel) >> 6)] = mb;
+            rBits[(size_t)((beg + rel) >> 6)] = rb;
+            s_c[rel >> 8][(rel >> 6) & 3] = (unsigned int)__popcll(mb);
         }
     }
     __syncthreads();
@@ -1019,7 +1023,7 @@ __global__ __launch_bounds__(MARK_THREADS) void lbvh_leafmark_kernel(int n, int 
         unsigned int acc = 0;
         for (int q = 0; q < MARK_SUBS; q++) {
             subBase[(size_t)blockIdx.x * MARK_SUBS + q] = acc;
-            for (int w = 0; w < MARK_THREADS / 64; w++) acc += s_c[q][w];
+            for (int w = 0; w < 4; w++) acc += s_c[q][w];
         }
         blockCount[blockIdx.x] = acc;
     }
@@ -1224,8 +1228,14 @@ int ntr_lbvh_build(int32_t numTris, const int32_t* d_triVtxIndex, int32_t numVer
             a.exports = (AggExport*)(ws + oExports); a.exportCount = (unsigned int*)(ws + oExportCount); a.slotG = (AggSlotG*)(ws + oSlot);
             a.abortFlag = osMisc + 4;
             // leaf starts and their prefix counts first: everything after it writes to final places
-            hipLaunchKernelGGL(lbvh_leafmark_kernel, dim3(cntTiles), dim3(MARK_THREADS), 0, s, n, leafSize, keys, (unsigned long long*)(ws + oLeafBits),
-                               (unsigned long long*)(ws + oRunBits), (unsigned int*)(ws + oTileCount), (unsigned int*)(ws + oSubBase), (unsigned char*)(ws + oRunDepth), state);
+            // small builds are latency chains: one position per thread (262 k triangles: leaf marks 21 -> 16 us); large ones are
+            // throughput: four positions per thread in a quarter of the threads (10 M: 70 against 82 us)
+            if (tun.lbvhMarkThreads == 256 || (tun.lbvhMarkThreads != 1024 && n >= (1 << 21)))
+                hipLaunchKernelGGL(lbvh_leafmark_kernel<256>, dim3(cntTiles), dim3(256), 0, s, n, leafSize, keys, (unsigned long long*)(ws + oLeafBits),
+                                   (unsigned long long*)(ws + oRunBits), (unsigned int*)(ws + oTileCount), (unsigned int*)(ws + oSubBase), (unsigned char*)(ws + oRunDepth), state);
+            else
+                hipLaunchKernelGGL(lbvh_leafmark_kernel<1024>, dim3(cntTiles), dim3(1024), 0, s, n, leafSize, keys, (unsigned long long*)(ws + oLeafBits),
+                                   (unsigned long long*)(ws + oRunBits), (unsigned int*)(ws + oTileCount), (unsigned int*)(ws + oSubBase), (unsigned char*)(ws + oRunDepth), state);
             hipLaunchKernelGGL(lbvh_markscan_kernel, dim3(1), dim3(MARK_THREADS), 0, s, n, cntTiles, (const unsigned int*)(ws + oTileCount),
                                (unsigned int*)(ws + oTileBase), state);
             pe.mark(4);

@@ -174,6 +174,7 @@ static void tunables_load_locked()
     t.lbvhAggLds = env_int("NTR_LBVH_AGG_LDS", 1);     // bottom-up emit: meetings inside a tile through LDS
     t.lbvhMortonKeys = env_int("NTR_LBVH_MORTON_KEYS", 0);  // triangles per thread of the Morton / histogram kernel (0 = 4)
     t.lbvhMortonThreads = env_int("NTR_LBVH_MORTON_THREADS", 0);
+    t.lbvhMarkThreads = env_int("NTR_LBVH_MARK_THREADS", 0);      // workgroup size of the leaf-mark kernel (256 / 1024; 0 = by size)
     t.lbvhSortItems = env_int("NTR_LBVH_SORT_ITEMS", 0);   // keys per thread of a one-sweep tile (8 / 16 / 24 / 32; 0 = by size)
     t.lbvhAggStaged = env_int("NTR_LBVH_AGG_STAGED", -1);  // bottom-up emit in two launches: -1 = from 2^20 triangles, 0 / 1 = never / always
     if (t.chunk < 1) t.chunk = 1;

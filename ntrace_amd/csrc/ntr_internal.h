@@ -13,7 +13,7 @@ struct Tunables {
     int chunk, fetchThreshold, leafSwitchBelow, blocksPerCU, blocksPerCUIncoherent, blocksPerCUDivergent, poolHeads, octant, anyHitWaves, closestWaves, unified, perrayUnified, flatFetch, uniformPrologue, splitSlice, wholeWave, prefetchAfter, minipool, minipoolThreshold, minipoolWide;
     int autoHint, autoHintMinRays, persistentHints, route, predict, predictPersistent, predictDepth, predictMinRays, predictMinNodes;
     int schedRefreshEvery, schedClasses;
-    int lbvhSplit, lbvhSubThreads, lbvhAggLds, lbvhAggStaged, lbvhSortItems, lbvhMortonKeys, lbvhMortonThreads;
+    int lbvhSplit, lbvhSubThreads, lbvhAggLds, lbvhAggStaged, lbvhSortItems, lbvhMortonKeys, lbvhMortonThreads, lbvhMarkThreads;
 };
 Tunables tunables();
 

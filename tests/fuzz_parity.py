@@ -154,7 +154,8 @@ def main(argv=None):
                                 NTR_LBVH_AGG_LDS=int(rng.choice([1, 1, 0])),
                                 NTR_LBVH_AGG_STAGED=int(rng.choice([-1, 0, 1])),
                                 NTR_LBVH_SORT_ITEMS=int(rng.choice([0, 0, 8, 16, 24, 32])),
-                                NTR_LBVH_MORTON_THREADS=int(rng.choice([0, 0, 256, 512, 1024])), NTR_LBVH_MORTON_KEYS=int(rng.choice([0, 0, 1, 2, 16])))
+                                NTR_LBVH_MORTON_THREADS=int(rng.choice([0, 0, 256, 512, 1024])), NTR_LBVH_MORTON_KEYS=int(rng.choice([0, 0, 1, 2, 16])),
+                                NTR_LBVH_MARK_THREADS=int(rng.choice([0, 256, 1024])))
                 if os.environ.get("NTR_FUZZ_VERBOSE"):
                     print("lbvh n=%d leaf=%d eps=%g %s" % (tri.shape[0], leaf, eps, {k: v for k, v in os.environ.items() if k.startswith("NTR_LBVH")}),
                           file=sys.stderr, flush=True)
