@@ -12,6 +12,7 @@
 #include <mutex>
 
 #include "ntr_internal.h"
+#include "device_scratch.h"
 #include "radix_sort.h"
 
 namespace ntr {
@@ -170,53 +171,14 @@ __global__ __launch_bounds__(256) void ray_reorder_kernel(int n, const int* __re
 using namespace ntr;
 
 namespace {
-// Grow-only scratch of ntr_ray_morton_sort, one per device, kept between calls: a renderer sorts sixteen batches per frame and must not
-// pay seven hipMalloc / hipFree pairs (each a device synchronisation) for every one of them.  Same rules as the LBVH builder's workspace
-// (lbvh_workspace.h): one caller per device at a time; regrown only after the device has drained; ntr_lbvh_release_workspace returns it.
-struct SortScratch {
-    void* p = nullptr;
-    size_t bytes = 0;
-};
-constexpr int kSortMaxDevices = 64;
-SortScratch g_sortScratch[kSortMaxDevices];
-std::mutex g_sortScratchMu;
-
-int sort_scratch_reserve(size_t bytes, void** out)
-{
-    int dev = 0;
-    NTR_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= kSortMaxDevices) return set_error(NTR_ERR_INVALID, "device index %d out of range", dev);
-    std::lock_guard<std::mutex> lk(g_sortScratchMu);
-    SortScratch& w = g_sortScratch[dev];
-    if (w.p && w.bytes < bytes) {
-        NTR_HIP(hipDeviceSynchronize());
-        NTR_HIP(hipFree(w.p));
-        w.p = nullptr; w.bytes = 0;
-    }
-    if (!w.p) {
-        NTR_HIP(hipMalloc(&w.p, bytes));
-        w.bytes = bytes;
-    }
-    *out = w.p;
-    return NTR_OK;
-}
+// Grow-only scratch of ntr_ray_morton_sort, one per device, kept between calls (device_scratch.h): a renderer sorts sixteen batches per
+// frame and must not pay seven hipMalloc / hipFree pairs (each a device synchronisation) for every one of them.
+// ntr_lbvh_release_workspace returns it.
+ntr::DeviceScratchPool g_sortScratch;
 }  // namespace
 
 namespace ntr {
-int raysort_scratch_release()
-{
-    int dev = 0;
-    NTR_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= kSortMaxDevices) return set_error(NTR_ERR_INVALID, "device index %d out of range", dev);
-    std::lock_guard<std::mutex> lk(g_sortScratchMu);
-    SortScratch& w = g_sortScratch[dev];
-    if (w.p) {
-        NTR_HIP(hipDeviceSynchronize());
-        NTR_HIP(hipFree(w.p));
-        w.p = nullptr; w.bytes = 0;
-    }
-    return NTR_OK;
-}
+int raysort_scratch_release() { return g_sortScratch.release(); }
 }  // namespace ntr
 
 // Framebuffer gather of the multi-GPU path (ntr_dist.cpp): a rank's pixels packed in slot order / scattered back on the root.
@@ -285,7 +247,7 @@ int ntr_ray_morton_sort(int32_t numRays, const NtrRay* d_inRays, const int32_t* 
     const size_t oZero = take((histWords + miscWords + stateWords) * 4), oBox = take(64);
     void* base = nullptr;
     {
-        const int rc = sort_scratch_reserve(off, &base);
+        const int rc = g_sortScratch.reserve(off, &base);
         if (rc != NTR_OK) return rc;
     }
     char* ws = (char*)base;
