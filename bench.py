@@ -693,7 +693,13 @@ def main():
         "primary_mrays": prim_live_total * args.steps / prim_kernel_max / 1e6,
         "ao_mrays": (ao_live_total * args.steps / ao_kernel_max / 1e6) if ao_kernel_max > 0 else None,
         "kernel_ms": {"primary": prim_ms, "ao_total": ao_ms, "per_step_rank0": float(kern_ms.sum(axis=1).mean()),
-                      "per_batch": [round(float(x), 4) for x in kern_ms.mean(axis=0)]},
+                      "per_batch": [round(float(x), 4) for x in kern_ms.mean(axis=0)],
+                      # (a single stalled launch -- a box's management agent sampling the GPU, say -- weighs on a mean over a few hundred steps:
+                      # 20 ms in one launch are 0.08 ms per step; the medians and the worst launch per batch make such a run readable)
+                      "per_batch_median": [round(float(x), 4) for x in np.median(kern_ms, axis=0)],
+                      "per_batch_max": [round(float(x), 4) for x in kern_ms.max(axis=0)],
+                      "per_step_rank0_median": float(np.median(kern_ms.sum(axis=1)))},
+        "value_median_step_rank0": (rays_per_step / (float(np.median(kern_ms.sum(axis=1))) * 1e-3) / 1e6) if world == 1 else None,
         "gather_ms": gather_ms,
         "gather_native": native_gather if native_gather is not None else ({"fallback": native_note} if native_note else None),
         "sharded_frame_check": frame_check,
