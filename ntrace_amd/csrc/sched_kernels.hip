@@ -402,11 +402,13 @@ namespace ntr {
 constexpr int SCHED_THREADS = 256;   // 64 classes x 256 threads x 4 B = 64 KB of static LDS (+ 1 KB of wave totals)
 constexpr int SCHED_MAX_CLASSES = 64;
 
+// MAXC: the classes the unrolled scans are written for (32: the default NTR_SCHED_CLASSES -- half the shuffles and registers of 64)
+template <int MAXC>
 __global__ __launch_bounds__(SCHED_THREADS) void sched_order_kernel(const unsigned int* __restrict__ cost, int numBlocks, int classes,
                                                                     unsigned int* __restrict__ order)
 {
-    __shared__ unsigned int s_cnt[SCHED_MAX_CLASSES][SCHED_THREADS];
-    __shared__ unsigned int s_tot[SCHED_MAX_CLASSES][SCHED_THREADS / 64];
+    __shared__ unsigned int s_cnt[MAXC][SCHED_THREADS];
+    __shared__ unsigned int s_tot[MAXC][SCHED_THREADS / 64];
     __shared__ unsigned int s_red[SCHED_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = (numBlocks + SCHED_THREADS - 1) / SCHED_THREADS;
@@ -430,28 +432,28 @@ __global__ __launch_bounds__(SCHED_THREADS) void sched_order_kernel(const unsign
     __syncthreads();
     // Exclusive scan over (class major, thread minor).  Every lane scans all its classes' counts across the wave at once (independent
     // shuffle chains), the waves exchange their totals once: three barriers in all instead of two per class.
-    unsigned int v[SCHED_MAX_CLASSES], incl[SCHED_MAX_CLASSES];
+    unsigned int v[MAXC], incl[MAXC];
 #pragma unroll
-    for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
+    for (int c = 0; c < MAXC; c++) {
         v[c] = c < classes ? s_cnt[c][tid] : 0u;
         incl[c] = v[c];
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
 #pragma unroll
-        for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
+        for (int c = 0; c < MAXC; c++) {
             const unsigned int u = (unsigned int)__shfl_up((int)incl[c], off);
             if (lane >= off) incl[c] += u;
         }
     }
     if (lane == 63) {
 #pragma unroll
-        for (int c = 0; c < SCHED_MAX_CLASSES; c++) s_tot[c][wave] = incl[c];
+        for (int c = 0; c < MAXC; c++) s_tot[c][wave] = incl[c];
     }
     __syncthreads();
     unsigned int running = 0;
 #pragma unroll
-    for (int c = 0; c < SCHED_MAX_CLASSES; c++) {
+    for (int c = 0; c < MAXC; c++) {
         if (c < classes) {
             unsigned int before = 0, total = 0;
 #pragma unroll
@@ -478,6 +480,9 @@ extern "C" hipError_t ntr_launch_sched_order(const unsigned int* d_cost, int num
 {
     if (classes < 1) classes = 1;
     if (classes > ntr::SCHED_MAX_CLASSES) classes = ntr::SCHED_MAX_CLASSES;
-    hipLaunchKernelGGL(ntr::sched_order_kernel, dim3(1), dim3(ntr::SCHED_THREADS), 0, stream, d_cost, numBlocks, classes, d_order);
+    if (classes <= 32)
+        hipLaunchKernelGGL(ntr::sched_order_kernel<32>, dim3(1), dim3(ntr::SCHED_THREADS), 0, stream, d_cost, numBlocks, classes, d_order);
+    else
+        hipLaunchKernelGGL(ntr::sched_order_kernel<ntr::SCHED_MAX_CLASSES>, dim3(1), dim3(ntr::SCHED_THREADS), 0, stream, d_cost, numBlocks, classes, d_order);
     return hipGetLastError();
 }
