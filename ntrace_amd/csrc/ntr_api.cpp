@@ -780,7 +780,7 @@ static int trace_impl(const char* kernelName, int32_t numRays, int32_t anyHit, c
     }
 
     // A hinted batch is predicted once (its hint then holds a measured order); its coherence words -- the batch word: mini-pool K, routing --
-    // are estimated again on the hint's refresh launches by a probe of their own (three small launches, every 16th launch): rays drift.
+    // are estimated again on the hint's refresh launches by a probe of their own (three small launches, on the refresh launches only -- trace_plan.h plan_hint_step): rays drift.
     const bool probeCoherence = !predScratch && hint && refresh && pl.probeOnRefresh;
     if (probeCoherence) {
         rc = top_table_get(d_nodes, nodesBytes, s, false, &predTable);

@@ -195,11 +195,15 @@ inline HintStep plan_hint_step(const Tunables& tun, bool valid, bool predicted, 
 {
     HintStep h;
     // costs measured under the natural order differ from those under the derived order, so the first launches all refresh; afterwards
-    // every `schedRefreshEvery`-th does (slowly drifting rays keep their schedule)
+    // the `schedRefreshEvery`-th does, the one twice and the one four times as late, and from then on every fourth period's (slowly
+    // drifting rays keep their schedule, and a schedule that has held for 64 launches is measured again less often than a new one: a
+    // refresh launch records costs and derives an order -- 25-30 us on a 2^20-ray batch, half of an AO launch's own time; round 6:
+    // at 16, 32, 48, ... they were 2.5 % of the headline step)
     const bool firstOfPrediction = predicted && valid;   // (ntr_sched_hint_predict cleared the K words itself)
     h.zeroK = uses == 0 && !firstOfPrediction;
     const int every = tun.schedRefreshEvery;
-    h.refresh = uses < 3 || every <= 1 || (uses % every) == 0;
+    const long long late = 4ll * every;
+    h.refresh = uses < 3 || every <= 1 || (uses < late ? (uses == every || uses == 2 * every) : (uses % late) == 0);
     if (firstOfPrediction) h.refresh = false;   // the first launch of a predicted order just runs it (a batch traced once pays nothing for feedback)
     h.useOrder = valid;
     return h;

@@ -134,7 +134,9 @@ def test_hint_life_cycle():
     assert st(False, False, 0) == dict(zeroK=True, refresh=True, useOrder=False)      # a new hint: measures under buffer order
     assert st(True, False, 1) == dict(zeroK=False, refresh=True, useOrder=True)       # first launches all refresh
     assert st(True, False, 2)["refresh"] and not st(True, False, 3)["refresh"]
-    assert st(True, False, 16)["refresh"] and not st(True, False, 17)["refresh"]      # then every 16th
+    assert st(True, False, 16)["refresh"] and not st(True, False, 17)["refresh"]      # then the 16th, the 32nd,
+    assert st(True, False, 32)["refresh"] and not st(True, False, 48)["refresh"]      # ... and every 64th from there on: a schedule that
+    assert [u for u in range(3, 300) if st(True, False, u)["refresh"]] == [16, 32, 64, 128, 192, 256]   # has held is re-measured less often
     assert st(True, True, 0) == dict(zeroK=False, refresh=False, useOrder=True)       # a predicted order just runs once
 
 
