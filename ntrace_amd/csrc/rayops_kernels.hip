@@ -113,6 +113,7 @@ __global__ void ray_aabb_decode_kernel(const unsigned int* __restrict__ box, flo
 
 // genMortonKeysKernel (RayBufferKernels.cu:140-175): 6 x 32 bits interleaved (component c, bit i -> bit c + 6 i).
 constexpr int RAY_KEY_DIGITS = 19;   // 8-bit digits of the 150 significant key bits: words 0..3 fully, word 4 bits 0..23
+static_assert(RAY_KEY_DIGITS <= OS_MAX_PASSES, "one clearing of the tile state serves all passes: the pass number must fit the status tag");
 
 __global__ __launch_bounds__(256) void ray_keys_kernel(int n, const NtrRay* __restrict__ rays, const float* __restrict__ box,
                                                        unsigned int* __restrict__ keys /* 6 words per ray */, int* __restrict__ idx,
