@@ -39,7 +39,7 @@ lview.trace(K0, rays.shape[0], False, d_pr.data_ptr(), d_pres.data_ptr(), stream
 d_nrm = up(scenes.tri_normals(tri, pos))
 per = (1 << 20) // 8
 nb = per * 8
-settings = ["-", "NTR_TRACE_ROUTE=0", "NTR_TRACE_ROUTE=0,NTR_TRACE_WHOLE_WAVE=0,NTR_TRACE_BLOCKS_PER_CU=3",
+settings = os.environ["STUDY_SETTINGS"].split("|") if os.environ.get("STUDY_SETTINGS") else ["-", "NTR_TRACE_ROUTE=0", "NTR_TRACE_ROUTE=0,NTR_TRACE_WHOLE_WAVE=0,NTR_TRACE_BLOCKS_PER_CU=3",
             "NTR_TRACE_ROUTE=0,NTR_TRACE_WHOLE_WAVE=0,NTR_TRACE_BLOCKS_PER_CU=4", "NTR_TRACE_ROUTE=0,NTR_TRACE_WHOLE_WAVE=0,NTR_TRACE_BLOCKS_PER_CU=7"]
 for frac in (0.5, 0.3):
     lo = int(rays.shape[0] * frac) // per * per
